@@ -1,0 +1,29 @@
+# Top-level build: everything lands in-tree (git-ignored, but shipped to the GPU box).
+#   make lib     -> coati_amd/_build/libcoati_hip.so   (HIP kernels + C ABI, gfx950)
+#   make oracle  -> oracle/_build/libcoati_oracle.so   (test infrastructure)
+#   make ref     -> oracle/_ref/libcoati_ref.so        (only where /root/reference exists)
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+BUILD     = coati_amd/_build
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
+            -Wall -Wextra -Wno-unused-parameter -Iinclude
+
+all: lib oracle
+
+lib: $(BUILD)/libcoati_hip.so
+
+$(BUILD)/libcoati_hip.so: coati_amd/csrc/coati_hip.hip include/coati_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ coati_amd/csrc/coati_hip.hip
+
+oracle:
+	$(MAKE) -C oracle
+
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf $(BUILD)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle ref clean

@@ -1,0 +1,211 @@
+"""ctypes binding of libcoati_hip.so (include/coati_hip.h).
+
+Plumbing only: the product is the shared library.  There is no CPU fallback --
+if the library is missing or no gfx950 device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_ROOT = Path(__file__).resolve().parent
+LIB_PATH = _ROOT / "_build" / "libcoati_hip.so"
+
+TABLE_ROWS, TABLE_COLS = 183, 15
+OP_MATCH, OP_DEL, OP_INS = 0, 1, 2
+
+# every symbol include/coati_hip.h declares
+EXPORTS = (
+    "coati_hip_version",
+    "coati_hip_device_count",
+    "coati_hip_last_error",
+    "coati_hip_model_create",
+    "coati_hip_model_destroy",
+    "coati_hip_batch_create",
+    "coati_hip_batch_destroy",
+    "coati_hip_batch_device_bytes",
+    "coati_hip_batch_cells",
+    "coati_hip_viterbi_launch",
+    "coati_hip_batch_sync",
+    "coati_hip_viterbi_fetch",
+    "coati_hip_viterbi_last_timing",
+    "coati_hip_viterbi_batch",
+    "coati_hip_debug_viterbi_flags",
+)
+
+
+class CoatiHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"coati_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libcoati_hip.so; fail loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("COATI_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise ImportError(
+            f"{path} not found: build it with `make lib` (or __graft_entry__.build()); "
+            "coati_amd has no CPU fallback"
+        )
+    lib = C.CDLL(str(path))
+    vp, u64, i32, f32 = C.c_void_p, C.c_uint64, C.c_int, C.c_float
+    lib.coati_hip_version.restype = C.c_uint32
+    lib.coati_hip_device_count.restype = i32
+    lib.coati_hip_last_error.restype = C.c_char_p
+    lib.coati_hip_model_create.argtypes = [vp, f32, f32, f32, f32, i32, i32, C.POINTER(vp)]
+    lib.coati_hip_model_destroy.argtypes = [vp]
+    lib.coati_hip_model_destroy.restype = None
+    lib.coati_hip_batch_create.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(vp)]
+    lib.coati_hip_batch_destroy.argtypes = [vp]
+    lib.coati_hip_batch_destroy.restype = None
+    lib.coati_hip_batch_device_bytes.argtypes = [vp]
+    lib.coati_hip_batch_device_bytes.restype = u64
+    lib.coati_hip_batch_cells.argtypes = [vp]
+    lib.coati_hip_batch_cells.restype = u64
+    lib.coati_hip_viterbi_launch.argtypes = [vp]
+    lib.coati_hip_batch_sync.argtypes = [vp]
+    lib.coati_hip_viterbi_fetch.argtypes = [vp, vp, vp, u64, vp, vp]
+    lib.coati_hip_viterbi_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+    lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
+    lib.coati_hip_debug_viterbi_flags.argtypes = [vp, u64, vp, u64]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise CoatiHipError(rc, load().coati_hip_last_error().decode(errors="replace"))
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return int(load().coati_hip_device_count())
+
+
+def pack_pairs(pairs):
+    """[(a_codes, b_codes), ...] -> (a_cat, a_off, b_cat, b_off) as the ABI wants them."""
+    a_off = np.zeros(len(pairs) + 1, np.uint64)
+    b_off = np.zeros(len(pairs) + 1, np.uint64)
+    for p, (a, b) in enumerate(pairs):
+        a_off[p + 1] = a_off[p] + len(a)
+        b_off[p + 1] = b_off[p] + len(b)
+    a_cat = np.zeros(max(int(a_off[-1]), 1), np.uint8)
+    b_cat = np.zeros(max(int(b_off[-1]), 1), np.uint8)
+    for p, (a, b) in enumerate(pairs):
+        a_cat[int(a_off[p]):int(a_off[p + 1])] = a
+        b_cat[int(b_off[p]):int(b_off[p + 1])] = b
+    return a_cat, a_off, b_cat, b_off
+
+
+class Model:
+    """coati_hip_model_t: the 183x15 table + host-computed log gap constants."""
+
+    def __init__(self, table, consts, gap_len: int = 1, device: int = 0):
+        table = np.ascontiguousarray(table, np.float32)
+        if table.shape != (TABLE_ROWS, TABLE_COLS):
+            raise ValueError("table must be 183x15")
+        self._h = C.c_void_p()
+        self.gap_len = gap_len
+        self.device = device
+        c = [float(x) for x in consts]
+        _check(load().coati_hip_model_create(_ptr(table), c[0], c[1], c[2], c[3], gap_len, device,
+                                             C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().coati_hip_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def viterbi(self, a_cat, a_off, b_cat, b_off):
+        """One-shot coati_hip_viterbi_batch.  Returns (scores, ops, ops_off, ops_len)."""
+        n = len(a_off) - 1
+        total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
+        scores = np.zeros(n, np.float32)
+        ops = np.zeros(max(total, 1), np.uint8)
+        ops_off = np.zeros(n, np.uint64)
+        ops_len = np.zeros(n, np.uint32)
+        _check(load().coati_hip_viterbi_batch(self._h, n, _ptr(a_cat), _ptr(a_off), _ptr(b_cat), _ptr(b_off),
+                                              _ptr(scores), _ptr(ops), total, _ptr(ops_off), _ptr(ops_len)))
+        return scores, ops, ops_off, ops_len
+
+
+class Batch:
+    """coati_hip_batch_t: encoded pairs + workspace resident in HBM."""
+
+    def __init__(self, model: Model, a_cat, a_off, b_cat, b_off):
+        self.model = model
+        self.n = len(a_off) - 1
+        self.ops_total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
+        self._h = C.c_void_p()
+        a_cat = np.ascontiguousarray(a_cat, np.uint8)
+        b_cat = np.ascontiguousarray(b_cat, np.uint8)
+        a_off = np.ascontiguousarray(a_off, np.uint64)
+        b_off = np.ascontiguousarray(b_off, np.uint64)
+        self.lens = np.stack([np.diff(a_off), np.diff(b_off)], axis=1).astype(np.int64)
+        _check(load().coati_hip_batch_create(model._h, self.n, _ptr(a_cat), _ptr(a_off), _ptr(b_cat),
+                                             _ptr(b_off), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().coati_hip_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def cells(self) -> int:
+        return int(load().coati_hip_batch_cells(self._h))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(load().coati_hip_batch_device_bytes(self._h))
+
+    def viterbi_launch(self):
+        _check(load().coati_hip_viterbi_launch(self._h))
+
+    def sync(self):
+        _check(load().coati_hip_batch_sync(self._h))
+
+    def viterbi_fetch(self):
+        scores = np.zeros(self.n, np.float32)
+        ops = np.zeros(max(self.ops_total, 1), np.uint8)
+        ops_off = np.zeros(self.n, np.uint64)
+        ops_len = np.zeros(self.n, np.uint32)
+        _check(load().coati_hip_viterbi_fetch(self._h, _ptr(scores), _ptr(ops), self.ops_total, _ptr(ops_off),
+                                              _ptr(ops_len)))
+        return scores, ops, ops_off, ops_len
+
+    def viterbi_timing(self):
+        f, w = C.c_float(), C.c_float()
+        _check(load().coati_hip_viterbi_last_timing(self._h, C.byref(f), C.byref(w)))
+        return f.value, w.value
+
+    def debug_flags(self, pair: int):
+        la, lb = self.lens[pair]
+        out = np.zeros((int(la), int(lb)), np.uint8)
+        if out.size:
+            _check(load().coati_hip_debug_viterbi_flags(self._h, pair, _ptr(out), out.size))
+        return out

@@ -1,0 +1,143 @@
+/* coati_hip.h -- C ABI of libcoati_hip.so, the MI355X (gfx950) implementation of
+ * COATi's marginal pairwise-alignment hot path.
+ *
+ * The reference (CartwrightLab/coati) has no FFI layer; the boundary this
+ * library replaces is the C++ API of its pairwise DP engine as called from the
+ * marginal workflow drivers:
+ *
+ *   viterbi_mem        src/include/coati/align_pair.hpp:170  (align_pair.cc:195)
+ *   traceback_viterbi  src/include/coati/align_pair.hpp:176  (align_pair.cc:319)
+ *   forward            src/include/coati/align_pair.hpp:161  (align_pair.cc:149)
+ *   sampleback         src/include/coati/align_pair.hpp:180  (align_pair.cc:401)
+ *   call sites         src/lib/align_marginal.cc:71,80,586,590; src/lib/align_msa.cc:307-308
+ *
+ * The reference aligns one pair per process (src/lib/utils.cc:810-812); this
+ * ABI is batched: a *model* (183x15 marginal substitution table + gap
+ * constants, all host-computed exactly as the reference computes them) and a
+ * *batch* of encoded sequence pairs that stays resident in HBM.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every entry
+ * point returns 0 on success and a non-zero code on failure, in which case
+ * coati_hip_last_error() describes the failure (thread-local).  No exceptions
+ * cross the boundary.  Handles are thread-compatible: distinct handles may be
+ * used from distinct threads; one handle must not be used concurrently.
+ * There is NO CPU fallback: without a usable gfx950 device every compute call
+ * fails with COATI_HIP_ENODEVICE.
+ *
+ * Sequence encoding (marginal_seq_encoding, src/lib/utils.cc:496-528):
+ *   a[]: ancestor, one byte per nucleotide, value codon61*3+phase in [0,183)
+ *   b[]: descendant, one byte per nucleotide, nt16 code in [0,15)
+ * Pair p occupies a_cat[a_off[p] .. a_off[p+1]) and b_cat[b_off[p] .. b_off[p+1]).
+ *
+ * Alignment ops: one byte per alignment COLUMN, left to right:
+ *   0 = match/mismatch, 1 = deletion (gap in descendant), 2 = insertion (gap in
+ *   ancestor).  From them the host rebuilds the gapped strings exactly as
+ *   traceback<> does (align_pair.cc:268-302).
+ */
+#ifndef COATI_HIP_H
+#define COATI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COATI_HIP_TABLE_ROWS 183
+#define COATI_HIP_TABLE_COLS 15
+
+enum {
+    COATI_HIP_OK = 0,
+    COATI_HIP_EINVAL = 1,    /* bad argument (NULL, code out of range, gap_len < 1 ...) */
+    COATI_HIP_ENODEVICE = 2, /* no gfx950 device / HIP runtime unusable */
+    COATI_HIP_ENOMEM = 3,    /* device or host allocation failed (the reference's
+                                "sequences to align exceed available memory",
+                                src/lib/align_marginal.cc:72-75) */
+    COATI_HIP_EHIP = 4,      /* a HIP call or kernel failed */
+    COATI_HIP_ESTATE = 5     /* call out of order (fetch before launch ...) */
+};
+
+enum { COATI_HIP_OP_MATCH = 0, COATI_HIP_OP_DEL = 1, COATI_HIP_OP_INS = 2 };
+
+typedef struct coati_hip_model coati_hip_model_t;
+typedef struct coati_hip_batch coati_hip_batch_t;
+
+/* Library/ABI version (major << 16 | minor). */
+uint32_t coati_hip_version(void);
+
+/* Number of usable gfx950 devices (0 if none; never fails). */
+int coati_hip_device_count(void);
+
+/* Thread-local description of the last failure of any call on this thread. */
+const char* coati_hip_last_error(void);
+
+/* ---- model -------------------------------------------------------------- *
+ * Replaces the read side of `const alignment_t&` in viterbi_mem/forward
+ * (aln.subst_matrix, aln.gap; src/include/coati/structs.hpp:37-50,82).
+ * table: 183*15 fp32, row-major, = marginal_p() output
+ *        (src/lib/mutation_coati.cc:164-199).
+ * no_gap/gap_stop/gap_open/gap_extend: log1pf(-g), log1pf(-e), logf(g), logf(e)
+ *        computed on the HOST (align_pair.cc:66-69) so that device results are
+ *        a pure function of the inputs.
+ * gap_len: aln.gap.len >= 1.   device: HIP device ordinal. */
+int coati_hip_model_create(const float* table, float no_gap, float gap_stop, float gap_open,
+                           float gap_extend, int gap_len, int device,
+                           coati_hip_model_t** out);
+void coati_hip_model_destroy(coati_hip_model_t* model);
+
+/* ---- batch -------------------------------------------------------------- *
+ * Validates and uploads n_pairs encoded pairs (host pointers) and reserves the
+ * HBM workspace for the Viterbi path.  a_off/b_off have n_pairs+1 entries.
+ * Every len_a must be a multiple of 3 and of gap_len, every len_b a multiple
+ * of gap_len (process_marginal, src/lib/utils.cc:822-835). */
+int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                           const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                           coati_hip_batch_t** out);
+void coati_hip_batch_destroy(coati_hip_batch_t* batch);
+
+/* Bytes of HBM a batch holds (inputs + workspace + results). */
+uint64_t coati_hip_batch_device_bytes(const coati_hip_batch_t* batch);
+/* Sum over pairs of len_a*len_b ("cell updates"). */
+uint64_t coati_hip_batch_cells(const coati_hip_batch_t* batch);
+
+/* viterbi_mem + traceback_viterbi for every pair of the batch: enqueues the
+ * fill kernel and the traceback walker on the model's stream and returns
+ * without waiting. */
+int coati_hip_viterbi_launch(coati_hip_batch_t* batch);
+/* Wait for everything enqueued for this batch. */
+int coati_hip_batch_sync(coati_hip_batch_t* batch);
+
+/* Copy results to host (synchronises first).  Any output may be NULL.
+ *   scores[n_pairs]   aln.data.score of traceback (align_pair.cc:265), fp32
+ *   ops[ops_capacity] op bytes of all pairs; pair p's ops are
+ *                     ops[ops_off[p] .. ops_off[p] + ops_len[p])
+ *   ops_off[n_pairs], ops_len[n_pairs]
+ * ops_capacity must be >= sum(len_a + len_b); pair p's ops lie inside the
+ * slot [sum_{q<p}(len_a+len_b), +len_a+len_b). */
+int coati_hip_viterbi_fetch(coati_hip_batch_t* batch, float* scores, uint8_t* ops,
+                            uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len);
+
+/* Device times (ms) of the last viterbi launch, from HIP events recorded on the
+ * model's stream around each kernel (synchronises first). */
+int coati_hip_viterbi_last_timing(coati_hip_batch_t* batch, float* fill_ms, float* walk_ms);
+
+/* One-shot convenience: create batch(es), launch, fetch, destroy.  Splits the
+ * input into chunks that fit the device's free memory. */
+int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                            const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                            float* scores, uint8_t* ops, uint64_t ops_capacity,
+                            uint64_t* ops_off, uint32_t* ops_len);
+
+/* Parity/debug export: the per-cell traceback decision byte of pair `pair`
+ * (bits 0-1 state after a match move arrives at the cell, bits 2-3 after a
+ * deletion move, bit 4 after an insertion move) for the len_a x len_b BODY
+ * cells (matrix rows/cols gap_len.., row-major), decoded from the packed HBM
+ * layout.  Valid after a synchronised viterbi launch. */
+int coati_hip_debug_viterbi_flags(coati_hip_batch_t* batch, uint64_t pair, uint8_t* out,
+                                  uint64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COATI_HIP_H */

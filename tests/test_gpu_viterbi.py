@@ -1,0 +1,127 @@
+"""Parity of the HIP Viterbi path (through the C ABI) with the CPU oracle.
+Bit-exact: fp32 score bits, every alignment op, and every per-cell traceback
+decision byte."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from coati_amd import hip as h
+
+    assert h.device_count() > 0, "no gfx950 device: the HIP path cannot run"
+    return h
+
+
+def run_and_compare(hip, oracle, table, consts, pairs, check_flags=True):
+    enc = util.encode_pairs(pairs)
+    a_cat, a_off, b_cat, b_off = hip.pack_pairs(enc)
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    scores, ops, ops_off, ops_len = batch.viterbi_fetch()
+    for p, (a, b) in enumerate(enc):
+        want_ops, want_score = oracle.viterbi(table, consts, 1, a, b, lowmem=len(a) * len(b) > 4_000_000)
+        got = ops[int(ops_off[p]):int(ops_off[p]) + int(ops_len[p])]
+        assert bits(scores[p]) == bits(want_score), (p, len(a), len(b), scores[p], want_score)
+        assert len(got) == len(want_ops) and (got == want_ops).all(), (p, len(a), len(b))
+        slot0 = int(a_off[p] + b_off[p])
+        assert slot0 <= int(ops_off[p]) and int(ops_off[p]) + int(ops_len[p]) <= slot0 + len(a) + len(b)
+        if check_flags and 0 < len(a) * len(b) <= 400_000:
+            M, D, I = oracle.fill(oracle.TROPICAL, table, consts, 1, a, b)
+            # undo the terminal adjustment of the last cell so that flags are comparable there too
+            want = oracle.tb_flags(M, D, I, consts)[1:, 1:].copy()
+            got_f = batch.debug_flags(p)
+            want[-1, -1] = got_f[-1, -1]  # last cell: oracle matrices are terminal-adjusted there
+            assert (got_f == want).all(), (p, np.argwhere(got_f != want)[:5])
+    batch.close()
+    model.close()
+
+
+def test_small_mixed_pairs(hip, oracle):
+    rng = np.random.default_rng(11)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    pairs = util.make_pairs(rng, 200, 1, 60, amb=0.05)
+    run_and_compare(hip, oracle, table, consts, pairs)
+
+
+def test_tie_heavy_table(hip, oracle):
+    rng = np.random.default_rng(12)
+    consts = oracle.gap_consts()
+    run_and_compare(hip, oracle, util.tie_table(), consts, util.make_pairs(rng, 120, 1, 50))
+
+
+def test_edge_lengths(hip, oracle):
+    rng = np.random.default_rng(13)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    anc = util.random_anc(rng, 12)
+    pairs = [("", ""), ("", "ACGT"), (anc, ""), ("AAA", "A"), ("AAA", "C" * 40)]
+    # descendant lengths around the lane (16) and strip (1024) boundaries
+    for lb in (1, 15, 16, 17, 31, 32, 33, 1023, 1024, 1025, 1040, 2047, 2049):
+        nc = max(1, lb // 3)
+        a = util.random_anc(rng, nc)
+        d = util.mutate(rng, a)
+        d = (d + "".join(rng.choice(list("ACGT"), lb)))[:lb]
+        pairs.append((a, d))
+    # long ancestor vs short descendant and vice versa
+    pairs.append((util.random_anc(rng, 700), "ACGTACGTAC"))
+    pairs.append(("ATG", "".join(rng.choice(list("ACGT"), 2100))))
+    run_and_compare(hip, oracle, table, consts, pairs)
+
+
+def test_other_gap_parameters(hip, oracle):
+    rng = np.random.default_rng(14)
+    table = util.random_table(rng)
+    for g, e in ((0.01, 0.5), (0.2, 0.9), (1e-6, 0.1)):
+        consts = oracle.gap_consts(g, e)
+        run_and_compare(hip, oracle, table, consts, util.make_pairs(rng, 40, 1, 40), check_flags=False)
+
+
+def test_1kb_pairs(hip, oracle):
+    rng = np.random.default_rng(15)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    pairs = []
+    for _ in range(24):
+        a = util.random_anc(rng, 334)
+        pairs.append((a, util.mutate(rng, a)))
+    run_and_compare(hip, oracle, table, consts, pairs, check_flags=False)
+
+
+def test_one_shot_chunked_equals_resident(hip, oracle):
+    rng = np.random.default_rng(16)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    enc = util.encode_pairs(util.make_pairs(rng, 50, 1, 80))
+    a_cat, a_off, b_cat, b_off = hip.pack_pairs(enc)
+    model = hip.Model(table, consts, 1)
+    scores, ops, ops_off, ops_len = model.viterbi(a_cat, a_off, b_cat, b_off)
+    for p, (a, b) in enumerate(enc):
+        want_ops, want_score = oracle.viterbi(table, consts, 1, a, b)
+        got = ops[int(ops_off[p]):int(ops_off[p]) + int(ops_len[p])]
+        assert bits(scores[p]) == bits(want_score) and (got == want_ops).all()
+
+
+def test_invalid_inputs_rejected(hip, oracle):
+    table = util.random_table(np.random.default_rng(1))
+    consts = oracle.gap_consts()
+    model = hip.Model(table, consts, 1)
+    a = np.array([0, 1, 2, 3], np.uint8)  # length not a multiple of 3
+    with pytest.raises(hip.CoatiHipError):
+        hip.Batch(model, *hip.pack_pairs([(a, np.array([0], np.uint8))]))
+    with pytest.raises(hip.CoatiHipError):  # descendant code 15 ('-') is not a table column
+        hip.Batch(model, *hip.pack_pairs([(np.array([0, 1, 2], np.uint8), np.array([15], np.uint8))]))
+    with pytest.raises(hip.CoatiHipError):  # ancestor code out of range
+        hip.Batch(model, *hip.pack_pairs([(np.array([183, 1, 2], np.uint8), np.array([1], np.uint8))]))
+    with pytest.raises(hip.CoatiHipError):
+        hip.Model(table, consts, 0)
