@@ -1,5 +1,6 @@
 # Top-level build: everything lands in-tree (git-ignored, but shipped to the GPU box).
 #   make lib     -> coati_amd/_build/libcoati_hip.so   (HIP kernels + C ABI, gfx950)
+#   make host    -> coati_amd/_build/libcoati_host.so  (C++ host layer: models, seq prep, I/O)
 #   make oracle  -> oracle/_build/libcoati_oracle.so   (test infrastructure)
 #   make ref     -> oracle/_ref/libcoati_ref.so        (only where /root/reference exists)
 HIPCC    ?= /opt/rocm/bin/hipcc
@@ -8,13 +9,24 @@ BUILD     = coati_amd/_build
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -Wall -Wextra -Wno-unused-parameter -Iinclude
 
-all: lib oracle
+all: lib host oracle
 
 lib: $(BUILD)/libcoati_hip.so
 
 $(BUILD)/libcoati_hip.so: coati_amd/csrc/coati_hip.hip include/coati_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ coati_amd/csrc/coati_hip.hip
+
+HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc coati_amd/host/capi.cc
+HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc
+CXX      ?= g++
+HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -Icoati_amd/host
+
+host: $(BUILD)/libcoati_host.so
+
+$(BUILD)/libcoati_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(BUILD)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC) -lm
 
 oracle:
 	$(MAKE) -C oracle
@@ -26,4 +38,4 @@ clean:
 	rm -rf $(BUILD)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle ref clean
+.PHONY: all lib host oracle ref clean

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GCUPS (DP cell updates/s) and pairs/s of the marginal
+Viterbi path (fill + traceback) on synthetic 1 kb x 1 kb pairs, mar-mg94
+(BASELINE.json configs[1]), inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (fill kernel + traceback walker, and for
+N > 1 the gather of all results to rank 0 over RCCL) over one batch of
+`--pairs` pairs PER GPU (weak scaling: the reference aligns one pair per
+process, pairs are independent, shards need no data-path collective).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_CELL = 1.0      # 1 B/cell packed traceback written ...
+# ... + (len_a + len_b) B of sequence read per pair (added per pair below)
+
+
+def cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off, budget_s=15.0):
+    """Timed CPU port (the oracle, reference data layout) on a bounded sample of the same workload."""
+    from oracle import pyoracle as orc  # checker/baseline only -- never on the product path
+
+    cores = os.cpu_count() or 1
+    # calibrate on a few pairs (1 thread), then size the sample for ~budget_s on all cores
+    n_cal = 4
+    t_cal, _ = orc.viterbi_batch_timed(table, consts, 1, a_cat, a_off[:n_cal + 1], b_cat, b_off[:n_cal + 1], 1)
+    per_pair = max(t_cal / n_cal, 1e-4)
+    n = int(min(len(a_off) - 1, max(cores, budget_s / per_pair * cores * 0.6)))
+    secs, _ = orc.viterbi_batch_timed(table, consts, 1, a_cat, a_off[:n + 1], b_cat, b_off[:n + 1], cores)
+    la = np.diff(a_off[:n + 1]).astype(np.float64)
+    lb = np.diff(b_off[:n + 1]).astype(np.float64)
+    cells = float((la * lb).sum())
+    return {"value": cells / secs / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+            "pairs_per_s": n / secs, "single_thread_gcups": float((la[:n_cal] * lb[:n_cal]).sum() / t_cal / 1e9),
+            "sample": f"first {n} pairs of the same synthetic set, oracle viterbi_mem+traceback "
+                      f"(3 fp32 matrices incl. fill), {cores} threads, {secs:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU per step")
+    ap.add_argument("--model", default="mar-mg", choices=["mar-mg", "mar-ecm"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from coati_amd import distributed as cd
+    from coati_amd import hip, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available() or hip.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: no gfx950 device visible (there is no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    # ---- model: built on rank 0, broadcast over RCCL --------------------------
+    if rank == 0:
+        table, consts, gap_len = host.set_subst(args.model), host.gap_consts(), 1
+    else:
+        table = consts = gap_len = None
+    if world > 1:
+        table, consts, gap_len = cd.broadcast_model(table, consts, gap_len, device)
+    model = hip.Model(table, consts, gap_len, device=local_rank)
+
+    # ---- this rank's shard of the synthetic workload, uploaded once ------------
+    first = rank * args.pairs
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(first, args.pairs)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    cells = batch.cells
+    seq_bytes = int(a_off[-1] + b_off[-1])
+
+    def step():
+        batch.viterbi_launch()
+        batch.sync()
+        if world > 1:
+            cd.gather_results(batch, device, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        batch.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    fill_ms, walk_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        f, w = batch.viterbi_timing()  # HIP events on the library's own stream
+        fill_ms.append(f)
+        walk_ms.append(w)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([cells], dtype=torch.float64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_cells = float(c.item())
+    else:
+        total_cells = float(cells)
+
+    # sanity: results are real (score of pair 0 finite, ops consume both sequences)
+    scores, ops, ops_off, ops_len = batch.viterbi_fetch()
+    assert np.isfinite(scores).all() and int(ops_len.min()) >= 900
+
+    if rank == 0:
+        fill = float(np.mean(fill_ms))
+        algo_bytes = cells * ALGO_BYTES_PER_CELL + seq_bytes
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic_latest.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get("viterbi_fill_l1_bytes_per_launch_10000_pairs")
+                if args.pairs != 10000:
+                    traffic = None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "GCUPS (DP cell updates/s), marginal Viterbi fill+traceback, mar-mg94 1kb x 1kb pairs",
+            "value": total_cells * args.steps / elapsed / 1e9,
+            "unit": "GCUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.pairs} synthetic 1 kb x 1 kb pairs per GPU, {args.model} "
+                                   "(BASELINE.json configs[1]; generator SURVEY.md §8(d))",
+                       "pairs_per_gpu": args.pairs, "global_pairs": args.pairs * world, "gap_len": 1,
+                       "parallelism": f"pairs sharded over {world} GPU(s), model broadcast + result gather (RCCL)"},
+            "pairs_per_s": args.pairs * world * args.steps / elapsed,
+            "kernel_ms": {"viterbi_fill_l1": fill, "viterbi_walk_l1": float(np.mean(walk_ms))},
+            "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "viterbi_fill_l1", "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "the fill is VALU-issue bound, not HBM bound: see DESIGN.md §Roofline"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

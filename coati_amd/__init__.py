@@ -6,4 +6,4 @@ include/coati_hip.h) plus the C++ host layer under coati_amd/host that mirrors
 libcoati's marginal API.  This Python package is only the plumbing the tests
 and bench.py use to reach them.
 """
-__all__ = ["hip"]
+__all__ = ["hip", "host"]

@@ -678,6 +678,17 @@ int coati_hip_viterbi_fetch(coati_hip_batch_t* b, float* scores, uint8_t* ops, u
     return COATI_HIP_OK;
 }
 
+int coati_hip_batch_result_ptrs(coati_hip_batch_t* b, void** scores, void** ops, uint64_t* ops_bytes,
+                                void** ops_off, void** ops_len) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "batch_result_ptrs: batch is NULL");
+    if(scores != nullptr) *scores = b->d_scores;
+    if(ops != nullptr) *ops = b->d_ops;
+    if(ops_bytes != nullptr) *ops_bytes = b->ops_total;
+    if(ops_off != nullptr) *ops_off = b->d_ops_start;
+    if(ops_len != nullptr) *ops_len = b->d_ops_len;
+    return COATI_HIP_OK;
+}
+
 int coati_hip_viterbi_last_timing(coati_hip_batch_t* b, float* fill_ms, float* walk_ms) {
     if(b == nullptr) return fail(COATI_HIP_EINVAL, "last_timing: batch is NULL");
     if(!b->launched) return fail(COATI_HIP_ESTATE, "last_timing: nothing was launched");

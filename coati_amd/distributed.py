@@ -1,0 +1,88 @@
+"""Multi-GPU plumbing: one process per GPU, pairs sharded contiguously, the model
+broadcast from rank 0 and the results gathered to rank 0 with torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The path has no data-path collective: pairs are independent (the reference
+aligns one pair per process, src/lib/utils.cc:810-812).  The only exchanges are
+the ~11 KB model blob before the first batch and the result gather after it.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TABLE_ELEMS = 183 * 15
+MODEL_BLOB_ELEMS = TABLE_ELEMS + 4 + 1  # table, 4 log gap constants, gap_len
+
+
+def shard_bounds(weights, world: int):
+    """Contiguous shards of ~equal total weight (cells).  Returns world+1 pair indices."""
+    w = np.asarray(weights, np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(int(np.searchsorted(cum, total * r / world, side="left")))
+    bounds.append(len(w))
+    return [min(max(b, 0), len(w)) for b in np.maximum.accumulate(bounds)]
+
+
+def pack_model(table, consts, gap_len: int) -> torch.Tensor:
+    blob = np.zeros(MODEL_BLOB_ELEMS, np.float32)
+    blob[:TABLE_ELEMS] = np.asarray(table, np.float32).ravel()
+    blob[TABLE_ELEMS:TABLE_ELEMS + 4] = np.asarray(consts, np.float32)
+    blob[-1] = float(gap_len)
+    return torch.from_numpy(blob)
+
+
+def unpack_model(blob: torch.Tensor):
+    v = blob.detach().cpu().numpy()
+    return v[:TABLE_ELEMS].reshape(183, 15).copy(), v[TABLE_ELEMS:TABLE_ELEMS + 4].copy(), int(v[-1])
+
+
+def broadcast_model(table, consts, gap_len, device, src: int = 0):
+    """Rank `src` supplies (table, consts, gap_len); every rank returns them bit-identical."""
+    if dist.get_rank() == src:
+        blob = pack_model(table, consts, gap_len).to(device)
+    else:
+        blob = torch.zeros(MODEL_BLOB_ELEMS, dtype=torch.float32, device=device)
+    dist.broadcast(blob, src=src)
+    return unpack_model(blob)
+
+
+def gather_ragged(t: torch.Tensor, dst: int = 0):
+    """Gather 1-D tensors of different lengths to rank dst (list of tensors there, None elsewhere)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    padded = t if t.numel() == cap else torch.cat([t, t.new_zeros(cap - t.numel())])
+    bucket = [torch.empty(cap, dtype=t.dtype, device=t.device) for _ in range(world)] if rank == dst else None
+    dist.gather(padded.contiguous(), bucket, dst=dst)
+    if rank != dst:
+        return None
+    return [b[:s] for b, s in zip(bucket, sizes)]
+
+
+class _DeviceArray:
+    """Zero-copy view of library-owned HBM for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def batch_result_tensors(batch, device):
+    """torch views (no copy) of a Batch's result arrays: scores f32, ops u8, ops_off i64, ops_len i32."""
+    sc, ops, nbytes, off, ln = batch.result_ptrs()
+    n = batch.n
+    mk = lambda ptr, cnt, ts: torch.as_tensor(_DeviceArray(ptr, max(cnt, 1), ts), device=device)[:cnt]
+    return mk(sc, n, "<f4"), mk(ops, nbytes, "|u1"), mk(off, n, "<i8"), mk(ln, n, "<i4")
+
+
+def gather_results(batch, device, dst: int = 0):
+    """The 'final gather over xGMI': every rank's scores / ops / offsets / lengths to rank dst."""
+    sc, ops, off, ln = batch_result_tensors(batch, device)
+    return tuple(gather_ragged(t, dst) for t in (sc, ops, off, ln))

@@ -32,6 +32,7 @@ EXPORTS = (
     "coati_hip_batch_sync",
     "coati_hip_viterbi_fetch",
     "coati_hip_viterbi_last_timing",
+    "coati_hip_batch_result_ptrs",
     "coati_hip_viterbi_batch",
     "coati_hip_debug_viterbi_flags",
 )
@@ -76,6 +77,8 @@ def load() -> C.CDLL:
     lib.coati_hip_batch_sync.argtypes = [vp]
     lib.coati_hip_viterbi_fetch.argtypes = [vp, vp, vp, u64, vp, vp]
     lib.coati_hip_viterbi_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+    lib.coati_hip_batch_result_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp),
+                                                C.POINTER(vp)]
     lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_debug_viterbi_flags.argtypes = [vp, u64, vp, u64]
     _lib = lib
@@ -202,6 +205,14 @@ class Batch:
         f, w = C.c_float(), C.c_float()
         _check(load().coati_hip_viterbi_last_timing(self._h, C.byref(f), C.byref(w)))
         return f.value, w.value
+
+    def result_ptrs(self):
+        """Device addresses (scores, ops, ops_bytes, ops_off, ops_len) of the result arrays."""
+        sc, ops, off, ln = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nbytes = C.c_uint64()
+        _check(load().coati_hip_batch_result_ptrs(self._h, C.byref(sc), C.byref(ops), C.byref(nbytes), C.byref(off),
+                                                  C.byref(ln)))
+        return sc.value, ops.value, int(nbytes.value), off.value, ln.value
 
     def debug_flags(self, pair: int):
         la, lb = self.lens[pair]

@@ -1,0 +1,136 @@
+"""ctypes binding of libcoati_host.so -- the C++ host layer (models, sequence
+preparation, synthetic workload).  Plumbing for tests and bench.py."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_ROOT = Path(__file__).resolve().parent
+LIB_PATH = _ROOT / "_build" / "libcoati_host.so"
+
+DEFAULT_PI = (0.308, 0.185, 0.199, 0.308)
+_lib = None
+
+
+class CoatiHostError(ValueError):
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get("COATI_HOST_LIB", LIB_PATH))
+        if not path.exists():
+            raise ImportError(f"{path} not found: build it with `make host` (or __graft_entry__.build())")
+        _lib = C.CDLL(str(path))
+        _lib.coati_host_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CoatiHostError(rc, load().coati_host_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f4(v):
+    return np.ascontiguousarray(v, np.float32)
+
+
+def gap_consts(gap_open=0.001, gap_extend=None) -> np.ndarray:
+    e = np.float32(1.0) - np.float32(1.0) / np.float32(6.0) if gap_extend is None else np.float32(gap_extend)
+    out = np.zeros(4, np.float32)
+    _check(load().coati_host_gap_consts(C.c_float(np.float32(gap_open)), C.c_float(e), _p(out)))
+    return out
+
+
+def mg94_p(br_len=0.0133, omega=0.2, pi=DEFAULT_PI, sigma=None) -> np.ndarray:
+    out = np.zeros((61, 61), np.float32)
+    sg = None if sigma is None else _f4(sigma)
+    _check(load().coati_host_mg94_p(C.c_float(np.float32(br_len)), C.c_float(np.float32(omega)), _p(_f4(pi)), _p(sg),
+                                    _p(out)))
+    return out
+
+
+def ecm_p(br_len=0.0133, omega=0.2) -> np.ndarray:
+    out = np.zeros((61, 61), np.float32)
+    _check(load().coati_host_ecm_p(C.c_float(np.float32(br_len)), C.c_float(np.float32(omega)), _p(out)))
+    return out
+
+
+def gtr_q(pi, sigma) -> np.ndarray:
+    out = np.zeros((4, 4), np.float32)
+    _check(load().coati_host_gtr_q(_p(_f4(pi)), _p(_f4(sigma)), _p(out)))
+    return out
+
+
+def marginal_p(P, pi=DEFAULT_PI, amb_best=False, sub_max=False) -> np.ndarray:
+    out = np.zeros((183, 15), np.float32)
+    _check(load().coati_host_marginal_p(_p(_f4(P)), _p(_f4(pi)), int(amb_best), int(sub_max), _p(out)))
+    return out
+
+
+def set_subst(model="mar-mg", br_len=0.0133, omega=0.2, pi=DEFAULT_PI, sigma=None, amb_best=False,
+              sub_max=False) -> np.ndarray:
+    out = np.zeros((183, 15), np.float32)
+    sg = None if sigma is None else _f4(sigma)
+    _check(load().coati_host_set_subst(model.encode(), C.c_float(np.float32(br_len)), C.c_float(np.float32(omega)),
+                                       _p(_f4(pi)), _p(sg), int(amb_best), int(sub_max), _p(out)))
+    return out
+
+
+def encode(anc: str, des: str):
+    a = np.zeros(max(len(anc), 1), np.uint8)
+    b = np.zeros(max(len(des), 1), np.uint8)
+    _check(load().coati_host_encode(anc.encode(), des.encode(), _p(a), _p(b)))
+    return a[:len(anc)].copy(), b[:len(des)].copy()
+
+
+def synth_encoded(first: int, n: int, seed_base: int = 0xC0A71, n_codons: int = 334):
+    """Encoded synthetic pairs [first, first+n) -> (a_cat, a_off, b_cat, b_off)."""
+    a_off = np.zeros(n + 1, np.uint64)
+    b_off = np.zeros(n + 1, np.uint64)
+    fn = load().coati_host_synth_encoded
+    _check(fn(C.c_ulonglong(first), C.c_ulonglong(n), C.c_ulonglong(seed_base), C.c_uint(n_codons), None, _p(a_off),
+              None, _p(b_off)))
+    a_cat = np.zeros(max(int(a_off[-1]), 1), np.uint8)
+    b_cat = np.zeros(max(int(b_off[-1]), 1), np.uint8)
+    _check(fn(C.c_ulonglong(first), C.c_ulonglong(n), C.c_ulonglong(seed_base), C.c_uint(n_codons), _p(a_cat),
+              _p(a_off), _p(b_cat), _p(b_off)))
+    return a_cat, a_off, b_cat, b_off
+
+
+def synth_raw(index: int, seed_base: int = 0xC0A71, n_codons: int = 334):
+    cap = n_codons * 3 * 3 + 64
+    a = C.create_string_buffer(cap)
+    d = C.create_string_buffer(cap)
+    _check(load().coati_host_synth_raw(C.c_ulonglong(index), C.c_ulonglong(seed_base), C.c_uint(n_codons), a, d,
+                                       C.c_ulonglong(cap)))
+    return a.value.decode(), d.value.decode()
+
+
+def trim_end_stops(s0: str, s1: str):
+    cap = max(len(s0), len(s1)) + 8
+    bufs = [C.create_string_buffer(cap) for _ in range(4)]
+    _check(load().coati_host_trim_end_stops(s0.encode(), s1.encode(), *bufs, C.c_ulonglong(cap)))
+    t0, t1, st0, st1 = (b.value.decode() for b in bufs)
+    return [t0, t1], [st0, st1]
+
+
+def restore_end_stops(aln0: str, aln1: str, stop0: str, stop1: str, score=0.0, gap_open=0.001, gap_extend=None):
+    e = np.float32(1.0) - np.float32(1.0) / np.float32(6.0) if gap_extend is None else np.float32(gap_extend)
+    cap = max(len(aln0), len(aln1)) + 16
+    b0 = C.create_string_buffer(aln0.encode(), cap)
+    b1 = C.create_string_buffer(aln1.encode(), cap)
+    sc = C.c_float(np.float32(score))
+    _check(load().coati_host_restore_end_stops(b0, b1, stop0.encode(), stop1.encode(), C.c_float(np.float32(gap_open)),
+                                               C.c_float(e), C.byref(sc), C.c_ulonglong(cap)))
+    return [b0.value.decode(), b1.value.decode()], np.float32(sc.value)

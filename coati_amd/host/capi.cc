@@ -1,0 +1,184 @@
+// C entry points of libcoati_host.so used by the Python tests and bench.py to
+// reach the C++ host layer (model construction, sequence preparation, the
+// synthetic workload).  Errors: non-zero return + coati_host_last_error().
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <string>
+
+#include "model.hpp"
+#include "seq.hpp"
+#include "synth.hpp"
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch(const std::invalid_argument& e) {
+        g_err = e.what();
+        return 1;
+    } catch(const std::out_of_range& e) {
+        g_err = e.what();
+        return 2;
+    } catch(const std::exception& e) {
+        g_err = e.what();
+        return 3;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* coati_host_last_error(void) { return g_err.c_str(); }
+
+int coati_host_gap_consts(float gap_open, float gap_extend, float out[4]) {
+    return guarded([&] {
+        coati_amd::gap_t g;
+        g.open = gap_open;
+        g.extend = gap_extend;
+        const auto c = coati_amd::gap_log_consts(g);
+        std::memcpy(out, c.data(), sizeof(float) * 4);
+    });
+}
+
+int coati_host_mg94_p(float br_len, float omega, const float pi[4], const float sigma[6], float out[3721]) {
+    return guarded([&] {
+        std::array<float, 4> p{pi[0], pi[1], pi[2], pi[3]};
+        std::array<float, 6> s{0, 0, 0, 0, 0, 0};
+        if(sigma != nullptr) std::memcpy(s.data(), sigma, sizeof(float) * 6);
+        const auto P = coati_amd::mg94_p(br_len, omega, p, s);
+        std::memcpy(out, P.data(), sizeof(float) * 3721);
+    });
+}
+
+int coati_host_ecm_p(float br_len, float omega, float out[3721]) {
+    return guarded([&] {
+        const auto P = coati_amd::ecm_p(br_len, omega);
+        std::memcpy(out, P.data(), sizeof(float) * 3721);
+    });
+}
+
+int coati_host_gtr_q(const float pi[4], const float sigma[6], float out[16]) {
+    return guarded([&] {
+        const auto q = coati_amd::gtr_q({pi[0], pi[1], pi[2], pi[3]},
+                                        {sigma[0], sigma[1], sigma[2], sigma[3], sigma[4], sigma[5]});
+        std::memcpy(out, q.data(), sizeof(float) * 16);
+    });
+}
+
+int coati_host_marginal_p(const float P[3721], const float pi[4], int amb_best, int sub_max, float out[2745]) {
+    return guarded([&] {
+        coati_amd::matrix61_t m(P, P + 3721);
+        const auto t = coati_amd::marginal_p(m, {pi[0], pi[1], pi[2], pi[3]},
+                                             amb_best ? coati_amd::AmbiguousNucs::BEST : coati_amd::AmbiguousNucs::SUM,
+                                             sub_max ? coati_amd::MarginalSubst::MAX : coati_amd::MarginalSubst::SUM);
+        std::memcpy(out, t.data(), sizeof(float) * 2745);
+    });
+}
+
+// set_subst: model "mar-mg" | "mar-ecm"
+int coati_host_set_subst(const char* model, float br_len, float omega, const float pi[4], const float sigma[6],
+                         int amb_best, int sub_max, float out[2745]) {
+    return guarded([&] {
+        coati_amd::model_params_t prm;
+        prm.model = model;
+        prm.br_len = br_len;
+        prm.omega = omega;
+        if(pi != nullptr) prm.pi = {pi[0], pi[1], pi[2], pi[3]};
+        if(sigma != nullptr) std::memcpy(prm.sigma.data(), sigma, sizeof(float) * 6);
+        prm.amb = amb_best ? coati_amd::AmbiguousNucs::BEST : coati_amd::AmbiguousNucs::SUM;
+        prm.sub = sub_max ? coati_amd::MarginalSubst::MAX : coati_amd::MarginalSubst::SUM;
+        const auto t = coati_amd::set_subst(prm);
+        std::memcpy(out, t.data(), sizeof(float) * 2745);
+    });
+}
+
+// marginal_seq_encoding: a_out needs strlen(anc) bytes, b_out strlen(des)
+int coati_host_encode(const char* anc, const char* des, unsigned char* a_out, unsigned char* b_out) {
+    return guarded([&] {
+        const auto enc = coati_amd::marginal_seq_encoding(anc, des);
+        std::memcpy(a_out, enc[0].data(), enc[0].size());
+        std::memcpy(b_out, enc[1].data(), enc[1].size());
+    });
+}
+
+// trim_end_stops + restore_end_stops round trip on two sequences: writes the
+// trimmed sequences / stops (buffers of capacity cap) and, given an alignment of
+// the trimmed sequences in aln_a/aln_b (in/out) and score (in/out), restores.
+int coati_host_trim_end_stops(const char* s0, const char* s1, char* t0, char* t1, char* stop0, char* stop1,
+                              unsigned long long cap) {
+    return guarded([&] {
+        coati_amd::data_t d;
+        d.names = {"a", "b"};
+        d.seqs = {s0, s1};
+        coati_amd::trim_end_stops(d);
+        if(d.seqs[0].size() + 1 > cap || d.seqs[1].size() + 1 > cap) throw std::invalid_argument("buffer too small");
+        std::strcpy(t0, d.seqs[0].c_str());
+        std::strcpy(t1, d.seqs[1].c_str());
+        std::strcpy(stop0, d.stops[0].c_str());
+        std::strcpy(stop1, d.stops[1].c_str());
+    });
+}
+
+int coati_host_restore_end_stops(char* aln0, char* aln1, const char* stop0, const char* stop1, float gap_open,
+                                 float gap_extend, float* score, unsigned long long cap) {
+    return guarded([&] {
+        coati_amd::data_t d;
+        d.names = {"a", "b"};
+        d.seqs = {aln0, aln1};
+        d.stops = {stop0, stop1};
+        d.score = *score;
+        coati_amd::gap_t g;
+        g.open = gap_open;
+        g.extend = gap_extend;
+        coati_amd::restore_end_stops(d, g);
+        if(d.seqs[0].size() + 1 > cap || d.seqs[1].size() + 1 > cap) throw std::invalid_argument("buffer too small");
+        std::strcpy(aln0, d.seqs[0].c_str());
+        std::strcpy(aln1, d.seqs[1].c_str());
+        *score = d.score;
+    });
+}
+
+// Encoded synthetic pairs [first, first+n): offsets have n+1 entries; call with
+// a_cat == NULL to size the buffers (offsets are filled either way).
+int coati_host_synth_encoded(unsigned long long first, unsigned long long n, unsigned long long seed_base,
+                             unsigned n_codons, unsigned char* a_cat, unsigned long long* a_off,
+                             unsigned char* b_cat, unsigned long long* b_off) {
+    return guarded([&] {
+        coati_amd::synth_params_t prm;
+        prm.seed_base = seed_base;
+        prm.n_codons = n_codons;
+        std::string anc, des;
+        a_off[0] = b_off[0] = 0;
+        for(unsigned long long p = 0; p < n; ++p) {
+            coati_amd::synth_pair(first + p, prm, anc, des);
+            a_off[p + 1] = a_off[p] + anc.size();
+            b_off[p + 1] = b_off[p] + des.size();
+            if(a_cat != nullptr) {
+                const auto enc = coati_amd::marginal_seq_encoding(anc, des);
+                std::memcpy(a_cat + a_off[p], enc[0].data(), enc[0].size());
+                std::memcpy(b_cat + b_off[p], enc[1].data(), enc[1].size());
+            }
+        }
+    });
+}
+
+// Raw text of synthetic pair `index` (buffers of capacity cap each, NUL-terminated).
+int coati_host_synth_raw(unsigned long long index, unsigned long long seed_base, unsigned n_codons, char* anc,
+                         char* des, unsigned long long cap) {
+    return guarded([&] {
+        coati_amd::synth_params_t prm;
+        prm.seed_base = seed_base;
+        prm.n_codons = n_codons;
+        std::string a, d;
+        coati_amd::synth_pair(index, prm, a, d);
+        if(a.size() + 1 > cap || d.size() + 1 > cap) throw std::invalid_argument("buffer too small");
+        std::memcpy(anc, a.c_str(), a.size() + 1);
+        std::memcpy(des, d.c_str(), d.size() + 1);
+    });
+}
+
+}  // extern "C"

@@ -122,6 +122,17 @@ int coati_hip_viterbi_fetch(coati_hip_batch_t* batch, float* scores, uint8_t* op
  * model's stream around each kernel (synchronises first). */
 int coati_hip_viterbi_last_timing(coati_hip_batch_t* batch, float* fill_ms, float* walk_ms);
 
+/* Device pointers of the result arrays of a batch (valid until the batch is
+ * destroyed; contents valid after a synchronised viterbi launch), so that a
+ * caller can hand them to a collective (RCCL gather) without a host round trip:
+ *   scores    float[n_pairs]
+ *   ops       uint8_t[sum(len_a+len_b)]
+ *   ops_off   uint64_t[n_pairs]  (absolute offset of pair p's first op in `ops`)
+ *   ops_len   uint32_t[n_pairs]
+ * Any output pointer may be NULL. */
+int coati_hip_batch_result_ptrs(coati_hip_batch_t* batch, void** scores, void** ops, uint64_t* ops_bytes,
+                                void** ops_off, void** ops_len);
+
 /* One-shot convenience: create batch(es), launch, fetch, destroy.  Splits the
  * input into chunks that fit the device's free memory. */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,

@@ -1,0 +1,68 @@
+"""world_size-2 gloo test of the multi-GPU plumbing (no GPU): shard planning, the
+model broadcast and the ragged result gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from coati_amd import distributed as cd
+
+
+def test_shard_bounds_balance_cells():
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 1000, 1000) ** 2
+    for world in (1, 2, 3, 8):
+        b = cd.shard_bounds(w, world)
+        assert b[0] == 0 and b[-1] == len(w) and all(x <= y for x, y in zip(b, b[1:]))
+        shares = [w[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(shares) - min(shares) <= 2 * w.max()
+    assert cd.shard_bounds([], 4) == [0, 0, 0, 0, 0]
+    assert cd.shard_bounds([5.0], 4)[-1] == 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(42)
+        table = rng.normal(size=(183, 15)).astype(np.float32)
+        consts = np.array([-0.001, -1.79, -6.9, -0.18], np.float32)
+        if rank == 0:
+            got = cd.broadcast_model(table, consts, 3, "cpu")
+        else:
+            got = cd.broadcast_model(None, None, None, "cpu")
+        ok = (got[0].view(np.uint32) == table.view(np.uint32)).all() and (got[1] == consts).all() and got[2] == 3
+        # ragged gather: rank r contributes r+2 elements
+        mine = torch.arange(rank + 2, dtype=torch.int64) + 100 * rank
+        parts = cd.gather_ragged(mine, dst=0)
+        if rank == 0:
+            ok = ok and len(parts) == world and all(
+                p.tolist() == (torch.arange(r + 2) + 100 * r).tolist() for r, p in enumerate(parts))
+        else:
+            ok = ok and parts is None
+        empty = cd.gather_ragged(torch.zeros(0 if rank else 3, dtype=torch.uint8), dst=0)
+        if rank == 0:
+            ok = ok and [p.numel() for p in empty] == [3] + [0] * (world - 1)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

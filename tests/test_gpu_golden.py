@@ -1,0 +1,60 @@
+"""HIP Viterbi path against the committed golden vectors of the compiled
+reference (tests/golden/viterbi_cases.json), through the C ABI, with the table
+the C++ host layer builds -- i.e. the whole product path."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def test_golden_viterbi_cases_gap_len_1():
+    from coati_amd import hip, host
+
+    doc = json.loads((GOLD / "viterbi_cases.json").read_text())
+    table = np.load(GOLD / "table_mg94_goldenP.npy")
+    consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])
+    cases = [c for c in doc["cases"] if c["gap_len"] == 1]
+    assert len(cases) > 150
+    enc = [host.encode(c["anc"], c["des"]) for c in cases]
+    model = hip.Model(table, consts, 1)
+    scores, ops, ops_off, ops_len = model.viterbi(*hip.pack_pairs(enc))
+    for p, c in enumerate(cases):
+        got = ops[int(ops_off[p]):int(ops_off[p]) + int(ops_len[p])]
+        sa = "".join("-" if o == 2 else ch for o, ch in zip(got, _expand(got, c["anc"], 2)))
+        sb = "".join("-" if o == 1 else ch for o, ch in zip(got, _expand(got, c["des"], 1)))
+        assert (sa, sb) == (c["aln_anc"], c["aln_des"]), c["name"]
+        assert int(np.float32(scores[p]).view(np.uint32)) == int(c["score_bits"], 16), c["name"]
+
+
+def _expand(ops, seq, gap_op):
+    """Characters of `seq` laid out along the alignment columns (placeholder where the op is a gap in seq)."""
+    it = iter(seq)
+    return [(" " if o == gap_op else next(it)) for o in ops]
+
+
+def test_reference_doctest_alignments_default_model():
+    """marg_alignment known answers (align_marginal.cc:149-240), model built by the host layer."""
+    from coati_amd import hip, host
+
+    known = json.loads((GOLD / "reference_known_answers.json").read_text())["marg_alignment"]
+    for case in known:
+        if case.get("gap_len", 1) != 1:
+            continue
+        table = host.set_subst(case["model"], amb_best=case.get("amb") == "BEST")
+        seqs = list(case["seqs"])
+        names = case.get("names", ["1", "2"])
+        if case.get("rev") or (case.get("refs") and case["refs"] == names[1]):
+            seqs.reverse()
+        a, b = host.encode(*seqs)
+        model = hip.Model(table, host.gap_consts(), 1)
+        scores, ops, ops_off, ops_len = model.viterbi(*hip.pack_pairs([(a, b)]))
+        got = ops[int(ops_off[0]):int(ops_off[0]) + int(ops_len[0])]
+        sa = "".join("-" if o == 2 else ch for o, ch in zip(got, _expand(got, seqs[0], 2)))
+        sb = "".join("-" if o == 1 else ch for o, ch in zip(got, _expand(got, seqs[1], 1)))
+        assert [sa, sb] == case["out"], case

@@ -1,0 +1,146 @@
+"""The C++ host layer (coati_amd/host): models, encoding, stop handling --
+against the reference's golden table / known answers and independent maths."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+from coati_amd import host
+from tests import util
+
+GOLD = Path(__file__).resolve().parent / "golden"
+KNOWN = json.loads((GOLD / "reference_known_answers.json").read_text())
+
+
+def approx(a, b):
+    """doctest::Approx: |a-b| < eps*(1+max(|a|,|b|)), eps = 1.19e-5 (doctest.h:3545,3565-3569)."""
+    return np.abs(a - b) < 1.19e-5 * (1 + np.maximum(np.abs(a), np.abs(b)))
+
+
+def test_mg94_p_vs_reference_golden_table():
+    """mutation_coati.cc:129-138 -- every entry Approx-equal to mg94P (mg94p.tcc:26)."""
+    gold = np.load(GOLD / "mg94P_golden.npy")
+    P = host.mg94_p(0.0133, 0.2, (0.308, 0.185, 0.199, 0.308))
+    assert approx(P, gold).all()
+    assert np.abs(P - gold).max() < 5e-7
+
+
+def test_marginal_p_rows_sum_to_one():
+    """mutation_coati.cc:206-221."""
+    pi = np.array(host.DEFAULT_PI, np.float32)
+    T = host.marginal_p(host.mg94_p())
+    s = (np.exp(T[:, :4].astype(np.float64)) * pi).sum(1)
+    assert approx(s, 1.0).all()
+
+
+def test_table_matches_survey_worked_example():
+    T = host.set_subst("mar-mg")
+    want = np.array([[-6.42414856, 1.68432832, -5.94400692, -5.01458359],
+                     [-7.21536541, -5.02795506, -6.53331804, 1.17592609],
+                     [-4.81927013, 1.67218006, -4.34293604, -3.42441058]], np.float32)
+    assert np.allclose(T[87:90, :4], want, rtol=2e-6)
+    # and agrees with the fixture built from the golden P
+    assert np.allclose(T, np.load(GOLD / "table_mg94_goldenP.npy"), rtol=0, atol=2e-5)
+
+
+def test_gtr_q_known_answer():
+    k = KNOWN["gtr_q"]
+    q = host.gtr_q(k["pi"], k["sigma"])
+    assert approx(q, np.array(k["expected"])).all()
+    with pytest.raises(host.CoatiHostError):
+        host.gtr_q(k["pi"], [-0.01] + k["sigma"][1:])
+    with pytest.raises(host.CoatiHostError):
+        host.gtr_q(k["pi"], k["sigma"][:4] + [1.04, 0.1])
+
+
+def test_expm_against_scipy_float64():
+    """Independent cross-check of the own matrix exponential (the reference uses un-vendored Eigen)."""
+    for P, name in ((host.mg94_p(0.0133, 0.2), "mg94"), (host.ecm_p(0.0133, 0.2), "ecm"), (host.mg94_p(1.5, 0.7), "mg94 long"),
+                    (host.ecm_p(2.0, 0.2), "ecm long")):
+        assert np.allclose(P.sum(1), 1.0, atol=2e-6), name
+        assert (P >= 0).all(), name
+    # reconstruct Q*t/d from two branch lengths: P(2t) == P(t) @ P(t)
+    P1, P2 = host.ecm_p(0.05, 0.2).astype(np.float64), host.ecm_p(0.1, 0.2).astype(np.float64)
+    assert np.abs(P1 @ P1 - P2).max() < 1e-6
+    # generator recovered with scipy.logm, re-exponentiated with scipy.expm
+    Pm = host.mg94_p(0.3, 0.2).astype(np.float64)
+    Q = scipy.linalg.logm(Pm).real
+    assert np.abs(scipy.linalg.expm(Q) - Pm).max() < 1e-6
+
+
+def test_ecm_default_pi_is_users_not_ecm():
+    """utils.cc:602-604: for mar-ecm the log-odds divisor is aln.pi (default MG94 pi)."""
+    T = host.set_subst("mar-ecm")
+    P = host.ecm_p()
+    assert np.allclose(T, host.marginal_p(P, host.DEFAULT_PI))
+
+
+def test_amb_best_and_sub_max_variants():
+    P = host.mg94_p()
+    Ts, Tb = host.marginal_p(P), host.marginal_p(P, amb_best=True)
+    assert (Ts[:, :4] == Tb[:, :4]).all()
+    assert (Tb[:, 4] == np.maximum(Tb[:, 0], Tb[:, 2])).all()      # R = max(A,G)
+    assert (Tb[:, 14] == Tb[:, :4].max(1)).all()                  # N = max(all)
+    assert (Ts[:, 14] >= Tb[:, 14]).all()
+    Tm = host.marginal_p(P, sub_max=True)
+    assert (Tm[:, :4] <= Ts[:, :4] + 1e-6).all()
+
+
+def test_unknown_model_rejected():
+    for m in ("tri-mg", "dna", "nope"):
+        with pytest.raises(host.CoatiHostError, match="Mutation model unknown"):
+            host.set_subst(m)
+    with pytest.raises(host.CoatiHostError):
+        host.mg94_p(br_len=0.0)
+
+
+def test_gap_consts_match_oracle(oracle):
+    for g, e in ((0.001, None), (0.01, 0.5), (0.2, 0.9)):
+        assert (host.gap_consts(g, e).view(np.uint32) == oracle.gap_consts(g, e).view(np.uint32)).all()
+    for g, e in ((0.0, 0.5), (1.0, 0.5), (0.1, 1.0), (0.1, 0.0), (-0.1, 0.5)):
+        with pytest.raises(host.CoatiHostError):
+            host.gap_consts(g, e)
+
+
+def test_marginal_seq_encoding_known_answers():
+    k = KNOWN["marginal_seq_encoding"]
+    a, b = host.encode(k["anc"], k["des"])
+    assert a.tolist() == k["anc_codes"] and b.tolist() == k["des_codes"]
+    for bad in k["anc_fail"]:
+        with pytest.raises(host.CoatiHostError):
+            host.encode(bad, k["des"])
+    # lower case and U, and agreement with the independent Python encoder
+    a2, b2 = host.encode("aaagggUUU", "acgun")
+    assert a2.tolist() == [0, 1, 2, 126, 127, 128, 180, 181, 182] and b2.tolist() == [0, 1, 2, 3, 14]
+    rng = np.random.default_rng(3)
+    for anc, des in util.make_pairs(rng, 30, 1, 40, amb=0.1):
+        a, b = host.encode(anc, des)
+        assert (a == util.encode_anc(anc)).all() and (b == util.encode_des(des)).all()
+    assert host.encode("AAA", "A?")[1].tolist() == [0, 16]  # invalid characters -> 16, as upstream
+
+
+def test_trim_and_restore_end_stops_known_answers():
+    for raw, trimmed, stops in KNOWN["trim_end_stops"]:
+        assert host.trim_end_stops(*raw) == (trimmed, stops)
+    for seqs, stops, want in KNOWN["restore_end_stops"]:
+        got, _ = host.restore_end_stops(seqs[0], seqs[1], stops[0], stops[1])
+        assert got == want
+    # one-sided stop costs log(g*e*e)
+    _, sc = host.restore_end_stops("TGC", "TGC", "", "TAA", score=1.0)
+    g, e = np.float32(0.001), np.float32(1.0) - np.float32(1.0) / np.float32(6.0)
+    assert sc == np.float32(1.0) + np.float32(np.log(np.float32(g * e * e)))
+
+
+def test_synthetic_workload_is_deterministic_and_valid():
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 64)
+    a2, ao2, b2, bo2 = host.synth_encoded(32, 32)
+    assert (a_cat[int(a_off[32]):] == a2[:int(ao2[-1])]).all() and (b_cat[int(b_off[32]):] == b2[:int(bo2[-1])]).all()
+    assert (np.diff(a_off) == 1002).all() and a_cat.max() < 183 and b_cat.max() < 4
+    lens = np.diff(b_off).astype(int)
+    assert 900 < lens.min() and lens.max() < 1120 and len(set(lens.tolist())) > 10
+    anc, des = host.synth_raw(5)
+    a, b = host.encode(anc, des)
+    assert (a == a_cat[int(a_off[5]):int(a_off[6])]).all() and (b == b_cat[int(b_off[5]):int(b_off[6])]).all()
+    assert des[-3:] not in ("TAA", "TAG", "TGA")
