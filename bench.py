@@ -97,8 +97,8 @@ def main():
 
     def step():
         batch.viterbi_launch()
-        batch.sync()
         if world > 1:
+            batch.sync()  # the gather reads the result arrays on torch's stream
             cd.gather_results(batch, device, dst=0)
 
     def fence():
@@ -110,15 +110,16 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    fill_ms, walk_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        f, w = batch.viterbi_timing()  # HIP events on the library's own stream
-        fill_ms.append(f)
-        walk_ms.append(w)
     fence()
     elapsed = time.perf_counter() - t0
+    # per-kernel device times of the timed launches: HIP events the library recorded on its
+    # own stream around each kernel (it keeps the last 64 launches)
+    timed = [batch.viterbi_timing(i) for i in range(min(args.steps, 64))]
+    fill_ms = [t[0] for t in timed]
+    walk_ms = [t[1] for t in timed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -30,10 +30,13 @@
 
 #include <cfloat>
 #include <cstdarg>
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -48,17 +51,17 @@ constexpr int kStrip = kWave * kW;           // columns per strip (1024)
 constexpr int kTabRows = COATI_HIP_TABLE_ROWS;
 constexpr int kTabCols = COATI_HIP_TABLE_COLS;
 constexpr int kTabStride = 17;               // LDS row stride in floats (bank spread, measured)
-constexpr int kPlanes = 5;                   // decision bit-planes per cell
-constexpr int kPairDwords = kPlanes * kWave; // dwords one pair of wavefront steps stores (320)
+constexpr int kPairDwords = 5 * kWave;       // dwords one pair of wavefront steps stores (320)
 constexpr int kFillWaves = 4;                // sequence pairs per workgroup
 constexpr float kLowest = -FLT_MAX;          // semiring zero(), semiring.hpp:83,113
 
-// Decision bit-planes.  Bit = 1 means:
-//   P_M1: D beats M after a match move     (max_mdi first test,  align_pair.cc:213-216)
-//   P_M2: I beats max(M,D) after a match   (max_mdi second test, align_pair.cc:217-219)
-//   P_D1, P_D2: the same two tests after a deletion move (align_pair.cc:285-287)
-//   P_IM: M beats I after an insertion move (max_mi, align_pair.cc:230-232; tie -> I)
-enum : int { P_M1 = 0, P_M2 = 1, P_D1 = 2, P_D2 = 3, P_IM = 4 };
+// Decision bits per cell.  Bit = 1 means:
+//   M1: D beats M after a match move     (max_mdi first test,  align_pair.cc:213-216)
+//   M2: I beats max(M,D) after a match   (max_mdi second test, align_pair.cc:217-219)
+//   D1, D2: the same two tests after a deletion move (align_pair.cc:285-287)
+//   IM: M beats I after an insertion move (max_mi, align_pair.cc:230-232; tie -> I)
+// Three per-lane accumulators: A = (M1,M2) pairs, B = (D1,D2) pairs, C = IM.
+enum : int { ACC_A = 0, ACC_B = 1, ACC_C = 2, kAccs = 3 };
 
 struct GapConsts {
     float ng, gs, go, ge;  // no_gap, gap_stop, gap_open, gap_extend (log space)
@@ -72,12 +75,14 @@ struct PairDesc {
     uint32_t la, lb;
 };
 
-// HBM layout of the decision bits of one strip (1024 columns) of one pair:
-//   dword[(k >> 1) * 320 + plane * 64 + lane], k = wavefront step = body_row + lane
-//   bits 31..16 = step k even, bits 15..0 = step k odd; inside a half, the cell
-//   of the lane's column c (0..15) is bit 15 - c.
-// A wavefront writes five fully coalesced 256-byte rows every two steps:
-// 5 bits per DP cell.
+// HBM layout of the decision bits of one strip (1024 columns) of one pair, per
+// pair of wavefront steps kp = k >> 1 (k = body_row + lane), 320 dwords:
+//   [kp*320 +   0 + lane]  A of the even step     [kp*320 + 128 + lane]  A of the odd step
+//   [kp*320 +  64 + lane]  B of the even step     [kp*320 + 192 + lane]  B of the odd step
+//   [kp*320 + 256 + lane]  C: bits 31..16 even step, 15..0 odd step
+// In A/B the lane's column c (0..15) holds its first test at bit 31-2c and its
+// second at bit 30-2c; in C column c is bit 15-c of its half.
+// Every store is a fully coalesced 256-byte row: 5 bits per DP cell.
 __host__ __device__ inline uint64_t strip_dwords(uint32_t la) {
     return static_cast<uint64_t>((la + kWave) / 2) * kPairDwords;
 }
@@ -100,18 +105,13 @@ __device__ __forceinline__ float read_lane(float v, int lane) {
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
 }
-// acc = (acc << 1) | signbit(d): one v_alignbit_b32
-__device__ __forceinline__ uint32_t push_sign(uint32_t acc, float d) {
-    return __builtin_amdgcn_alignbit(acc, __builtin_bit_cast(uint32_t, d), 31);
-}
-
 // Register state of one lane: its 16 columns of the row it processed last.
 struct LaneState {
     float X[kW];  // max((M+ng)+ng, D+gs, (I+gs)+ng): feeds M of the next diagonal cell
     float Y[kW];  // max((M+ng)+go, D+ge, (I+gs)+go): the D value of the cell below (gap_len 1)
     float xlast_old;  // X[15] of the row before: the right neighbour's diagonal input
     float zlast;      // max(M+go, I+ge) of column 15: the right neighbour's I value
-    uint32_t acc[kPlanes];  // decision bits, shifted in cell by cell
+    uint32_t acc[kAccs];    // decision bits, shifted in cell by cell
 };
 
 // One DP cell for gap_len == 1 (align_pair.cc:97-124 with look_back = 1, where
@@ -125,47 +125,167 @@ struct LaneState {
 // when they are equal (gradual underflow is on) and no -0.0f occurs here.  On
 // gfx950 v_sub_f32 issues at twice the rate of v_cmp_f32 and the bit is
 // deposited with a single v_alignbit_b32 (measured: tools/ubench).
+// One DP cell = ONE asm block of 27 VALU instructions with a fixed order and a
+// hand register allocation.  Why not leave it to the compiler (all measured or
+// observed):
+//  * on gfx950 v_add/v_sub_f32 and v_add_u32 issue every 2 cycles, v_max_f32 and
+//    v_alignbit_b32 have a 4-cycle initiation interval; a slow op costs nothing
+//    extra only if fast ops sit on both sides of it.  The order below alternates
+//    them (F/S) and keeps every consumer >= 2 instructions behind its producer.
+//  * hipcc batches the X/Y maxes of a whole row (32 back-to-back v_max), and once
+//    values are opaque adds canonicalising v_max around every fmaxf (IEEE mode);
+//    between adjacent dependent inline-asm statements the hazard recognizer
+//    inserts s_nop.  One block per cell has none of that.
+// No instruction here has a software-visible hazard (no trans ops, no DPP or
+// readlane consumer inside).  The deposit of the cell's last decision (D2) is
+// carried in `pend` into the next cell; the LDS address of this column's score
+// for the NEXT wavefront step is computed here, the ds_read is issued by the
+// compiler right after the block (so that it also places the s_waitcnt).
+#define COATI_CELL_HEAD                                                                     \
+    "v_add_f32 %[t0], %[diag], %[s]\n\t"      /* F  M  = diag + s                        */ \
+    "v_add_f32 %[t1], %[ge], %[zl]\n\t"       /* F  z2 = I + ge                          */
+#define COATI_CELL_PEND                                                                     \
+    "v_alignbit_b32 %[aB], %[aB], %[pend], 31\n\t" /* S  D2 of the previous cell         */
+#define COATI_CELL_BODY                                                                     \
+    "v_add_f32 %[t2], %[gs], %[zl]\n\t"       /* F  i1 = I + gs                          */ \
+    "v_add_f32 %[t3], %[go], %[t0]\n\t"       /* F  z1 = M + go                          */ \
+    "v_add_f32 %[t0], %[ng], %[t0]\n\t"       /* F  m1 = M + ng                          */ \
+    "v_max_f32 %[zl], %[t3], %[t1]\n\t"       /* S  Z  = max(z1,z2) -> I of next column  */ \
+    "v_add_f32 %[t4], %[ng], %[t0]\n\t"       /* F  x1 = m1 + ng                         */ \
+    "v_add_f32 %[t5], %[gs], %[y]\n\t"        /* F  x2 = D + gs                          */ \
+    "v_sub_f32 %[t1], %[t1], %[t3]\n\t"       /* F  z2 - z1  (sign: z1 > z2)             */ \
+    "v_max_f32 %[t3], %[t4], %[t5]\n\t"       /* S  xm = max(x1,x2)                      */ \
+    "v_add_f32 %[pend], %[ng], %[t2]\n\t"     /* F  x3 = i1 + ng                         */ \
+    "v_alignbit_b32 %[aC], %[aC], %[t1], 31\n\t" /* S  IM                                */ \
+    "v_sub_f32 %[t1], %[t4], %[t5]\n\t"       /* F  x1 - x2  (sign: x2 > x1)             */ \
+    "v_max_f32 %[x], %[t3], %[pend]\n\t"      /* S  X  = max(xm,x3)                      */ \
+    "v_sub_f32 %[t4], %[t3], %[pend]\n\t"     /* F  xm - x3  (sign: x3 > xm)             */ \
+    "v_add_f32 %[t5], %[go], %[t0]\n\t"       /* F  y1 = m1 + go                         */ \
+    "v_alignbit_b32 %[aA], %[aA], %[t1], 31\n\t" /* S  M1                                */ \
+    "v_add_f32 %[t1], %[ge], %[y]\n\t"        /* F  y2 = D + ge                          */ \
+    "v_add_f32 %[t3], %[go], %[t2]\n\t"       /* F  y3 = i1 + go                         */ \
+    "v_max_f32 %[t0], %[t5], %[t1]\n\t"       /* S  ym = max(y1,y2)                      */ \
+    "v_sub_f32 %[t2], %[t5], %[t1]\n\t"       /* F  y1 - y2  (sign: y2 > y1)             */ \
+    "v_alignbit_b32 %[aA], %[aA], %[t4], 31\n\t" /* S  M2                                */ \
+    "v_add_u32 %[addr], %[lds], %[boff]\n\t"  /* F  LDS address of next step's score     */ \
+    "v_max_f32 %[y], %[t0], %[t3]\n\t"        /* S  Y  = max(ym,y3)                      */ \
+    "v_sub_f32 %[pend], %[t0], %[t3]\n\t"     /* F  ym - y3  (sign: y3 > ym), carried    */ \
+    "v_alignbit_b32 %[aB], %[aB], %[t2], 31"  /* S  D1                                   */
+
 template <int C>
-__device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState& st, float& diag, float& zl, float s) {
-    const float M = diag + s;
-    const float D = st.Y[C];
-    const float I = zl;
-    diag = st.X[C];
-    const float m1 = M + k.ng;
-    const float x1 = m1 + k.ng;
-    const float y1 = m1 + k.go;
-    const float z1 = M + k.go;
-    const float x2 = D + k.gs;
-    const float y2 = D + k.ge;
-    const float i1 = I + k.gs;
-    const float x3 = i1 + k.ng;
-    const float y3 = i1 + k.go;
-    const float z2 = I + k.ge;
-    const float xm = fmaxf(x1, x2);
-    const float ym = fmaxf(y1, y2);
-    st.X[C] = fmaxf(xm, x3);
-    st.Y[C] = fmaxf(ym, y3);
-    zl = fmaxf(z1, z2);
-    st.acc[P_M1] = push_sign(st.acc[P_M1], x1 - x2);  // x2 > x1
-    st.acc[P_M2] = push_sign(st.acc[P_M2], xm - x3);  // x3 > max(x1,x2)
-    st.acc[P_D1] = push_sign(st.acc[P_D1], y1 - y2);
-    st.acc[P_D2] = push_sign(st.acc[P_D2], ym - y3);
-    st.acc[P_IM] = push_sign(st.acc[P_IM], z2 - z1);  // z1 > z2
+__device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState& st, float& diag, float& zl, float& pend,
+                                        float& s, uint32_t lds_next_row, uint32_t boff) {
+    float x_new, t0, t1, t2, t3, t4, t5;
+    uint32_t addr;
+#define COATI_CELL_OPERANDS                                                                              \
+    : [x] "=&v"(x_new), [y] "+v"(st.Y[C]), [zl] "+v"(zl), [pend] "+v"(pend), [aA] "+v"(st.acc[ACC_A]),   \
+      [aB] "+v"(st.acc[ACC_B]), [aC] "+v"(st.acc[ACC_C]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
+      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [addr] "=&v"(addr)                                  \
+    : [diag] "v"(diag), [s] "v"(s), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng),          \
+      [gs] "s"(k.gs), [go] "s"(k.go), [ge] "s"(k.ge)
+    if constexpr(C > 0) {
+        asm volatile(COATI_CELL_HEAD COATI_CELL_PEND COATI_CELL_BODY COATI_CELL_OPERANDS);
+    } else {
+        asm volatile(COATI_CELL_HEAD COATI_CELL_BODY COATI_CELL_OPERANDS);
+    }
+#undef COATI_CELL_OPERANDS
+    diag = st.X[C];  // the next column's diagonal input is this column's previous-row X
+    st.X[C] = x_new;
+    // s was consumed by the block's first instruction: reuse it for the next step's score
+    s = *reinterpret_cast<const __attribute__((address_space(3))) float*>(addr);
 }
 
 template <int... C>
 __device__ __forceinline__ void row_l1(const GapConsts& k, LaneState& st, float diag, float zl,
-                                       const float (&s)[kW], std::integer_sequence<int, C...>) {
+                                       float (&s)[kW], uint32_t lds_next_row, const uint32_t (&boff)[kW],
+                                       std::integer_sequence<int, C...>) {
     st.xlast_old = st.X[kW - 1];
-    (cell_l1<C>(k, st, diag, zl, s[C]), ...);
+    float pend = 0.0f;
+    (cell_l1<C>(k, st, diag, zl, pend, s[C], lds_next_row, boff[C]), ...);
+    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(st.acc[ACC_B]) : "v"(pend));  // D2 of column 15
     st.zlast = zl;
 }
 
-// Viterbi fill for gap_len == 1.  grid = ceil(n_pairs / 4) workgroups of 4
-// waves; wave w of block b owns pair 4b+w.
-__global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_fill_l1(
+// Read-only per-strip context of one wavefront.
+struct StripCtx {
+    GapConsts k;
+    uint32_t la, col0, nsteps, pair, lds_tab;
+    int lane, last_lane, last_c;
+    bool last_strip;
+    uint32_t* fout;
+    float *bnd_x, *bnd_z, *scores;
+};
+
+// Up to 64 wavefront steps.  kFirst: chunk 0 only, where lane l starts (takes its
+// margin-row state) at step l.  The main loop is a separate instantiation so
+// that it carries no trace of the start-up code (spill reloads there would put
+// an s_waitcnt vmcnt(0) -- a wait for the previous step's HBM stores -- into
+// every step).
+template <bool kFirst>
+__device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uint32_t& arow, float (&s)[kW],
+                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float bx,
+                                          float bz) {
+    const GapConsts& k = cx.k;
+    const int lane = cx.lane;
+    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    for(uint32_t kk = 0; kk < kend; ++kk) {
+        const uint32_t kstep = kbase + kk;
+        if constexpr(kFirst) {
+            if(kk == static_cast<uint32_t>(lane)) {
+                // This lane starts now: state of the margin row (matrix row 0,
+                // align_pair.cc:88-90): M = D = lowest, I = go + ge*float(j-1).
+                uint32_t bj0 = cx.col0 + lane * kW;
+                asm volatile("" : "+v"(bj0));  // compute in place: hoisted, these 32 values get spilled
+#pragma unroll
+                for(int c = 0; c < kW; ++c) {
+                    const float im = k.go + k.ge * static_cast<float>(bj0 + c);
+                    const float i1 = im + k.gs;
+                    st.X[c] = i1 + k.ng;
+                    st.Y[c] = i1 + k.go;
+                }
+                if(!cx.last_strip && lane == kWave - 1) cx.bnd_x[0] = st.X[kW - 1];
+            }
+        }
+        // ---- hand-off from the left neighbour (full exec)
+        const float diag = shift_in(st.xlast_old, read_lane(bx, kk));
+        const float zl = shift_in(st.zlast, read_lane(bz, kk));
+        const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
+        // ---- the 16 cells (and the LDS gather for the next step)
+        row_l1(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, kW>{});
+        arow = arow_next;
+        // ---- decision bits: two coalesced 256-byte rows per step, a third every second step
+        {
+            uint32_t* dst = cx.fout + static_cast<uint64_t>(kstep >> 1) * kPairDwords + (kstep & 1u) * (2 * kWave);
+            dst[0] = st.acc[ACC_A];
+            dst[kWave] = st.acc[ACC_B];
+            if(kstep & 1u) dst[2 * kWave] = st.acc[ACC_C];  // = pair base + 256
+        }
+        const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
+        if(!cx.last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(cx.la)) {
+            cx.bnd_x[r + 1] = st.X[kW - 1];
+            cx.bnd_z[r] = st.zlast;
+        }
+        if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
+            // score = max(M,D,I) of the terminal-adjusted last cell
+            // (align_pair.cc:130-138,265) = X of the last body cell.
+            float sc = st.X[0];
+#pragma unroll
+            for(int c = 1; c < kW; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
+            cx.scores[cx.pair] = sc;
+        }
+    }
+}
+
+// Viterbi fill for gap_len == 1.  PERSISTENT: the grid is sized to fill every CU
+// with the same number of workgroups (host: fill_launch_shape) and each
+// wavefront pulls pair indices from an atomic queue until it is empty.  (With one
+// workgroup per 4 pairs the hardware dispatcher packs workgroups unevenly --
+// in-kernel clocks showed SIMDs running 2x the waves of others -- and a kernel
+// took ~2x the time its work implies.)  `order` lists the pairs longest first.
+__global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_fill_l1(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
-    uint32_t n_pairs, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
+    const uint32_t* __restrict__ order, uint32_t n_pairs, uint32_t* __restrict__ queue,
+    const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores) {
     __shared__ float tab[kTabRows * kTabStride];
     for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
@@ -175,14 +295,19 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_fill_l1(
     __syncthreads();
 
     const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t pair = blockIdx.x * kFillWaves + (threadIdx.x >> 6);
-    if(pair >= n_pairs) return;
+    const char* tab_bytes = reinterpret_cast<const char*>(tab);
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
+    for(;;) {
+    uint32_t ticket = 0;
+    if(lane == 0) ticket = atomicAdd(queue, 1u);
+    ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+    if(ticket >= n_pairs) break;
+    const uint32_t pair = order[ticket];
     const PairDesc pd = pairs[pair];
     const uint32_t la = pd.la, lb = pd.lb;
-    if(la == 0 || lb == 0) return;  // no body cells: the walker handles the margins
+    if(la == 0 || lb == 0) continue;  // no body cells: the walker handles the margins
     const uint8_t* __restrict__ a = a_cat + pd.a_off;
     const uint8_t* __restrict__ b = b_cat + pd.b_off;
-    const char* tab_bytes = reinterpret_cast<const char*>(tab);
 
     const uint32_t strips = n_strips(lb);
     for(uint32_t strip = 0; strip < strips; ++strip) {
@@ -205,22 +330,31 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_fill_l1(
             boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
         }
 
+        const StripCtx cx{k, la, col0, nsteps, pair, lds_tab, lane,
+                          static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
+                          last_strip, fout, bnd_x, bnd_z, scores};
         LaneState st;
 #pragma unroll
         for(int c = 0; c < kW; ++c) st.X[c] = st.Y[c] = 0.0f;
 #pragma unroll
-        for(int p = 0; p < kPlanes; ++p) st.acc[p] = 0u;
+        for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
         st.xlast_old = 0.0f;
         st.zlast = 0.0f;
-        uint32_t arow = 0;
+        // table-row byte offset of the row this lane processes at the CURRENT step,
+        // and the 16 substitution scores gathered for it one step earlier
+        uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+        float s[kW];
+#pragma unroll
+        for(int c = 0; c < kW; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
 
         for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
             // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l
+            // (boundary column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
             const uint32_t crow = kbase + lane;
             uint32_t a_chunk = 0;
             float bx = kLowest, bz = kLowest;
+            if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
             if(crow < la) {
-                a_chunk = static_cast<uint32_t>(a[crow]) * (kTabStride * 4u);
                 if(strip == 0) {
                     // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
                     if(crow == 0) {
@@ -234,62 +368,17 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_fill_l1(
                     bz = bnd_z[crow];
                 }
             }
-            const uint32_t kend = min(static_cast<uint32_t>(kWave), nsteps - kbase);
-            for(uint32_t kk = 0; kk < kend; ++kk) {
-                const uint32_t kstep = kbase + kk;
-                if(kbase == 0 && kk == static_cast<uint32_t>(lane)) {
-                    // This lane starts now: state of the margin row (matrix row 0,
-                    // align_pair.cc:88-90): M = D = lowest, I = go + ge*float(j-1).
-#pragma unroll
-                    for(int c = 0; c < kW; ++c) {
-                        const uint32_t bj = col0 + lane * kW + c;
-                        const float im = k.go + k.ge * static_cast<float>(bj);
-                        const float i1 = im + k.gs;
-                        st.X[c] = i1 + k.ng;
-                        st.Y[c] = i1 + k.go;
-                    }
-                    if(!last_strip && lane == kWave - 1) bnd_x[0] = st.X[kW - 1];
-                }
-                // ---- hand-off from the left neighbour (full exec)
-                const float diag = shift_in(st.xlast_old, read_lane(bx, kk));
-                const float zl = shift_in(st.zlast, read_lane(bz, kk));
-                arow = shift_in(arow, read_lane(a_chunk, kk));
-                // ---- substitution scores of this lane's 16 cells
-                float s[kW];
-#pragma unroll
-                for(int c = 0; c < kW; ++c)
-                    s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
-                // ---- the 16 cells
-                row_l1(k, st, diag, zl, s, std::make_integer_sequence<int, kW>{});
-                // ---- every second step: five coalesced 256-byte rows of decision bits
-                if(kstep & 1u) {
-                    uint32_t* dst = fout + static_cast<uint64_t>(kstep >> 1) * kPairDwords;
-#pragma unroll
-                    for(int p = 0; p < kPlanes; ++p) dst[p * kWave] = st.acc[p];
-                }
-                const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
-                if(!last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(la)) {
-                    bnd_x[r + 1] = st.X[kW - 1];
-                    bnd_z[r] = st.zlast;
-                }
-                if(last_strip && r == static_cast<int>(la) - 1 &&
-                   lane == static_cast<int>(((lb - 1) & (kStrip - 1)) / kW)) {
-                    // score = max(M,D,I) of the terminal-adjusted last cell
-                    // (align_pair.cc:130-138,265) = X of the last body cell.
-                    const int cl = (lb - 1) & (kW - 1);
-                    float sc = st.X[0];
-#pragma unroll
-                    for(int c = 1; c < kW; ++c) sc = (c == cl) ? st.X[c] : sc;
-                    scores[pair] = sc;
-                }
-            }
+            // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
+            asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
+            if(kbase == 0)
+                run_chunk<true>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+            else
+                run_chunk<false>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
         }
-        if(nsteps & 1u) {  // the last (even) step has no odd partner: flush it to the high half
-            uint32_t* dst = fout + static_cast<uint64_t>(nsteps >> 1) * kPairDwords;
-#pragma unroll
-            for(int p = 0; p < kPlanes; ++p) dst[p * kWave] = st.acc[p] << 16;
-        }
+        if(nsteps & 1u)  // the last (even) step has no odd partner: flush its IM bits to the high half
+            fout[static_cast<uint64_t>(nsteps >> 1) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << 16;
     }
+    }  // next ticket
 }
 
 // ---------------------------------------------------------------------------
@@ -297,27 +386,32 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_fill_l1(
 // one lane per pair.  Emits ops right-to-left into the pair's slot so that they
 // end up in left-to-right order at [ops_start, ops_start + ops_len).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t plane_bit(const uint32_t* __restrict__ flags, uint64_t base,
-                                              uint32_t la, uint32_t bi, uint32_t bj, int plane) {
+struct CellAddr {
+    uint64_t pair_base;  // dword index of the step pair
+    uint32_t odd, t, c;
+};
+__device__ __forceinline__ CellAddr cell_addr(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj) {
     const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
     const uint32_t kstep = bi + t;
-    const uint64_t d = base + strip * strip_dwords(la) + static_cast<uint64_t>(kstep >> 1) * kPairDwords +
-                       plane * kWave + t;
-    const uint32_t bit = ((kstep & 1u) ? 0u : 16u) + (kW - 1 - c);
-    return (flags[d] >> bit) & 1u;
+    return {base + strip * strip_dwords(la) + static_cast<uint64_t>(kstep >> 1) * kPairDwords, kstep & 1u, t, c};
+}
+// two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
+__device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
+    const uint32_t w = flags[ca.pair_base + ca.odd * (2 * kWave) + which * kWave + ca.t];
+    return (w >> (30 - 2 * ca.c)) & 3u;  // bit1 = first test, bit0 = second test
+}
+__device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
+    const uint32_t w = flags[ca.pair_base + 4 * kWave + ca.t];
+    return (w >> ((ca.odd ? 0u : 16u) + (kW - 1 - ca.c))) & 1u;
 }
 
 __device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, uint64_t base,
                                            uint32_t la, uint32_t bi, uint32_t bj, int moved) {
-    if(moved == COATI_HIP_OP_MATCH) {
-        if(plane_bit(flags, base, la, bi, bj, P_M2)) return COATI_HIP_OP_INS;
-        return plane_bit(flags, base, la, bi, bj, P_M1) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
-    }
-    if(moved == COATI_HIP_OP_DEL) {
-        if(plane_bit(flags, base, la, bi, bj, P_D2)) return COATI_HIP_OP_INS;
-        return plane_bit(flags, base, la, bi, bj, P_D1) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
-    }
-    return plane_bit(flags, base, la, bi, bj, P_IM) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+    const CellAddr ca = cell_addr(base, la, bi, bj);
+    if(moved == COATI_HIP_OP_INS) return im_bit(flags, ca) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+    const uint32_t two = pair_bits(flags, ca, moved == COATI_HIP_OP_DEL ? 1 : 0);
+    if(two & 1u) return COATI_HIP_OP_INS;  // second test: I beats max(M,D)
+    return (two & 2u) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
 }
 
 __global__ __launch_bounds__(64) void viterbi_walk_l1(
@@ -375,12 +469,9 @@ __global__ void decode_flags(const PairDesc* __restrict__ pairs, uint32_t pair,
     for(uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; idx < n;
         idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
-        const uint32_t m1 = plane_bit(flags, pd.flags_off, pd.la, bi, bj, P_M1);
-        const uint32_t m2 = plane_bit(flags, pd.flags_off, pd.la, bi, bj, P_M2);
-        const uint32_t d1 = plane_bit(flags, pd.flags_off, pd.la, bi, bj, P_D1);
-        const uint32_t d2 = plane_bit(flags, pd.flags_off, pd.la, bi, bj, P_D2);
-        const uint32_t im = plane_bit(flags, pd.flags_off, pd.la, bi, bj, P_IM);
-        const uint32_t fm = m2 ? 2u : m1, fd = d2 ? 2u : d1;
+        const CellAddr ca = cell_addr(pd.flags_off, pd.la, bi, bj);
+        const uint32_t mm = pair_bits(flags, ca, 0), dd = pair_bits(flags, ca, 1), im = im_bit(flags, ca);
+        const uint32_t fm = (mm & 1u) ? 2u : (mm >> 1), fd = (dd & 1u) ? 2u : (dd >> 1);
         out[idx] = static_cast<uint8_t>(fm | (fd << 2) | ((im ^ 1u) << 4));
     }
 }
@@ -412,6 +503,46 @@ int fail(int code, const char* fmt, ...) {
                         "%s failed: %s", #expr, hipGetErrorString(e_));                     \
     } while(0)
 
+// Launch shape of the persistent fill kernel: `blocks_per_cu` workgroups on each
+// of the 256 CUs (one wave per SIMD each), enforced by padding the launch with
+// unused dynamic LDS so that exactly that many fit.  More resident waves hide
+// latency better; fewer quantise the end of a small batch more finely.  Cost of
+// one pair relative to a saturated SIMD when w waves share it (measured,
+// in-kernel clocks): w=1 1.85, w=2 1.10, w=3 1.03.
+struct FillShape {
+    uint32_t grid;
+    size_t dynamic_lds;
+};
+FillShape fill_launch_shape(uint32_t n_pairs) {
+    constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
+    constexpr int kMaxBlocks = 3;  // 168 VGPRs -> 3 waves per SIMD
+    constexpr double kCost[4] = {0.0, 1.85, 1.10, 1.03};
+    static const int forced = [] {
+        const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
+        return e != nullptr ? std::atoi(e) : 0;
+    }();
+    int best = kMaxBlocks;
+    if(forced >= 1 && forced <= kMaxBlocks) {
+        best = forced;
+    } else {
+        double best_t = 1e300;
+        for(int w = kMaxBlocks; w >= 1; --w) {
+            const uint64_t per_simd = (static_cast<uint64_t>(n_pairs) + kSimds - 1) / kSimds;  // pairs on the busiest SIMD
+            const uint64_t rounds = (per_simd + w - 1) / w;
+            const double t = static_cast<double>(rounds) * w * kCost[w];
+            if(t < best_t * 0.98) {
+                best_t = t;
+                best = w;
+            }
+        }
+    }
+    constexpr size_t kLdsPerCU = 160 * 1024, kStatic = kTabRows * kTabStride * sizeof(float);
+    // LDS footprint per block that admits exactly `best` blocks per CU
+    const size_t per_block = kLdsPerCU / best;
+    const size_t dyn = best < 12 && per_block > kStatic + 512 ? per_block - kStatic - 512 : 0;
+    return {kCUs * static_cast<uint32_t>(best), dyn};
+}
+
 bool device_is_gfx950(int dev) {
     hipDeviceProp_t prop;
     if(hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
@@ -439,12 +570,16 @@ struct coati_hip_batch {
     std::vector<PairDesc> desc;
     // device
     PairDesc* d_desc = nullptr;
+    uint32_t* d_order = nullptr;   // pair indices, most cells first
+    uint32_t* d_queue = nullptr;   // ticket counter of the persistent fill kernel
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
     uint32_t* d_flags = nullptr;
     float *d_bnd = nullptr, *d_scores = nullptr;
     uint64_t* d_ops_start = nullptr;
     uint32_t* d_ops_len = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kTimingRing = 64;  // launches whose kernel times can still be read back
+    hipEvent_t ev[kTimingRing][3] = {};
+    uint64_t n_launches = 0;
     bool launched = false;
 };
 
@@ -512,12 +647,13 @@ void coati_hip_model_destroy(coati_hip_model_t* m) {
 void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(b == nullptr) return;
     if(b->model != nullptr) (void)hipSetDevice(b->model->device);
-    void* ptrs[] = {b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
+    void* ptrs[] = {b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
                     b->d_bnd,  b->d_scores, b->d_ops_start, b->d_ops_len};
     for(void* p : ptrs)
         if(p != nullptr) (void)hipFree(p);
-    for(hipEvent_t e : b->ev)
-        if(e != nullptr) (void)hipEventDestroy(e);
+    for(auto& trio : b->ev)
+        for(hipEvent_t e : trio)
+            if(e != nullptr) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -613,11 +749,22 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
     B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_scores), n_pairs * sizeof(float)));
     B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops_start), n_pairs * sizeof(uint64_t)));
     B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops_len), n_pairs * sizeof(uint32_t)));
-    if(n_pairs > 0)
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_order), n_pairs * sizeof(uint32_t)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_queue), sizeof(uint32_t)));
+    if(n_pairs > 0) {
         B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
+        // longest-processing-time-first order for the dynamic queue
+        std::vector<uint32_t> order(n_pairs);
+        for(uint64_t p = 0; p < n_pairs; ++p) order[p] = static_cast<uint32_t>(p);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
+        });
+        B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
     if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));
-    for(auto& e : b->ev) B_TRY(hipEventCreate(&e));
+    for(auto& trio : b->ev)
+        for(auto& e : trio) B_TRY(hipEventCreate(&e));
 #undef B_TRY
     *out = b;
     return COATI_HIP_OK;
@@ -631,21 +778,27 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
     coati_hip_model* m = b->model;
     HIP_TRY(hipSetDevice(m->device));
     const uint32_t n = static_cast<uint32_t>(b->n_pairs);
-    HIP_TRY(hipEventRecord(b->ev[0], m->stream));
+    hipEvent_t* ev = b->ev[b->n_launches % coati_hip_batch::kTimingRing];
+    HIP_TRY(hipEventRecord(ev[0], m->stream));
     if(n > 0) {
-        const uint32_t grid = (n + kFillWaves - 1) / kFillWaves;
-        hipLaunchKernelGGL(viterbi_fill_l1, dim3(grid), dim3(kFillWaves * kWave), 0, m->stream,
-                           m->d_table, m->k, b->d_desc, n, b->d_a, b->d_b, b->d_flags, b->d_bnd,
-                           b->d_scores);
+        HIP_TRY(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), m->stream));
+        const FillShape shape = fill_launch_shape(n);
+        if(shape.dynamic_lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_fill_l1),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds)));
+        hipLaunchKernelGGL(viterbi_fill_l1, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, m->stream,
+                           m->d_table, m->k, b->d_desc, b->d_order, n, b->d_queue, b->d_a, b->d_b, b->d_flags,
+                           b->d_bnd, b->d_scores);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(b->ev[1], m->stream));
+    HIP_TRY(hipEventRecord(ev[1], m->stream));
     if(n > 0) {
         hipLaunchKernelGGL(viterbi_walk_l1, dim3((n + 63) / 64), dim3(64), 0, m->stream, m->k, b->d_desc, n,
                            b->d_flags, b->d_ops, b->d_ops_start, b->d_ops_len, b->d_scores);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(b->ev[2], m->stream));
+    HIP_TRY(hipEventRecord(ev[2], m->stream));
+    b->n_launches += 1;
     b->launched = true;
     return COATI_HIP_OK;
 }
@@ -689,17 +842,24 @@ int coati_hip_batch_result_ptrs(coati_hip_batch_t* b, void** scores, void** ops,
     return COATI_HIP_OK;
 }
 
-int coati_hip_viterbi_last_timing(coati_hip_batch_t* b, float* fill_ms, float* walk_ms) {
-    if(b == nullptr) return fail(COATI_HIP_EINVAL, "last_timing: batch is NULL");
-    if(!b->launched) return fail(COATI_HIP_ESTATE, "last_timing: nothing was launched");
+int coati_hip_viterbi_timing(coati_hip_batch_t* b, uint32_t launches_back, float* fill_ms, float* walk_ms) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_timing: batch is NULL");
+    if(!b->launched) return fail(COATI_HIP_ESTATE, "viterbi_timing: nothing was launched");
+    if(launches_back >= coati_hip_batch::kTimingRing || launches_back >= b->n_launches)
+        return fail(COATI_HIP_EINVAL, "viterbi_timing: launch %u back is not recorded", launches_back);
     int rc = coati_hip_batch_sync(b);
     if(rc != COATI_HIP_OK) return rc;
+    hipEvent_t* ev = b->ev[(b->n_launches - 1 - launches_back) % coati_hip_batch::kTimingRing];
     float f = 0.f, w = 0.f;
-    HIP_TRY(hipEventElapsedTime(&f, b->ev[0], b->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&w, b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&w, ev[1], ev[2]));
     if(fill_ms != nullptr) *fill_ms = f;
     if(walk_ms != nullptr) *walk_ms = w;
     return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_last_timing(coati_hip_batch_t* b, float* fill_ms, float* walk_ms) {
+    return coati_hip_viterbi_timing(b, 0, fill_ms, walk_ms);
 }
 
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,

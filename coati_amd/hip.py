@@ -32,6 +32,7 @@ EXPORTS = (
     "coati_hip_batch_sync",
     "coati_hip_viterbi_fetch",
     "coati_hip_viterbi_last_timing",
+    "coati_hip_viterbi_timing",
     "coati_hip_batch_result_ptrs",
     "coati_hip_viterbi_batch",
     "coati_hip_debug_viterbi_flags",
@@ -77,6 +78,7 @@ def load() -> C.CDLL:
     lib.coati_hip_batch_sync.argtypes = [vp]
     lib.coati_hip_viterbi_fetch.argtypes = [vp, vp, vp, u64, vp, vp]
     lib.coati_hip_viterbi_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+    lib.coati_hip_viterbi_timing.argtypes = [vp, C.c_uint32, C.POINTER(f32), C.POINTER(f32)]
     lib.coati_hip_batch_result_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp),
                                                 C.POINTER(vp)]
     lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
@@ -201,9 +203,10 @@ class Batch:
                                               _ptr(ops_len)))
         return scores, ops, ops_off, ops_len
 
-    def viterbi_timing(self):
+    def viterbi_timing(self, launches_back: int = 0):
+        """(fill_ms, walk_ms) of the launch issued `launches_back` launches before the last one."""
         f, w = C.c_float(), C.c_float()
-        _check(load().coati_hip_viterbi_last_timing(self._h, C.byref(f), C.byref(w)))
+        _check(load().coati_hip_viterbi_timing(self._h, launches_back, C.byref(f), C.byref(w)))
         return f.value, w.value
 
     def result_ptrs(self):

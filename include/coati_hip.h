@@ -121,6 +121,11 @@ int coati_hip_viterbi_fetch(coati_hip_batch_t* batch, float* scores, uint8_t* op
 /* Device times (ms) of the last viterbi launch, from HIP events recorded on the
  * model's stream around each kernel (synchronises first). */
 int coati_hip_viterbi_last_timing(coati_hip_batch_t* batch, float* fill_ms, float* walk_ms);
+/* Same for the launch issued `launches_back` launches before the last one (0 =
+ * last; the most recent 64 launches are kept), so that a caller can enqueue many
+ * launches back to back and read their kernel times afterwards. */
+int coati_hip_viterbi_timing(coati_hip_batch_t* batch, uint32_t launches_back, float* fill_ms,
+                             float* walk_ms);
 
 /* Device pointers of the result arrays of a batch (valid until the batch is
  * destroyed; contents valid after a synchronised viterbi launch), so that a
