@@ -119,7 +119,6 @@ def main():
     # own stream around each kernel (it keeps the last 64 launches)
     timed = [batch.viterbi_timing(i) for i in range(min(args.steps, 64))]
     fill_ms = [t[0] for t in timed]
-    walk_ms = [t[1] for t in timed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -141,7 +140,7 @@ def main():
         tfile = ROOT / "profiles" / "traffic_latest.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("viterbi_fill_l1_bytes_per_launch_10000_pairs")
+                traffic = json.loads(tfile.read_text()).get("viterbi_l1_bytes_per_launch_10000_pairs")
                 if args.pairs != 10000:
                     traffic = None
             except Exception:
@@ -164,10 +163,10 @@ def main():
                        "pairs_per_gpu": args.pairs, "global_pairs": args.pairs * world, "gap_len": 1,
                        "parallelism": f"pairs sharded over {world} GPU(s), model broadcast + result gather (RCCL)"},
             "pairs_per_s": args.pairs * world * args.steps / elapsed,
-            "kernel_ms": {"viterbi_fill_l1": fill, "viterbi_walk_l1": float(np.mean(walk_ms))},
+            "kernel_ms": {"viterbi_l1 (fill + fused traceback)": fill},
             "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "viterbi_fill_l1", "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": "viterbi_l1", "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "the fill is VALU-issue bound, not HBM bound: see DESIGN.md §Roofline"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -206,6 +206,98 @@ __device__ __forceinline__ void row_l1(const GapConsts& k, LaneState& st, float 
     st.zlast = zl;
 }
 
+struct CellAddr {
+    uint64_t pair_base;  // dword index of the step pair
+    uint32_t odd, t, c;
+};
+__device__ __forceinline__ CellAddr cell_addr(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj) {
+    const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
+    const uint32_t kstep = bi + t;
+    return {base + strip * strip_dwords(la) + static_cast<uint64_t>(kstep >> 1) * kPairDwords, kstep & 1u, t, c};
+}
+// two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
+__device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
+    const uint32_t w = flags[ca.pair_base + ca.odd * (2 * kWave) + which * kWave + ca.t];
+    return (w >> (30 - 2 * ca.c)) & 3u;  // bit1 = first test, bit0 = second test
+}
+__device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
+    const uint32_t w = flags[ca.pair_base + 4 * kWave + ca.t];
+    return (w >> ((ca.odd ? 0u : 16u) + (kW - 1 - ca.c))) & 1u;
+}
+
+__device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, uint64_t base,
+                                           uint32_t la, uint32_t bi, uint32_t bj, int moved) {
+    const CellAddr ca = cell_addr(base, la, bi, bj);
+    if(moved == COATI_HIP_OP_INS) return im_bit(flags, ca) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+    const uint32_t two = pair_bits(flags, ca, moved == COATI_HIP_OP_DEL ? 1 : 0);
+    if(two & 1u) return COATI_HIP_OP_INS;  // second test: I beats max(M,D)
+    return (two & 2u) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
+}
+
+// State the reference's walk is in after arriving at matrix cell (i, j) by a move
+// of kind `moved` (align_pair.cc:275-296).  On column 0 only D, on row 0 only I
+// is finite (align_pair.cc:82-91), so margin cells need no stored bits.
+constexpr int kWalkEnd = 3;
+__device__ __forceinline__ int arrival_state(const uint32_t* __restrict__ flags, uint64_t base, uint32_t la,
+                                             uint32_t i, uint32_t j, int moved) {
+    if(i == 0 && j == 0) return kWalkEnd;
+    if(j == 0) return COATI_HIP_OP_DEL;
+    if(i == 0) return COATI_HIP_OP_INS;
+    return state_after(flags, base, la, i - 1, j - 1, moved);
+}
+
+// traceback<tropical> (align_pair.cc:249-303, gap_len 1) by one WAVEFRONT.
+// A walk is a chain of dependent loads, but it consists of long runs of the same
+// move.  So the 64 lanes speculate: lane l looks up the state the walk would be
+// in after l+1 further moves of the current kind; a ballot finds the first lane
+// where the run ends; all moves up to there are emitted at once (coalesced
+// byte stores) and the walk jumps.  Memory round trips per pair drop from
+// len_a+len_b to about (number of runs + length/64).
+// Ops are written right-to-left into the pair's slot so they end up in alignment
+// order; all lanes must call this (it uses ballots).
+__device__ __forceinline__ void walk_pair_l1(int lane, const GapConsts& k, const PairDesc& pd, uint32_t pair,
+                                             const uint32_t* __restrict__ flags, uint8_t* __restrict__ ops,
+                                             uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len,
+                                             float* __restrict__ scores) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    uint32_t i = la, j = lb;  // matrix coordinates (row 0 / column 0 are the margins)
+    uint64_t pos = pd.ops_off + la + lb;
+    int st;
+    if(la == 0 || lb == 0) {
+        // No body cell: the last cell is a margin cell (align_pair.cc:82-91,130-138).
+        float m = kLowest, d = kLowest, in = kLowest;
+        if(la == 0 && lb == 0) m = 0.0f;
+        if(la > 0) d = (k.ng + k.go) + k.ge * static_cast<float>(la - 1);
+        if(lb > 0) in = k.go + k.ge * static_cast<float>(lb - 1);
+        const float tm = (m + k.ng) + k.ng, td = d + k.gs, ti = (in + k.gs) + k.ng;
+        if(lane == 0) scores[pair] = fmaxf(fmaxf(tm, td), ti);
+        st = la > 0 ? COATI_HIP_OP_DEL : (lb > 0 ? COATI_HIP_OP_INS : kWalkEnd);
+    } else {
+        // max_mdi of the terminal-adjusted last cell == its "after match" decision
+        st = __builtin_amdgcn_readfirstlane(state_after(flags, pd.flags_off, la, la - 1, lb - 1, COATI_HIP_OP_MATCH));
+    }
+    while(st != kWalkEnd) {
+        const uint32_t di = st != COATI_HIP_OP_INS ? 1u : 0u, dj = st != COATI_HIP_OP_DEL ? 1u : 0u;
+        // lane l: where the walk is after l+1 more moves of kind st, and in which state
+        const uint32_t step = static_cast<uint32_t>(lane) + 1u;
+        const bool valid = di * step <= i && dj * step <= j;
+        int next = kWalkEnd;
+        if(valid) next = arrival_state(flags, pd.flags_off, la, i - di * step, j - dj * step, st);
+        const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
+        const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
+        const uint32_t moves = run == kWave ? kWave : run + 1u;
+        if(static_cast<uint32_t>(lane) < moves) ops[pos - 1 - lane] = static_cast<uint8_t>(st);
+        pos -= moves;
+        i -= di * moves;
+        j -= dj * moves;
+        if(run < kWave) st = __builtin_amdgcn_readlane(next, static_cast<int>(run));
+    }
+    if(lane == 0) {
+        ops_start[pair] = pos;
+        ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
+    }
+}
+
 // Read-only per-strip context of one wavefront.
 struct StripCtx {
     GapConsts k;
@@ -282,11 +374,12 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uin
 // workgroup per 4 pairs the hardware dispatcher packs workgroups unevenly --
 // in-kernel clocks showed SIMDs running 2x the waves of others -- and a kernel
 // took ~2x the time its work implies.)  `order` lists the pairs longest first.
-__global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_fill_l1(
+__global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const uint32_t* __restrict__ order, uint32_t n_pairs, uint32_t* __restrict__ queue,
     const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
-    uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores) {
+    uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
+    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
     __shared__ float tab[kTabRows * kTabStride];
     for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
         const int r = idx / kTabCols, c = idx - r * kTabCols;
@@ -305,7 +398,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_fill_l1(
     const uint32_t pair = order[ticket];
     const PairDesc pd = pairs[pair];
     const uint32_t la = pd.la, lb = pd.lb;
-    if(la == 0 || lb == 0) continue;  // no body cells: the walker handles the margins
+    if(la > 0 && lb > 0) {  // (without body cells only the margins are walked)
     const uint8_t* __restrict__ a = a_cat + pd.a_off;
     const uint8_t* __restrict__ b = b_cat + pd.b_off;
 
@@ -378,87 +471,13 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_fill_l1(
         if(nsteps & 1u)  // the last (even) step has no odd partner: flush its IM bits to the high half
             fout[static_cast<uint64_t>(nsteps >> 1) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << 16;
     }
+    }
+    // ---- traceback of this pair by the same wavefront, while its bits are still
+    // in L2.  The wave reads what it wrote itself: wait until its stores are
+    // acknowledged; nobody read these (128-byte aligned) lines before, so L1 is cold.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    walk_pair_l1(lane, k, pd, pair, flags, ops, ops_start, ops_len, scores);
     }  // next ticket
-}
-
-// ---------------------------------------------------------------------------
-// Traceback walker (traceback<tropical>, align_pair.cc:249-303, gap_len 1):
-// one lane per pair.  Emits ops right-to-left into the pair's slot so that they
-// end up in left-to-right order at [ops_start, ops_start + ops_len).
-// ---------------------------------------------------------------------------
-struct CellAddr {
-    uint64_t pair_base;  // dword index of the step pair
-    uint32_t odd, t, c;
-};
-__device__ __forceinline__ CellAddr cell_addr(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj) {
-    const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
-    const uint32_t kstep = bi + t;
-    return {base + strip * strip_dwords(la) + static_cast<uint64_t>(kstep >> 1) * kPairDwords, kstep & 1u, t, c};
-}
-// two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
-__device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
-    const uint32_t w = flags[ca.pair_base + ca.odd * (2 * kWave) + which * kWave + ca.t];
-    return (w >> (30 - 2 * ca.c)) & 3u;  // bit1 = first test, bit0 = second test
-}
-__device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
-    const uint32_t w = flags[ca.pair_base + 4 * kWave + ca.t];
-    return (w >> ((ca.odd ? 0u : 16u) + (kW - 1 - ca.c))) & 1u;
-}
-
-__device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, uint64_t base,
-                                           uint32_t la, uint32_t bi, uint32_t bj, int moved) {
-    const CellAddr ca = cell_addr(base, la, bi, bj);
-    if(moved == COATI_HIP_OP_INS) return im_bit(flags, ca) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
-    const uint32_t two = pair_bits(flags, ca, moved == COATI_HIP_OP_DEL ? 1 : 0);
-    if(two & 1u) return COATI_HIP_OP_INS;  // second test: I beats max(M,D)
-    return (two & 2u) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
-}
-
-__global__ __launch_bounds__(64) void viterbi_walk_l1(
-    GapConsts k, const PairDesc* __restrict__ pairs, uint32_t n_pairs,
-    const uint32_t* __restrict__ flags, uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
-    uint32_t* __restrict__ ops_len, float* __restrict__ scores) {
-    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if(pair >= n_pairs) return;
-    const PairDesc pd = pairs[pair];
-    const uint32_t la = pd.la, lb = pd.lb;
-    uint32_t i = la, j = lb;  // matrix coordinates (row 0 / column 0 are the margins)
-    uint64_t pos = pd.ops_off + la + lb;
-    int st;
-    if(la == 0 || lb == 0) {
-        // No body cell: the last cell is a margin cell (align_pair.cc:82-91,130-138).
-        float m = kLowest, d = kLowest, in = kLowest;
-        if(la == 0 && lb == 0) m = 0.0f;
-        if(la > 0) d = (k.ng + k.go) + k.ge * static_cast<float>(la - 1);
-        if(lb > 0) in = k.go + k.ge * static_cast<float>(lb - 1);
-        const float tm = (m + k.ng) + k.ng, td = d + k.gs, ti = (in + k.gs) + k.ng;
-        scores[pair] = fmaxf(fmaxf(tm, td), ti);
-        st = la > 0 ? COATI_HIP_OP_DEL : COATI_HIP_OP_INS;
-    } else {
-        // max_mdi of the terminal-adjusted last cell == its "after match" decision
-        st = state_after(flags, pd.flags_off, la, la - 1, lb - 1, COATI_HIP_OP_MATCH);
-    }
-    while(i > 0 || j > 0) {
-        ops[--pos] = static_cast<uint8_t>(st);
-        if(st == COATI_HIP_OP_MATCH) {
-            --i;
-            --j;
-        } else if(st == COATI_HIP_OP_DEL) {
-            --i;
-        } else {
-            --j;
-        }
-        if(i == 0 && j == 0) break;
-        if(j == 0) {
-            st = COATI_HIP_OP_DEL;  // column 0: only D is finite (align_pair.cc:82-86)
-        } else if(i == 0) {
-            st = COATI_HIP_OP_INS;  // row 0: only I is finite (align_pair.cc:88-90)
-        } else {
-            st = state_after(flags, pd.flags_off, la, i - 1, j - 1, st);
-        }
-    }
-    ops_start[pair] = pos;
-    ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
 }
 
 // Debug: decode one pair's bit-planes into the oracle's byte-per-cell encoding.
@@ -784,20 +803,15 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
         HIP_TRY(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), m->stream));
         const FillShape shape = fill_launch_shape(n);
         if(shape.dynamic_lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_fill_l1),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_l1),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds)));
-        hipLaunchKernelGGL(viterbi_fill_l1, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, m->stream,
+        hipLaunchKernelGGL(viterbi_l1, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, m->stream,
                            m->d_table, m->k, b->d_desc, b->d_order, n, b->d_queue, b->d_a, b->d_b, b->d_flags,
-                           b->d_bnd, b->d_scores);
+                           b->d_bnd, b->d_scores, b->d_ops, b->d_ops_start, b->d_ops_len);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev[1], m->stream));
-    if(n > 0) {
-        hipLaunchKernelGGL(viterbi_walk_l1, dim3((n + 63) / 64), dim3(64), 0, m->stream, m->k, b->d_desc, n,
-                           b->d_flags, b->d_ops, b->d_ops_start, b->d_ops_len, b->d_scores);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(ev[2], m->stream));
+    HIP_TRY(hipEventRecord(ev[2], m->stream));  // (the traceback is fused into the fill kernel)
     b->n_launches += 1;
     b->launched = true;
     return COATI_HIP_OK;
