@@ -13,9 +13,10 @@ all: lib host oracle
 
 lib: $(BUILD)/libcoati_hip.so
 
-$(BUILD)/libcoati_hip.so: coati_amd/csrc/coati_hip.hip include/coati_hip.h
+HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/viterbi_l1.hip coati_amd/csrc/dp_generic.hip
+$(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ coati_amd/csrc/coati_hip.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
 HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc coati_amd/host/capi.cc
 HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc

@@ -1,0 +1,515 @@
+// abi.hip -- host side of the C ABI of include/coati_hip.h: handles, validation,
+// HBM arenas, launches, result transfer.  The kernels live in viterbi_l1.hip,
+// dp_generic.hip and sampleback.hip.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace coati_hip_detail;
+
+namespace {
+
+// Debug: decode one pair's bit-planes into the oracle's byte-per-cell encoding.
+__global__ void decode_flags(const PairDesc* __restrict__ pairs, uint32_t pair,
+                             const uint32_t* __restrict__ flags, uint8_t* __restrict__ out) {
+    const PairDesc pd = pairs[pair];
+    const uint64_t n = static_cast<uint64_t>(pd.la) * pd.lb;
+    for(uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; idx < n;
+        idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
+        const CellAddr ca = cell_addr(pd.flags_off, pd.la, bi, bj);
+        const uint32_t mm = pair_bits(flags, ca, 0), dd = pair_bits(flags, ca, 1), im = im_bit(flags, ca);
+        const uint32_t fm = (mm & 1u) ? 2u : (mm >> 1), fd = (dd & 1u) ? 2u : (dd >> 1);
+        out[idx] = static_cast<uint8_t>(fm | (fd << 2) | ((im ^ 1u) << 4));
+    }
+}
+
+
+// Debug: gather one pair's Forward M/D/I into three row-major la x lb matrices.
+__global__ void decode_mdi(const PairDesc* __restrict__ pairs, uint32_t pair, const float* __restrict__ mdi,
+                           float* __restrict__ out) {
+    const PairDesc pd = pairs[pair];
+    const uint64_t n = static_cast<uint64_t>(pd.la) * pd.lb;
+    for(uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; idx < n;
+        idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
+        for(int mat = 0; mat < 3; ++mat) out[mat * n + idx] = mdi[mdi_index(pd.mdi_off, pd.la, bi, bj, mat)];
+    }
+}
+
+}  // namespace
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if(e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,      \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+    } while(0)
+
+bool device_is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+struct coati_hip_model {
+    int device = 0;
+    int gap_len = 1;
+    GapConsts k{};
+    float* d_table = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+struct coati_hip_batch {
+    coati_hip_model* model = nullptr;
+    uint64_t n_pairs = 0;
+    uint64_t cells = 0;
+    uint64_t ops_total = 0;    // sum(la + lb)
+    uint64_t flag_dwords = 0;  // dwords in the bit-plane arena
+    uint64_t bnd_floats = 0;
+    uint64_t mdi_floats = 0;   // floats the Forward M/D/I arena needs (allocated on first use)
+    uint64_t device_bytes = 0;
+    std::vector<PairDesc> desc;
+    // device
+    PairDesc* d_desc = nullptr;
+    uint32_t* d_order = nullptr;   // pair indices, most cells first
+    uint32_t* d_queue = nullptr;   // ticket counter of the persistent fill kernel
+    uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
+    uint32_t* d_flags = nullptr;
+    float *d_bnd = nullptr, *d_scores = nullptr;
+    float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward
+    bool forward_done = false;
+    uint64_t* d_ops_start = nullptr;
+    uint32_t* d_ops_len = nullptr;
+    static constexpr int kTimingRing = 64;  // launches whose kernel times can still be read back
+    hipEvent_t ev[kTimingRing][3] = {};
+    uint64_t n_launches = 0;
+    bool launched = false;
+};
+
+namespace {
+BatchDeviceView device_view(const coati_hip_batch* b) {
+    const coati_hip_model* m = b->model;
+    return BatchDeviceView{m->d_table,  m->k,      static_cast<uint32_t>(m->gap_len),
+                           b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
+                           b->d_queue,  b->d_a,    b->d_b,
+                           b->d_flags,  b->d_bnd,  b->d_scores,
+                           b->d_ops,    b->d_ops_start, b->d_ops_len,
+                           b->d_mdi,    b->d_final_mdi};
+}
+}  // namespace
+
+extern "C" {
+
+uint32_t coati_hip_version(void) { return (0u << 16) | 1u; }
+
+const char* coati_hip_last_error(void) { return g_error.c_str(); }
+
+int coati_hip_device_count(void) {
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for(int d = 0; d < n; ++d) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+int coati_hip_model_create(const float* table, float no_gap, float gap_stop, float gap_open,
+                           float gap_extend, int gap_len, int device, coati_hip_model_t** out) {
+    if(out == nullptr) return fail(COATI_HIP_EINVAL, "model_create: out is NULL");
+    *out = nullptr;
+    if(table == nullptr) return fail(COATI_HIP_EINVAL, "model_create: table is NULL");
+    if(gap_len < 1) return fail(COATI_HIP_EINVAL, "model_create: gap_len must be >= 1 (got %d)", gap_len);
+    if(gap_len > 8)
+        return fail(COATI_HIP_EINVAL, "model_create: gap_len %d not supported by the GPU path (1..8)", gap_len);
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(COATI_HIP_ENODEVICE, "model_create: no HIP device available");
+    if(device < 0 || device >= n)
+        return fail(COATI_HIP_EINVAL, "model_create: device %d out of range [0,%d)", device, n);
+    if(!device_is_gfx950(device))
+        return fail(COATI_HIP_ENODEVICE, "model_create: device %d is not gfx950 (MI355X)", device);
+    auto* m = new(std::nothrow) coati_hip_model;
+    if(m == nullptr) return fail(COATI_HIP_ENOMEM, "model_create: host allocation failed");
+    m->device = device;
+    m->gap_len = gap_len;
+    m->k = GapConsts{no_gap, gap_stop, gap_open, gap_extend};
+    auto cleanup = [&](int rc) {
+        coati_hip_model_destroy(m);
+        return rc;
+    };
+    hipError_t e;
+    if((e = hipSetDevice(device)) != hipSuccess)
+        return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice: %s", hipGetErrorString(e)));
+    if((e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess)
+        return cleanup(fail(COATI_HIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    const size_t bytes = sizeof(float) * kTabRows * kTabCols;
+    if((e = hipMalloc(&m->d_table, bytes)) != hipSuccess)
+        return cleanup(fail(COATI_HIP_ENOMEM, "hipMalloc(table): %s", hipGetErrorString(e)));
+    if((e = hipMemcpy(m->d_table, table, bytes, hipMemcpyHostToDevice)) != hipSuccess)
+        return cleanup(fail(COATI_HIP_EHIP, "hipMemcpy(table): %s", hipGetErrorString(e)));
+    *out = m;
+    return COATI_HIP_OK;
+}
+
+void coati_hip_model_destroy(coati_hip_model_t* m) {
+    if(m == nullptr) return;
+    (void)hipSetDevice(m->device);
+    if(m->d_table != nullptr) (void)hipFree(m->d_table);
+    if(m->stream != nullptr) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+void coati_hip_batch_destroy(coati_hip_batch_t* b) {
+    if(b == nullptr) return;
+    if(b->model != nullptr) (void)hipSetDevice(b->model->device);
+    void* ptrs[] = {b->d_mdi, b->d_final_mdi, b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
+                    b->d_bnd,  b->d_scores, b->d_ops_start, b->d_ops_len};
+    for(void* p : ptrs)
+        if(p != nullptr) (void)hipFree(p);
+    for(auto& trio : b->ev)
+        for(hipEvent_t e : trio)
+            if(e != nullptr) (void)hipEventDestroy(e);
+    delete b;
+}
+
+int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                           const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                           coati_hip_batch_t** out) {
+    if(out == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: out is NULL");
+    *out = nullptr;
+    if(model == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: model is NULL");
+    if(a_off == nullptr || b_off == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: offsets are NULL");
+    if(n_pairs > 0xffffffffull) return fail(COATI_HIP_EINVAL, "batch_create: too many pairs");
+    const uint64_t a_total = a_off[n_pairs] - a_off[0], b_total = b_off[n_pairs] - b_off[0];
+    if((a_total > 0 && a_cat == nullptr) || (b_total > 0 && b_cat == nullptr))
+        return fail(COATI_HIP_EINVAL, "batch_create: sequence data is NULL");
+
+    auto* b = new(std::nothrow) coati_hip_batch;
+    if(b == nullptr) return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
+    b->model = model;
+    b->n_pairs = n_pairs;
+    auto cleanup = [&](int rc) {
+        coati_hip_batch_destroy(b);
+        return rc;
+    };
+    try {
+        b->desc.resize(n_pairs);
+    } catch(const std::bad_alloc&) {
+        return cleanup(fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed"));
+    }
+    const uint64_t L = static_cast<uint64_t>(model->gap_len);
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: offsets of pair %llu decrease",
+                                static_cast<unsigned long long>(p)));
+        const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+        if(la > 0x7fffff00ull || lb > 0x7fffff00ull)
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: pair %llu too long",
+                                static_cast<unsigned long long>(p)));
+        // process_marginal, src/lib/utils.cc:822-835
+        if(la % 3 != 0 || la % L != 0)
+            return cleanup(fail(COATI_HIP_EINVAL,
+                                "Length of reference sequence must be multiple of 3 and gap unit "
+                                "length. (pair %llu)",
+                                static_cast<unsigned long long>(p)));
+        if(lb % L != 0)
+            return cleanup(fail(COATI_HIP_EINVAL,
+                                "Length of descendant sequence must be multiple of gap unit length. "
+                                "(pair %llu)",
+                                static_cast<unsigned long long>(p)));
+        for(uint64_t q = a_off[p]; q < a_off[p + 1]; ++q)
+            if(a_cat[q] >= kTabRows)
+                return cleanup(fail(COATI_HIP_EINVAL, "batch_create: ancestor code %u out of range (pair %llu)",
+                                    a_cat[q], static_cast<unsigned long long>(p)));
+        for(uint64_t q = b_off[p]; q < b_off[p + 1]; ++q)
+            if(b_cat[q] >= kTabCols)
+                return cleanup(fail(COATI_HIP_EINVAL, "batch_create: descendant code %u out of range (pair %llu)",
+                                    b_cat[q], static_cast<unsigned long long>(p)));
+        PairDesc& d = b->desc[p];
+        d.a_off = a_off[p] - a_off[0];
+        d.b_off = b_off[p] - b_off[0];
+        d.la = static_cast<uint32_t>(la);
+        d.lb = static_cast<uint32_t>(lb);
+        d.flags_off = b->flag_dwords;
+        d.bnd_off = b->bnd_floats;
+        d.ops_off = b->ops_total;
+        d.mdi_off = b->mdi_floats;
+        const uint32_t ns = n_strips(d.lb);
+        if(la > 0 && lb > 0) b->flag_dwords += ns * strip_dwords(d.la);
+        // 128-byte aligned so that no two waves ever share a cache line of it
+        if(ns > 1) b->bnd_floats += ((la + 1) * (3 + 2 * L) + 31) / 32 * 32;  // covers both kernels' layouts
+        if(la > 0 && lb > 0) b->mdi_floats += ns * strip_mdi_floats(d.la);
+        b->ops_total += la + lb;
+        b->cells += la * lb;
+    }
+
+    if(hipSetDevice(model->device) != hipSuccess)
+        return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice failed"));
+    auto dmalloc = [&](void** p, uint64_t bytes) -> hipError_t {
+        if(bytes == 0) bytes = 16;
+        b->device_bytes += bytes;
+        return hipMalloc(p, bytes);
+    };
+#define B_TRY(expr)                                                                             \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if(e_ != hipSuccess)                                                                    \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,  \
+                                "%s failed: %s", #expr, hipGetErrorString(e_)));                \
+    } while(0)
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_desc), n_pairs * sizeof(PairDesc)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_a), a_total));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_b), b_total));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops), b->ops_total));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_flags), b->flag_dwords * sizeof(uint32_t)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_bnd), b->bnd_floats * sizeof(float)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_scores), n_pairs * sizeof(float)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops_start), n_pairs * sizeof(uint64_t)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops_len), n_pairs * sizeof(uint32_t)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_order), n_pairs * sizeof(uint32_t)));
+    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_queue), sizeof(uint32_t)));
+    if(n_pairs > 0) {
+        B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
+        // longest-processing-time-first order for the dynamic queue
+        std::vector<uint32_t> order(n_pairs);
+        for(uint64_t p = 0; p < n_pairs; ++p) order[p] = static_cast<uint32_t>(p);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
+        });
+        B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
+    if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));
+    for(auto& trio : b->ev)
+        for(auto& e : trio) B_TRY(hipEventCreate(&e));
+#undef B_TRY
+    *out = b;
+    return COATI_HIP_OK;
+}
+
+uint64_t coati_hip_batch_device_bytes(const coati_hip_batch_t* b) { return b ? b->device_bytes : 0; }
+uint64_t coati_hip_batch_cells(const coati_hip_batch_t* b) { return b ? b->cells : 0; }
+
+int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_launch: batch is NULL");
+    coati_hip_model* m = b->model;
+    HIP_TRY(hipSetDevice(m->device));
+    const uint32_t n = static_cast<uint32_t>(b->n_pairs);
+    hipEvent_t* ev = b->ev[b->n_launches % coati_hip_batch::kTimingRing];
+    HIP_TRY(hipEventRecord(ev[0], m->stream));
+    if(n > 0) {
+        const BatchDeviceView v = device_view(b);
+        static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+        if(m->gap_len == 1 && !force_generic)
+            HIP_TRY(launch_viterbi_l1(v, m->stream));
+        else
+            HIP_TRY(launch_dp_generic(v, /*forward=*/false, m->stream));
+    }
+    HIP_TRY(hipEventRecord(ev[1], m->stream));
+    HIP_TRY(hipEventRecord(ev[2], m->stream));  // (the traceback is fused into the fill kernel)
+    b->n_launches += 1;
+    b->launched = true;
+    return COATI_HIP_OK;
+}
+
+int coati_hip_batch_sync(coati_hip_batch_t* b) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "batch_sync: batch is NULL");
+    HIP_TRY(hipSetDevice(b->model->device));
+    HIP_TRY(hipStreamSynchronize(b->model->stream));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_fetch(coati_hip_batch_t* b, float* scores, uint8_t* ops, uint64_t ops_capacity,
+                            uint64_t* ops_off, uint32_t* ops_len) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_fetch: batch is NULL");
+    if(!b->launched) return fail(COATI_HIP_ESTATE, "viterbi_fetch: nothing was launched");
+    if(ops != nullptr && ops_capacity < b->ops_total)
+        return fail(COATI_HIP_EINVAL, "viterbi_fetch: ops_capacity %llu < %llu",
+                    static_cast<unsigned long long>(ops_capacity),
+                    static_cast<unsigned long long>(b->ops_total));
+    int rc = coati_hip_batch_sync(b);
+    if(rc != COATI_HIP_OK) return rc;
+    const uint64_t n = b->n_pairs;
+    if(n == 0) return COATI_HIP_OK;
+    if(scores != nullptr) HIP_TRY(hipMemcpy(scores, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost));
+    if(ops != nullptr && b->ops_total > 0) HIP_TRY(hipMemcpy(ops, b->d_ops, b->ops_total, hipMemcpyDeviceToHost));
+    if(ops_off != nullptr)
+        HIP_TRY(hipMemcpy(ops_off, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if(ops_len != nullptr)
+        HIP_TRY(hipMemcpy(ops_len, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_batch_result_ptrs(coati_hip_batch_t* b, void** scores, void** ops, uint64_t* ops_bytes,
+                                void** ops_off, void** ops_len) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "batch_result_ptrs: batch is NULL");
+    if(scores != nullptr) *scores = b->d_scores;
+    if(ops != nullptr) *ops = b->d_ops;
+    if(ops_bytes != nullptr) *ops_bytes = b->ops_total;
+    if(ops_off != nullptr) *ops_off = b->d_ops_start;
+    if(ops_len != nullptr) *ops_len = b->d_ops_len;
+    return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_timing(coati_hip_batch_t* b, uint32_t launches_back, float* fill_ms, float* walk_ms) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_timing: batch is NULL");
+    if(!b->launched) return fail(COATI_HIP_ESTATE, "viterbi_timing: nothing was launched");
+    if(launches_back >= coati_hip_batch::kTimingRing || launches_back >= b->n_launches)
+        return fail(COATI_HIP_EINVAL, "viterbi_timing: launch %u back is not recorded", launches_back);
+    int rc = coati_hip_batch_sync(b);
+    if(rc != COATI_HIP_OK) return rc;
+    hipEvent_t* ev = b->ev[(b->n_launches - 1 - launches_back) % coati_hip_batch::kTimingRing];
+    float f = 0.f, w = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&w, ev[1], ev[2]));
+    if(fill_ms != nullptr) *fill_ms = f;
+    if(walk_ms != nullptr) *walk_ms = w;
+    return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_last_timing(coati_hip_batch_t* b, float* fill_ms, float* walk_ms) {
+    return coati_hip_viterbi_timing(b, 0, fill_ms, walk_ms);
+}
+
+int coati_hip_forward_launch(coati_hip_batch_t* b) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "forward_launch: batch is NULL");
+    coati_hip_model* m = b->model;
+    HIP_TRY(hipSetDevice(m->device));
+    if(b->d_mdi == nullptr) {  // the 12 B/cell arena is only reserved when Forward is actually used
+        const uint64_t bytes = std::max<uint64_t>(b->mdi_floats * sizeof(float), 16);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_mdi), bytes);
+        if(e != hipSuccess)
+            return fail(COATI_HIP_ENOMEM, "forward_launch: %llu bytes for the Forward matrices: %s",
+                        static_cast<unsigned long long>(bytes), hipGetErrorString(e));
+        b->device_bytes += bytes;
+        const uint64_t fb = std::max<uint64_t>(b->n_pairs * 3 * sizeof(float), 16);
+        e = hipMalloc(reinterpret_cast<void**>(&b->d_final_mdi), fb);
+        if(e != hipSuccess) return fail(COATI_HIP_ENOMEM, "forward_launch: %s", hipGetErrorString(e));
+        b->device_bytes += fb;
+    }
+    if(b->n_pairs > 0) HIP_TRY(launch_dp_generic(device_view(b), /*forward=*/true, m->stream));
+    b->forward_done = true;
+    return COATI_HIP_OK;
+}
+
+int coati_hip_forward_final(coati_hip_batch_t* b, float* final_mdi) {
+    if(b == nullptr || final_mdi == nullptr) return fail(COATI_HIP_EINVAL, "forward_final: NULL argument");
+    if(!b->forward_done) return fail(COATI_HIP_ESTATE, "forward_final: forward was not launched");
+    int rc = coati_hip_batch_sync(b);
+    if(rc != COATI_HIP_OK) return rc;
+    if(b->n_pairs > 0)
+        HIP_TRY(hipMemcpy(final_mdi, b->d_final_mdi, b->n_pairs * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_debug_forward_matrices(coati_hip_batch_t* b, uint64_t pair, float* M, float* D, float* I,
+                                     uint64_t capacity) {
+    if(b == nullptr || M == nullptr || D == nullptr || I == nullptr)
+        return fail(COATI_HIP_EINVAL, "debug_forward_matrices: NULL argument");
+    if(!b->forward_done) return fail(COATI_HIP_ESTATE, "debug_forward_matrices: forward was not launched");
+    if(pair >= b->n_pairs) return fail(COATI_HIP_EINVAL, "debug_forward_matrices: pair out of range");
+    const uint64_t n = static_cast<uint64_t>(b->desc[pair].la) * b->desc[pair].lb;
+    if(capacity < n) return fail(COATI_HIP_EINVAL, "debug_forward_matrices: capacity too small");
+    if(n == 0) return COATI_HIP_OK;
+    int rc = coati_hip_batch_sync(b);
+    if(rc != COATI_HIP_OK) return rc;
+    float* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), 3 * n * sizeof(float)));
+    hipLaunchKernelGGL(decode_mdi, dim3(static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 4096))), dim3(256), 0,
+                       b->model->stream, b->d_desc, static_cast<uint32_t>(pair), b->d_mdi, d_out);
+    hipError_t e = hipStreamSynchronize(b->model->stream);
+    if(e == hipSuccess) e = hipMemcpy(M, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+    if(e == hipSuccess) e = hipMemcpy(D, d_out + n, n * sizeof(float), hipMemcpyDeviceToHost);
+    if(e == hipSuccess) e = hipMemcpy(I, d_out + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if(e != hipSuccess) return fail(COATI_HIP_EHIP, "debug_forward_matrices: %s", hipGetErrorString(e));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                            const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                            float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off,
+                            uint32_t* ops_len) {
+    if(model == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_batch: model is NULL");
+    if(a_off == nullptr || b_off == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets are NULL");
+    HIP_TRY(hipSetDevice(model->device));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = static_cast<uint64_t>(free_b * 0.8);
+    uint64_t ops_base = 0;  // slot start of the first pair of the current chunk
+    uint64_t p0 = 0;
+    while(p0 < n_pairs) {
+        // grow the chunk until the workspace estimate exceeds the budget
+        uint64_t p1 = p0, need = 0, chunk_ops = 0;
+        while(p1 < n_pairs) {
+            const uint64_t la = a_off[p1 + 1] - a_off[p1], lb = b_off[p1 + 1] - b_off[p1];
+            const uint64_t w = (la > 0 && lb > 0) ? n_strips(static_cast<uint32_t>(lb)) * strip_dwords(static_cast<uint32_t>(la)) * 4 : 0;
+            const uint64_t add = w + 3 * (la + lb) + 8 * (la + 1) + 128;
+            if(p1 > p0 && need + add > budget) break;
+            need += add;
+            chunk_ops += la + lb;
+            ++p1;
+        }
+        coati_hip_batch_t* b = nullptr;
+        int rc = coati_hip_batch_create(model, p1 - p0, a_cat, a_off + p0, b_cat, b_off + p0, &b);
+        if(rc != COATI_HIP_OK) return rc;
+        rc = coati_hip_viterbi_launch(b);
+        if(rc == COATI_HIP_OK)
+            rc = coati_hip_viterbi_fetch(b, scores ? scores + p0 : nullptr, ops ? ops + ops_base : nullptr,
+                                         ops ? ops_capacity - ops_base : 0, ops_off ? ops_off + p0 : nullptr,
+                                         ops_len ? ops_len + p0 : nullptr);
+        coati_hip_batch_destroy(b);
+        if(rc != COATI_HIP_OK) return rc;
+        if(ops_off != nullptr)
+            for(uint64_t p = p0; p < p1; ++p) ops_off[p] += ops_base;
+        ops_base += chunk_ops;
+        p0 = p1;
+    }
+    return COATI_HIP_OK;
+}
+
+int coati_hip_debug_viterbi_flags(coati_hip_batch_t* b, uint64_t pair, uint8_t* out, uint64_t capacity) {
+    if(b == nullptr || out == nullptr) return fail(COATI_HIP_EINVAL, "debug_viterbi_flags: NULL argument");
+    if(!b->launched) return fail(COATI_HIP_ESTATE, "debug_viterbi_flags: nothing was launched");
+    if(pair >= b->n_pairs) return fail(COATI_HIP_EINVAL, "debug_viterbi_flags: pair out of range");
+    const uint64_t n = static_cast<uint64_t>(b->desc[pair].la) * b->desc[pair].lb;
+    if(capacity < n) return fail(COATI_HIP_EINVAL, "debug_viterbi_flags: capacity too small");
+    if(n == 0) return COATI_HIP_OK;
+    int rc = coati_hip_batch_sync(b);
+    if(rc != COATI_HIP_OK) return rc;
+    uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n));
+    hipLaunchKernelGGL(decode_flags, dim3(static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 4096))),
+                       dim3(256), 0, b->model->stream, b->d_desc, static_cast<uint32_t>(pair), b->d_flags, d_out);
+    hipError_t e = hipStreamSynchronize(b->model->stream);
+    if(e == hipSuccess) e = hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if(e != hipSuccess) return fail(COATI_HIP_EHIP, "debug_viterbi_flags: %s", hipGetErrorString(e));
+    return COATI_HIP_OK;
+}
+
+}  // extern "C"

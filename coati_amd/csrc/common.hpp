@@ -1,0 +1,259 @@
+// Shared definitions of libcoati_hip.so: constants, the per-pair descriptor, the
+// HBM layouts, the decision-bit lookups and the wave-cooperative traceback
+// walker (used by both Viterbi kernels).
+#ifndef COATI_HIP_COMMON_HPP
+#define COATI_HIP_COMMON_HPP
+
+#include "coati_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+namespace coati_hip_detail {
+
+constexpr int kWave = 64;
+constexpr int kW = 16;                       // columns per lane
+constexpr int kStrip = kWave * kW;           // columns per strip (1024)
+constexpr int kTabRows = COATI_HIP_TABLE_ROWS;
+constexpr int kTabCols = COATI_HIP_TABLE_COLS;
+constexpr int kTabStride = 17;               // LDS row stride in floats (bank spread, measured)
+constexpr int kPairDwords = 5 * kWave;       // dwords one pair of wavefront steps stores (320)
+constexpr int kFillWaves = 4;                // sequence pairs per workgroup
+constexpr float kLowest = -FLT_MAX;          // semiring zero(), semiring.hpp:83,113
+
+// Decision bits per cell.  Bit = 1 means:
+//   M1: D beats M after a match move     (max_mdi first test,  align_pair.cc:213-216)
+//   M2: I beats max(M,D) after a match   (max_mdi second test, align_pair.cc:217-219)
+//   D1, D2: the same two tests after a deletion move (align_pair.cc:285-287)
+//   IM: M beats I after an insertion move (max_mi, align_pair.cc:230-232; tie -> I)
+// Three per-lane accumulators: A = (M1,M2) pairs, B = (D1,D2) pairs, C = IM.
+enum : int { ACC_A = 0, ACC_B = 1, ACC_C = 2, kAccs = 3 };
+
+struct GapConsts {
+    float ng, gs, go, ge;  // no_gap, gap_stop, gap_open, gap_extend (log space)
+};
+
+struct PairDesc {
+    uint64_t a_off, b_off;  // into the concatenated code arrays
+    uint64_t flags_off;     // dwords into the bit-plane arena
+    uint64_t bnd_off;       // floats into the strip-boundary arena
+    uint64_t ops_off;       // slot start in the ops arena (slot = la + lb bytes)
+    uint64_t mdi_off;       // floats into the Forward M/D/I arena
+    uint32_t la, lb;
+};
+
+// HBM layout of the decision bits of one strip (1024 columns) of one pair, per
+// pair of wavefront steps kp = k >> 1 (k = body_row + lane), 320 dwords:
+//   [kp*320 +   0 + lane]  A of the even step     [kp*320 + 128 + lane]  A of the odd step
+//   [kp*320 +  64 + lane]  B of the even step     [kp*320 + 192 + lane]  B of the odd step
+//   [kp*320 + 256 + lane]  C: bits 31..16 even step, 15..0 odd step
+// In A/B the lane's column c (0..15) holds its first test at bit 31-2c and its
+// second at bit 30-2c; in C column c is bit 15-c of its half.
+// Every store is a fully coalesced 256-byte row: 5 bits per DP cell.
+__host__ __device__ inline uint64_t strip_dwords(uint32_t la) {
+    return static_cast<uint64_t>((la + kWave) / 2) * kPairDwords;
+}
+__host__ __device__ inline uint32_t n_strips(uint32_t lb) { return (lb + kStrip - 1) / kStrip; }
+
+// lane l receives lane l-1's `v`; lane 0 receives `lane0` (DPP keeps `old` where
+// the shift has no source lane).
+__device__ __forceinline__ float shift_in(float v, float lane0) {
+    const int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0), __builtin_bit_cast(int, v),
+                                              0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ uint32_t shift_in(uint32_t v, uint32_t lane0) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(lane0), static_cast<int>(v),
+                                                             0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
+
+// ---------------------------------------------------------------------------
+// decision-bit lookups (layout above); (bi, bj) are BODY coordinates
+// ---------------------------------------------------------------------------
+struct CellAddr {
+    uint64_t pair_base;  // dword index of the step pair
+    uint32_t odd, t, c;
+};
+__device__ __forceinline__ CellAddr cell_addr(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj) {
+    const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
+    const uint32_t kstep = bi + t;
+    return {base + strip * strip_dwords(la) + static_cast<uint64_t>(kstep >> 1) * kPairDwords, kstep & 1u, t, c};
+}
+// two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
+__device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
+    const uint32_t w = flags[ca.pair_base + ca.odd * (2 * kWave) + which * kWave + ca.t];
+    return (w >> (30 - 2 * ca.c)) & 3u;  // bit1 = first test, bit0 = second test
+}
+__device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
+    const uint32_t w = flags[ca.pair_base + 4 * kWave + ca.t];
+    return (w >> ((ca.odd ? 0u : 16u) + (kW - 1 - ca.c))) & 1u;
+}
+// state entered after a move of kind `moved` arrives at body cell (bi, bj)
+__device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, uint64_t base,
+                                           uint32_t la, uint32_t bi, uint32_t bj, int moved) {
+    const CellAddr ca = cell_addr(base, la, bi, bj);
+    if(moved == COATI_HIP_OP_INS) return im_bit(flags, ca) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+    const uint32_t two = pair_bits(flags, ca, moved == COATI_HIP_OP_DEL ? 1 : 0);
+    if(two & 1u) return COATI_HIP_OP_INS;  // second test: I beats max(M,D)
+    return (two & 2u) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
+}
+
+// ---------------------------------------------------------------------------
+// margins (align_pair.cc:82-91): values of matrix cell (i, j) with i < L or j < L
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void margin_mdi(const GapConsts& k, uint32_t L, uint32_t i, uint32_t j, float& m,
+                                           float& d, float& in) {
+    const uint32_t start = L - 1;
+    m = d = in = kLowest;
+    if(i == start && j == start) m = 0.0f;
+    if(j == start && i > start && (i - start) % L == 0) d = (k.ng + k.go) + k.ge * static_cast<float>(i - 1);
+    if(i == start && j > start && (j - start) % L == 0) in = k.go + k.ge * static_cast<float>(j - 1);
+}
+// max_mdi (align_pair.cc:210-224): ties M over D over I
+__device__ __forceinline__ int max_mdi(float cm, float cd, float ci) {
+    int w = COATI_HIP_OP_MATCH;
+    float best = cm;
+    if(cd > best) {
+        best = cd;
+        w = COATI_HIP_OP_DEL;
+    }
+    return ci > best ? COATI_HIP_OP_INS : w;
+}
+// the three "which state next" rules of align_pair.cc:275-296 on a cell's M/D/I
+__device__ __forceinline__ int decide_after(const GapConsts& k, int moved, float m, float d, float in) {
+    if(moved == COATI_HIP_OP_INS) return (m + k.go) > (in + k.ge) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+    if(moved == COATI_HIP_OP_MATCH) return max_mdi((m + k.ng) + k.ng, d + k.gs, (in + k.gs) + k.ng);
+    return max_mdi((m + k.ng) + k.go, d + k.ge, (in + k.gs) + k.go);
+}
+
+constexpr int kWalkEnd = 3;
+// State the reference's walk is in after arriving at MATRIX cell (i, j) by a move of
+// kind `moved`: body cells from the stored bits, margin cells by formula.
+__device__ __forceinline__ int arrival_state(const GapConsts& k, uint32_t L, const uint32_t* __restrict__ flags,
+                                             uint64_t base, uint32_t la, uint32_t i, uint32_t j, int moved) {
+    if(i < L && j < L) return kWalkEnd;  // loop condition of align_pair.cc:268
+    if(i >= L && j >= L) return state_after(flags, base, la, i - L, j - L, moved);
+    float m, d, in;
+    margin_mdi(k, L, i, j, m, d, in);
+    return decide_after(k, moved, m, d, in);
+}
+
+// traceback<tropical> (align_pair.cc:249-303) by one WAVEFRONT.
+// A walk is a chain of dependent loads, but it consists of long runs of the same
+// move.  So the 64 lanes speculate: lane l looks up the state the walk would be
+// in after l+1 further moves of the current kind; a ballot finds the first lane
+// where the run ends; all moves up to there are emitted at once (coalesced
+// byte stores) and the walk jumps.  Memory round trips per pair drop from
+// len_a+len_b to about (number of runs + length/64).
+// Ops (one byte per alignment column; a gap move emits L of them) are written
+// right-to-left into the pair's slot so they end up in alignment order.  All
+// lanes must call this (it uses ballots).  `start_state` is max_mdi of the
+// terminal-adjusted last cell.
+__device__ __forceinline__ void walk_pair(int lane, const GapConsts& k, uint32_t L, const PairDesc& pd,
+                                          uint32_t pair, int start_state, const uint32_t* __restrict__ flags,
+                                          uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
+                                          uint32_t* __restrict__ ops_len) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    uint32_t i = la + L - 1, j = lb + L - 1;  // matrix coordinates of the last cell
+    uint64_t pos = pd.ops_off + la + lb;
+    int st = (i < L && j < L) ? kWalkEnd : start_state;
+    while(st != kWalkEnd) {
+        const uint32_t di = st == COATI_HIP_OP_MATCH ? 1u : (st == COATI_HIP_OP_DEL ? L : 0u);
+        const uint32_t dj = st == COATI_HIP_OP_MATCH ? 1u : (st == COATI_HIP_OP_INS ? L : 0u);
+        const uint32_t width = st == COATI_HIP_OP_MATCH ? 1u : L;  // alignment columns per move
+        // lane l: where the walk is after l+1 more moves of kind st, and in which state
+        const uint32_t step = static_cast<uint32_t>(lane) + 1u;
+        const bool valid = di * step <= i && dj * step <= j;
+        int next = kWalkEnd;
+        if(valid) next = arrival_state(k, L, flags, pd.flags_off, la, i - di * step, j - dj * step, st);
+        if(di > i || dj > j) break;  // cannot happen for decision bits of a finite path; never walk off the matrix
+        const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
+        const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
+        const uint32_t moves = run == kWave ? kWave : run + 1u;
+        for(uint32_t q = lane; q < moves * width; q += kWave) ops[pos - 1 - q] = static_cast<uint8_t>(st);
+        pos -= static_cast<uint64_t>(moves) * width;
+        i -= di * moves;
+        j -= dj * moves;
+        if(run < kWave) st = __builtin_amdgcn_readlane(next, static_cast<int>(run));
+    }
+    if(lane == 0) {
+        ops_start[pair] = pos;
+        ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
+    }
+}
+
+// Terminal adjustment (align_pair.cc:130-138) + score + max_mdi of a last cell with
+// UNADJUSTED values (m, d, in).
+__device__ __forceinline__ int terminal_state(const GapConsts& k, float m, float d, float in, float& score) {
+    const float tm = (m + k.ng) + k.ng, td = d + k.gs, ti = (in + k.gs) + k.ng;
+    score = fmaxf(fmaxf(tm, td), ti);
+    return max_mdi(tm, td, ti);
+}
+
+// Viterbi epilogue of one pair (all lanes): start state + score where the fill did
+// not produce them (no body cells), then the walk.
+__device__ __forceinline__ void viterbi_finish(int lane, const GapConsts& k, uint32_t L, const PairDesc& pd,
+                                               uint32_t pair, const uint32_t* __restrict__ flags,
+                                               uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
+                                               uint32_t* __restrict__ ops_len, float* __restrict__ scores) {
+    int start_state;
+    if(pd.la > 0 && pd.lb > 0) {
+        // max_mdi of the terminal-adjusted last cell == its "after match" decision
+        start_state = __builtin_amdgcn_readfirstlane(
+            state_after(flags, pd.flags_off, pd.la, pd.la - 1, pd.lb - 1, COATI_HIP_OP_MATCH));
+    } else {
+        float m, d, in, score;
+        margin_mdi(k, L, pd.la + L - 1, pd.lb + L - 1, m, d, in);
+        start_state = terminal_state(k, m, d, in, score);
+        if(lane == 0) scores[pair] = score;
+    }
+    walk_pair(lane, k, L, pd, pair, start_state, flags, ops, ops_start, ops_len);
+}
+
+// Forward: HBM layout of the fp32 M/D/I of the body cells of one strip of one pair:
+//   float[((k * 3 + mat) * 16 + c) * 64 + lane], k = wavefront step = body_row + lane,
+//   mat 0/1/2 = M/D/I, c = the lane's column.  Every (k, mat, c) is one coalesced
+//   256-byte row.  12 bytes per cell.
+constexpr int kMdiStepFloats = 3 * kW * kWave;  // 3072
+__host__ __device__ inline uint64_t strip_mdi_floats(uint32_t la) {
+    return static_cast<uint64_t>(la + kWave) * kMdiStepFloats;
+}
+__device__ __forceinline__ uint64_t mdi_index(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj, int mat) {
+    const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
+    return base + strip * strip_mdi_floats(la) + ((static_cast<uint64_t>(bi + t) * 3 + mat) * kW + c) * kWave + t;
+}
+
+// ---------------------------------------------------------------------------
+// launchers implemented in the kernel translation units
+// ---------------------------------------------------------------------------
+struct BatchDeviceView {
+    const float* table;
+    GapConsts k;
+    uint32_t gap_len;
+    const PairDesc* pairs;
+    const uint32_t* order;
+    uint32_t n_pairs;
+    uint32_t* queue;
+    const uint8_t *a_cat, *b_cat;
+    uint32_t* flags;
+    float* bnd;
+    float* scores;
+    uint8_t* ops;
+    uint64_t* ops_start;
+    uint32_t* ops_len;
+    float* mdi;        // Forward: fp32 M/D/I of every body cell
+    float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
+};
+hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
+hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
+
+}  // namespace coati_hip_detail
+#endif

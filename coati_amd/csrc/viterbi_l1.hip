@@ -1,0 +1,380 @@
+// viterbi_l1: the hand-scheduled Viterbi kernel for gap_len == 1 (the default and
+// by far the common case): persistent wavefronts, one sequence pair at a time
+// per wavefront, fill + fused traceback.
+//
+// What it replaces in the reference (all CPU, one pair per process):
+//   forward_impl<tropical, align_pair_work_mem_t>   src/lib/align_pair.cc:62-139
+//   traceback<tropical> / max_mdi / max_mi          src/lib/align_pair.cc:210-303
+//
+// Design (DESIGN.md has the derivations and the measurements):
+//   * a lane owns 16 consecutive descendant columns and walks down the ancestor
+//     rows, skewed by one row per lane (anti-diagonal wavefront).  All M/D/I
+//     state lives in registers; no fp32 matrix ever reaches memory.
+//   * neighbour hand-off between lanes is a DPP `wave_shr:1` move (no LDS).
+//   * the 183x15 substitution table is staged in LDS (row stride 17 floats so
+//     that a wave's 64 different rows spread over the 32 banks).
+//   * the traceback is NOT an arg-max recorded in the fill.  The reference
+//     re-derives each decision from the stored scores of the cell it arrives at
+//     (align_pair.cc:275-296), so the kernel evaluates exactly those five
+//     comparisons per cell (as the sign of a subtraction, deposited with
+//     v_alignbit) and stores 5 bits per cell in coalesced 256-byte rows.
+//   * the same wavefront then walks its pair's bits (common.hpp: walk_pair).
+//
+// fp32 only, adds/max/compares in the reference's evaluation order; built with
+// -ffp-contract=off -fno-slp-vectorize.
+#include "common.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace coati_hip_detail {
+namespace {
+
+// Register state of one lane: its 16 columns of the row it processed last.
+struct LaneState {
+    float X[kW];  // max((M+ng)+ng, D+gs, (I+gs)+ng): feeds M of the next diagonal cell
+    float Y[kW];  // max((M+ng)+go, D+ge, (I+gs)+go): the D value of the cell below (gap_len 1)
+    float xlast_old;  // X[15] of the row before: the right neighbour's diagonal input
+    float zlast;      // max(M+go, I+ge) of column 15: the right neighbour's I value
+    uint32_t acc[kAccs];    // decision bits, shifted in cell by cell
+};
+
+// One DP cell for gap_len == 1 (align_pair.cc:97-124 with look_back = 1, where
+// power(gap_extend, 0) is -0.0f and adding it is the identity).  Because fp32
+// addition is monotone, max(x1+s, x2+s, x3+s) == max(x1,x2,x3)+s bit for bit,
+// so M = X(diagonal cell) + s.
+//
+// The five decisions are max_mdi / max_mi (align_pair.cc:210-232) on the
+// expressions of align_pair.cc:275-296.  Each `p > q` is taken as the sign bit
+// of q - p: exact, because fp32 subtraction of two finite numbers is zero only
+// when they are equal (gradual underflow is on) and no -0.0f occurs here.  On
+// gfx950 v_sub_f32 issues at twice the rate of v_cmp_f32 and the bit is
+// deposited with a single v_alignbit_b32 (measured: tools/ubench).
+// One DP cell = ONE asm block of 27 VALU instructions with a fixed order and a
+// hand register allocation.  Why not leave it to the compiler (all measured or
+// observed):
+//  * on gfx950 v_add/v_sub_f32 and v_add_u32 issue every 2 cycles, v_max_f32 and
+//    v_alignbit_b32 have a 4-cycle initiation interval; a slow op costs nothing
+//    extra only if fast ops sit on both sides of it.  The order below alternates
+//    them (F/S) and keeps every consumer >= 2 instructions behind its producer.
+//  * hipcc batches the X/Y maxes of a whole row (32 back-to-back v_max), and once
+//    values are opaque adds canonicalising v_max around every fmaxf (IEEE mode);
+//    between adjacent dependent inline-asm statements the hazard recognizer
+//    inserts s_nop.  One block per cell has none of that.
+// No instruction here has a software-visible hazard (no trans ops, no DPP or
+// readlane consumer inside).  The deposit of the cell's last decision (D2) is
+// carried in `pend` into the next cell; the LDS address of this column's score
+// for the NEXT wavefront step is computed here, the ds_read is issued by the
+// compiler right after the block (so that it also places the s_waitcnt).
+#define COATI_CELL_HEAD                                                                     \
+    "v_add_f32 %[t0], %[diag], %[s]\n\t"      /* F  M  = diag + s                        */ \
+    "v_add_f32 %[t1], %[ge], %[zl]\n\t"       /* F  z2 = I + ge                          */
+#define COATI_CELL_PEND                                                                     \
+    "v_alignbit_b32 %[aB], %[aB], %[pend], 31\n\t" /* S  D2 of the previous cell         */
+#define COATI_CELL_BODY                                                                     \
+    "v_add_f32 %[t2], %[gs], %[zl]\n\t"       /* F  i1 = I + gs                          */ \
+    "v_add_f32 %[t3], %[go], %[t0]\n\t"       /* F  z1 = M + go                          */ \
+    "v_add_f32 %[t0], %[ng], %[t0]\n\t"       /* F  m1 = M + ng                          */ \
+    "v_max_f32 %[zl], %[t3], %[t1]\n\t"       /* S  Z  = max(z1,z2) -> I of next column  */ \
+    "v_add_f32 %[t4], %[ng], %[t0]\n\t"       /* F  x1 = m1 + ng                         */ \
+    "v_add_f32 %[t5], %[gs], %[y]\n\t"        /* F  x2 = D + gs                          */ \
+    "v_sub_f32 %[t1], %[t1], %[t3]\n\t"       /* F  z2 - z1  (sign: z1 > z2)             */ \
+    "v_max_f32 %[t3], %[t4], %[t5]\n\t"       /* S  xm = max(x1,x2)                      */ \
+    "v_add_f32 %[pend], %[ng], %[t2]\n\t"     /* F  x3 = i1 + ng                         */ \
+    "v_alignbit_b32 %[aC], %[aC], %[t1], 31\n\t" /* S  IM                                */ \
+    "v_sub_f32 %[t1], %[t4], %[t5]\n\t"       /* F  x1 - x2  (sign: x2 > x1)             */ \
+    "v_max_f32 %[x], %[t3], %[pend]\n\t"      /* S  X  = max(xm,x3)                      */ \
+    "v_sub_f32 %[t4], %[t3], %[pend]\n\t"     /* F  xm - x3  (sign: x3 > xm)             */ \
+    "v_add_f32 %[t5], %[go], %[t0]\n\t"       /* F  y1 = m1 + go                         */ \
+    "v_alignbit_b32 %[aA], %[aA], %[t1], 31\n\t" /* S  M1                                */ \
+    "v_add_f32 %[t1], %[ge], %[y]\n\t"        /* F  y2 = D + ge                          */ \
+    "v_add_f32 %[t3], %[go], %[t2]\n\t"       /* F  y3 = i1 + go                         */ \
+    "v_max_f32 %[t0], %[t5], %[t1]\n\t"       /* S  ym = max(y1,y2)                      */ \
+    "v_sub_f32 %[t2], %[t5], %[t1]\n\t"       /* F  y1 - y2  (sign: y2 > y1)             */ \
+    "v_alignbit_b32 %[aA], %[aA], %[t4], 31\n\t" /* S  M2                                */ \
+    "v_add_u32 %[addr], %[lds], %[boff]\n\t"  /* F  LDS address of next step's score     */ \
+    "v_max_f32 %[y], %[t0], %[t3]\n\t"        /* S  Y  = max(ym,y3)                      */ \
+    "v_sub_f32 %[pend], %[t0], %[t3]\n\t"     /* F  ym - y3  (sign: y3 > ym), carried    */ \
+    "v_alignbit_b32 %[aB], %[aB], %[t2], 31"  /* S  D1                                   */
+
+template <int C>
+__device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState& st, float& diag, float& zl, float& pend,
+                                        float& s, uint32_t lds_next_row, uint32_t boff) {
+    float x_new, t0, t1, t2, t3, t4, t5;
+    uint32_t addr;
+#define COATI_CELL_OPERANDS                                                                              \
+    : [x] "=&v"(x_new), [y] "+v"(st.Y[C]), [zl] "+v"(zl), [pend] "+v"(pend), [aA] "+v"(st.acc[ACC_A]),   \
+      [aB] "+v"(st.acc[ACC_B]), [aC] "+v"(st.acc[ACC_C]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
+      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [addr] "=&v"(addr)                                  \
+    : [diag] "v"(diag), [s] "v"(s), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng),          \
+      [gs] "s"(k.gs), [go] "s"(k.go), [ge] "s"(k.ge)
+    if constexpr(C > 0) {
+        asm volatile(COATI_CELL_HEAD COATI_CELL_PEND COATI_CELL_BODY COATI_CELL_OPERANDS);
+    } else {
+        asm volatile(COATI_CELL_HEAD COATI_CELL_BODY COATI_CELL_OPERANDS);
+    }
+#undef COATI_CELL_OPERANDS
+    diag = st.X[C];  // the next column's diagonal input is this column's previous-row X
+    st.X[C] = x_new;
+    // s was consumed by the block's first instruction: reuse it for the next step's score
+    s = *reinterpret_cast<const __attribute__((address_space(3))) float*>(addr);
+}
+
+template <int... C>
+__device__ __forceinline__ void row_l1(const GapConsts& k, LaneState& st, float diag, float zl,
+                                       float (&s)[kW], uint32_t lds_next_row, const uint32_t (&boff)[kW],
+                                       std::integer_sequence<int, C...>) {
+    st.xlast_old = st.X[kW - 1];
+    float pend = 0.0f;
+    (cell_l1<C>(k, st, diag, zl, pend, s[C], lds_next_row, boff[C]), ...);
+    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(st.acc[ACC_B]) : "v"(pend));  // D2 of column 15
+    st.zlast = zl;
+}
+
+
+// Read-only per-strip context of one wavefront.
+struct StripCtx {
+    GapConsts k;
+    uint32_t la, col0, nsteps, pair, lds_tab;
+    int lane, last_lane, last_c;
+    bool last_strip;
+    uint32_t* fout;
+    float *bnd_x, *bnd_z, *scores;
+};
+
+// Up to 64 wavefront steps.  kFirst: chunk 0 only, where lane l starts (takes its
+// margin-row state) at step l.  The main loop is a separate instantiation so
+// that it carries no trace of the start-up code (spill reloads there would put
+// an s_waitcnt vmcnt(0) -- a wait for the previous step's HBM stores -- into
+// every step).
+template <bool kFirst>
+__device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uint32_t& arow, float (&s)[kW],
+                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float bx,
+                                          float bz) {
+    const GapConsts& k = cx.k;
+    const int lane = cx.lane;
+    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    for(uint32_t kk = 0; kk < kend; ++kk) {
+        const uint32_t kstep = kbase + kk;
+        if constexpr(kFirst) {
+            if(kk == static_cast<uint32_t>(lane)) {
+                // This lane starts now: state of the margin row (matrix row 0,
+                // align_pair.cc:88-90): M = D = lowest, I = go + ge*float(j-1).
+                uint32_t bj0 = cx.col0 + lane * kW;
+                asm volatile("" : "+v"(bj0));  // compute in place: hoisted, these 32 values get spilled
+#pragma unroll
+                for(int c = 0; c < kW; ++c) {
+                    const float im = k.go + k.ge * static_cast<float>(bj0 + c);
+                    const float i1 = im + k.gs;
+                    st.X[c] = i1 + k.ng;
+                    st.Y[c] = i1 + k.go;
+                }
+                if(!cx.last_strip && lane == kWave - 1) cx.bnd_x[0] = st.X[kW - 1];
+            }
+        }
+        // ---- hand-off from the left neighbour (full exec)
+        const float diag = shift_in(st.xlast_old, read_lane(bx, kk));
+        const float zl = shift_in(st.zlast, read_lane(bz, kk));
+        const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
+        // ---- the 16 cells (and the LDS gather for the next step)
+        row_l1(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, kW>{});
+        arow = arow_next;
+        // ---- decision bits: two coalesced 256-byte rows per step, a third every second step
+        {
+            uint32_t* dst = cx.fout + static_cast<uint64_t>(kstep >> 1) * kPairDwords + (kstep & 1u) * (2 * kWave);
+            dst[0] = st.acc[ACC_A];
+            dst[kWave] = st.acc[ACC_B];
+            if(kstep & 1u) dst[2 * kWave] = st.acc[ACC_C];  // = pair base + 256
+        }
+        const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
+        if(!cx.last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(cx.la)) {
+            cx.bnd_x[r + 1] = st.X[kW - 1];
+            cx.bnd_z[r] = st.zlast;
+        }
+        if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
+            // score = max(M,D,I) of the terminal-adjusted last cell
+            // (align_pair.cc:130-138,265) = X of the last body cell.
+            float sc = st.X[0];
+#pragma unroll
+            for(int c = 1; c < kW; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
+            cx.scores[cx.pair] = sc;
+        }
+    }
+}
+
+// Viterbi fill for gap_len == 1.  PERSISTENT: the grid is sized to fill every CU
+// with the same number of workgroups (host: fill_launch_shape) and each
+// wavefront pulls pair indices from an atomic queue until it is empty.  (With one
+// workgroup per 4 pairs the hardware dispatcher packs workgroups unevenly --
+// in-kernel clocks showed SIMDs running 2x the waves of others -- and a kernel
+// took ~2x the time its work implies.)  `order` lists the pairs longest first.
+__global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
+    const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+    const uint32_t* __restrict__ order, uint32_t n_pairs, uint32_t* __restrict__ queue,
+    const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
+    uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
+    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
+    __shared__ float tab[kTabRows * kTabStride];
+    for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
+        const int r = idx / kTabCols, c = idx - r * kTabCols;
+        tab[r * kTabStride + c] = table[idx];
+    }
+    __syncthreads();
+
+    const int lane_id = threadIdx.x & (kWave - 1);
+    const char* tab_bytes = reinterpret_cast<const char*>(tab);
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
+    for(;;) {
+    // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
+    // loop-invariant condition and may peel/unswitch this loop per lane, after which the
+    // wave-level operations inside (readfirstlane, DPP, ballots) no longer see the whole wave.
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);  // every lane takes part; lane 0 draws
+    ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+    if(ticket >= n_pairs) break;
+    const uint32_t pair = order[ticket];
+    const PairDesc pd = pairs[pair];
+    const uint32_t la = pd.la, lb = pd.lb;
+    if(la > 0 && lb > 0) {  // (without body cells only the margins are walked)
+    const uint8_t* __restrict__ a = a_cat + pd.a_off;
+    const uint8_t* __restrict__ b = b_cat + pd.b_off;
+
+    const uint32_t strips = n_strips(lb);
+    for(uint32_t strip = 0; strip < strips; ++strip) {
+        const uint32_t col0 = strip * kStrip;
+        const uint32_t ncol = min(static_cast<uint32_t>(kStrip), lb - col0);
+        const uint32_t nlanes = (ncol + kW - 1) / kW;
+        const uint32_t nsteps = la + nlanes - 1;
+        const bool last_strip = strip + 1 == strips;
+        uint32_t* __restrict__ fout = flags + pd.flags_off + strip * strip_dwords(la) + lane;
+        // strip-boundary columns: [0, la] = X of the last column (index r = X of
+        // body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
+        float* __restrict__ bnd_x = bnd + pd.bnd_off;
+        float* __restrict__ bnd_z = bnd_x + (la + 1);
+
+        // byte offsets of this lane's 16 table columns
+        uint32_t boff[kW];
+#pragma unroll
+        for(int c = 0; c < kW; ++c) {
+            const uint32_t bj = col0 + lane * kW + c;
+            boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+        }
+
+        const StripCtx cx{k, la, col0, nsteps, pair, lds_tab, lane,
+                          static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
+                          last_strip, fout, bnd_x, bnd_z, scores};
+        LaneState st;
+#pragma unroll
+        for(int c = 0; c < kW; ++c) st.X[c] = st.Y[c] = 0.0f;
+#pragma unroll
+        for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
+        st.xlast_old = 0.0f;
+        st.zlast = 0.0f;
+        // table-row byte offset of the row this lane processes at the CURRENT step,
+        // and the 16 substitution scores gathered for it one step earlier
+        uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+        float s[kW];
+#pragma unroll
+        for(int c = 0; c < kW; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
+
+        for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+            // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l
+            // (boundary column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
+            const uint32_t crow = kbase + lane;
+            uint32_t a_chunk = 0;
+            float bx = kLowest, bz = kLowest;
+            if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+            if(crow < la) {
+                if(strip == 0) {
+                    // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
+                    if(crow == 0) {
+                        bx = (0.0f + k.ng) + k.ng;
+                    } else {
+                        const float dm = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
+                        bx = dm + k.gs;
+                    }
+                } else {
+                    bx = bnd_x[crow];
+                    bz = bnd_z[crow];
+                }
+            }
+            // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
+            asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
+            if(kbase == 0)
+                run_chunk<true>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+            else
+                run_chunk<false>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+        }
+        if(nsteps & 1u)  // the last (even) step has no odd partner: flush its IM bits to the high half
+            fout[static_cast<uint64_t>(nsteps >> 1) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << 16;
+    }
+    }
+    // ---- traceback of this pair by the same wavefront, while its bits are still
+    // in L2.  The wave reads what it wrote itself: wait until its stores are
+    // acknowledged; nobody read these (128-byte aligned) lines before, so L1 is cold.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
+    }  // next ticket
+}
+
+
+// Launch shape of the persistent fill kernel: `blocks_per_cu` workgroups on each
+// of the 256 CUs (one wave per SIMD each), enforced by padding the launch with
+// unused dynamic LDS so that exactly that many fit.  More resident waves hide
+// latency better; fewer quantise the end of a small batch more finely.  Cost of
+// one pair relative to a saturated SIMD when w waves share it (measured,
+// in-kernel clocks): w=1 1.85, w=2 1.10, w=3 1.03.
+struct FillShape {
+    uint32_t grid;
+    size_t dynamic_lds;
+};
+FillShape fill_launch_shape(uint32_t n_pairs) {
+    constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
+    constexpr int kMaxBlocks = 3;  // 168 VGPRs -> 3 waves per SIMD
+    constexpr double kCost[4] = {0.0, 1.85, 1.10, 1.03};
+    static const int forced = [] {
+        const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
+        return e != nullptr ? std::atoi(e) : 0;
+    }();
+    int best = kMaxBlocks;
+    if(forced >= 1 && forced <= kMaxBlocks) {
+        best = forced;
+    } else {
+        double best_t = 1e300;
+        for(int w = kMaxBlocks; w >= 1; --w) {
+            const uint64_t per_simd = (static_cast<uint64_t>(n_pairs) + kSimds - 1) / kSimds;  // pairs on the busiest SIMD
+            const uint64_t rounds = (per_simd + w - 1) / w;
+            const double t = static_cast<double>(rounds) * w * kCost[w];
+            if(t < best_t * 0.98) {
+                best_t = t;
+                best = w;
+            }
+        }
+    }
+    constexpr size_t kLdsPerCU = 160 * 1024, kStatic = kTabRows * kTabStride * sizeof(float);
+    // LDS footprint per block that admits exactly `best` blocks per CU
+    const size_t per_block = kLdsPerCU / best;
+    const size_t dyn = best < 12 && per_block > kStatic + 512 ? per_block - kStatic - 512 : 0;
+    return {kCUs * static_cast<uint32_t>(best), dyn};
+}
+
+}  // namespace
+
+hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
+    if(e != hipSuccess) return e;
+    const FillShape shape = fill_launch_shape(v.n_pairs);
+    if(shape.dynamic_lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_l1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(shape.dynamic_lds));
+        if(e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(viterbi_l1, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, stream, v.table, v.k,
+                       v.pairs, v.order, v.n_pairs, v.queue, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops,
+                       v.ops_start, v.ops_len);
+    return hipGetLastError();
+}
+
+}  // namespace coati_hip_detail

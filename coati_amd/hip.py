@@ -34,6 +34,9 @@ EXPORTS = (
     "coati_hip_viterbi_last_timing",
     "coati_hip_viterbi_timing",
     "coati_hip_batch_result_ptrs",
+    "coati_hip_forward_launch",
+    "coati_hip_forward_final",
+    "coati_hip_debug_forward_matrices",
     "coati_hip_viterbi_batch",
     "coati_hip_debug_viterbi_flags",
 )
@@ -81,6 +84,9 @@ def load() -> C.CDLL:
     lib.coati_hip_viterbi_timing.argtypes = [vp, C.c_uint32, C.POINTER(f32), C.POINTER(f32)]
     lib.coati_hip_batch_result_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp),
                                                 C.POINTER(vp)]
+    lib.coati_hip_forward_launch.argtypes = [vp]
+    lib.coati_hip_forward_final.argtypes = [vp, vp]
+    lib.coati_hip_debug_forward_matrices.argtypes = [vp, u64, vp, vp, vp, u64]
     lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_debug_viterbi_flags.argtypes = [vp, u64, vp, u64]
     _lib = lib
@@ -208,6 +214,24 @@ class Batch:
         f, w = C.c_float(), C.c_float()
         _check(load().coati_hip_viterbi_timing(self._h, launches_back, C.byref(f), C.byref(w)))
         return f.value, w.value
+
+    def forward_launch(self):
+        _check(load().coati_hip_forward_launch(self._h))
+
+    def forward_final(self):
+        """Terminal-adjusted (M, D, I) of the last cell of every pair: array (n, 3)."""
+        out = np.zeros((self.n, 3), np.float32)
+        _check(load().coati_hip_forward_final(self._h, _ptr(out)))
+        return out
+
+    def debug_forward_matrices(self, pair: int):
+        la, lb = (int(x) for x in self.lens[pair])
+        M = np.zeros((la, lb), np.float32)
+        D = np.zeros_like(M)
+        I = np.zeros_like(M)
+        if M.size:
+            _check(load().coati_hip_debug_forward_matrices(self._h, pair, _ptr(M), _ptr(D), _ptr(I), M.size))
+        return M, D, I
 
     def result_ptrs(self):
         """Device addresses (scores, ops, ops_bytes, ops_off, ops_len) of the result arrays."""

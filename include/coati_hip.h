@@ -138,6 +138,21 @@ int coati_hip_viterbi_timing(coati_hip_batch_t* batch, uint32_t launches_back, f
 int coati_hip_batch_result_ptrs(coati_hip_batch_t* batch, void** scores, void** ops, uint64_t* ops_bytes,
                                 void** ops_off, void** ops_len);
 
+/* ---- Forward (coati sample) ------------------------------------------------ *
+ * forward(): forward_impl<log, align_pair_work_t> (align_pair.cc:62-139,149) for
+ * every pair of the batch.  Keeps the fp32 M/D/I of all body cells resident in HBM
+ * (12 bytes per cell, reserved on the first call) for coati_hip_sampleback; the
+ * eight edge matrices of align_pair_work_t are recomputed on demand.  Enqueues and
+ * returns. */
+int coati_hip_forward_launch(coati_hip_batch_t* batch);
+/* Terminal-adjusted M, D, I of the last cell (align_pair.cc:130-138), 3 floats per
+ * pair (synchronises). */
+int coati_hip_forward_final(coati_hip_batch_t* batch, float* final_mdi);
+/* Parity/debug export: the Forward M, D, I of the len_a x len_b body cells of one
+ * pair as three row-major matrices (the last cell NOT terminal-adjusted). */
+int coati_hip_debug_forward_matrices(coati_hip_batch_t* batch, uint64_t pair, float* M, float* D, float* I,
+                                     uint64_t capacity);
+
 /* One-shot convenience: create batch(es), launch, fetch, destroy.  Splits the
  * input into chunks that fit the device's free memory. */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
