@@ -450,6 +450,94 @@ int coati_hip_debug_forward_matrices(coati_hip_batch_t* b, uint64_t pair, float*
     return COATI_HIP_OK;
 }
 
+int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
+                         float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                         uint64_t* rng_state_out) {
+    if(b == nullptr || rng_state == nullptr) return fail(COATI_HIP_EINVAL, "sampleback: NULL argument");
+    if(!b->forward_done) return fail(COATI_HIP_ESTATE, "sampleback: forward was not launched");
+    const uint64_t n = b->n_pairs;
+    if(n == 0 || n_samples == 0) return COATI_HIP_OK;
+    coati_hip_model* m = b->model;
+    HIP_TRY(hipSetDevice(m->device));
+    // ops slots: pair p, sample s at sample_base[p] + s * (la + lb)
+    std::vector<uint64_t> base(n);
+    uint64_t total = 0;
+    for(uint64_t p = 0; p < n; ++p) {
+        base[p] = total;
+        total += static_cast<uint64_t>(n_samples) * (static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb);
+    }
+    if(ops != nullptr && ops_capacity < total)
+        return fail(COATI_HIP_EINVAL, "sampleback: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
+                    static_cast<unsigned long long>(total));
+    const uint64_t walkers = independent_streams ? n * n_samples : n;
+    std::vector<uint64_t> states(2 * walkers);
+    if(independent_streams) {
+        // sample s of pair p starts s * 2^32 draws into the pair's stream: state * (MULT^(2^32))^s mod 2^128
+        using u128 = unsigned __int128;
+        u128 jump = static_cast<u128>(0xda942042e4dd58b5ULL);
+        for(int sq = 0; sq < 32; ++sq) jump *= jump;
+        for(uint64_t p = 0; p < n; ++p) {
+            u128 st = (static_cast<u128>(rng_state[2 * p + 1]) << 64) | rng_state[2 * p];
+            for(uint32_t sidx = 0; sidx < n_samples; ++sidx) {
+                states[2 * (p * n_samples + sidx)] = static_cast<uint64_t>(st);
+                states[2 * (p * n_samples + sidx) + 1] = static_cast<uint64_t>(st >> 64);
+                st *= jump;
+            }
+        }
+    } else {
+        std::memcpy(states.data(), rng_state, sizeof(uint64_t) * 2 * n);
+    }
+    const uint64_t n_out = n * n_samples;
+    uint64_t *d_states = nullptr, *d_base = nullptr, *d_start = nullptr;
+    uint8_t* d_ops = nullptr;
+    uint32_t* d_len = nullptr;
+    float* d_lw = nullptr;
+    auto release = [&]() {
+        void* ptrs[] = {d_states, d_base, d_start, d_ops, d_len, d_lw};
+        for(void* q : ptrs)
+            if(q != nullptr) (void)hipFree(q);
+    };
+    auto attempt = [&]() -> hipError_t {
+        hipError_t e;
+        if((e = hipMalloc(reinterpret_cast<void**>(&d_states), states.size() * sizeof(uint64_t))) != hipSuccess) return e;
+        if((e = hipMalloc(reinterpret_cast<void**>(&d_base), n * sizeof(uint64_t))) != hipSuccess) return e;
+        if((e = hipMalloc(reinterpret_cast<void**>(&d_start), n_out * sizeof(uint64_t))) != hipSuccess) return e;
+        if((e = hipMalloc(reinterpret_cast<void**>(&d_ops), std::max<uint64_t>(total, 16))) != hipSuccess) return e;
+        if((e = hipMalloc(reinterpret_cast<void**>(&d_len), n_out * sizeof(uint32_t))) != hipSuccess) return e;
+        if((e = hipMalloc(reinterpret_cast<void**>(&d_lw), n_out * sizeof(float))) != hipSuccess) return e;
+        if((e = hipMemcpyAsync(d_states, states.data(), states.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
+        if((e = hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
+        if((e = launch_sampleback(device_view(b), n_samples, independent_streams != 0, d_states, d_base, d_ops, d_start, d_len,
+                                  d_lw, m->stream)) != hipSuccess) return e;
+        if((e = hipStreamSynchronize(m->stream)) != hipSuccess) return e;
+        if(log_weights != nullptr && (e = hipMemcpy(log_weights, d_lw, n_out * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(ops != nullptr && total > 0 && (e = hipMemcpy(ops, d_ops, total, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(ops_off != nullptr && (e = hipMemcpy(ops_off, d_start, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(ops_len != nullptr && (e = hipMemcpy(ops_len, d_len, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(rng_state_out != nullptr && !independent_streams &&
+           (e = hipMemcpy(rng_state_out, d_states, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        return hipSuccess;
+    };
+    const hipError_t e = attempt();
+    release();
+    if(e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "sampleback: %s", hipGetErrorString(e));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out) {
+    if(model == nullptr || rng_state == nullptr || out == nullptr) return fail(COATI_HIP_EINVAL, "debug_rng_f24: NULL argument");
+    HIP_TRY(hipSetDevice(model->device));
+    float* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), std::max<uint32_t>(n, 1) * sizeof(float)));
+    hipError_t e = launch_rng_f24(rng_state, n, d_out, model->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(model->stream);
+    if(e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if(e != hipSuccess) return fail(COATI_HIP_EHIP, "debug_rng_f24: %s", hipGetErrorString(e));
+    return COATI_HIP_OK;
+}
+
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                             const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                             float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off,

@@ -1,0 +1,237 @@
+// sampleback: stochastic traceback over the Forward matrices resident in HBM.
+//
+//   sampleback, sample_mdi, sample_mi          src/lib/align_pair.cc:336-458
+//   Lehmer64Fast::operator(), random_f24       contrib/random/random.hpp:80-136,213-216
+//
+// The reference keeps eight edge matrices (align_pair.hpp:94-103); here the three
+// (or two) edge values a step needs are recomputed from the predecessor cell's
+// M/D/I with the fill's own expressions (align_pair.cc:97-119), so only M/D/I
+// (12 B/cell) are stored.  A walk is a serial chain (one f24() draw per step, the
+// next cell depends on the draw), so the parallelism is across walks:
+//   * exact stream (independent = 0): one walker per PAIR draws its n samples one
+//     after the other from one Lehmer stream, exactly like marg_sample's loop
+//     (src/lib/align_marginal.cc:590-593);
+//   * independent streams (independent = 1): one walker per (pair, sample); sample n
+//     starts from the pair's state advanced by n * 2^32 draws (host: jump-ahead),
+//     so sample 0 is the reference's first sample and the rest are statistically
+//     equivalent but not the same draws.
+// fp32 throughout; device expf/logf differ from glibc by ulps (log-weights agree
+// to ~1e-6 relative; tests allow the 1e-5 north_star states).
+#include "common.hpp"
+
+namespace coati_hip_detail {
+namespace {
+
+struct Rng128 {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ float rng_f24(Rng128& s) {
+    constexpr uint64_t kMult = 0xda942042e4dd58b5ULL;  // random.hpp:95
+    const uint64_t lo = s.lo * kMult;
+    const uint64_t hi = s.hi * kMult + __umul64hi(s.lo, kMult);
+    s.lo = lo;
+    s.hi = hi;
+    return static_cast<float>(static_cast<int64_t>(hi >> 40)) / 16777216.0f;
+}
+
+struct Walker {
+    const GapConsts k;
+    const uint32_t L, la, lb;
+    const float ext_lm1, ext_l;
+    const float* __restrict__ table;
+    const uint8_t* __restrict__ a;
+    const uint8_t* __restrict__ b;
+    const float* __restrict__ mdi;
+    const uint64_t mdi_off;
+
+    // M/D/I of MATRIX cell (i, j); the last cell carries the terminal adjustment
+    // (the reference stores it adjusted, align_pair.cc:130-138).
+    __device__ __forceinline__ void cell(uint32_t i, uint32_t j, float& m, float& d, float& in) const {
+        if(i >= L && j >= L) {
+            m = mdi[mdi_index(mdi_off, la, i - L, j - L, 0)];
+            d = mdi[mdi_index(mdi_off, la, i - L, j - L, 1)];
+            in = mdi[mdi_index(mdi_off, la, i - L, j - L, 2)];
+        } else {
+            margin_mdi(k, L, i, j, m, d, in);
+        }
+        if(i == la + L - 1 && j == lb + L - 1) {
+            m = (m + k.ng) + k.ng;
+            in = (in + k.gs) + k.ng;
+            d = d + k.gs;
+        }
+    }
+    // like cell() but never adjusted: the fill's inputs (a predecessor is never the last cell)
+    __device__ __forceinline__ void pred(uint32_t i, uint32_t j, float& m, float& d, float& in) const {
+        if(i >= L && j >= L) {
+            m = mdi[mdi_index(mdi_off, la, i - L, j - L, 0)];
+            d = mdi[mdi_index(mdi_off, la, i - L, j - L, 1)];
+            in = mdi[mdi_index(mdi_off, la, i - L, j - L, 2)];
+        } else {
+            margin_mdi(k, L, i, j, m, d, in);
+        }
+    }
+    __device__ __forceinline__ float subst(uint32_t i, uint32_t j) const {
+        return table[static_cast<uint32_t>(a[i - L]) * kTabCols + b[j - L]];
+    }
+};
+
+// sample_mdi (align_pair.cc:336-358): returns the state, adds log(x) - log(scale) to score
+__device__ __forceinline__ int sample3(float lm, float ld, float li, float p, float& score) {
+    const float m = expf(lm), d = expf(ld), i = expf(li);
+    const float scale = m + d + i;
+    p *= scale;
+    int st;
+    float lx;
+    if(p < m) {
+        st = COATI_HIP_OP_MATCH;
+        lx = lm;
+    } else if(p < d + m) {
+        st = COATI_HIP_OP_DEL;
+        lx = ld;
+    } else {
+        st = COATI_HIP_OP_INS;
+        lx = li;
+    }
+    score += lx - logf(scale);
+    return st;
+}
+// sample_mi (align_pair.cc:370-385)
+__device__ __forceinline__ int sample2(float lm, float li, float p, float& score) {
+    const float m = expf(lm), i = expf(li);
+    const float scale = m + i;
+    p *= scale;
+    const bool pick_m = p < m;
+    score += (pick_m ? lm : li) - logf(scale);
+    return pick_m ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+}
+
+// One walk (sampleback, align_pair.cc:401-458).  Ops are written right-to-left into
+// [slot, slot + la + lb); returns the position of the first op.
+__device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restrict__ ops, uint64_t slot, float& score) {
+    const uint32_t L = w.L;
+    uint32_t i = w.la + L - 1, j = w.lb + L - 1;
+    uint64_t pos = slot + w.la + w.lb;
+    score = 0.0f;
+    float m, d, in;
+    w.cell(i, j, m, d, in);
+    float top = fmaxf(fmaxf(m, d), in);
+    int st = sample3(m - top, d - top, in - top, rng_f24(rng), score);
+    while(j > L - 1 || i > L - 1) {
+        const bool body = i >= L && j >= L;
+        if(st == COATI_HIP_OP_MATCH) {
+            ops[--pos] = COATI_HIP_OP_MATCH;
+            w.cell(i, j, m, d, in);
+            top = m;
+            float mm = kLowest, dm = kLowest, im = kLowest;
+            if(body) {
+                float pm, pdd, pi;
+                w.pred(i - 1, j - 1, pm, pdd, pi);
+                const float s = w.subst(i, j);
+                mm = ((pm + w.k.ng) + w.k.ng) + s;
+                dm = (pdd + w.k.gs) + s;
+                im = ((pi + w.k.gs) + w.k.ng) + s;
+            }
+            st = sample3(mm - top, dm - top, im - top, rng_f24(rng), score);
+            --i;
+            --j;
+        } else if(st == COATI_HIP_OP_DEL) {
+            for(uint32_t q = 0; q < L; ++q) ops[--pos] = COATI_HIP_OP_DEL;
+            w.cell(i, j, m, d, in);
+            top = d;
+            float md = kLowest, dd = kLowest, id = kLowest;
+            if(body) {
+                float pm, pdd, pi;
+                w.pred(i - L, j, pm, pdd, pi);
+                md = ((pm + w.k.ng) + w.k.go) + w.ext_lm1;
+                dd = pdd + w.ext_l;
+                id = ((pi + w.k.gs) + w.k.go) + w.ext_lm1;
+            } else {
+                // margins: del_del is a copy of the margin D made BEFORE the terminal adjustment
+                // (init_margins, align_pair.hpp:108-111)
+                float mm0, dm0, im0;
+                margin_mdi(w.k, L, i, j, mm0, dm0, im0);
+                dd = dm0;
+            }
+            st = sample3(md - top, dd - top, id - top, rng_f24(rng), score);
+            i -= L;
+        } else {
+            for(uint32_t q = 0; q < L; ++q) ops[--pos] = COATI_HIP_OP_INS;
+            w.cell(i, j, m, d, in);
+            top = in;
+            float mi = kLowest, ii = kLowest;
+            if(body) {
+                float pm, pdd, pi;
+                w.pred(i, j - L, pm, pdd, pi);
+                mi = (pm + w.k.go) + w.ext_lm1;
+                ii = pi + w.ext_l;
+            } else {
+                float mm0, dm0, im0;
+                margin_mdi(w.k, L, i, j, mm0, dm0, im0);
+                ii = im0;
+            }
+            st = sample2(mi - top, ii - top, rng_f24(rng), score);
+            j -= L;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(64) void sampleback_kernel(const float* __restrict__ table, GapConsts k, uint32_t L,
+                                                        const PairDesc* __restrict__ pairs, uint32_t n_pairs,
+                                                        uint32_t n_samples, int independent,
+                                                        const uint8_t* __restrict__ a_cat,
+                                                        const uint8_t* __restrict__ b_cat,
+                                                        const float* __restrict__ mdi, uint64_t* __restrict__ rng_states,
+                                                        const uint64_t* __restrict__ sample_base, uint8_t* __restrict__ ops,
+                                                        uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len,
+                                                        float* __restrict__ log_weights) {
+    const uint64_t walker = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    const uint64_t n_walkers = independent ? static_cast<uint64_t>(n_pairs) * n_samples : n_pairs;
+    if(walker >= n_walkers) return;
+    const uint32_t pair = independent ? static_cast<uint32_t>(walker / n_samples) : static_cast<uint32_t>(walker);
+    const uint32_t first = independent ? static_cast<uint32_t>(walker % n_samples) : 0u;
+    const uint32_t count = independent ? 1u : n_samples;
+    const PairDesc pd = pairs[pair];
+    const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
+                   table, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
+    Rng128 rng{rng_states[2 * walker], rng_states[2 * walker + 1]};
+    const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;
+    for(uint32_t n = first; n < first + count; ++n) {
+        const uint64_t idx = static_cast<uint64_t>(pair) * n_samples + n;
+        const uint64_t slot = sample_base[pair] + n * width;
+        float score;
+        const uint64_t pos = sample_walk(w, rng, ops, slot, score);
+        ops_start[idx] = pos;
+        ops_len[idx] = static_cast<uint32_t>(slot + width - pos);
+        log_weights[idx] = score;
+    }
+    rng_states[2 * walker] = rng.lo;  // the stream continues where this launch stopped
+    rng_states[2 * walker + 1] = rng.hi;
+}
+
+// Debug/parity: the first n f24() draws of a stream (one thread).
+__global__ void rng_f24_kernel(uint64_t lo, uint64_t hi, uint32_t n, float* __restrict__ out) {
+    Rng128 r{lo, hi};
+    for(uint32_t q = 0; q < n; ++q) out[q] = rng_f24(r);
+}
+
+}  // namespace
+
+hipError_t launch_rng_f24(const uint64_t state[2], uint32_t n, float* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(rng_f24_kernel, dim3(1), dim3(1), 0, stream, state[0], state[1], n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool independent, uint64_t* rng_states,
+                             const uint64_t* sample_base, uint8_t* ops, uint64_t* ops_start, uint32_t* ops_len,
+                             float* log_weights, hipStream_t stream) {
+    const uint64_t walkers = independent ? static_cast<uint64_t>(v.n_pairs) * n_samples : v.n_pairs;
+    if(walkers == 0) return hipSuccess;
+    const uint32_t grid = static_cast<uint32_t>((walkers + 63) / 64);
+    hipLaunchKernelGGL(sampleback_kernel, dim3(grid), dim3(64), 0, stream, v.table, v.k, v.gap_len, v.pairs, v.n_pairs,
+                       n_samples, independent ? 1 : 0, v.a_cat, v.b_cat, v.mdi, rng_states, sample_base, ops, ops_start,
+                       ops_len, log_weights);
+    return hipGetLastError();
+}
+
+}  // namespace coati_hip_detail

@@ -37,6 +37,8 @@ EXPORTS = (
     "coati_hip_forward_launch",
     "coati_hip_forward_final",
     "coati_hip_debug_forward_matrices",
+    "coati_hip_sampleback",
+    "coati_hip_debug_rng_f24",
     "coati_hip_viterbi_batch",
     "coati_hip_debug_viterbi_flags",
 )
@@ -87,6 +89,8 @@ def load() -> C.CDLL:
     lib.coati_hip_forward_launch.argtypes = [vp]
     lib.coati_hip_forward_final.argtypes = [vp, vp]
     lib.coati_hip_debug_forward_matrices.argtypes = [vp, u64, vp, vp, vp, u64]
+    lib.coati_hip_sampleback.argtypes = [vp, C.c_uint32, vp, i32, vp, vp, u64, vp, vp, vp]
+    lib.coati_hip_debug_rng_f24.argtypes = [vp, vp, C.c_uint32, vp]
     lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_debug_viterbi_flags.argtypes = [vp, u64, vp, u64]
     _lib = lib
@@ -145,6 +149,12 @@ class Model:
             self.close()
         except Exception:
             pass
+
+    def debug_rng_f24(self, state, n: int):
+        st = np.ascontiguousarray(state, np.uint64)
+        out = np.zeros(n, np.float32)
+        _check(load().coati_hip_debug_rng_f24(self._h, _ptr(st), n, _ptr(out)))
+        return out
 
     def viterbi(self, a_cat, a_off, b_cat, b_off):
         """One-shot coati_hip_viterbi_batch.  Returns (scores, ops, ops_off, ops_len)."""
@@ -232,6 +242,20 @@ class Batch:
         if M.size:
             _check(load().coati_hip_debug_forward_matrices(self._h, pair, _ptr(M), _ptr(D), _ptr(I), M.size))
         return M, D, I
+
+    def sampleback(self, n_samples: int, rng_states, independent: bool = False):
+        """rng_states: (n, 2) uint64 (lo, hi).  Returns (log_weights (n, S), ops, ops_off (n, S), ops_len (n, S),
+        rng_states_out)."""
+        st = np.ascontiguousarray(rng_states, np.uint64).reshape(self.n, 2)
+        total = int(n_samples * self.lens.sum())
+        lw = np.zeros((self.n, n_samples), np.float32)
+        ops = np.zeros(max(total, 1), np.uint8)
+        off = np.zeros((self.n, n_samples), np.uint64)
+        ln = np.zeros((self.n, n_samples), np.uint32)
+        st_out = np.zeros_like(st)
+        _check(load().coati_hip_sampleback(self._h, n_samples, _ptr(st), int(independent), _ptr(lw), _ptr(ops), total,
+                                           _ptr(off), _ptr(ln), _ptr(st_out)))
+        return lw, ops, off, ln, st_out
 
     def result_ptrs(self):
         """Device addresses (scores, ops, ops_bytes, ops_off, ops_len) of the result arrays."""

@@ -134,3 +134,19 @@ def restore_end_stops(aln0: str, aln1: str, stop0: str, stop1: str, score=0.0, g
     _check(load().coati_host_restore_end_stops(b0, b1, stop0.encode(), stop1.encode(), C.c_float(np.float32(gap_open)),
                                                C.c_float(e), C.byref(sc), C.c_ulonglong(cap)))
     return [b0.value.decode(), b1.value.decode()], np.float32(sc.value)
+
+
+def rng_seed(seeds) -> np.ndarray:
+    """Lehmer64Fast state (lo, hi) after rand.Seed(string_seed_seq(seeds))."""
+    arr = (C.c_char_p * len(seeds))(*[x.encode() for x in seeds])
+    out = np.zeros(2, np.uint64)
+    _check(load().coati_host_rng_seed(arr, len(seeds), _p(out)))
+    return out
+
+
+def rng_f24(state, n: int):
+    """n draws; returns (draws, advanced state)."""
+    st = np.array(state, np.uint64)
+    out = np.zeros(n, np.float32)
+    _check(load().coati_host_rng_f24(_p(st), n, _p(out)))
+    return out, st

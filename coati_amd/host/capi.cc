@@ -7,6 +7,7 @@
 #include <string>
 
 #include "model.hpp"
+#include "random.hpp"
 #include "seq.hpp"
 #include "synth.hpp"
 
@@ -139,6 +140,29 @@ int coati_host_restore_end_stops(char* aln0, char* aln1, const char* stop0, cons
         std::strcpy(aln0, d.seqs[0].c_str());
         std::strcpy(aln1, d.seqs[1].c_str());
         *score = d.score;
+    });
+}
+
+// string_seed_seq + Random::Seed: n seed strings -> Lehmer state (lo, hi)
+int coati_host_rng_seed(const char* const* seeds, int n, unsigned long long out[2]) {
+    return guarded([&] {
+        std::vector<std::string> v;
+        for(int q = 0; q < n; ++q) v.emplace_back(seeds[q]);
+        coati_amd::random_t r;
+        r.seed(v);
+        out[0] = r.lo();
+        out[1] = r.hi();
+    });
+}
+
+// n f24() draws from state (lo, hi); the state is advanced in place
+int coati_host_rng_f24(unsigned long long state[2], int n, float* out) {
+    return guarded([&] {
+        coati_amd::random_t r;
+        r.set_state(state[0], state[1]);
+        for(int q = 0; q < n; ++q) out[q] = r.f24();
+        state[0] = r.lo();
+        state[1] = r.hi();
     });
 }
 

@@ -153,6 +153,25 @@ int coati_hip_forward_final(coati_hip_batch_t* batch, float* final_mdi);
 int coati_hip_debug_forward_matrices(coati_hip_batch_t* batch, uint64_t pair, float* M, float* D, float* I,
                                      uint64_t capacity);
 
+/* sampleback() (align_pair.cc:401-458) n_samples times for every pair of a batch
+ * whose Forward matrices are resident (coati_hip_forward_launch).  Synchronous.
+ *   rng_state[2*p], rng_state[2*p+1]   low / high 64 bits of pair p's Lehmer64Fast state
+ *                      (contrib/random/random.hpp:80-136), i.e. what rand.Seed(seed_seq)
+ *                      leaves (random.hpp:408-413) -- seeding stays on the host.
+ *   independent_streams = 0: pair p's samples are drawn one after the other from that one
+ *                      stream, exactly as marg_sample does (align_marginal.cc:590-593);
+ *                      rng_state_out (may be NULL) receives the advanced states.
+ *   independent_streams = 1: sample s of pair p starts s * 2^32 draws into the stream
+ *                      (all samples in parallel; sample 0 equals the reference's first).
+ * Outputs (any may be NULL), sample s of pair p at index p * n_samples + s:
+ *   log_weights[]  aln.data.score of the sample
+ *   ops / ops_off[] / ops_len[]  as for Viterbi; ops_capacity >= n_samples * sum(len_a+len_b) */
+int coati_hip_sampleback(coati_hip_batch_t* batch, uint32_t n_samples, const uint64_t* rng_state,
+                         int independent_streams, float* log_weights, uint8_t* ops, uint64_t ops_capacity,
+                         uint64_t* ops_off, uint32_t* ops_len, uint64_t* rng_state_out);
+/* Parity/debug: the first n f24() draws (random.hpp:213-216) of a stream, computed on the device. */
+int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out);
+
 /* One-shot convenience: create batch(es), launch, fetch, destroy.  Splits the
  * input into chunks that fit the device's free memory. */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,

@@ -1,0 +1,154 @@
+"""Stochastic traceback on the GPU (`coati sample` path): device RNG stream, exact-
+stream sampling vs the oracle / golden vectors, log-weights, independent streams."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def rel_close(got, want, tol=1e-5):
+    got, want = np.float64(got), np.float64(want)
+    return abs(got - want) <= tol * max(1.0, abs(want))
+
+
+def test_device_rng_stream_bit_exact():
+    from coati_amd import hip, host
+
+    model = hip.Model(host.set_subst("mar-mg"), host.gap_consts(), 1)
+    for entry in json.loads((GOLD / "rng_streams.json").read_text()):
+        st = host.rng_seed(entry["seeds"])
+        got = model.debug_rng_f24(st, len(entry["f24_bits"]))
+        assert got.view(np.uint32).tolist() == [int(h, 16) for h in entry["f24_bits"]], entry["seeds"]
+
+
+def run_exact(hip, host, oracle, table, consts, L, pairs, seeds, n_samples):
+    enc = util.encode_pairs(pairs)
+    model = hip.Model(table, consts, L)
+    batch = hip.Batch(model, *hip.pack_pairs(enc))
+    batch.forward_launch()
+    states = np.stack([host.rng_seed(seeds) for _ in enc])
+    lw, ops, off, ln, st_out = batch.sampleback(n_samples, states, independent=False)
+    identical = total = 0
+    for p, (a, b) in enumerate(enc):
+        M, D, I = oracle.fill(oracle.LOG, table, consts, L, a, b)
+        rng = oracle.rng_seed(seeds)
+        in_sync = True
+        for s in range(n_samples):
+            got = ops[int(off[p, s]):int(off[p, s]) + int(ln[p, s])]
+            # every GPU sample is a valid path whose log-weight the oracle reproduces (1e-5 relative)
+            assert (got == 1).sum() + (got == 0).sum() == len(a) and (got == 2).sum() + (got == 0).sum() == len(b)
+            want_lw = oracle.path_logweight(M, D, I, table, consts, L, a, b, got)
+            assert rel_close(lw[p, s], want_lw), (p, s, lw[p, s], want_lw)
+            if in_sync:  # same draws as the oracle until a (rare) ulp-level flip shifts the stream
+                w_ops, w_lw = oracle.sampleback_mdi(M, D, I, table, consts, L, a, b, rng)
+                total += 1
+                if len(w_ops) == len(got) and (w_ops == got).all():
+                    identical += 1
+                    assert rel_close(lw[p, s], w_lw)
+                else:
+                    in_sync = False
+        if in_sync:  # the stream was consumed draw for draw
+            assert (int(st_out[p, 0]), int(st_out[p, 1])) == (rng.lo, rng.hi)
+    batch.close()
+    model.close()
+    return identical, total
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_exact_stream_matches_oracle(oracle, L):
+    from coati_amd import hip, host
+
+    rng = np.random.default_rng(50 + L)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    pairs = util.make_pairs(rng, 24, 1, 40, L=L) + [("", ""), ("ACGACG" if L == 3 else "ACG", "")]
+    identical, total = run_exact(hip, host, oracle, table, consts, L, pairs, ["42"], 20)
+    assert identical >= 0.98 * total, (identical, total)
+
+
+def test_reference_doctest_marg_sample():
+    """marg_sample known answers (align_marginal.cc:653-672), seed "42", default model."""
+    from coati_amd import hip, host
+
+    known = json.loads((GOLD / "reference_known_answers.json").read_text())["marg_sample"]
+    table = host.set_subst("mar-mg")
+    for case in known:
+        anc, des = case["seqs"]
+        a, b = host.encode(anc, des)
+        model = hip.Model(table, host.gap_consts(), 1)
+        batch = hip.Batch(model, *hip.pack_pairs([(a, b)]))
+        batch.forward_launch()
+        lw, ops, off, ln, _ = batch.sampleback(len(case["out"]), host.rng_seed(["42"]).reshape(1, 2))
+        for s, ((want_a, want_b), want_s) in enumerate(zip(case["out"], case["scores"])):
+            got = ops[int(off[0, s]):int(off[0, s]) + int(ln[0, s])]
+            ia, ib = iter(anc), iter(des)
+            sa = "".join("-" if o == 2 else next(ia) for o in got)
+            sb = "".join("-" if o == 1 else next(ib) for o in got)
+            assert (sa, sb) == (want_a, want_b)
+            assert rel_close(lw[0, s], float(want_s), 1e-5)
+
+
+def test_golden_sample_cases_exact_stream(oracle):
+    """Samples of the compiled reference (tests/golden/sample_cases.json): same seeds -> same alignments
+    (up to rare ulp-level flips), log-weights within 1e-5."""
+    from coati_amd import hip, host
+
+    doc = json.loads((GOLD / "sample_cases.json").read_text())
+    table = np.load(GOLD / "table_mg94_goldenP.npy")
+    consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])
+    same = total = 0
+    for c in doc["cases"]:
+        a, b = host.encode(c["anc"], c["des"])
+        model = hip.Model(table, consts, c["gap_len"])
+        batch = hip.Batch(model, *hip.pack_pairs([(a, b)]))
+        batch.forward_launch()
+        n = len(c["samples"])
+        lw, ops, off, ln, _ = batch.sampleback(n, host.rng_seed(c["seeds"]).reshape(1, 2))
+        for s, want in enumerate(c["samples"]):
+            got = ops[int(off[0, s]):int(off[0, s]) + int(ln[0, s])]
+            sa, sb = oracle.ops_to_strings(got, c["anc"], c["des"])
+            total += 1
+            if (sa, sb) == (want["anc"], want["des"]):
+                same += 1
+                w = np.array([int(want["score_bits"], 16)], np.uint32).view(np.float32)[0]
+                assert rel_close(lw[0, s], w), (c["name"], s)
+            else:
+                break  # the stream shifted; later samples of this case are different draws
+        batch.close()
+        model.close()
+    assert same >= 0.97 * total, (same, total)
+
+
+def test_independent_streams(oracle):
+    from coati_amd import hip, host
+
+    rng = np.random.default_rng(60)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    pairs = util.make_pairs(rng, 6, 10, 60)
+    enc = util.encode_pairs(pairs)
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc))
+    batch.forward_launch()
+    states = np.stack([host.rng_seed([f"s{p}"]) for p in range(len(enc))])
+    n = 200
+    lw_i, ops_i, off_i, ln_i, _ = batch.sampleback(n, states, independent=True)
+    lw_e, ops_e, off_e, ln_e, _ = batch.sampleback(n, states, independent=False)
+    for p, (a, b) in enumerate(enc):
+        M, D, I = oracle.fill(oracle.LOG, table, consts, 1, a, b)
+        # sample 0 of both modes is the same draw sequence
+        g0 = ops_i[int(off_i[p, 0]):int(off_i[p, 0]) + int(ln_i[p, 0])]
+        e0 = ops_e[int(off_e[p, 0]):int(off_e[p, 0]) + int(ln_e[p, 0])]
+        assert len(g0) == len(e0) and (g0 == e0).all() and lw_i[p, 0] == lw_e[p, 0]
+        for s in range(0, n, 17):
+            got = ops_i[int(off_i[p, s]):int(off_i[p, s]) + int(ln_i[p, s])]
+            assert rel_close(lw_i[p, s], oracle.path_logweight(M, D, I, table, consts, 1, a, b, got))
+        # both modes sample the same distribution: mean log-weights agree within sampling error
+        se = np.sqrt(lw_i[p].var() / n + lw_e[p].var() / n) + 1e-6
+        assert abs(lw_i[p].mean() - lw_e[p].mean()) < 6 * se

@@ -144,3 +144,19 @@ def test_synthetic_workload_is_deterministic_and_valid():
     a, b = host.encode(anc, des)
     assert (a == a_cat[int(a_off[5]):int(a_off[6])]).all() and (b == b_cat[int(b_off[5]):int(b_off[6])]).all()
     assert des[-3:] not in ("TAA", "TAG", "TGA")
+
+
+def test_rng_seeding_and_stream_match_reference_golden():
+    """contrib/random/random.hpp seeding + f24 stream: golden draws of the compiled reference."""
+    for entry in json.loads((GOLD / "rng_streams.json").read_text()):
+        st = host.rng_seed(entry["seeds"])
+        assert st[0] & 1  # Lehmer state is forced odd
+        draws, _ = host.rng_f24(st, len(entry["f24_bits"]))
+        assert draws.view(np.uint32).tolist() == [int(h, 16) for h in entry["f24_bits"]], entry["seeds"]
+
+
+def test_rng_seed_matches_oracle(oracle):
+    for seeds in (["42"], [""], ["a", "b"], ["-5"], ["99999999999"]):
+        r = oracle.rng_seed(seeds)
+        st = host.rng_seed(seeds)
+        assert (int(st[0]), int(st[1])) == (r.lo, r.hi)
