@@ -19,16 +19,21 @@ $(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
-HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc coati_amd/host/capi.cc
+HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc coati_amd/host/io.cc \
+           coati_amd/host/align.cc coati_amd/host/cli.cc coati_amd/host/capi.cc
 HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc
 CXX      ?= g++
 HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -Icoati_amd/host
 
-host: $(BUILD)/libcoati_host.so
+host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample
 
-$(BUILD)/libcoati_host.so: $(HOST_SRC) $(HOST_HDR)
+# the host layer calls the DP through the C ABI of libcoati_hip.so only
+$(BUILD)/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so
 	@mkdir -p $(BUILD)
-	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC) -lm
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm
+
+$(BUILD)/coati-%: coati_amd/host/coati_%.cc $(BUILD)/libcoati_host.so
+	$(CXX) $(HOSTFLAGS) -o $@ $< -L$(BUILD) -lcoati_host -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm
 
 oracle:
 	$(MAKE) -C oracle

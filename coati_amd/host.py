@@ -150,3 +150,37 @@ def rng_f24(state, n: int):
     out = np.zeros(n, np.float32)
     _check(load().coati_host_rng_f24(_p(st), n, _p(out)))
     return out, st
+
+
+def extract_file_type(path: str):
+    a, b = C.create_string_buffer(len(path) + 8), C.create_string_buffer(len(path) + 8)
+    _check(load().coati_host_extract_file_type(path.encode(), a, b, C.c_ulonglong(len(path) + 8)))
+    return a.value.decode(), b.value.decode()
+
+
+def convert(in_path: str, out_path: str, score: float = float("nan")):
+    _check(load().coati_host_convert(str(in_path).encode(), str(out_path).encode(), C.c_float(score)))
+
+
+def write_json_array(in_path: str, out_path: str, count: int):
+    _check(load().coati_host_write_json_array(str(in_path).encode(), str(out_path).encode(), C.c_uint(count)))
+
+
+def json_number(v) -> str:
+    buf = C.create_string_buffer(64)
+    _check(load().coati_host_json_number(C.c_float(np.float32(v)), buf, C.c_ulonglong(64)))
+    return buf.value.decode()
+
+
+def alignment_score(aln_anc: str, aln_des: str, model="mar-mg", gap_open=0.001, gap_extend=None, gap_len=1):
+    e = np.float32(1.0) - np.float32(1.0) / np.float32(6.0) if gap_extend is None else np.float32(gap_extend)
+    out = C.c_float()
+    _check(load().coati_host_alignment_score(aln_anc.encode(), aln_des.encode(), model.encode(),
+                                             C.c_float(np.float32(gap_open)), C.c_float(e), C.c_uint(gap_len), C.byref(out)))
+    return np.float32(out.value)
+
+
+def parse_matrix_csv(path) -> np.ndarray:
+    out = np.zeros((61, 61), np.float32)
+    _check(load().coati_host_parse_matrix_csv(str(path).encode(), _p(out)))
+    return out

@@ -1,0 +1,319 @@
+#include "align.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+#include "coati_hip.h"
+#include "codon.hpp"
+#include "io.hpp"
+
+namespace coati_amd {
+
+namespace {
+[[noreturn]] void throw_hip(int rc) {
+    const std::string msg = coati_hip_last_error();
+    if(rc == COATI_HIP_ENOMEM) throw std::bad_alloc();
+    if(rc == COATI_HIP_EINVAL) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+void hip_check(int rc) {
+    if(rc != COATI_HIP_OK) throw_hip(rc);
+}
+coati_hip_model* make_model(const alignment_t& aln) {
+    if(aln.gap.len < 1) throw std::invalid_argument("Gap unit length must be positive.");
+    if(aln.subst_matrix.size() != kTableRows * kTableCols) throw std::invalid_argument("Substitution matrix not set.");
+    const auto k = gap_log_consts(aln.gap);
+    coati_hip_model* m = nullptr;
+    hip_check(coati_hip_model_create(aln.subst_matrix.data(), k[0], k[1], k[2], k[3], static_cast<int>(aln.gap.len),
+                                     aln.device, &m));
+    return m;
+}
+void release(align_pair_work_mem_t& w) {
+    if(w.batch != nullptr) coati_hip_batch_destroy(w.batch);
+    if(w.model != nullptr) coati_hip_model_destroy(w.model);
+    w.batch = nullptr;
+    w.model = nullptr;
+}
+void make_pair_batch(align_pair_work_mem_t& work, const seq_view_t& a, const seq_view_t& b, const alignment_t& aln) {
+    release(work);
+    work.model = make_model(aln);
+    const uint64_t a_off[2] = {0, a.size()}, b_off[2] = {0, b.size()};
+    hip_check(coati_hip_batch_create(work.model, 1, a.data(), a_off, b.data(), b_off, &work.batch));
+}
+}  // namespace
+
+align_pair_work_mem_t::~align_pair_work_mem_t() { release(*this); }
+
+void set_subst(alignment_t& aln) {
+    if(!aln.rate.empty()) {
+        aln.model = "user_marg_model";
+        aln.subst_matrix = marginal_p(parse_matrix_csv(aln.rate), aln.pi, aln.amb, aln.sub);
+        return;
+    }
+    model_params_t prm;
+    prm.model = aln.model;
+    prm.br_len = aln.br_len;
+    prm.omega = aln.omega;
+    prm.pi = aln.pi;
+    prm.sigma = aln.sigma;
+    prm.amb = aln.amb;
+    prm.sub = aln.sub;
+    aln.subst_matrix = set_subst(prm);
+}
+
+void viterbi_mem(align_pair_work_mem_t& work, const seq_view_t& a, const seq_view_t& b, const alignment_t& aln) {
+    make_pair_batch(work, a, b, aln);
+    hip_check(coati_hip_viterbi_launch(work.batch));
+    work.ops.assign(a.size() + b.size() + 1, 0);
+    uint64_t off = 0;
+    uint32_t len = 0;
+    hip_check(coati_hip_viterbi_fetch(work.batch, &work.score, work.ops.data(), a.size() + b.size(), &off, &len));
+    work.ops.erase(work.ops.begin(), work.ops.begin() + static_cast<std::ptrdiff_t>(off));
+    work.ops.resize(len);
+}
+
+void traceback_viterbi(const align_pair_work_mem_t& work, const std::string& a, const std::string& b,
+                       alignment_t& aln, std::size_t /*look_back*/) {
+    aln.data.seqs.assign(2, std::string());
+    ops_to_alignment(work.ops.data(), work.ops.size(), a, b, aln.data.seqs[0], aln.data.seqs[1]);
+    aln.data.score = work.score;
+}
+
+void forward(align_pair_work_t& work, const seq_view_t& a, const seq_view_t& b, const alignment_t& aln) {
+    make_pair_batch(work, a, b, aln);
+    hip_check(coati_hip_forward_launch(work.batch));
+}
+
+void sampleback(const align_pair_work_t& work, const std::string& a, const std::string& b, alignment_t& aln,
+                std::size_t /*look_back*/, random_t& rand) {
+    if(work.batch == nullptr) throw std::runtime_error("sampleback: forward() was not run.");
+    const uint64_t state_in[2] = {rand.lo(), rand.hi()};
+    uint64_t state_out[2] = {0, 0};
+    std::vector<uint8_t> ops(a.size() + b.size() + 1);
+    uint64_t off = 0;
+    uint32_t len = 0;
+    float lw = 0.f;
+    hip_check(coati_hip_sampleback(work.batch, 1, state_in, /*independent_streams=*/0, &lw, ops.data(),
+                                   a.size() + b.size(), &off, &len, state_out));
+    rand.set_state(state_out[0], state_out[1]);  // the stream continues where the device walker stopped
+    aln.data.seqs.assign(2, std::string());
+    ops_to_alignment(ops.data() + off, len, a, b, aln.data.seqs[0], aln.data.seqs[1]);
+    aln.data.score = lw;
+}
+
+bool marg_alignment(alignment_t& aln) {
+    aln.data = read_input(aln.data.path);
+    set_subst(aln);
+    if(aln.score) {
+        std::cout << alignment_score(aln, aln.subst_matrix) << std::endl;
+        return true;
+    }
+    process_marginal(aln.data, aln.gap, aln.refs, aln.rev);
+    const std::string anc = aln.seq(0), des = aln.seq(1);
+    const auto seq_pair = marginal_seq_encoding(anc, des);
+    check_descendant_codes(seq_pair[1]);
+    align_pair_work_mem_t work;
+    try {
+        viterbi_mem(work, seq_pair[0], seq_pair[1], aln);
+    } catch(const std::bad_alloc&) {
+        std::cerr << "ERROR: sequences to align exceed available memory." << std::endl;
+        return false;  // (upstream returns EXIT_FAILURE from a bool function, i.e. true: align_marginal.cc:72-75)
+    }
+    traceback_viterbi(work, anc, des, aln, aln.gap.len);
+    restore_end_stops(aln.data, aln.gap);
+    write_output(aln.data, aln.output);
+    return true;
+}
+
+bool marg_alignment_batch(alignment_t& aln) {
+    data_t all = read_input(aln.data.path);
+    if(all.size() == 0 || all.size() % 2 != 0) throw std::invalid_argument("Batch input needs an even number of sequences.");
+    set_subst(aln);
+    const std::size_t n = all.size() / 2;
+    std::vector<data_t> pairs(n);
+    std::vector<std::string> ancs(n), dess(n);
+    std::vector<unsigned char> a_cat, b_cat;
+    std::vector<uint64_t> a_off{0}, b_off{0};
+    for(std::size_t p = 0; p < n; ++p) {
+        pairs[p].names = {all.names[2 * p], all.names[2 * p + 1]};
+        pairs[p].seqs = {all.seqs[2 * p], all.seqs[2 * p + 1]};
+        process_marginal(pairs[p], aln.gap, std::string(), aln.rev);
+        ancs[p] = pairs[p].seqs[0];
+        dess[p] = pairs[p].seqs[1];
+        const auto enc = marginal_seq_encoding(ancs[p], dess[p]);
+        check_descendant_codes(enc[1]);
+        a_cat.insert(a_cat.end(), enc[0].begin(), enc[0].end());
+        b_cat.insert(b_cat.end(), enc[1].begin(), enc[1].end());
+        a_off.push_back(a_cat.size());
+        b_off.push_back(b_cat.size());
+    }
+    coati_hip_model* model = make_model(aln);
+    std::vector<float> scores(n);
+    std::vector<uint8_t> ops(a_cat.size() + b_cat.size() + 1);
+    std::vector<uint64_t> off(n);
+    std::vector<uint32_t> len(n);
+    const int rc = coati_hip_viterbi_batch(model, n, a_cat.data(), a_off.data(), b_cat.data(), b_off.data(), scores.data(),
+                                           ops.data(), a_cat.size() + b_cat.size(), off.data(), len.data());
+    coati_hip_model_destroy(model);
+    hip_check(rc);
+    std::ofstream file;
+    std::ostream* out = &std::cout;
+    if(!(aln.output.empty() || aln.output == "-")) {
+        file.open(extract_file_type(aln.output).path);
+        if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
+        out = &file;
+    }
+    for(std::size_t p = 0; p < n; ++p) {
+        pairs[p].seqs.assign(2, std::string());
+        ops_to_alignment(ops.data() + off[p], len[p], ancs[p], dess[p], pairs[p].seqs[0], pairs[p].seqs[1]);
+        pairs[p].score = scores[p];
+        restore_end_stops(pairs[p], aln.gap);
+        write_json(pairs[p], *out, p, n);
+    }
+    return true;
+}
+
+namespace {
+// utils::process_alignment (src/lib/utils.cc:847-938): validate an input alignment, blank terminal
+// stop codons, return the expanded CIGAR and leave the ungapped sequences in data.seqs.
+std::string process_alignment(alignment_t& aln) {
+    data_t& data = aln.data;
+    if(data.size() != 2) throw std::invalid_argument("Exactly two sequences required.");
+    if(!aln.refs.empty() || aln.rev) order_ref(data, aln.refs, aln.rev);
+    const std::size_t len = data.seqs[0].length();
+    if(len != data.seqs[1].length())
+        throw std::invalid_argument("For alignment scoring both sequences must have equal length.");
+    for(std::size_t i = 0; i < 2; ++i) {
+        std::string& seq = data.seqs[i];
+        const std::size_t p3 = seq.find_last_not_of('-');
+        std::size_t p2 = std::string::npos, p1 = std::string::npos;
+        if(p3 != std::string::npos && p3 >= 2) p2 = seq.find_last_not_of('-', p3 - 1);
+        if(p2 != std::string::npos && p2 >= 1) p1 = seq.find_last_not_of('-', p2 - 1);
+        if(p1 == std::string::npos) {
+            data.stops.emplace_back("");
+            continue;
+        }
+        const char cod[4] = {seq[p1], seq[p2], seq[p3], '\0'};
+        if(is_stop64(cod_int(cod))) {
+            data.stops.emplace_back(cod);
+            seq[p1] = seq[p2] = seq[p3] = '-';
+        } else {
+            data.stops.emplace_back("");
+        }
+    }
+    std::string cigar;
+    cigar.reserve(len);
+    for(std::size_t i = 0; i < len; ++i) {
+        const char a = data.seqs[0][i], b = data.seqs[1][i];
+        if(a != '-' && b != '-')
+            cigar.push_back('M');
+        else if(a != '-')
+            cigar.push_back('D');
+        else if(b != '-')
+            cigar.push_back('I');
+    }
+    for(std::string& s : data.seqs) s.erase(std::remove(s.begin(), s.end(), '-'), s.end());
+    const std::size_t len_a = data.seqs[0].length(), len_b = data.seqs[1].length();
+    if(len_a % 3 != 0 || len_a % aln.gap.len != 0)
+        throw std::invalid_argument("Length of reference sequence must be multiple of 3 and gap unit length.");
+    if(len_b % aln.gap.len != 0)
+        throw std::invalid_argument("Length of descendant sequence must be multiple of gap unit length.");
+    return cigar;
+}
+}  // namespace
+
+float alignment_score(alignment_t& aln, const table_t& p_marg) {
+    const std::string cigar = process_alignment(aln);
+    const auto enc = marginal_seq_encoding(aln.data.seqs[0], aln.data.seqs[1]);
+    check_descendant_codes(enc[1]);
+    const auto k = gap_log_consts(aln.gap);
+    const float no_gap = k[0], gap_stop = k[1], gap_open = k[2], gap_extend = k[3];
+    auto subst = [&](std::size_t pa, std::size_t pb) { return p_marg[enc[0][pa] * kTableCols + enc[1][pb]]; };
+    auto pw = [](float x, std::size_t n) { return x * static_cast<float>(n); };
+    // one closed gap run (align_marginal.cc:421-437,450-463); `last` adds the trailing no_gap of the both-kinds case
+    auto close_gap = [&](float score, std::size_t nins, std::size_t ndel, bool last) {
+        if(nins == 0) return (((score + no_gap) + gap_open) + pw(gap_extend, ndel - 1)) + gap_stop;
+        if(ndel == 0) return (((score + gap_open) + pw(gap_extend, nins - 1)) + gap_stop) + no_gap;
+        float s = (((score + gap_open) + gap_open) + pw(gap_extend, nins + ndel - 2)) + gap_stop;
+        s = s + gap_stop;
+        return last ? s + no_gap : s;
+    };
+    bool in_gap = false;
+    float score = 0.f;
+    std::size_t nins = 0, ndel = 0, apos = 0, bpos = 0;
+    for(const char op : cigar) {
+        if(op == 'I') {
+            ++nins;
+            ++bpos;
+            in_gap = true;
+        } else if(op == 'D') {
+            ++ndel;
+            ++apos;
+            in_gap = true;
+        } else if(!in_gap) {
+            score = ((score + no_gap) + no_gap) + subst(apos, bpos);
+            ++apos;
+            ++bpos;
+        } else {
+            score = close_gap(score, nins, ndel, false);
+            score = score + subst(apos, bpos);
+            nins = ndel = 0;
+            in_gap = false;
+            ++apos;
+            ++bpos;
+        }
+    }
+    score = in_gap ? close_gap(score, nins, ndel, true) : (score + no_gap) + no_gap;
+    aln.data.score = score;
+    restore_end_stops(aln.data, aln.gap);
+    return aln.data.score;
+}
+
+void marg_sample(alignment_t& aln, std::size_t sample_size, random_t& rand) {
+    aln.data = read_input(aln.data.path);
+    if(aln.data.size() != 2) throw std::invalid_argument("Exactly two sequences required.");
+    std::ofstream file;
+    std::ostream* out = &std::cout;
+    if(!(aln.output.empty() || aln.output == "-")) {
+        file.open(aln.output);
+        if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
+        out = &file;
+    }
+    const std::size_t len_a = aln.seq(0).length();
+    if(len_a % 3 != 0 || len_a % aln.gap.len != 0)
+        throw std::invalid_argument("Length of reference sequence must be multiple of 3.");
+    if(aln.seq(1).length() % aln.gap.len != 0)
+        throw std::invalid_argument("Length of descendant sequence must be multiple of " + std::to_string(aln.gap.len) + ".");
+    trim_end_stops(aln.data);
+    const std::string anc = aln.seq(0), des = aln.seq(1);
+    const auto seq_pair = marginal_seq_encoding(anc, des);
+    check_descendant_codes(seq_pair[1]);
+    set_subst(aln);
+    align_pair_work_t work;
+    forward(work, seq_pair[0], seq_pair[1], aln);
+    if(sample_size == 0) return;
+    // all samples in one device call: the walker draws them one after the other from `rand`'s
+    // stream, exactly as the loop of align_marginal.cc:590-593 does
+    const uint64_t state_in[2] = {rand.lo(), rand.hi()};
+    uint64_t state_out[2] = {0, 0};
+    const std::size_t width = anc.size() + des.size();
+    std::vector<uint8_t> ops(sample_size * width + 1);
+    std::vector<uint64_t> off(sample_size);
+    std::vector<uint32_t> len(sample_size);
+    std::vector<float> lw(sample_size);
+    hip_check(coati_hip_sampleback(work.batch, static_cast<uint32_t>(sample_size), state_in, /*independent_streams=*/0,
+                                   lw.data(), ops.data(), sample_size * width, off.data(), len.data(), state_out));
+    rand.set_state(state_out[0], state_out[1]);
+    for(std::size_t i = 0; i < sample_size; ++i) {
+        aln.data.seqs.assign(2, std::string());
+        ops_to_alignment(ops.data() + off[i], len[i], anc, des, aln.data.seqs[0], aln.data.seqs[1]);
+        aln.data.score = lw[i];
+        restore_end_stops(aln.data, aln.gap);
+        write_json(aln.data, *out, i, sample_size);
+    }
+}
+
+}  // namespace coati_amd

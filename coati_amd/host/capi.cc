@@ -3,9 +3,12 @@
 // synthetic workload).  Errors: non-zero return + coati_host_last_error().
 #include <cstring>
 #include <exception>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 
+#include "align.hpp"
+#include "io.hpp"
 #include "model.hpp"
 #include "random.hpp"
 #include "seq.hpp"
@@ -163,6 +166,65 @@ int coati_host_rng_f24(unsigned long long state[2], int n, float* out) {
         for(int q = 0; q < n; ++q) out[q] = r.f24();
         state[0] = r.lo();
         state[1] = r.hi();
+    });
+}
+
+// extract_file_type (buffers of capacity cap)
+int coati_host_extract_file_type(const char* path, char* out_path, char* out_ext, unsigned long long cap) {
+    return guarded([&] {
+        const auto ft = coati_amd::extract_file_type(path);
+        if(ft.path.size() + 1 > cap || ft.type_ext.size() + 1 > cap) throw std::invalid_argument("buffer too small");
+        std::strcpy(out_path, ft.path.c_str());
+        std::strcpy(out_ext, ft.type_ext.c_str());
+    });
+}
+
+// read_input(in) -> write_output(out): format conversion through the readers/writers
+int coati_host_convert(const char* in_path, const char* out_path, float score) {
+    return guarded([&] {
+        coati_amd::data_t d = coati_amd::read_input(in_path);
+        if(score == score) d.score = score;  // NaN = keep what the reader found
+        coati_amd::write_output(d, out_path);
+    });
+}
+
+// element-of-array JSON writer used by `sample` and the batch extension
+int coati_host_write_json_array(const char* in_path, const char* out_path, unsigned count) {
+    return guarded([&] {
+        const coati_amd::data_t d = coati_amd::read_input(in_path);
+        std::ofstream out(out_path);
+        for(unsigned i = 0; i < count; ++i) coati_amd::write_json(d, out, i, count);
+    });
+}
+
+int coati_host_json_number(float v, char* out, unsigned long long cap) {
+    return guarded([&] {
+        const std::string s = coati_amd::json_number(v);
+        if(s.size() + 1 > cap) throw std::invalid_argument("buffer too small");
+        std::strcpy(out, s.c_str());
+    });
+}
+
+// alignment_score of an aligned pair under a marginal model (mar-mg / mar-ecm)
+int coati_host_alignment_score(const char* aln_anc, const char* aln_des, const char* model, float gap_open,
+                               float gap_extend, unsigned gap_len, float* score) {
+    return guarded([&] {
+        coati_amd::alignment_t aln;
+        aln.model = model;
+        aln.gap.open = gap_open;
+        aln.gap.extend = gap_extend;
+        aln.gap.len = gap_len;
+        aln.data.names = {"A", "B"};
+        aln.data.seqs = {aln_anc, aln_des};
+        coati_amd::set_subst(aln);
+        *score = coati_amd::alignment_score(aln, aln.subst_matrix);
+    });
+}
+
+int coati_host_parse_matrix_csv(const char* path, float out[3721]) {
+    return guarded([&] {
+        const auto P = coati_amd::parse_matrix_csv(path);
+        std::memcpy(out, P.data(), sizeof(float) * 3721);
     });
 }
 

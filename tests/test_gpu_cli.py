@@ -1,0 +1,117 @@
+"""End-to-end: the coati-alignpair / coati-sample executables (C++ host layer ->
+C ABI -> HIP kernels) on the reference's own doctest cases and sample data."""
+import json
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "coati_amd" / "_build"
+KNOWN = json.loads((ROOT / "tests" / "golden" / "reference_known_answers.json").read_text())
+
+
+def run(binary, *args):
+    return subprocess.run([str(BIN / binary), *[str(a) for a in args]], capture_output=True, text=True, timeout=300)
+
+
+def test_example_001_default_json_to_stdout(tmp_path):
+    """BASELINE.json configs[0]: coati alignpair sampledata/example-001.fasta -m mar-mg."""
+    fa = tmp_path / "example-001.fasta"
+    fa.write_text(">1\nCTCTGGATAGTG\n>2\nCTATAGTG\n")  # content of sampledata/example-001.fasta
+    r = run("coati-alignpair", fa, "-m", "mar-mg")
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["alignment"] == {"1": "CTCTGGATAGTG", "2": "CT----ATAGTG"}
+    assert out["score"] == pytest.approx(1.50913, rel=1e-5)
+    assert r.stdout.startswith('{\n  "alignment": {\n    "1": "CTCTGGATAGTG",')
+
+
+def test_marg_alignment_doctest_cases(tmp_path):
+    """src/lib/align_marginal.cc:149-240."""
+    for k, case in enumerate(KNOWN["marg_alignment"]):
+        names = case.get("names", ["1", "2"])
+        fa = tmp_path / f"c{k}.fasta"
+        fa.write_text("".join(f">{n}\n{s}\n" for n, s in zip(names, case["seqs"])))
+        out = tmp_path / f"c{k}.out.fasta"
+        args = [fa, "-m", case["model"], "-o", out]
+        if "refs" in case:
+            args += ["-r", case["refs"]]
+        if case.get("rev"):
+            args += ["-v"]
+        if "gap_len" in case:
+            args += ["-k", case["gap_len"]]
+        if "amb" in case:
+            args += ["-a", case["amb"]]
+        r = run("coati-alignpair", *args)
+        assert r.returncode == 0, (case, r.stderr)
+        toks = out.read_text().split()
+        want_names = case.get("out_names", names)
+        assert toks == [">" + want_names[0], case["out"][0], ">" + want_names[1], case["out"][1]], case
+
+
+def test_marg_alignment_failures(tmp_path):
+    for k, case in enumerate(KNOWN["marg_alignment_fail"]):
+        fa = tmp_path / f"f{k}.fasta"
+        fa.write_text("".join(f">{i + 1}\n{s}\n" for i, s in enumerate(case["seqs"])))
+        args = [fa]
+        if "gap_len" in case:
+            args += ["-k", case["gap_len"]]
+        if "refs" in case:
+            args += ["-r", case["refs"]]
+        r = run("coati-alignpair", *args)
+        assert r.returncode == 1 and r.stderr.startswith("ERROR:"), (case, r.stderr)
+
+
+def test_phylip_output_and_stop_codons(tmp_path):
+    fa = tmp_path / "s.fasta"
+    fa.write_text(">anc\nGCGATTGCTGTTTGA\n>des\nGCGACTGTT\n")  # terminal stop only in the ancestor
+    out = tmp_path / "s.phy"
+    r = run("coati-alignpair", fa, "-o", out)
+    assert r.returncode == 0, r.stderr
+    lines = out.read_text().split("\n")
+    assert lines[0] == "2 15" and lines[1] == "anc       GCGATTGCTGTTTGA" and lines[2] == "des       GCGA---CTGTT---"
+    # score: -s prints the score of a given alignment; re-scoring the output reproduces the aligner's score
+    js = tmp_path / "s.json"
+    assert run("coati-alignpair", fa, "-o", js).returncode == 0
+    score = json.loads(js.read_text())["score"]
+    al = tmp_path / "al.fasta"
+    al.write_text(">anc\nGCGATTGCTGTTTGA\n>des\nGCGA---CTGTT---\n")
+    r = run("coati-alignpair", al, "-s")
+    assert r.returncode == 0 and float(r.stdout.split()[-1]) == pytest.approx(score, rel=1e-5)
+
+
+def test_batch_extension(tmp_path):
+    fa = tmp_path / "b.fasta"
+    fa.write_text(">a1\nCTCTGGATAGTG\n>b1\nCTATAGTG\n>a2\nGCGATTGCTGTT\n>b2\nGCGACTGTT\n")
+    r = run("coati-alignpair", fa, "--batch")
+    assert r.returncode == 0, r.stderr
+    arr = json.loads(r.stdout)
+    assert [list(x["alignment"].values()) for x in arr] == [["CTCTGGATAGTG", "CT----ATAGTG"], ["GCGATTGCTGTT", "GCGA---CTGTT"]]
+    assert arr[0]["score"] == pytest.approx(1.50913, rel=1e-5) and arr[1]["score"] == pytest.approx(3.79779, rel=1e-5)
+
+
+def test_sample_doctest_cases(tmp_path):
+    """src/lib/align_marginal.cc:598-672: seed 42, exact JSON layout; scores to 1e-5 (device libm, own expm)."""
+    for k, case in enumerate(KNOWN["marg_sample"]):
+        fa = tmp_path / f"s{k}.fasta"
+        fa.write_text(f">A\n{case['seqs'][0]}\n>B\n{case['seqs'][1]}\n")
+        out = tmp_path / f"s{k}.json"
+        r = run("coati-sample", fa, "-n", len(case["out"]), "-s", "42", "-o", out)
+        assert r.returncode == 0, r.stderr
+        text = out.read_text()
+        lines = text.split("\n")
+        assert lines[0] == "[" and lines[1] == "{" and lines[2] == '  "alignment": {'
+        arr = json.loads(text)
+        assert len(arr) == len(case["out"])
+        for got, (wa, wb), ws in zip(arr, case["out"], case["scores"]):
+            assert got["alignment"] == {"A": wa, "B": wb}
+            assert got["score"] == pytest.approx(float(ws), rel=1e-5)
+    # failures (align_marginal.cc:673-722)
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">seq1\nAC\n>seq2\nACG\n")
+    assert run("coati-sample", bad).returncode == 1
+    one = tmp_path / "one.fasta"
+    one.write_text(">A\nCCC\n")
+    assert run("coati-sample", one).returncode == 1

@@ -1,0 +1,150 @@
+"""Host layer: I/O formats, alignment_score known answers, CLI argument handling
+(no GPU needed: the alignment itself is exercised in test_gpu_cli.py)."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+from coati_amd import host
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden"
+KNOWN = json.loads((GOLD / "reference_known_answers.json").read_text())
+BIN = ROOT / "coati_amd" / "_build"
+
+
+def test_extract_file_type_known_answers():
+    """src/lib/utils.cc:657-676."""
+    for path, want in (("foo.bar", ("foo.bar", ".bar")), ("my:foo.bar", ("foo.bar", ".my")), (".bar", (".bar", "")),
+                       (".", (".", "")), ("..", ("..", "")), ("my:.foo.bar", (".foo.bar", ".my")),
+                       (".foo.bar", (".foo.bar", ".bar")), ("", ("", "")), ("foo:-", ("-", ".foo")), ("foo:bar", ("bar", ".foo")),
+                       ("bar:", ("", ".bar")), ("c:foo.bar", ("c:foo.bar", ".bar")),
+                       (" \f\n\r\t\vfoo.bar \f\n\r\t\v", ("foo.bar", ".bar")), (" \f\n\r\t\vmy:foo.bar \f\n\r\t\v", ("foo.bar", ".my")),
+                       (" \f\n\r\t\v", ("", ""))):
+        assert host.extract_file_type(path) == want, path
+
+
+def test_fasta_reader_and_writers(tmp_path):
+    src = tmp_path / "in.fasta"
+    src.write_text("; comment\njunk before\n>seq one with spaces\nCTCTGG ATA\nGTC\n\n>2\nCTATAGTC\n")
+    host.convert(src, tmp_path / "out.fa")
+    assert (tmp_path / "out.fa").read_text() == ">seq one with spaces\nCTCTGGATAGTC\n>2\nCTATAGTC\n"
+    long = tmp_path / "long.fasta"
+    long.write_text(">1\n" + "A" * 100 + "\n>2\n" + "A" * 100 + "\n")
+    host.convert(long, tmp_path / "wrap.fasta")
+    assert (tmp_path / "wrap.fasta").read_text() == ">1\n" + "A" * 60 + "\n" + "A" * 40 + "\n>2\n" + "A" * 60 + "\n" + "A" * 40 + "\n"
+    # phylip output (src/lib/phylip.cc:253-272): 10-char names, first block 50 columns, then 60
+    host.convert(long, tmp_path / "out.phy")
+    lines = (tmp_path / "out.phy").read_text().split("\n")
+    assert lines[0] == "2 100" and lines[1] == "1         " + "A" * 50 and lines[2] == "2         " + "A" * 50
+    assert lines[3] == "" and lines[4] == "A" * 50 and lines[5] == "A" * 50
+    # and back
+    host.convert(tmp_path / "out.phy", tmp_path / "back.fa")
+    assert (tmp_path / "back.fa").read_text() == (tmp_path / "wrap.fasta").read_text()
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">\nCTC\n>2\nCTA\n")
+    with pytest.raises(host.CoatiHostError, match="without a name"):
+        host.convert(bad, tmp_path / "x.fa")
+    (tmp_path / "in.txt").write_text(">1\nAAA\n")
+    with pytest.raises(host.CoatiHostError, match="Invalid input"):
+        host.convert(tmp_path / "in.txt", tmp_path / "x.fa")
+    with pytest.raises(host.CoatiHostError, match="Opening input file"):
+        host.convert(tmp_path / "missing.fa", tmp_path / "x.fa")
+    with pytest.raises(host.CoatiHostError, match="Invalid output format"):
+        host.convert(src, tmp_path / "x.txt")
+
+
+def test_json_format(tmp_path):
+    """src/lib/json.cc:176-199: 2-space indent, "score": 0.0; sample arrays json.cc:232-290."""
+    src = tmp_path / "in.fa"
+    src.write_text(">a\nATGTCTTCTCACAAGACA\n>b\nATGTCTTCTCACAAGACA\n")
+    host.convert(src, tmp_path / "out.json", 0.0)
+    want = '{\n  "alignment": {\n    "a": "ATGTCTTCTCACAAGACA",\n    "b": "ATGTCTTCTCACAAGACA"\n  },\n  "score": 0.0\n}\n'
+    assert (tmp_path / "out.json").read_text() == want
+    host.convert(tmp_path / "out.json", tmp_path / "rt.fa")
+    assert (tmp_path / "rt.fa").read_text() == src.read_text()
+    host.write_json_array(src, tmp_path / "arr.json", 2)
+    body = want.rstrip("\n")
+    assert (tmp_path / "arr.json").read_text() == "[\n" + body + ",\n" + body + "\n]\n"
+    assert json.loads((tmp_path / "arr.json").read_text())[1]["score"] == 0.0
+    (tmp_path / "noscore.json").write_text('{"alignment": {"a": "AAA", "b": "AAA"}}')
+    with pytest.raises(host.CoatiHostError):
+        host.convert(tmp_path / "noscore.json", tmp_path / "x.fa")
+    # numbers print like nlohmann::json prints a float widened to double
+    assert host.json_number(np.float32(-1.9466571807861328)) == "-1.9466571807861328"
+    assert host.json_number(0.0) == "0.0" and host.json_number(2.0) == "2.0" and host.json_number(1.5) == "1.5"
+
+
+def test_alignment_score_known_answers():
+    """align_marginal.cc:489-508: 19 scores, doctest::Approx."""
+    for anc, des, want in KNOWN["alignment_score"]:
+        got = host.alignment_score(anc, des)
+        assert abs(got - want) < 1.19e-5 * (1 + max(abs(got), abs(want))), (anc, des, got, want)
+    with pytest.raises(host.CoatiHostError):
+        host.alignment_score("ATAC", "ATA-")  # reference length not a multiple of 3
+    with pytest.raises(host.CoatiHostError):
+        host.alignment_score("ATACGG", "ATA")  # unequal lengths
+
+
+def test_alignment_score_equals_viterbi_score_on_golden_alignments(oracle):
+    """Rescoring the reference's own optimal alignments reproduces their Viterbi score (same model)."""
+    doc = json.loads((GOLD / "viterbi_cases.json").read_text())
+    n = 0
+    for c in doc["cases"]:
+        if c["gap_len"] != 1 or not (0 < len(c["anc"]) <= 200) or set(c["des"]) - set("ACGT"):
+            continue
+        if c["des"][-3:] in ("TAA", "TAG", "TGA"):
+            continue  # alignment_score blanks a terminal stop codon and charges a gap for it
+        cols = ["M" if x != "-" and y != "-" else ("D" if y == "-" else "I") for x, y in zip(c["aln_anc"], c["aln_des"])]
+        runs = "".join(cols).replace("M", " ").split()
+        if any("D" in r and "I" in r for r in runs):
+            continue  # mixed gap runs are scored with their own closed form (align_marginal.cc:430-434)
+        got = host.alignment_score(c["aln_anc"], c["aln_des"])
+        assert got == pytest.approx(c["score"], rel=2e-5, abs=2e-5), c["name"]
+        n += 1
+    assert n > 50
+
+
+def test_user_rate_matrix_csv(tmp_path):
+    """--sub (io.cc:48-88): branch length, then 3721 'cod,cod,rate' lines -> exp(Q t)."""
+    sense = [c for c in range(64) if c not in (48, 50, 56)]
+    cod = lambda c: "ACGT"[(c >> 4) & 3] + "ACGT"[(c >> 2) & 3] + "ACGT"[c & 3]
+    rng = np.random.default_rng(2)
+    Q = rng.uniform(0, 0.05, (61, 61))
+    np.fill_diagonal(Q, 0)
+    np.fill_diagonal(Q, -Q.sum(1))
+    path = tmp_path / "q.csv"
+    with path.open("w") as f:
+        f.write("0.5\n")
+        for i in range(61):
+            for j in range(61):
+                f.write(f"{cod(sense[i])},{cod(sense[j])},{Q[i, j]:.9g}\n")
+    P = host.parse_matrix_csv(path)
+    assert np.abs(P - scipy.linalg.expm(np.float32(Q).astype(np.float64) * 0.5)).max() < 1e-6
+    short = tmp_path / "short.csv"
+    short.write_text("0.5\nAAA,AAC,0.1\n")
+    with pytest.raises(host.CoatiHostError):
+        host.parse_matrix_csv(short)
+
+
+def run(binary, *args):
+    return subprocess.run([str(BIN / binary), *args], capture_output=True, text=True, timeout=120)
+
+
+def test_cli_usage_errors(tmp_path):
+    assert "Usage" in run("coati-alignpair", "--help").stdout
+    assert run("coati-alignpair").returncode != 0  # input required
+    fa = tmp_path / "p.fasta"
+    fa.write_text(">1\nCTCTGGATAGTG\n>2\nCTATAGTG\n")
+    for bad in (["-t", "-1"], ["-g", "0"], ["--nope"], ["-k", "0"], ["-a", "WORST"], ["-m", "mar-mg", "--sub", "x.csv"],
+                ["-r", "1", "-v"], ["-p", "0.1", "0.2"]):
+        r = run("coati-alignpair", str(fa), *bad)
+        assert r.returncode != 0, bad
+    # models of the FST aligner are not served by this build
+    r = run("coati-alignpair", str(fa), "-m", "tri-mg")
+    assert r.returncode == 1 and "ERROR" in r.stderr
+    r = run("coati-sample", str(fa), "-m", "dna")
+    assert r.returncode == 1 and "Sampling only available" in r.stderr
