@@ -98,6 +98,9 @@ struct coati_hip_batch {
     PairDesc* d_desc = nullptr;
     uint32_t* d_order = nullptr;   // pair indices, most cells first
     uint32_t* d_queue = nullptr;   // ticket counter of the persistent fill kernel
+    WorkItem* d_items = nullptr;   // viterbi_l1 work list: (pair, strip), longest pairs first
+    uint32_t* d_progress = nullptr;
+    uint32_t n_items = 0;
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
     uint32_t* d_flags = nullptr;
     float *d_bnd = nullptr, *d_scores = nullptr;
@@ -116,7 +119,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
     const coati_hip_model* m = b->model;
     return BatchDeviceView{m->d_table,  m->k,      static_cast<uint32_t>(m->gap_len),
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
-                           b->d_queue,  b->d_a,    b->d_b,
+                           b->d_queue,  b->d_items, b->n_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len,
                            b->d_mdi,    b->d_final_mdi};
@@ -186,7 +189,7 @@ void coati_hip_model_destroy(coati_hip_model_t* m) {
 void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(b == nullptr) return;
     if(b->model != nullptr) (void)hipSetDevice(b->model->device);
-    void* ptrs[] = {b->d_mdi, b->d_final_mdi, b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
+    void* ptrs[] = {b->d_items, b->d_progress, b->d_mdi, b->d_final_mdi, b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
                     b->d_bnd,  b->d_scores, b->d_ops_start, b->d_ops_len};
     for(void* p : ptrs)
         if(p != nullptr) (void)hipFree(p);
@@ -261,7 +264,8 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
         const uint32_t ns = n_strips(d.lb);
         if(la > 0 && lb > 0) b->flag_dwords += ns * strip_dwords(d.la);
         // 128-byte aligned so that no two waves ever share a cache line of it
-        if(ns > 1) b->bnd_floats += ((la + 1) * (3 + 2 * L) + 31) / 32 * 32;  // covers both kernels' layouts
+        // viterbi_l1: one 2(la+1) array per strip boundary; dp_generic: one (la+1)(3+2L) array
+        if(ns > 1) b->bnd_floats += (std::max<uint64_t>((ns - 1) * 2 * (la + 1), (la + 1) * (3 + 2 * L)) + 31) / 32 * 32;
         if(la > 0 && lb > 0) b->mdi_floats += ns * strip_mdi_floats(d.la);
         b->ops_total += la + lb;
         b->cells += la * lb;
@@ -301,6 +305,15 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
             return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
         });
         B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<WorkItem> items;
+        for(const uint32_t p : order) {
+            const uint32_t ns = (b->desc[p].la > 0 && b->desc[p].lb > 0) ? n_strips(b->desc[p].lb) : 1u;
+            for(uint32_t st = 0; st < ns; ++st) items.push_back(WorkItem{p, st});
+        }
+        b->n_items = static_cast<uint32_t>(items.size());
+        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_items), items.size() * sizeof(WorkItem)));
+        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_progress), std::max<size_t>(items.size(), 4) * sizeof(uint32_t)));
+        B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
     }
     if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
     if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));

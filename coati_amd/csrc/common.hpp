@@ -234,6 +234,12 @@ __device__ __forceinline__ uint64_t mdi_index(uint64_t base, uint32_t la, uint32
 // ---------------------------------------------------------------------------
 // launchers implemented in the kernel translation units
 // ---------------------------------------------------------------------------
+// One unit of work of the persistent Viterbi kernel: one strip (1024 descendant
+// columns) of one pair.  The strips of a pair are consecutive items.
+struct WorkItem {
+    uint32_t pair, strip;
+};
+
 struct BatchDeviceView {
     const float* table;
     GapConsts k;
@@ -242,6 +248,9 @@ struct BatchDeviceView {
     const uint32_t* order;
     uint32_t n_pairs;
     uint32_t* queue;
+    const WorkItem* items;  // viterbi_l1: (pair, strip) work list, longest pairs first
+    uint32_t n_items;
+    uint32_t* progress;     // viterbi_l1: rows of each item whose boundary column is published
     const uint8_t *a_cat, *b_cat;
     uint32_t* flags;
     float* bnd;

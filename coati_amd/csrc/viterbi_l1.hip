@@ -24,6 +24,7 @@
 // -ffp-contract=off -fno-slp-vectorize.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -133,6 +134,27 @@ __device__ __forceinline__ void row_l1(const GapConsts& k, LaneState& st, float 
 }
 
 
+// Strip-boundary hand-off between wavefronts (cdna_hip_programming.md Guideline 16, recipe R1):
+// the payload is stored write-through (agent-scope relaxed atomic store = `sc1`), the storing
+// wave drains (s_waitcnt vmcnt(0)) and ONE lane publishes a progress word; the consumer polls that
+// word relaxed and then executes ONE agent-scope acquire before its plain loads.
+__device__ __forceinline__ void store_through(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_progress(uint32_t* word, uint32_t rows, bool leader) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if(leader) __hip_atomic_store(word, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false if the producer did not get there within the spin bound (never hang the GPU)
+__device__ __forceinline__ bool wait_progress(const uint32_t* word, uint32_t need) {
+    for(uint32_t spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spins) {
+        if(spins > (1u << 26)) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
 // Read-only per-strip context of one wavefront.
 struct StripCtx {
     GapConsts k;
@@ -170,7 +192,7 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uin
                     st.X[c] = i1 + k.ng;
                     st.Y[c] = i1 + k.go;
                 }
-                if(!cx.last_strip && lane == kWave - 1) cx.bnd_x[0] = st.X[kW - 1];
+                if(!cx.last_strip && lane == kWave - 1) store_through(&cx.bnd_x[0], st.X[kW - 1]);
             }
         }
         // ---- hand-off from the left neighbour (full exec)
@@ -189,8 +211,8 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uin
         }
         const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
         if(!cx.last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(cx.la)) {
-            cx.bnd_x[r + 1] = st.X[kW - 1];
-            cx.bnd_z[r] = st.zlast;
+            store_through(&cx.bnd_x[r + 1], st.X[kW - 1]);
+            store_through(&cx.bnd_z[r], st.zlast);
         }
         if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
             // score = max(M,D,I) of the terminal-adjusted last cell
@@ -211,8 +233,8 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uin
 // took ~2x the time its work implies.)  `order` lists the pairs longest first.
 __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
-    const uint32_t* __restrict__ order, uint32_t n_pairs, uint32_t* __restrict__ queue,
-    const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
+    const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
+    uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
     uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
     __shared__ float tab[kTabRows * kTabStride];
@@ -233,26 +255,31 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     asm volatile("" : "+v"(lane));
     uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);  // every lane takes part; lane 0 draws
     ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
-    if(ticket >= n_pairs) break;
-    const uint32_t pair = order[ticket];
+    if(ticket >= n_items) break;
+    const WorkItem item = items[ticket];
+    const uint32_t pair = item.pair, strip = item.strip;
     const PairDesc pd = pairs[pair];
     const uint32_t la = pd.la, lb = pd.lb;
+    const uint32_t strips = (la > 0 && lb > 0) ? n_strips(lb) : 1u;
+    bool handoff_ok = true;
     if(la > 0 && lb > 0) {  // (without body cells only the margins are walked)
     const uint8_t* __restrict__ a = a_cat + pd.a_off;
     const uint8_t* __restrict__ b = b_cat + pd.b_off;
-
-    const uint32_t strips = n_strips(lb);
-    for(uint32_t strip = 0; strip < strips; ++strip) {
+    {
         const uint32_t col0 = strip * kStrip;
         const uint32_t ncol = min(static_cast<uint32_t>(kStrip), lb - col0);
         const uint32_t nlanes = (ncol + kW - 1) / kW;
         const uint32_t nsteps = la + nlanes - 1;
         const bool last_strip = strip + 1 == strips;
         uint32_t* __restrict__ fout = flags + pd.flags_off + strip * strip_dwords(la) + lane;
-        // strip-boundary columns: [0, la] = X of the last column (index r = X of
-        // body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
-        float* __restrict__ bnd_x = bnd + pd.bnd_off;
+        // strip-boundary columns, one array per strip boundary: [0, la] = X of the strip's last
+        // column (index r = X of body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
+        // The strips of a pair run on different wavefronts, pipelined through these arrays.
+        const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
+        float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
         float* __restrict__ bnd_z = bnd_x + (la + 1);
+        const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
+        const float* __restrict__ in_z = in_x + (la + 1);
 
         // byte offsets of this lane's 16 table columns
         uint32_t boff[kW];
@@ -295,9 +322,14 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
                         const float dm = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
                         bx = dm + k.gs;
                     }
-                } else {
-                    bx = bnd_x[crow];
-                    bz = bnd_z[crow];
+                }
+            }
+            if(strip > 0) {
+                // rows kbase .. kbase+63 of the left neighbour's last column must be published
+                handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
+                if(crow < la) {
+                    bx = in_x[crow];
+                    bz = in_z[crow];
                 }
             }
             // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
@@ -306,16 +338,34 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
                 run_chunk<true>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
             else
                 run_chunk<false>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+            if(!last_strip) {
+                // lane 63 has now finished body rows < kbase + 64 - 63; the final count (la) is
+                // published below, after the release of the decision bits
+                const uint32_t done = min(kbase + kWave, nsteps);
+                if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
+            }
         }
         if(nsteps & 1u)  // the last (even) step has no odd partner: flush its IM bits to the high half
             fout[static_cast<uint64_t>(nsteps >> 1) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << 16;
+        if(!last_strip) {
+            // The pair's traceback runs on the wavefront of the LAST strip: release this strip's
+            // (plainly stored) decision bits before saying "complete".
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            publish_progress(progress + ticket, la, lane == kWave - 1);
+        }
     }
     }
-    // ---- traceback of this pair by the same wavefront, while its bits are still
-    // in L2.  The wave reads what it wrote itself: wait until its stores are
-    // acknowledged; nobody read these (128-byte aligned) lines before, so L1 is cold.
+    if(strip + 1 < strips) continue;  // not the last strip of its pair: no traceback here
+    // ---- traceback of this pair by the wavefront of its last strip, while the bits are still
+    // in L2.  What the wave wrote itself: wait until the stores are acknowledged (nobody read
+    // these 128-byte aligned lines before, so L1 is cold).  What other wavefronts wrote (earlier
+    // strips): they released before publishing "complete", which this wave polled; acquire.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if(strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
     viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
+    if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");
     }  // next ticket
 }
 
@@ -365,15 +415,17 @@ FillShape fill_launch_shape(uint32_t n_pairs) {
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
     if(e != hipSuccess) return e;
-    const FillShape shape = fill_launch_shape(v.n_pairs);
+    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);  // polled words: zero every launch
+    if(e != hipSuccess) return e;
+    const FillShape shape = fill_launch_shape(v.n_items);
     if(shape.dynamic_lds > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_l1), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(shape.dynamic_lds));
         if(e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(viterbi_l1, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, stream, v.table, v.k,
-                       v.pairs, v.order, v.n_pairs, v.queue, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops,
-                       v.ops_start, v.ops_len);
+                       v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
+                       v.ops, v.ops_start, v.ops_len);
     return hipGetLastError();
 }
 

@@ -575,6 +575,57 @@ float oracle_path_logweight(const float* M, const float* D, const float* I, uint
     return score;
 }
 
+float oracle_path_score(const float* table, const float consts[4], int gap_len, const uint8_t* a,
+                        uint64_t len_a, const uint8_t* b, uint64_t len_b, const uint8_t* ops,
+                        int64_t n_ops) {
+    const Consts k(consts);
+    const uint64_t L = gap_len, start = L - 1, rows = len_a + L, cols = len_b + L;
+    const float ext_lm1 = pw(k.gap_extend, L - 1), ext_l = pw(k.gap_extend, L);
+    uint64_t i = start, j = start;  // matrix cell the path has reached
+    int st = ORACLE_OP_M;           // state at that cell
+    float v = 0.0f;                 // M(start, start) = one()
+    int64_t t = 0;
+    while(t < n_ops) {
+        const int op = ops[t];
+        if(op == ORACLE_OP_M) {
+            if(i + 1 >= rows || j + 1 >= cols) return kLowest;
+            ++i;
+            ++j;
+            const float s = table[static_cast<size_t>(a[i - L]) * kTableCols + b[j - L]];
+            v = st == ORACLE_OP_M ? ((v + k.no_gap) + k.no_gap) + s
+                                  : (st == ORACLE_OP_D ? (v + k.gap_stop) + s : ((v + k.gap_stop) + k.no_gap) + s);
+            t += 1;
+        } else if(op == ORACLE_OP_D) {
+            if(i + L >= rows) return kLowest;
+            for(uint64_t q = 0; q < L; ++q)
+                if(t + static_cast<int64_t>(q) >= n_ops || ops[t + q] != ORACLE_OP_D) return kLowest;
+            i += L;
+            if(j == start)  // margin column (align_pair.cc:82-86)
+                v = (k.no_gap + k.gap_open) + pw(k.gap_extend, i - 1);
+            else
+                v = st == ORACLE_OP_M ? ((v + k.no_gap) + k.gap_open) + ext_lm1
+                                      : (st == ORACLE_OP_D ? v + ext_l : ((v + k.gap_stop) + k.gap_open) + ext_lm1);
+            t += static_cast<int64_t>(L);
+        } else {
+            if(j + L >= cols || st == ORACLE_OP_D) return kLowest;  // no D -> I edge in the model
+            for(uint64_t q = 0; q < L; ++q)
+                if(t + static_cast<int64_t>(q) >= n_ops || ops[t + q] != ORACLE_OP_I) return kLowest;
+            j += L;
+            if(i == start)  // margin row (align_pair.cc:88-90)
+                v = k.gap_open + pw(k.gap_extend, j - 1);
+            else
+                v = st == ORACLE_OP_M ? (v + k.gap_open) + ext_lm1 : v + ext_l;
+            t += static_cast<int64_t>(L);
+        }
+        st = op;
+    }
+    if(i != rows - 1 || j != cols - 1) return kLowest;
+    // terminal state (align_pair.cc:130-138)
+    if(st == ORACLE_OP_M) return (v + k.no_gap) + k.no_gap;
+    if(st == ORACLE_OP_D) return v + k.gap_stop;
+    return (v + k.gap_stop) + k.no_gap;
+}
+
 double oracle_viterbi_batch_timed(const float* table, const float consts[4], int gap_len,
                                   uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                                   const uint8_t* b_cat, const uint64_t* b_off, int threads,

@@ -102,6 +102,15 @@ float oracle_path_logweight(const float* M, const float* D, const float* I, uint
                             int gap_len, const uint8_t* a, const uint8_t* b,
                             const uint8_t* ops, int64_t n_ops);
 
+/* Size-independent check for pairs too large for the full oracle: re-derive, in
+ * O(n_ops), the Viterbi value the fill assigns along a GIVEN path (ops per column),
+ * with the recurrences and margin formulas of align_pair.cc:82-138 in their own
+ * evaluation order.  For the optimal path this equals the DP's final score bit for
+ * bit.  Returns lowest() if the ops do not describe a path of this pair. */
+float oracle_path_score(const float* table, const float consts[4], int gap_len, const uint8_t* a,
+                        uint64_t len_a, const uint8_t* b, uint64_t len_b, const uint8_t* ops,
+                        int64_t n_ops);
+
 /* Timed CPU baseline: run oracle_viterbi (reference data layout: three fp32
  * matrices incl. their fill) over a batch on `threads` host threads, one pair
  * per thread at a time.  Returns wall seconds. */

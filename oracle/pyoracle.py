@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         L.oracle_sampleback.restype = C.c_int64
         L.oracle_sampleback_mdi.restype = C.c_int64
         L.oracle_path_logweight.restype = C.c_float
+        L.oracle_path_score.restype = C.c_float
         L.oracle_rng_f24.restype = C.c_float
         L.oracle_rng_bits.restype = C.c_uint64
         L.oracle_viterbi_batch_timed.restype = C.c_double
@@ -158,6 +159,15 @@ def path_logweight(M, D, I, table, consts, L, a, b, ops):
     ops = np.ascontiguousarray(ops, np.uint8)
     return np.float32(lib().oracle_path_logweight(_p(M), _p(D), _p(I), _u64(rows), _u64(cols), _p(table),
                                                   _p(consts), L, _p(a), _p(b), _p(ops), C.c_int64(len(ops))))
+
+
+def path_score(table, consts, L, a, b, ops):
+    """Viterbi value along a given path, O(len(ops)); equals the DP score for the optimal path."""
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    ops = np.ascontiguousarray(ops, np.uint8)
+    return np.float32(lib().oracle_path_score(_p(table), _p(consts), L, _p(a), _u64(len(a)), _p(b), _u64(len(b)), _p(ops),
+                                               C.c_int64(len(ops))))
 
 
 def viterbi_batch_timed(table, consts, L, a_cat, a_off, b_cat, b_off, threads=1):

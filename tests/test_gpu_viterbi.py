@@ -125,3 +125,17 @@ def test_invalid_inputs_rejected(hip, oracle):
         hip.Batch(model, *hip.pack_pairs([(np.array([183, 1, 2], np.uint8), np.array([1], np.uint8))]))
     with pytest.raises(hip.CoatiHipError):
         hip.Model(table, consts, 0)
+
+
+def test_long_pair_strips_pipelined_across_wavefronts(hip, oracle):
+    """A 21 kb x 20 kb pair = 20 strips handed from wavefront to wavefront, in a batch that also holds
+    short pairs (uneven load), vs the oracle's low-memory Viterbi."""
+    rng = np.random.default_rng(17)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    a = util.random_anc(rng, 7000)
+    d = util.mutate(rng, a, n_indel=40, mean_len=9)[:20000]
+    pairs = util.make_pairs(rng, 300, 1, 120) + [(a, d)] + util.make_pairs(rng, 100, 50, 400)
+    a2 = util.random_anc(rng, 1500)
+    pairs.insert(7, (a2, util.mutate(rng, a2, n_indel=10)))  # a second multi-strip pair (5 strips)
+    run_and_compare(hip, oracle, table, consts, pairs, check_flags=False)
