@@ -27,6 +27,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Secondary (and for this recurrence the binding) ceiling, DESIGN.md §4: the gap_len-1 cell is
+# 27 VALU instructions; non-packed fp32 VALU issues 32 lanes/clk/SIMD (measured, tools/ubench):
+# 1024 SIMDs x 32 x 2.4 GHz / 27 = 2.9 TCUPS.
+VALU_PEAK_GCUPS = 1024 * 32 * 2.4 / 27.0
 ALGO_BYTES_PER_CELL = 1.0      # 1 B/cell packed traceback written ...
 # ... + (len_a + len_b) B of sequence read per pair (added per pair below)
 
@@ -35,6 +39,8 @@ def cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off, budget_s=15.0):
     """Timed CPU port (the oracle, reference data layout) on a bounded sample of the same workload."""
     from oracle import pyoracle as orc  # checker/baseline only -- never on the product path
 
+    from coati_amd import host as _host
+    host_synth_raw = _host.synth_raw
     cores = os.cpu_count() or 1
     # calibrate on a few pairs (1 thread), then size the sample for ~budget_s on all cores
     n_cal = 4
@@ -45,10 +51,27 @@ def cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off, budget_s=15.0):
     la = np.diff(a_off[:n + 1]).astype(np.float64)
     lb = np.diff(b_off[:n + 1]).astype(np.float64)
     cells = float((la * lb).sum())
-    return {"value": cells / secs / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+    out = {}
+    if orc.ref_available():
+        # the UNMODIFIED reference engine (oracle/_ref, built in the build container from the
+        # reference's own sources): viterbi_mem + traceback_viterbi, one thread, a few pairs
+        try:
+            import time as _t
+            raw = [host_synth_raw(i) for i in range(n_cal)]
+            t0 = _t.perf_counter()
+            for i, (anc, des) in enumerate(raw):
+                orc.ref_viterbi(table, 0.001, float(np.float32(1.0) - np.float32(1.0) / np.float32(6.0)), 1, anc, des,
+                                a_cat[a_off[i]:a_off[i + 1]], b_cat[b_off[i]:b_off[i + 1]], want_matrices=False)
+            t_ref = _t.perf_counter() - t0
+            out["reference_single_thread_gcups"] = float((la[:n_cal] * lb[:n_cal]).sum() / t_ref / 1e9)
+        except Exception as exc:  # the baseline must never fail the bench
+            out["reference_single_thread_gcups"] = None
+            out["reference_error"] = repr(exc)
+    out.update({"value": cells / secs / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
             "pairs_per_s": n / secs, "single_thread_gcups": float((la[:n_cal] * lb[:n_cal]).sum() / t_cal / 1e9),
             "sample": f"first {n} pairs of the same synthetic set, oracle viterbi_mem+traceback "
-                      f"(3 fp32 matrices incl. fill), {cores} threads, {secs:.1f} s"}
+                      f"(3 fp32 matrices incl. fill), {cores} threads, {secs:.1f} s"})
+    return out
 
 
 def main():
@@ -138,13 +161,18 @@ def main():
         algo_bytes = cells * ALGO_BYTES_PER_CELL + seq_bytes
         traffic = None
         tfile = ROOT / "profiles" / "traffic_latest.json"
-        if tfile.exists():
+        if tfile.exists() and args.pairs == 10000 and args.model == "mar-mg":
             try:
                 traffic = json.loads(tfile.read_text()).get("viterbi_l1_bytes_per_launch_10000_pairs")
-                if args.pairs != 10000:
-                    traffic = None
             except Exception:
                 traffic = None
+        # PCIe-inclusive rate of the one-shot ABI call (upload + kernels + download of ops/scores);
+        # reported next to `value`, never as `value`
+        e2e = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            model.viterbi(a_cat, a_off, b_cat, b_off)
+            e2e = min(e2e, time.perf_counter() - t0)
         out = {
             "metric": "GCUPS (DP cell updates/s), marginal Viterbi fill+traceback, mar-mg94 1kb x 1kb pairs",
             "value": total_cells * args.steps / elapsed / 1e9,
@@ -167,7 +195,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "viterbi_l1", "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "the fill is VALU-issue bound, not HBM bound: see DESIGN.md §Roofline"},
+                         "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
+                         "note": "the kernel is VALU-issue bound, not HBM bound: see DESIGN.md §4"},
+            "pcie_inclusive": {"gcups": cells / e2e / 1e9, "pairs_per_s": args.pairs / e2e, "ms": e2e * 1e3,
+                               "what": "coati_hip_viterbi_batch on rank 0: H2D of the encoded batch + kernels + D2H of "
+                                       "scores/ops, pageable host memory, one call"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)

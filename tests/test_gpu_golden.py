@@ -58,3 +58,26 @@ def test_reference_doctest_alignments_default_model():
         sa = "".join("-" if o == 2 else ch for o, ch in zip(got, _expand(got, seqs[0], 2)))
         sb = "".join("-" if o == 1 else ch for o, ch in zip(got, _expand(got, seqs[1], 1)))
         assert [sa, sb] == case["out"], case
+
+
+@pytest.mark.parametrize("key", ["10k", "20k", "40k", "80k", "160k"])
+def test_long_sample_pairs(key):
+    """BASELINE configs[2]: the reference's long sample pairs (sanitised)
+    up to 160 002 x 160 002 nt.  Their strips run on different wavefronts, pipelined through HBM
+    boundary columns.  Expected score bits / columns / CRC32(ops) come from the compiled reference
+    (10k-40k) and from the low-memory oracle those pin (80k, 160k): bit-exact."""
+    import zlib
+
+    from coati_amd import hip, host
+
+    a, b, case, doc = util.load_long_pair(key)
+    table = np.load(GOLD / doc["table"])
+    consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])
+    model = hip.Model(table, consts, 1)
+    scores, ops, ops_off, ops_len = model.viterbi(*hip.pack_pairs([(a, b)]))
+    got = ops[int(ops_off[0]):int(ops_off[0]) + int(ops_len[0])]
+    assert int(np.float32(scores[0]).view(np.uint32)) == int(case["score_bits"], 16)
+    assert len(got) == case["columns"]
+    assert (int((got == 0).sum()), int((got == 1).sum()), int((got == 2).sum())) == (case["n_match"], case["n_del"],
+                                                                                     case["n_ins"])
+    assert "%08x" % zlib.crc32(got.tobytes()) == case["ops_crc32"]

@@ -104,3 +104,21 @@ def test_flag_walk_equals_matrix_walk(oracle, table):
             o1, s1 = oracle.viterbi(table, consts, L, a, b)
             o2, s2 = oracle.viterbi(table, consts, L, a, b, lowmem=True)
             assert (o1 == o2).all() and bits(s1) == bits(s2)
+
+
+@pytest.mark.parametrize("key", ["10k", "20k"])
+def test_long_sample_pairs_lowmem_oracle(oracle, key):
+    """Sanitised sampledata/example-{10k,20k}.fasta: the low-memory oracle reproduces what the
+    compiled reference produced (score bits, column count, CRC32 of the ops)."""
+    import zlib
+
+    a, b, case, doc = util.load_long_pair(key)
+    assert "reference engine" in case["source"]
+    table = np.load(GOLD / doc["table"])
+    consts = oracle.gap_consts(doc["gap_open"], doc["gap_extend"])
+    ops, sc = oracle.viterbi(table, consts, 1, a, b, lowmem=True)
+    assert bits(sc) == int(case["score_bits"], 16)
+    assert len(ops) == case["columns"]
+    assert "%08x" % zlib.crc32(ops.tobytes()) == case["ops_crc32"]
+    # and the O(n) path re-scoring used for pairs too large for any oracle
+    assert bits(oracle.path_score(table, consts, 1, a, b, ops)) == int(case["score_bits"], 16)

@@ -96,3 +96,28 @@ def make_pairs(rng, n, min_cod=1, max_cod=120, L=1, amb=0.02):
 
 def encode_pairs(pairs):
     return [(encode_anc(a), encode_des(b)) for a, b in pairs]
+
+
+def load_long_pair(key: str):
+    """Encoded (a, b) of one sanitised long sample pair from tests/golden/long_pairs.npz (2 bit/base;
+    see tools/make_golden_long.py) and its expectation record."""
+    import json
+    from pathlib import Path
+
+    gold = Path(__file__).resolve().parent / "golden"
+    doc = json.loads((gold / "long_pairs.json").read_text())
+    case = next(c for c in doc["cases"] if c["key"] == key)
+    z = np.load(gold / "long_pairs.npz")
+
+    def unpack(v, n):
+        nt = np.stack([v & 3, (v >> 2) & 3, (v >> 4) & 3, (v >> 6) & 3], axis=1).reshape(-1)[:n].astype(np.uint8)
+        return nt
+
+    anc_nt = unpack(z[f"anc_{key}"], case["len_a"])
+    des_nt = unpack(z[f"des_{key}"], case["len_b"])
+    # ancestor: codon61*3 + phase (utils.cc:496-528); descendant: nt16 code = 0..3 for ACGT
+    cod = (anc_nt[0::3].astype(np.int32) << 4) | (anc_nt[1::3].astype(np.int32) << 2) | anc_nt[2::3]
+    assert not np.isin(cod, STOPS64).any()
+    c61 = cod - sum((cod > s).astype(np.int32) for s in STOPS64)
+    a = (c61[:, None] * 3 + np.arange(3)[None, :]).reshape(-1).astype(np.uint8)
+    return a, des_nt, case, doc
