@@ -19,6 +19,12 @@ $(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
+# debug variant with per-wave clock stamps in the fill kernel (tools/trace_fill.py)
+trace: $(BUILD)/libcoati_hip_trace.so
+$(BUILD)/libcoati_hip_trace.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -DCOATI_FILL_TRACE -shared -o $@ $(HIP_SRC)
+
 HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc coati_amd/host/io.cc \
            coati_amd/host/align.cc coati_amd/host/cli.cc coati_amd/host/capi.cc
 HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc

@@ -30,6 +30,18 @@
 #include <utility>
 
 namespace coati_hip_detail {
+#ifdef COATI_FILL_TRACE
+// Debug build only (make trace): per-wave wall-clock stamps (s_memrealtime, 100 MHz) of the
+// persistent loop, read back by tools/trace_fill.py through coati_hip_debug_trace.
+__device__ unsigned long long g_fill_trace[4096 * 16];
+#define COATI_STAMP(slot)                                                                          \
+    do {                                                                                           \
+        if(lane_id == 0 && trace_n + (slot) < 16)                                                  \
+            g_fill_trace[trace_wave * 16 + trace_n + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+    } while(0)
+#else
+#define COATI_STAMP(slot) do { } while(0)
+#endif
 namespace {
 
 // Register state of one lane: its 16 columns of the row it processed last.
@@ -247,6 +259,17 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     const int lane_id = threadIdx.x & (kWave - 1);
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
+#ifdef COATI_FILL_TRACE
+    const uint32_t trace_wave = (blockIdx.x * kFillWaves + threadIdx.x / kWave) & 4095u;
+    uint32_t trace_n = 1;
+    if(lane_id == 0) {
+        g_fill_trace[trace_wave * 16] = __builtin_amdgcn_s_memrealtime();
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        g_fill_trace[trace_wave * 16 + 15] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
+    }
+#endif
     for(;;) {
     // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
     // loop-invariant condition and may peel/unswitch this loop per lane, after which the
@@ -356,6 +379,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
         }
     }
     }
+    COATI_STAMP(0);  // fill of this item done
     if(strip + 1 < strips) continue;  // not the last strip of its pair: no traceback here
     // ---- traceback of this pair by the wavefront of its last strip, while the bits are still
     // in L2.  What the wave wrote itself: wait until the stores are acknowledged (nobody read
@@ -366,51 +390,56 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
     viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
     if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");
+    COATI_STAMP(1);  // traceback done
+#ifdef COATI_FILL_TRACE
+    trace_n += 2;
+#endif
     }  // next ticket
 }
 
 
-// Launch shape of the persistent fill kernel: `blocks_per_cu` workgroups on each
-// of the 256 CUs (one wave per SIMD each), enforced by padding the launch with
-// unused dynamic LDS so that exactly that many fit.  More resident waves hide
-// latency better; fewer quantise the end of a small batch more finely.  Cost of
-// one pair relative to a saturated SIMD when w waves share it (measured,
-// in-kernel clocks): w=1 1.85, w=2 1.10, w=3 1.03.
+// Launch shape of the persistent fill kernel: `blocks_per_cu` workgroups on each of the 256
+// CUs (one wave per SIMD each), enforced by padding the launch with unused dynamic LDS so that
+// exactly that many fit.  Three resident waves per SIMD (the VGPR budget) saturate VALU issue
+// (measured cost of a pair relative to a saturated SIMD: 1 wave 1.85, 2 waves 1.10, 3 waves
+// 1.03).  All waves start together and draw tickets at once, so a grid with more waves than
+// items would scatter the items unevenly over the SIMDs: use no more waves than items.
 struct FillShape {
     uint32_t grid;
     size_t dynamic_lds;
 };
-FillShape fill_launch_shape(uint32_t n_pairs) {
+FillShape fill_launch_shape(uint32_t n_items) {
     constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
-    constexpr int kMaxBlocks = 3;  // 168 VGPRs -> 3 waves per SIMD
-    constexpr double kCost[4] = {0.0, 1.85, 1.10, 1.03};
+    constexpr int kMaxBlocks = 3;  // <= 168 VGPRs -> 3 waves per SIMD
     static const int forced = [] {
         const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
         return e != nullptr ? std::atoi(e) : 0;
     }();
-    int best = kMaxBlocks;
-    if(forced >= 1 && forced <= kMaxBlocks) {
-        best = forced;
-    } else {
-        double best_t = 1e300;
-        for(int w = kMaxBlocks; w >= 1; --w) {
-            const uint64_t per_simd = (static_cast<uint64_t>(n_pairs) + kSimds - 1) / kSimds;  // pairs on the busiest SIMD
-            const uint64_t rounds = (per_simd + w - 1) / w;
-            const double t = static_cast<double>(rounds) * w * kCost[w];
-            if(t < best_t * 0.98) {
-                best_t = t;
-                best = w;
-            }
-        }
-    }
-    constexpr size_t kLdsPerCU = 160 * 1024, kStatic = kTabRows * kTabStride * sizeof(float);
-    // LDS footprint per block that admits exactly `best` blocks per CU
-    const size_t per_block = kLdsPerCU / best;
-    const size_t dyn = best < 12 && per_block > kStatic + 512 ? per_block - kStatic - 512 : 0;
+    int best = static_cast<int>(std::min<uint64_t>(kMaxBlocks, (static_cast<uint64_t>(n_items) + kSimds - 1) / kSimds));
+    best = std::max(best, 1);
+    if(forced >= 1 && forced <= kMaxBlocks) best = forced;
+    // LDS footprint per block that admits exactly `best` blocks on a CU's 160 KB: more than
+    // 160/(best+1) KB, and `best` of them fit with room for the allocation granule.  (A first
+    // version used 160 KB/best minus 512 B: the allocator rounds up, only best-1 blocks fitted and
+    // the rest of the grid started after the queue was empty -- seen in the trace build.)
+    constexpr size_t kStatic = kTabRows * kTabStride * sizeof(float);
+    constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 48 * 1024};
+    const size_t dyn = kPerBlock[best] - ((kStatic + 255) / 256) * 256;
     return {kCUs * static_cast<uint32_t>(best), dyn};
 }
 
 }  // namespace
+
+#ifdef COATI_FILL_TRACE
+extern "C" int coati_hip_debug_trace(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_trace), sizeof(g_fill_trace));
+    if(e != hipSuccess) return static_cast<int>(e);
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_fill_trace));
+    if(e != hipSuccess) return static_cast<int>(e);
+    return static_cast<int>(hipMemset(p, 0, sizeof(g_fill_trace)));  // next launch starts clean
+}
+#endif
 
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
