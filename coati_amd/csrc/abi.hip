@@ -264,8 +264,9 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
         const uint32_t ns = n_strips(d.lb);
         if(la > 0 && lb > 0) b->flag_dwords += ns * strip_dwords(d.la);
         // 128-byte aligned so that no two waves ever share a cache line of it
-        // viterbi_l1: one 2(la+1) array per strip boundary; dp_generic: one (la+1)(3+2L) array
-        if(ns > 1) b->bnd_floats += (std::max<uint64_t>((ns - 1) * 2 * (la + 1), (la + 1) * (3 + 2 * L)) + 31) / 32 * 32;
+        // viterbi_l1 / forward_l1: one 2(la+1) / 3(la+1) array per strip boundary; dp_generic: one
+        // (la+1)(3+2L) array
+        if(ns > 1) b->bnd_floats += (std::max<uint64_t>((ns - 1) * 3 * (la + 1), (la + 1) * (3 + 2 * L)) + 31) / 32 * 32;
         if(la > 0 && lb > 0) b->mdi_floats += ns * strip_mdi_floats(d.la);
         b->ops_total += la + lb;
         b->cells += la * lb;
@@ -424,7 +425,13 @@ int coati_hip_forward_launch(coati_hip_batch_t* b) {
         if(e != hipSuccess) return fail(COATI_HIP_ENOMEM, "forward_launch: %s", hipGetErrorString(e));
         b->device_bytes += fb;
     }
-    if(b->n_pairs > 0) HIP_TRY(launch_dp_generic(device_view(b), /*forward=*/true, m->stream));
+    if(b->n_pairs > 0) {
+        static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+        if(m->gap_len == 1 && !force_generic)
+            HIP_TRY(launch_forward_l1(device_view(b), m->stream));
+        else
+            HIP_TRY(launch_dp_generic(device_view(b), /*forward=*/true, m->stream));
+    }
     b->forward_done = true;
     return COATI_HIP_OK;
 }

@@ -1,0 +1,284 @@
+// forward_l1: the Forward fill (log semiring) for gap_len == 1, in the wavefront shape of
+// viterbi_l1: persistent wavefronts, one strip (1024 descendant columns) of one pair at a
+// time per wavefront, a lane owns 16 columns, one row of skew per lane, DPP hand-off.
+//
+// What it replaces in the reference:
+//   forward -> forward_impl<log, align_pair_work_t>   src/lib/align_pair.cc:62-139,149
+//   semiring::log::plus, log_sum_exp, log1p_exp       src/include/coati/semiring.hpp:86-121,
+//                                                     src/include/coati/utils.hpp:134-156
+//
+// Output: fp32 M/D/I of every body cell in HBM (12 B/cell, layout in common.hpp) for
+// sampleback, and the terminal-adjusted last cell per pair.  The reference's eight edge
+// matrices (align_pair.hpp:94-103) are not stored; the sampler recomputes what it needs.
+//
+// Every cell evaluates the reference's expressions in the reference's order
+// (align_pair.cc:97-124); only `plus` is computed differently:
+//   plus(a, b) = max(a, b) + log1p(exp(-|a - b|))
+// with the hardware exp2/log2 (v_exp_f32, v_log_f32, ~1 ulp) instead of glibc expf/log1pf.
+// log1p(e) for e in [0, 1] is taken as log(u) + (e - (u - 1)) with u = fl(1 + e): the second
+// term is the exact rounding residue of 1 + e, so the result degrades gracefully to `e` when
+// 1 + e rounds to 1 -- the same value utils.hpp:142-144 returns for y <= -16.  Absolute error
+// of one plus() is below 1e-7; the results are NOT bit-identical to the CPU (neither were
+// expf/log1pf of the device library) and agree within the 1e-5 relative the north star states.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace coati_hip_detail {
+namespace {
+
+__device__ __forceinline__ float log_plus(float a, float b) {
+    constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+    const float hi = fmaxf(a, b);
+    const float t = -fabsf(a - b) * kLog2e;        // <= 0 (or -inf); abs/neg are source modifiers
+    const float e = __builtin_amdgcn_exp2f(t);     // v_exp_f32: exp(-|a-b|) in [0, 1]
+    const float u = 1.0f + e;
+    const float resid = e - (u - 1.0f);            // exact
+    const float l2 = __builtin_amdgcn_logf(u);     // v_log_f32: log2(u) in [0, 1]
+    return hi + __builtin_fmaf(l2, kLn2, resid);
+}
+
+struct FwdLane {
+    float M[kW], D[kW], I[kW];     // the lane's 16 columns of the row it processed last
+    float oM, oD, oI;              // column 15 of the row before that: the right neighbour's diagonal
+};
+
+struct FwdCtx {
+    GapConsts k;
+    uint32_t la, col0, nsteps, pair;
+    int lane, last_lane, last_c;
+    bool last_strip;
+    float* mout;
+    float* bnd_out;   // [la + 1][3]: M, D, I of this strip's last column; entry 0 = the margin row
+    float* final_mdi;
+};
+
+__device__ __forceinline__ void store_through(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Up to 64 wavefront steps (see viterbi_l1.hip: run_chunk).  ch*: what lane 0 needs at step
+// kbase + l, held by lane l: diagonal cell (M, D, I) and left cell (M, I) of column col0 - 1.
+template <bool kFirst>
+__device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
+                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float chDM,
+                                          float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
+    const GapConsts& k = cx.k;
+    const int lane = cx.lane;
+    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    for(uint32_t kk = 0; kk < kend; ++kk) {
+        const uint32_t kstep = kbase + kk;
+        if constexpr(kFirst) {
+            if(kk == static_cast<uint32_t>(lane)) {
+                // the lane starts: the row above is matrix row 0 (align_pair.cc:88-90):
+                // M = D = lowest, I = go + ge*float(j-1)
+                uint32_t bj0 = cx.col0 + lane * kW;
+                asm volatile("" : "+v"(bj0));
+#pragma unroll
+                for(int c = 0; c < kW; ++c) {
+                    st.M[c] = kLowest;
+                    st.D[c] = kLowest;
+                    st.I[c] = k.go + k.ge * static_cast<float>(bj0 + c);
+                }
+                if(!cx.last_strip && lane == kWave - 1) {
+                    store_through(&cx.bnd_out[0], kLowest);
+                    store_through(&cx.bnd_out[1], kLowest);
+                    store_through(&cx.bnd_out[2], st.I[kW - 1]);
+                }
+            }
+        }
+        // ---- hand-off from the left neighbour (full exec)
+        float dgM = shift_in(st.oM, read_lane(chDM, kk));
+        float dgD = shift_in(st.oD, read_lane(chDD, kk));
+        float dgI = shift_in(st.oI, read_lane(chDI, kk));
+        float lfM = shift_in(st.M[kW - 1], read_lane(chLM, kk));
+        float lfI = shift_in(st.I[kW - 1], read_lane(chLI, kk));
+        const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
+        st.oM = st.M[kW - 1];
+        st.oD = st.D[kW - 1];
+        st.oI = st.I[kW - 1];
+        float* dst = cx.mout + static_cast<uint64_t>(kstep) * kMdiStepFloats;
+#pragma unroll
+        for(int c = 0; c < kW; ++c) {
+            const float sc = s[c];
+            // gather the next step's score now (consumed a step later)
+            s[c] = *reinterpret_cast<const float*>(tab_bytes + arow_next + boff[c]);
+            const float upM = st.M[c], upD = st.D[c], upI = st.I[c];
+            // align_pair.cc:97-119 with look_back 1 (power(ge, 0) = -0.0f is the additive identity)
+            const float m2m = ((dgM + k.ng) + k.ng) + sc;
+            const float d2m = (dgD + k.gs) + sc;
+            const float i2m = ((dgI + k.gs) + k.ng) + sc;
+            const float m2d = (upM + k.ng) + k.go;
+            const float i2d = (upI + k.gs) + k.go;
+            const float d2d = upD + k.ge;
+            const float m2i = lfM + k.go;
+            const float i2i = lfI + k.ge;
+            const float M = log_plus(log_plus(m2m, d2m), i2m);
+            const float D = log_plus(log_plus(m2d, d2d), i2d);
+            const float I = log_plus(m2i, i2i);
+            dgM = upM;
+            dgD = upD;
+            dgI = upI;
+            lfM = M;
+            lfI = I;
+            st.M[c] = M;
+            st.D[c] = D;
+            st.I[c] = I;
+            dst[c * kWave] = M;
+            dst[(kW + c) * kWave] = D;
+            dst[(2 * kW + c) * kWave] = I;
+        }
+        arow = arow_next;
+        const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
+        if(!cx.last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(cx.la)) {
+            float* b = cx.bnd_out + 3 * static_cast<uint64_t>(r + 1);
+            store_through(&b[0], st.M[kW - 1]);
+            store_through(&b[1], st.D[kW - 1]);
+            store_through(&b[2], st.I[kW - 1]);
+        }
+        if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
+            float m = st.M[0], d = st.D[0], in = st.I[0];
+#pragma unroll
+            for(int c = 1; c < kW; ++c) {
+                m = (c == cx.last_c) ? st.M[c] : m;
+                d = (c == cx.last_c) ? st.D[c] : d;
+                in = (c == cx.last_c) ? st.I[c] : in;
+            }
+            // terminal adjustment (align_pair.cc:130-138)
+            float* f = cx.final_mdi + 3 * static_cast<uint64_t>(cx.pair);
+            f[0] = (m + k.ng) + k.ng;
+            f[1] = d + k.gs;
+            f[2] = (in + k.gs) + k.ng;
+        }
+    }
+}
+
+__device__ __forceinline__ void publish(uint32_t* word, uint32_t rows, bool leader) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if(leader) __hip_atomic_store(word, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool wait_rows(const uint32_t* word, uint32_t need) {
+    for(uint32_t spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spins) {
+        if(spins > (1u << 26)) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+__global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
+    const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+    const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
+    uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
+    float* __restrict__ bnd, float* __restrict__ mdi, float* __restrict__ final_mdi) {
+    __shared__ float tab[kTabRows * kTabStride];
+    for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
+        const int r = idx / kTabCols, c = idx - r * kTabCols;
+        tab[r * kTabStride + c] = table[idx];
+    }
+    __syncthreads();
+    const int lane_id = threadIdx.x & (kWave - 1);
+    const char* tab_bytes = reinterpret_cast<const char*>(tab);
+    for(;;) {
+        int lane = lane_id;  // opaque per iteration (see viterbi_l1.hip)
+        asm volatile("" : "+v"(lane));
+        uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);
+        ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        if(ticket >= n_items) break;
+        const WorkItem item = items[ticket];
+        const uint32_t pair = item.pair, strip = item.strip;
+        const PairDesc pd = pairs[pair];
+        const uint32_t la = pd.la, lb = pd.lb;
+        if(la == 0 || lb == 0) {  // no body cells: the last cell is a margin cell
+            float m, d, in;
+            margin_mdi(k, 1u, la, lb, m, d, in);
+            if(lane == 0) {
+                final_mdi[3 * static_cast<uint64_t>(pair) + 0] = (m + k.ng) + k.ng;
+                final_mdi[3 * static_cast<uint64_t>(pair) + 1] = d + k.gs;
+                final_mdi[3 * static_cast<uint64_t>(pair) + 2] = (in + k.gs) + k.ng;
+            }
+            continue;
+        }
+        const uint8_t* __restrict__ a = a_cat + pd.a_off;
+        const uint8_t* __restrict__ b = b_cat + pd.b_off;
+        const uint32_t strips = n_strips(lb);
+        const uint32_t col0 = strip * kStrip;
+        const uint32_t ncol = min(static_cast<uint32_t>(kStrip), lb - col0);
+        const uint32_t nlanes = (ncol + kW - 1) / kW;
+        const uint32_t nsteps = la + nlanes - 1;
+        const bool last_strip = strip + 1 == strips;
+        const uint64_t bstride = 3 * (static_cast<uint64_t>(la) + 1);
+        float* __restrict__ bnd_out = bnd + pd.bnd_off + strip * bstride;
+        const float* __restrict__ bnd_in = bnd + pd.bnd_off + (strip - 1) * bstride;  // strip > 0 only
+
+        uint32_t boff[kW];
+#pragma unroll
+        for(int c = 0; c < kW; ++c) {
+            const uint32_t bj = col0 + lane * kW + c;
+            boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+        }
+        const FwdCtx cx{k, la, col0, nsteps, pair, lane,
+                        static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
+                        last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats(la) + lane, bnd_out, final_mdi};
+        FwdLane st;
+#pragma unroll
+        for(int c = 0; c < kW; ++c) st.M[c] = st.D[c] = st.I[c] = kLowest;
+        st.oM = st.oD = st.oI = kLowest;
+        uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+        float s[kW];
+#pragma unroll
+        for(int c = 0; c < kW; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
+
+        bool ok = true;
+        for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+            const uint32_t crow = kbase + lane;  // the body row lane 0 processes at step kbase + lane
+            uint32_t a_chunk = 0;
+            float chDM = kLowest, chDD = kLowest, chDI = kLowest, chLM = kLowest, chLI = kLowest;
+            if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+            if(strip == 0) {
+                // matrix column 0 (align_pair.cc:82-86): diagonal of body row r is matrix cell (r, 0)
+                if(crow == 0) chDM = 0.0f;
+                else if(crow < la) chDD = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
+            } else {
+                ok = ok && wait_rows(progress + ticket - 1, min(la, kbase + kWave));
+                if(crow < la) {
+                    const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
+                    const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
+                    chDM = dgp[0];
+                    chDD = dgp[1];
+                    chDI = dgp[2];
+                    chLM = lfp[0];
+                    chLI = lfp[2];
+                }
+            }
+            asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
+            if(kbase == 0)
+                fwd_chunk<true>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            else
+                fwd_chunk<false>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            if(!last_strip) {
+                const uint32_t done = min(kbase + kWave, nsteps);
+                if(done > kWave - 1) publish(progress + ticket, min(la, done - (kWave - 1)), lane == kWave - 1);
+            }
+        }
+        if(!last_strip) publish(progress + ticket, la, lane == kWave - 1);
+        if(!ok && last_strip && lane == 0) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
+    }
+}
+
+}  // namespace
+
+hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
+    if(e != hipSuccess) return e;
+    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);
+    if(e != hipSuccess) return e;
+    // two workgroups (8 wavefronts) per CU; fewer when there are fewer items than wavefronts
+    const uint32_t blocks = std::min<uint32_t>(512u, std::max<uint32_t>(256u, (v.n_items + kFillWaves - 1) / kFillWaves));
+    hipLaunchKernelGGL(forward_l1, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.items,
+                       v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+    return hipGetLastError();
+}
+
+}  // namespace coati_hip_detail

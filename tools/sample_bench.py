@@ -17,7 +17,7 @@ sys.path.insert(0, str(ROOT))
 from coati_amd import hip, host  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--pairs", type=int, default=2000)
+ap.add_argument("--pairs", type=int, default=6144)
 ap.add_argument("--sample-pairs", type=int, default=16)
 ap.add_argument("--samples", type=int, default=1000)
 args = ap.parse_args()
@@ -60,5 +60,4 @@ for mode, indep in (("exact_stream", False), ("independent_streams", True)):
 out["forward_fill_16_pairs_ms"] = t_fwd * 1e3
 batch.close()
 
-# ---- generic-kernel Viterbi (what gap_len 3 runs), forced for gap_len 1 to compare like for like
 print(json.dumps(out))
