@@ -24,7 +24,7 @@ __global__ void decode_flags(const PairDesc* __restrict__ pairs, uint32_t pair,
     for(uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; idx < n;
         idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
-        const CellAddr ca = cell_addr(pd.flags_off, pd.la, bi, bj);
+        const CellAddr ca = cell_addr(pd, bi, bj);
         const uint32_t mm = pair_bits(flags, ca, 0), dd = pair_bits(flags, ca, 1), im = im_bit(flags, ca);
         const uint32_t fm = (mm & 1u) ? 2u : (mm >> 1), fd = (dd & 1u) ? 2u : (dd >> 1);
         out[idx] = static_cast<uint8_t>(fm | (fd << 2) | ((im ^ 1u) << 4));
@@ -99,6 +99,8 @@ struct coati_hip_batch {
     uint32_t* d_order = nullptr;   // pair indices, most cells first
     uint32_t* d_queue = nullptr;   // ticket counter of the persistent fill kernel
     WorkItem* d_items = nullptr;   // viterbi_l1 work list: (pair, strip), longest pairs first
+    WorkItem* d_fwd_items = nullptr;  // forward_l1 work list (1024-column strips)
+    uint32_t n_fwd_items = 0;
     uint32_t* d_progress = nullptr;
     uint32_t n_items = 0;
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
@@ -119,7 +121,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
     const coati_hip_model* m = b->model;
     return BatchDeviceView{m->d_table,  m->k,      static_cast<uint32_t>(m->gap_len),
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
-                           b->d_queue,  b->d_items, b->n_items, b->d_progress, b->d_a,    b->d_b,
+                           b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len,
                            b->d_mdi,    b->d_final_mdi};
@@ -189,7 +191,7 @@ void coati_hip_model_destroy(coati_hip_model_t* m) {
 void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(b == nullptr) return;
     if(b->model != nullptr) (void)hipSetDevice(b->model->device);
-    void* ptrs[] = {b->d_items, b->d_progress, b->d_mdi, b->d_final_mdi, b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
+    void* ptrs[] = {b->d_items, b->d_fwd_items, b->d_progress, b->d_mdi, b->d_final_mdi, b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
                     b->d_bnd,  b->d_scores, b->d_ops_start, b->d_ops_len};
     for(void* p : ptrs)
         if(p != nullptr) (void)hipFree(p);
@@ -257,19 +259,59 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
         d.b_off = b_off[p] - b_off[0];
         d.la = static_cast<uint32_t>(la);
         d.lb = static_cast<uint32_t>(lb);
-        d.flags_off = b->flag_dwords;
-        d.bnd_off = b->bnd_floats;
         d.ops_off = b->ops_total;
         d.mdi_off = b->mdi_floats;
-        const uint32_t ns = n_strips(d.lb);
-        if(la > 0 && lb > 0) b->flag_dwords += ns * strip_dwords(d.la);
-        // 128-byte aligned so that no two waves ever share a cache line of it
-        // viterbi_l1 / forward_l1: one 2(la+1) / 3(la+1) array per strip boundary; dp_generic: one
-        // (la+1)(3+2L) array
-        if(ns > 1) b->bnd_floats += (std::max<uint64_t>((ns - 1) * 3 * (la + 1), (la + 1) * (3 + 2 * L)) + 31) / 32 * 32;
-        if(la > 0 && lb > 0) b->mdi_floats += ns * strip_mdi_floats(d.la);
+        if(la > 0 && lb > 0) b->mdi_floats += n_strips(d.lb) * strip_mdi_floats(d.la);
         b->ops_total += la + lb;
         b->cells += la * lb;
+    }
+
+    // ---- Viterbi strip plan (common.hpp).  Full-speed strips are 16 columns per lane; the last
+    // strip of a pair takes the narrowest shape that holds the remainder.  When the whole batch
+    // has fewer strips than the GPU has SIMDs (a few long pairs), narrower strips everywhere put
+    // more wavefronts to work on each pair.  dp_generic (gap_len > 1) writes 16-column strips only.
+    uint32_t w_main = kW;
+    const bool plan_l1 = L == 1 && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;  // viterbi_l1 will run
+    if(plan_l1) {
+        auto count_items = [&](uint32_t w) {
+            uint64_t items = 0;
+            for(uint64_t p = 0; p < n_pairs; ++p) {
+                uint32_t ns = 1, wl = w;
+                if(b->desc[p].la > 0 && b->desc[p].lb > 0) viterbi_strip_plan(b->desc[p].lb, w, ns, wl);
+                items += ns;
+            }
+            return items;
+        };
+        constexpr uint64_t kSimds = 1024;
+        while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
+        if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
+            const int w = std::atoi(e);
+            if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
+        }
+    }
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        PairDesc& d = b->desc[p];
+        const uint64_t la = d.la;
+        uint32_t ns = 1, wl = w_main;
+        if(plan_l1) {
+            if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main, ns, wl);
+        } else {
+            ns = std::max(1u, n_strips(d.lb));
+        }
+        d.v_strips = ns;
+        d.v_wmain = static_cast<uint8_t>(w_main);
+        d.v_wlast = static_cast<uint8_t>(wl);
+        d.flags_off = b->flag_dwords;
+        d.bnd_off = b->bnd_floats;
+        if(d.la > 0 && d.lb > 0)
+            b->flag_dwords += (ns - 1) * strip_dwords(d.la, w_main) + strip_dwords(d.la, wl);
+        // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
+        // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
+        // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
+        const uint64_t nf = n_strips(d.lb);
+        const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
+                                                  nf > 1 ? (la + 1) * (3 + 2 * L) : 0});
+        b->bnd_floats += (need + 31) / 32 * 32;
     }
 
     if(hipSetDevice(model->device) != hipSuccess)
@@ -306,15 +348,20 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
             return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
         });
         B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
-        std::vector<WorkItem> items;
+        std::vector<WorkItem> items, fwd_items;
         for(const uint32_t p : order) {
-            const uint32_t ns = (b->desc[p].la > 0 && b->desc[p].lb > 0) ? n_strips(b->desc[p].lb) : 1u;
-            for(uint32_t st = 0; st < ns; ++st) items.push_back(WorkItem{p, st});
+            for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
+            const uint32_t nf = (b->desc[p].la > 0 && b->desc[p].lb > 0) ? n_strips(b->desc[p].lb) : 1u;
+            for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
         }
         b->n_items = static_cast<uint32_t>(items.size());
+        b->n_fwd_items = static_cast<uint32_t>(fwd_items.size());
         B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_items), items.size() * sizeof(WorkItem)));
-        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_progress), std::max<size_t>(items.size(), 4) * sizeof(uint32_t)));
+        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_fwd_items), fwd_items.size() * sizeof(WorkItem)));
+        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_progress),
+                      std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)));
         B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+        B_TRY(hipMemcpy(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
     }
     if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
     if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));

@@ -42,20 +42,45 @@ struct PairDesc {
     uint64_t ops_off;       // slot start in the ops arena (slot = la + lb bytes)
     uint64_t mdi_off;       // floats into the Forward M/D/I arena
     uint32_t la, lb;
+    // Viterbi strip plan (decision-bit layout): v_strips strips; all but the last are 64*v_wmain
+    // columns wide (v_wmain columns per lane), the last one has v_wlast columns per lane.
+    uint32_t v_strips;
+    uint8_t v_wmain, v_wlast, pad_[2];
 };
 
-// HBM layout of the decision bits of one strip (1024 columns) of one pair, per
-// pair of wavefront steps kp = k >> 1 (k = body_row + lane), 320 dwords:
-//   [kp*320 +   0 + lane]  A of the even step     [kp*320 + 128 + lane]  A of the odd step
-//   [kp*320 +  64 + lane]  B of the even step     [kp*320 + 192 + lane]  B of the odd step
-//   [kp*320 + 256 + lane]  C: bits 31..16 even step, 15..0 odd step
-// In A/B the lane's column c (0..15) holds its first test at bit 31-2c and its
-// second at bit 30-2c; in C column c is bit 15-c of its half.
+// HBM layout of the decision bits of one strip of one pair.  A strip is 64*W descendant
+// columns, W = 4, 8 or 16 columns per lane (W = 16 is the full-speed shape; narrower strips are
+// for short descendants, for the remainder of a long one and to get more strips in flight when a
+// batch has few pairs).  Wavefront step k = body_row + lane.  Steps are stored in groups of
+// mC = 32/W steps, 320 dwords per group:
+//   [g*320 +   0 + lane]  A of the group's first half      [g*320 + 128 + lane]  A of its second half
+//   [g*320 +  64 + lane]  B of the first half              [g*320 + 192 + lane]  B of the second half
+//   [g*320 + 256 + lane]  C of the whole group
+// An A/B dword holds mA = 16/W steps: step t' (0..mA-1) of its half, column c (0..W-1) at
+// position p = t'*W + c: first test at bit 31-2p, second test at bit 30-2p.  The C dword holds
+// step q (0..mC-1) of the group, column c at bit 31 - (q*W + c).
+// (W = 16: one step per A/B dword, even/odd step = first/second half, C = two steps.)
 // Every store is a fully coalesced 256-byte row: 5 bits per DP cell.
-__host__ __device__ inline uint64_t strip_dwords(uint32_t la) {
-    return static_cast<uint64_t>((la + kWave) / 2) * kPairDwords;
+__host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
+    const uint32_t mc = 32u / w;
+    return static_cast<uint64_t>((la + kWave - 1 + mc - 1) / mc) * kPairDwords;
 }
 __host__ __device__ inline uint32_t n_strips(uint32_t lb) { return (lb + kStrip - 1) / kStrip; }
+// Viterbi strip plan of a descendant of lb columns with w_main columns per lane in every strip
+// but the last: the last strip takes the narrowest shape (4, 8, 16 columns per lane, at most
+// w_main) that holds the remainder.
+inline void viterbi_strip_plan(uint32_t lb, uint32_t w_main, uint32_t& strips, uint32_t& w_last) {
+    const uint32_t full = kWave * w_main;
+    const uint32_t whole = lb / full, rem = lb % full;
+    if(rem == 0 && whole > 0) {
+        strips = whole;
+        w_last = w_main;
+        return;
+    }
+    strips = whole + 1;
+    w_last = 4;
+    while(w_last < w_main && kWave * w_last < rem) w_last *= 2;
+}
 
 // lane l receives lane l-1's `v`; lane 0 receives `lane0` (DPP keeps `old` where
 // the shift has no source lane).
@@ -79,27 +104,40 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) {
 // decision-bit lookups (layout above); (bi, bj) are BODY coordinates
 // ---------------------------------------------------------------------------
 struct CellAddr {
-    uint64_t pair_base;  // dword index of the step pair
-    uint32_t odd, t, c;
+    uint64_t group_base;          // dword index of the step group
+    uint32_t half_off, t;         // 0 or 128; lane that owns the column
+    uint32_t sh_ab, sh_c;         // shifts that bring the cell's bits to the bottom
 };
-__device__ __forceinline__ CellAddr cell_addr(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj) {
-    const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
+__device__ __forceinline__ CellAddr cell_addr(const PairDesc& pd, uint32_t bi, uint32_t bj) {
+    const uint32_t full = kWave * pd.v_wmain;
+    uint32_t strip = bj / full, w = pd.v_wmain;
+    if(strip + 1 >= pd.v_strips) {
+        strip = pd.v_strips - 1;
+        w = pd.v_wlast;
+    }
+    const uint32_t lg = 31u - static_cast<uint32_t>(__clz(static_cast<int>(w)));  // w = 4, 8, 16
+    const uint32_t colin = bj - strip * full;
+    const uint32_t t = colin >> lg, c = colin & (w - 1u);
     const uint32_t kstep = bi + t;
-    return {base + strip * strip_dwords(la) + static_cast<uint64_t>(kstep >> 1) * kPairDwords, kstep & 1u, t, c};
+    const uint32_t lg_mc = 5u - lg, lg_ma = 4u - lg;          // steps per C dword / per A,B dword
+    const uint32_t g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
+    const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
+    return {pd.flags_off + strip * strip_dwords(pd.la, pd.v_wmain) + static_cast<uint64_t>(g) * kPairDwords,
+            half * (2u * kWave), t, 30u - 2u * ((tt << lg) + c), 31u - ((q << lg) + c)};
 }
 // two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
 __device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
-    const uint32_t w = flags[ca.pair_base + ca.odd * (2 * kWave) + which * kWave + ca.t];
-    return (w >> (30 - 2 * ca.c)) & 3u;  // bit1 = first test, bit0 = second test
+    const uint32_t w = flags[ca.group_base + ca.half_off + which * kWave + ca.t];
+    return (w >> ca.sh_ab) & 3u;  // bit1 = first test, bit0 = second test
 }
 __device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
-    const uint32_t w = flags[ca.pair_base + 4 * kWave + ca.t];
-    return (w >> ((ca.odd ? 0u : 16u) + (kW - 1 - ca.c))) & 1u;
+    const uint32_t w = flags[ca.group_base + 4 * kWave + ca.t];
+    return (w >> ca.sh_c) & 1u;
 }
 // state entered after a move of kind `moved` arrives at body cell (bi, bj)
-__device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, uint64_t base,
-                                           uint32_t la, uint32_t bi, uint32_t bj, int moved) {
-    const CellAddr ca = cell_addr(base, la, bi, bj);
+__device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, const PairDesc& pd, uint32_t bi,
+                                           uint32_t bj, int moved) {
+    const CellAddr ca = cell_addr(pd, bi, bj);
     if(moved == COATI_HIP_OP_INS) return im_bit(flags, ca) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
     const uint32_t two = pair_bits(flags, ca, moved == COATI_HIP_OP_DEL ? 1 : 0);
     if(two & 1u) return COATI_HIP_OP_INS;  // second test: I beats max(M,D)
@@ -138,9 +176,9 @@ constexpr int kWalkEnd = 3;
 // State the reference's walk is in after arriving at MATRIX cell (i, j) by a move of
 // kind `moved`: body cells from the stored bits, margin cells by formula.
 __device__ __forceinline__ int arrival_state(const GapConsts& k, uint32_t L, const uint32_t* __restrict__ flags,
-                                             uint64_t base, uint32_t la, uint32_t i, uint32_t j, int moved) {
+                                             const PairDesc& pd, uint32_t i, uint32_t j, int moved) {
     if(i < L && j < L) return kWalkEnd;  // loop condition of align_pair.cc:268
-    if(i >= L && j >= L) return state_after(flags, base, la, i - L, j - L, moved);
+    if(i >= L && j >= L) return state_after(flags, pd, i - L, j - L, moved);
     float m, d, in;
     margin_mdi(k, L, i, j, m, d, in);
     return decide_after(k, moved, m, d, in);
@@ -173,7 +211,7 @@ __device__ __forceinline__ void walk_pair(int lane, const GapConsts& k, uint32_t
         const uint32_t step = static_cast<uint32_t>(lane) + 1u;
         const bool valid = di * step <= i && dj * step <= j;
         int next = kWalkEnd;
-        if(valid) next = arrival_state(k, L, flags, pd.flags_off, la, i - di * step, j - dj * step, st);
+        if(valid) next = arrival_state(k, L, flags, pd, i - di * step, j - dj * step, st);
         if(di > i || dj > j) break;  // cannot happen for decision bits of a finite path; never walk off the matrix
         const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
         const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
@@ -208,7 +246,7 @@ __device__ __forceinline__ void viterbi_finish(int lane, const GapConsts& k, uin
     if(pd.la > 0 && pd.lb > 0) {
         // max_mdi of the terminal-adjusted last cell == its "after match" decision
         start_state = __builtin_amdgcn_readfirstlane(
-            state_after(flags, pd.flags_off, pd.la, pd.la - 1, pd.lb - 1, COATI_HIP_OP_MATCH));
+            state_after(flags, pd, pd.la - 1, pd.lb - 1, COATI_HIP_OP_MATCH));
     } else {
         float m, d, in, score;
         margin_mdi(k, L, pd.la + L - 1, pd.lb + L - 1, m, d, in);
@@ -234,8 +272,8 @@ __device__ __forceinline__ uint64_t mdi_index(uint64_t base, uint32_t la, uint32
 // ---------------------------------------------------------------------------
 // launchers implemented in the kernel translation units
 // ---------------------------------------------------------------------------
-// One unit of work of the persistent Viterbi kernel: one strip (1024 descendant
-// columns) of one pair.  The strips of a pair are consecutive items.
+// One unit of work of the persistent kernels: one strip of one pair.  The strips of a pair are
+// consecutive items in ascending order.
 struct WorkItem {
     uint32_t pair, strip;
 };
@@ -248,9 +286,11 @@ struct BatchDeviceView {
     const uint32_t* order;
     uint32_t n_pairs;
     uint32_t* queue;
-    const WorkItem* items;  // viterbi_l1: (pair, strip) work list, longest pairs first
+    const WorkItem* items;  // viterbi_l1: (pair, strip) work list of the Viterbi strip plan, longest pairs first
     uint32_t n_items;
-    uint32_t* progress;     // viterbi_l1: rows of each item whose boundary column is published
+    const WorkItem* fwd_items;  // forward_l1: the same for fixed 1024-column strips
+    uint32_t n_fwd_items;
+    uint32_t* progress;     // rows of each item whose boundary column is published
     const uint8_t *a_cat, *b_cat;
     uint32_t* flags;
     float* bnd;

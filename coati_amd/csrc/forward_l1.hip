@@ -272,12 +272,12 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
 hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
     if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);
+    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_fwd_items, 4u), stream);
     if(e != hipSuccess) return e;
     // two workgroups (8 wavefronts) per CU; fewer when there are fewer items than wavefronts
-    const uint32_t blocks = std::min<uint32_t>(512u, std::max<uint32_t>(256u, (v.n_items + kFillWaves - 1) / kFillWaves));
-    hipLaunchKernelGGL(forward_l1, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.items,
-                       v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+    const uint32_t blocks = std::min<uint32_t>(512u, std::max<uint32_t>(256u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
+    hipLaunchKernelGGL(forward_l1, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.fwd_items,
+                       v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
     return hipGetLastError();
 }
 

@@ -44,12 +44,13 @@ __device__ unsigned long long g_fill_trace[4096 * 16];
 #endif
 namespace {
 
-// Register state of one lane: its 16 columns of the row it processed last.
+// Register state of one lane: its W columns (W = 16, 8 or 4) of the row it processed last.
+template <int W>
 struct LaneState {
-    float X[kW];  // max((M+ng)+ng, D+gs, (I+gs)+ng): feeds M of the next diagonal cell
-    float Y[kW];  // max((M+ng)+go, D+ge, (I+gs)+go): the D value of the cell below (gap_len 1)
-    float xlast_old;  // X[15] of the row before: the right neighbour's diagonal input
-    float zlast;      // max(M+go, I+ge) of column 15: the right neighbour's I value
+    float X[W];  // max((M+ng)+ng, D+gs, (I+gs)+ng): feeds M of the next diagonal cell
+    float Y[W];  // max((M+ng)+go, D+ge, (I+gs)+go): the D value of the cell below (gap_len 1)
+    float xlast_old;  // X[W-1] of the row before: the right neighbour's diagonal input
+    float zlast;      // max(M+go, I+ge) of column W-1: the right neighbour's I value
     uint32_t acc[kAccs];    // decision bits, shifted in cell by cell
 };
 
@@ -111,8 +112,8 @@ struct LaneState {
     "v_sub_f32 %[pend], %[t0], %[t3]\n\t"     /* F  ym - y3  (sign: y3 > ym), carried    */ \
     "v_alignbit_b32 %[aB], %[aB], %[t2], 31"  /* S  D1                                   */
 
-template <int C>
-__device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState& st, float& diag, float& zl, float& pend,
+template <int C, int W>
+__device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState<W>& st, float& diag, float& zl, float& pend,
                                         float& s, uint32_t lds_next_row, uint32_t boff) {
     float x_new, t0, t1, t2, t3, t4, t5;
     uint32_t addr;
@@ -134,14 +135,14 @@ __device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState& st, float
     s = *reinterpret_cast<const __attribute__((address_space(3))) float*>(addr);
 }
 
-template <int... C>
-__device__ __forceinline__ void row_l1(const GapConsts& k, LaneState& st, float diag, float zl,
-                                       float (&s)[kW], uint32_t lds_next_row, const uint32_t (&boff)[kW],
+template <int W, int... C>
+__device__ __forceinline__ void row_l1(const GapConsts& k, LaneState<W>& st, float diag, float zl,
+                                       float (&s)[W], uint32_t lds_next_row, const uint32_t (&boff)[W],
                                        std::integer_sequence<int, C...>) {
-    st.xlast_old = st.X[kW - 1];
+    st.xlast_old = st.X[W - 1];
     float pend = 0.0f;
-    (cell_l1<C>(k, st, diag, zl, pend, s[C], lds_next_row, boff[C]), ...);
-    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(st.acc[ACC_B]) : "v"(pend));  // D2 of column 15
+    (cell_l1<C, W>(k, st, diag, zl, pend, s[C], lds_next_row, boff[C]), ...);
+    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(st.acc[ACC_B]) : "v"(pend));  // D2 of the last column
     st.zlast = zl;
 }
 
@@ -182,10 +183,11 @@ struct StripCtx {
 // that it carries no trace of the start-up code (spill reloads there would put
 // an s_waitcnt vmcnt(0) -- a wait for the previous step's HBM stores -- into
 // every step).
-template <bool kFirst>
-__device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uint32_t& arow, float (&s)[kW],
-                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float bx,
+template <int W, bool kFirst>
+__device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState<W>& st, uint32_t& arow, float (&s)[W],
+                                          const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk, float bx,
                                           float bz) {
+    constexpr uint32_t kMA = 16 / W, kMC = 32 / W;  // wavefront steps per A/B dword and per C dword
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
     const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
@@ -195,35 +197,37 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uin
             if(kk == static_cast<uint32_t>(lane)) {
                 // This lane starts now: state of the margin row (matrix row 0,
                 // align_pair.cc:88-90): M = D = lowest, I = go + ge*float(j-1).
-                uint32_t bj0 = cx.col0 + lane * kW;
+                uint32_t bj0 = cx.col0 + lane * W;
                 asm volatile("" : "+v"(bj0));  // compute in place: hoisted, these 32 values get spilled
 #pragma unroll
-                for(int c = 0; c < kW; ++c) {
+                for(int c = 0; c < W; ++c) {
                     const float im = k.go + k.ge * static_cast<float>(bj0 + c);
                     const float i1 = im + k.gs;
                     st.X[c] = i1 + k.ng;
                     st.Y[c] = i1 + k.go;
                 }
-                if(!cx.last_strip && lane == kWave - 1) store_through(&cx.bnd_x[0], st.X[kW - 1]);
+                if(!cx.last_strip && lane == kWave - 1) store_through(&cx.bnd_x[0], st.X[W - 1]);
             }
         }
         // ---- hand-off from the left neighbour (full exec)
         const float diag = shift_in(st.xlast_old, read_lane(bx, kk));
         const float zl = shift_in(st.zlast, read_lane(bz, kk));
         const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
-        // ---- the 16 cells (and the LDS gather for the next step)
-        row_l1(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, kW>{});
+        // ---- the W cells (and the LDS gather for the next step)
+        row_l1<W>(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
         arow = arow_next;
-        // ---- decision bits: two coalesced 256-byte rows per step, a third every second step
-        {
-            uint32_t* dst = cx.fout + static_cast<uint64_t>(kstep >> 1) * kPairDwords + (kstep & 1u) * (2 * kWave);
+        // ---- decision bits (layout in common.hpp): coalesced 256-byte rows, A and B whenever 32
+        // bits are complete (every 16/W steps), C every 32/W steps
+        if((kstep & (kMA - 1u)) == kMA - 1u) {
+            const uint32_t q = kstep & (kMC - 1u);
+            uint32_t* dst = cx.fout + static_cast<uint64_t>(kstep / kMC) * kPairDwords + (q / kMA) * (2 * kWave);
             dst[0] = st.acc[ACC_A];
             dst[kWave] = st.acc[ACC_B];
-            if(kstep & 1u) dst[2 * kWave] = st.acc[ACC_C];  // = pair base + 256
+            if(q == kMC - 1u) cx.fout[static_cast<uint64_t>(kstep / kMC) * kPairDwords + 4 * kWave] = st.acc[ACC_C];
         }
         const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
         if(!cx.last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(cx.la)) {
-            store_through(&cx.bnd_x[r + 1], st.X[kW - 1]);
+            store_through(&cx.bnd_x[r + 1], st.X[W - 1]);
             store_through(&cx.bnd_z[r], st.zlast);
         }
         if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
@@ -231,18 +235,131 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState& st, uin
             // (align_pair.cc:130-138,265) = X of the last body cell.
             float sc = st.X[0];
 #pragma unroll
-            for(int c = 1; c < kW; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
+            for(int c = 1; c < W; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
             cx.scores[cx.pair] = sc;
         }
     }
 }
 
+// One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false
+// if the left neighbour's boundary column did not arrive within the spin bound.
+template <int W>
+__device__ __forceinline__ bool fill_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip,
+                                           uint32_t ticket, int lane, uint32_t lds_tab, const char* tab_bytes,
+                                           const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                           uint32_t* __restrict__ flags, float* __restrict__ bnd,
+                                           float* __restrict__ scores, uint32_t* __restrict__ progress) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    const uint32_t col0 = strip * (kWave * pd.v_wmain);  // every strip before this one has the main width
+    const uint32_t ncol = min(static_cast<uint32_t>(kWave * W), lb - col0);
+    const uint32_t nlanes = (ncol + W - 1) / W;
+    const uint32_t nsteps = la + nlanes - 1;
+    const bool last_strip = strip + 1 == pd.v_strips;
+    uint32_t* __restrict__ fout = flags + pd.flags_off + strip * strip_dwords(la, pd.v_wmain) + lane;
+    // strip-boundary columns, one array per strip boundary: [0, la] = X of the strip's last
+    // column (index r = X of body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
+    // The strips of a pair run on different wavefronts, pipelined through these arrays.
+    const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
+    float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
+    float* __restrict__ bnd_z = bnd_x + (la + 1);
+    const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
+    const float* __restrict__ in_z = in_x + (la + 1);
+    bool handoff_ok = true;
+
+    // byte offsets of this lane's W table columns
+    uint32_t boff[W];
+#pragma unroll
+    for(int c = 0; c < W; ++c) {
+        const uint32_t bj = col0 + lane * W + c;
+        boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+    }
+
+    const StripCtx cx{k, la, col0, nsteps, pair, lds_tab, lane,
+                      static_cast<int>((lb - 1 - col0) / W), static_cast<int>((lb - 1 - col0) % W),
+                      last_strip, fout, bnd_x, bnd_z, scores};
+    LaneState<W> st;
+#pragma unroll
+    for(int c = 0; c < W; ++c) st.X[c] = st.Y[c] = 0.0f;
+#pragma unroll
+    for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
+    st.xlast_old = 0.0f;
+    st.zlast = 0.0f;
+    // table-row byte offset of the row this lane processes at the CURRENT step,
+    // and the W substitution scores gathered for it one step earlier
+    uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+    float s[W];
+#pragma unroll
+    for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
+
+    for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+        // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l
+        // (boundary column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
+        const uint32_t crow = kbase + lane;
+        uint32_t a_chunk = 0;
+        float bx = kLowest, bz = kLowest;
+        if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+        if(crow < la) {
+            if(strip == 0) {
+                // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
+                if(crow == 0) {
+                    bx = (0.0f + k.ng) + k.ng;
+                } else {
+                    const float dm = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
+                    bx = dm + k.gs;
+                }
+            }
+        }
+        if(strip > 0) {
+            // rows kbase .. kbase+63 of the left neighbour's last column must be published
+            handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
+            if(crow < la) {
+                bx = in_x[crow];
+                bz = in_z[crow];
+            }
+        }
+        // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
+        asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
+        if(kbase == 0)
+            run_chunk<W, true>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+        else
+            run_chunk<W, false>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+        if(!last_strip) {
+            // lane 63 has now finished body rows < kbase + 64 - 63; the final count (la) is
+            // published below, after the release of the decision bits
+            const uint32_t done = min(kbase + kWave, nsteps);
+            if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
+        }
+    }
+    // flush the accumulators of an incomplete last dword, left-aligned (layout in common.hpp)
+    {
+        constexpr uint32_t kMA = 16 / W, kMC = 32 / W;
+        const uint32_t g = nsteps / kMC, q = nsteps & (kMC - 1u);  // q steps of the last group are done
+        if constexpr(kMA > 1) {
+            const uint32_t ra = nsteps & (kMA - 1u);
+            if(ra != 0) {
+                uint32_t* dst = fout + static_cast<uint64_t>(g) * kPairDwords + (q / kMA) * (2 * kWave);
+                dst[0] = st.acc[ACC_A] << (32u - 2u * W * ra);
+                dst[kWave] = st.acc[ACC_B] << (32u - 2u * W * ra);
+            }
+        }
+        if(q != 0) fout[static_cast<uint64_t>(g) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << (32u - W * q);
+    }
+    if(!last_strip) {
+        // The pair's traceback runs on the wavefront of the LAST strip: release this strip's
+        // (plainly stored) decision bits before saying "complete".
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        publish_progress(progress + ticket, la, lane == kWave - 1);
+    }
+    return handoff_ok;
+}
+
 // Viterbi fill for gap_len == 1.  PERSISTENT: the grid is sized to fill every CU
 // with the same number of workgroups (host: fill_launch_shape) and each
-// wavefront pulls pair indices from an atomic queue until it is empty.  (With one
+// wavefront pulls work items from an atomic queue until it is empty.  (With one
 // workgroup per 4 pairs the hardware dispatcher packs workgroups unevenly --
 // in-kernel clocks showed SIMDs running 2x the waves of others -- and a kernel
-// took ~2x the time its work implies.)  `order` lists the pairs longest first.
+// took ~2x the time its work implies.)  `items` lists the pairs longest first.
 __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
@@ -271,128 +388,42 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     }
 #endif
     for(;;) {
-    // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
-    // loop-invariant condition and may peel/unswitch this loop per lane, after which the
-    // wave-level operations inside (readfirstlane, DPP, ballots) no longer see the whole wave.
-    int lane = lane_id;
-    asm volatile("" : "+v"(lane));
-    uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);  // every lane takes part; lane 0 draws
-    ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
-    if(ticket >= n_items) break;
-    const WorkItem item = items[ticket];
-    const uint32_t pair = item.pair, strip = item.strip;
-    const PairDesc pd = pairs[pair];
-    const uint32_t la = pd.la, lb = pd.lb;
-    const uint32_t strips = (la > 0 && lb > 0) ? n_strips(lb) : 1u;
-    bool handoff_ok = true;
-    if(la > 0 && lb > 0) {  // (without body cells only the margins are walked)
-    const uint8_t* __restrict__ a = a_cat + pd.a_off;
-    const uint8_t* __restrict__ b = b_cat + pd.b_off;
-    {
-        const uint32_t col0 = strip * kStrip;
-        const uint32_t ncol = min(static_cast<uint32_t>(kStrip), lb - col0);
-        const uint32_t nlanes = (ncol + kW - 1) / kW;
-        const uint32_t nsteps = la + nlanes - 1;
-        const bool last_strip = strip + 1 == strips;
-        uint32_t* __restrict__ fout = flags + pd.flags_off + strip * strip_dwords(la) + lane;
-        // strip-boundary columns, one array per strip boundary: [0, la] = X of the strip's last
-        // column (index r = X of body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
-        // The strips of a pair run on different wavefronts, pipelined through these arrays.
-        const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
-        float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
-        float* __restrict__ bnd_z = bnd_x + (la + 1);
-        const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
-        const float* __restrict__ in_z = in_x + (la + 1);
-
-        // byte offsets of this lane's 16 table columns
-        uint32_t boff[kW];
-#pragma unroll
-        for(int c = 0; c < kW; ++c) {
-            const uint32_t bj = col0 + lane * kW + c;
-            boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
-        }
-
-        const StripCtx cx{k, la, col0, nsteps, pair, lds_tab, lane,
-                          static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
-                          last_strip, fout, bnd_x, bnd_z, scores};
-        LaneState st;
-#pragma unroll
-        for(int c = 0; c < kW; ++c) st.X[c] = st.Y[c] = 0.0f;
-#pragma unroll
-        for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
-        st.xlast_old = 0.0f;
-        st.zlast = 0.0f;
-        // table-row byte offset of the row this lane processes at the CURRENT step,
-        // and the 16 substitution scores gathered for it one step earlier
-        uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
-        float s[kW];
-#pragma unroll
-        for(int c = 0; c < kW; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
-
-        for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
-            // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l
-            // (boundary column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
-            const uint32_t crow = kbase + lane;
-            uint32_t a_chunk = 0;
-            float bx = kLowest, bz = kLowest;
-            if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
-            if(crow < la) {
-                if(strip == 0) {
-                    // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
-                    if(crow == 0) {
-                        bx = (0.0f + k.ng) + k.ng;
-                    } else {
-                        const float dm = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
-                        bx = dm + k.gs;
-                    }
-                }
-            }
-            if(strip > 0) {
-                // rows kbase .. kbase+63 of the left neighbour's last column must be published
-                handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
-                if(crow < la) {
-                    bx = in_x[crow];
-                    bz = in_z[crow];
-                }
-            }
-            // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
-            asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
-            if(kbase == 0)
-                run_chunk<true>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
+        // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
+        // loop-invariant condition and may peel/unswitch this loop per lane, after which the
+        // wave-level operations inside (readfirstlane, DPP, ballots) no longer see the whole wave.
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);  // every lane takes part; lane 0 draws
+        ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        if(ticket >= n_items) break;
+        const WorkItem item = items[ticket];
+        const uint32_t pair = item.pair, strip = item.strip;
+        const PairDesc pd = pairs[pair];
+        bool handoff_ok = true;
+        if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
+            const uint8_t* __restrict__ a = a_cat + pd.a_off;
+            const uint8_t* __restrict__ b = b_cat + pd.b_off;
+            const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
+            if(w == 16)
+                handoff_ok = fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, flags, bnd, scores, progress);
+            else if(w == 8)
+                handoff_ok = fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, flags, bnd, scores, progress);
             else
-                run_chunk<false>(cx, st, arow, s, boff, kbase, a_chunk, bx, bz);
-            if(!last_strip) {
-                // lane 63 has now finished body rows < kbase + 64 - 63; the final count (la) is
-                // published below, after the release of the decision bits
-                const uint32_t done = min(kbase + kWave, nsteps);
-                if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
-            }
+                handoff_ok = fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, flags, bnd, scores, progress);
         }
-        if(nsteps & 1u)  // the last (even) step has no odd partner: flush its IM bits to the high half
-            fout[static_cast<uint64_t>(nsteps >> 1) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << 16;
-        if(!last_strip) {
-            // The pair's traceback runs on the wavefront of the LAST strip: release this strip's
-            // (plainly stored) decision bits before saying "complete".
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            publish_progress(progress + ticket, la, lane == kWave - 1);
-        }
-    }
-    }
-    COATI_STAMP(0);  // fill of this item done
-    if(strip + 1 < strips) continue;  // not the last strip of its pair: no traceback here
-    // ---- traceback of this pair by the wavefront of its last strip, while the bits are still
-    // in L2.  What the wave wrote itself: wait until the stores are acknowledged (nobody read
-    // these 128-byte aligned lines before, so L1 is cold).  What other wavefronts wrote (earlier
-    // strips): they released before publishing "complete", which this wave polled; acquire.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if(strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
-    viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
-    if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");
-    COATI_STAMP(1);  // traceback done
+        COATI_STAMP(0);  // fill of this item done
+        if(strip + 1 < pd.v_strips) continue;  // not the last strip of its pair: no traceback here
+        // ---- traceback of this pair by the wavefront of its last strip, while the bits are still
+        // in L2.  What the wave wrote itself: wait until the stores are acknowledged (nobody read
+        // these 128-byte aligned lines before, so L1 is cold).  What other wavefronts wrote (earlier
+        // strips): they released before publishing "complete", which this wave polled; acquire.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
+        if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
+        COATI_STAMP(1);  // traceback done
 #ifdef COATI_FILL_TRACE
-    trace_n += 2;
+        trace_n += 2;
 #endif
     }  // next ticket
 }

@@ -139,3 +139,48 @@ def test_long_pair_strips_pipelined_across_wavefronts(hip, oracle):
     a2 = util.random_anc(rng, 1500)
     pairs.insert(7, (a2, util.mutate(rng, a2, n_indel=10)))  # a second multi-strip pair (5 strips)
     run_and_compare(hip, oracle, table, consts, pairs, check_flags=False)
+
+
+@pytest.mark.parametrize("strip_w", ["4", "8", "16"])
+def test_strip_shapes_forced(oracle, strip_w):
+    """The three strip shapes (4, 8, 16 columns per lane) produce the same bit-exact results;
+    COATI_HIP_STRIP_W forces the main shape, the last strip of a pair picks its own.  Runs in a
+    child process because the library reads the variable when a batch is created."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from coati_amd import hip
+from oracle import pyoracle as orc
+from tests import util
+rng = np.random.default_rng(77)
+table = util.random_table(rng)
+consts = orc.gap_consts()
+pairs = util.make_pairs(rng, 40, 1, 420, L=1, amb=0.02)
+# descendant lengths around every shape boundary, one pair spanning several strips of any shape
+for nb in (1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1030, 1290, 1540, 2049):
+    anc = util.random_anc(rng, max(1, nb // 3 + int(rng.integers(0, 3))))
+    des = "".join(rng.choice(list(util.NT), nb))
+    pairs.append((anc, des))
+pairs.append((util.random_anc(rng, 900), util.mutate(rng, util.random_anc(rng, 1100), n_indel=6)))
+enc = util.encode_pairs(pairs)
+model = hip.Model(table, consts, 1)
+scores, ops, off, ln = model.viterbi(*hip.pack_pairs(enc))
+bad = 0
+for p, (a, b) in enumerate(enc):
+    w_ops, w_sc = orc.viterbi(table, consts, 1, a, b)
+    got = ops[int(off[p]):int(off[p]) + int(ln[p])]
+    if not (len(got) == len(w_ops) and (got == w_ops).all() and np.float32(scores[p]).view(np.uint32) == np.float32(w_sc).view(np.uint32)):
+        bad += 1
+        print("MISMATCH pair", p, len(a), len(b))
+print("checked", len(enc), "bad", bad)
+sys.exit(1 if bad else 0)
+''' % str(root)
+    env = dict(os.environ, COATI_HIP_STRIP_W=strip_w)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
