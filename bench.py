@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU per step")
     ap.add_argument("--model", default="mar-mg", choices=["mar-mg", "mar-ecm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive steps alternate between two resident copies of the shard on two library "
+                         "streams, so the ragged end of one launch overlaps the start of the next (DESIGN.md 4.1)")
     args = ap.parse_args()
 
     import torch
@@ -93,8 +96,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # COATI_BENCH_SELFTEST_GATHER=1 runs the N > 1 code path (second slot, packed gather, overlap)
+    # with a one-rank RCCL group: a functional check on a 1-GPU box, not a benchmark configuration
+    selftest = world == 1 and os.environ.get("COATI_BENCH_SELFTEST_GATHER") == "1"
+    multi = world > 1 or selftest
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if selftest:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available() or hip.device_count() == 0:
@@ -107,7 +119,7 @@ def main():
         table, consts, gap_len = host.set_subst(args.model), host.gap_consts(), 1
     else:
         table = consts = gap_len = None
-    if world > 1:
+    if multi:
         table, consts, gap_len = cd.broadcast_model(table, consts, gap_len, device)
     model = hip.Model(table, consts, gap_len, device=local_rank)
 
@@ -118,16 +130,42 @@ def main():
     cells = batch.cells
     seq_bytes = int(a_off[-1] + b_off[-1])
 
+    # N > 1: every step's results go to rank 0 (one packed RCCL gather per step).  Two resident
+    # copies of the shard alternate, so that the gather of step i runs on torch's collective stream
+    # while the kernel of step i+1 runs: nothing is skipped, K launches and K gathers happen inside
+    # the timed region.  By default both copies use ONE library stream (kernels never overlap each
+    # other; the gather waits for its own launch only, coati_hip_viterbi_wait); --streams 2 gives each
+    # copy its own stream.
+    slots = [(model, batch)]
+    gathers = []
+    if multi or args.streams == 2:
+        model2 = hip.Model(table, consts, gap_len, device=local_rank) if args.streams == 2 else model
+        slots.append((model2, hip.Batch(model2, a_cat, a_off, b_cat, b_off)))
+    if multi:
+        gathers = [cd.PackedGather(cd.batch_result_tensors(bt, device), dst=0) for _, bt in slots]
+    state = {"i": 0, "pending": None}
+
     def step():
-        batch.viterbi_launch()
-        if world > 1:
-            batch.sync()  # the gather reads the result arrays on torch's stream
-            cd.gather_results(batch, device, dst=0)
+        cur = state["i"] % len(slots)
+        slots[cur][1].viterbi_launch()
+        if multi:
+            drain()
+            state["pending"] = cur
+        state["i"] += 1
+
+    def drain():
+        pend = state["pending"]
+        if pend is not None:
+            slots[pend][1].wait()  # its own launch only: the launch just issued keeps running
+            gathers[pend]()
+            state["pending"] = None
 
     def fence():
-        if world > 1:
+        if multi:
+            drain()
             dist.barrier()
-        batch.sync()
+        for _, bt in slots:
+            bt.sync()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -140,7 +178,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel device times of the timed launches: HIP events the library recorded on its
     # own stream around each kernel (it keeps the last 64 launches)
-    timed = [batch.viterbi_timing(i) for i in range(min(args.steps, 64))]
+    timed = [bt.viterbi_timing(i) for _, bt in slots for i in range(min(args.steps // len(slots), 64))]
     fill_ms = [t[0] for t in timed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -158,6 +196,13 @@ def main():
 
     if rank == 0:
         fill = float(np.mean(fill_ms))
+        kernel_ms = {"viterbi_l1 (fill + fused traceback)": fill}
+        if args.streams == 2:
+            # launches overlap: the event pair around one kernel also spans its wait behind the other
+            # stream's kernel, so the average launch duration is taken as region time / launches
+            kernel_ms["viterbi_l1 event span incl. queueing behind the other stream"] = fill
+            fill = elapsed / args.steps * 1e3
+            kernel_ms["viterbi_l1 (fill + fused traceback)"] = fill
         algo_bytes = cells * ALGO_BYTES_PER_CELL + seq_bytes
         traffic = None
         tfile = ROOT / "profiles" / "traffic_latest.json"
@@ -188,10 +233,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.pairs} synthetic 1 kb x 1 kb pairs per GPU, {args.model} "
                                    "(BASELINE.json configs[1]; generator SURVEY.md §8(d))",
-                       "pairs_per_gpu": args.pairs, "global_pairs": args.pairs * world, "gap_len": 1,
+                       "streams": args.streams, "pairs_per_gpu": args.pairs, "global_pairs": args.pairs * world, "gap_len": 1,
                        "parallelism": f"pairs sharded over {world} GPU(s), model broadcast + result gather (RCCL)"},
             "pairs_per_s": args.pairs * world * args.steps / elapsed,
-            "kernel_ms": {"viterbi_l1 (fill + fused traceback)": fill},
+            "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "viterbi_l1", "algorithmic_bytes_per_launch": algo_bytes,
@@ -204,9 +249,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)
         print(json.dumps(out), flush=True)
-    batch.close()
-    model.close()
-    if world > 1:
+    if selftest and rank == 0:
+        # the gathered copy of the last step equals what a direct fetch returns
+        sc, ops, off, ln = gathers[(state["i"] - 1) % len(slots)].unpack(0)
+        f_sc, f_ops, f_off, f_ln = slots[(state["i"] - 1) % len(slots)][1].viterbi_fetch()
+        assert (sc.cpu().numpy().view(np.uint32) == f_sc.view(np.uint32)).all() and (ln.cpu().numpy() == f_ln).all()
+        assert (ops.cpu().numpy() == f_ops).all()
+        print("selftest: gathered results identical to a direct fetch", file=sys.stderr)
+    for md, bt in slots:
+        bt.close()
+    for md in {id(m): m for m, _ in slots}.values():
+        md.close()
+    if multi:
         dist.destroy_process_group()
 
 

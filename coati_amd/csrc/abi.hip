@@ -272,6 +272,15 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
     // more wavefronts to work on each pair.  dp_generic (gap_len > 1) writes 16-column strips only.
     uint32_t w_main = kW;
     const bool plan_l1 = L == 1 && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;  // viterbi_l1 will run
+    // longest-processing-time-first order for the dynamic queue
+    std::vector<uint32_t> order(n_pairs);
+    for(uint64_t p = 0; p < n_pairs; ++p) order[p] = static_cast<uint32_t>(p);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
+    });
+    // Experimental: the last `tail_pairs` pairs of the queue in narrow strips (finer items at the
+    // ragged end of a batch).  COATI_HIP_TAIL_PAIRS / COATI_HIP_TAIL_W.
+    std::vector<uint8_t> pair_w(n_pairs, 0);
     if(plan_l1) {
         auto count_items = [&](uint32_t w) {
             uint64_t items = 0;
@@ -288,23 +297,30 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
             const int w = std::atoi(e);
             if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
         }
+        const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS");
+        const char* tw = std::getenv("COATI_HIP_TAIL_W");
+        const uint64_t tail_pairs = tp != nullptr ? std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10)) : 0;
+        const int tail_w = tw != nullptr ? std::atoi(tw) : 4;
+        if(tail_w == 4 || tail_w == 8)
+            for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = static_cast<uint8_t>(tail_w);
     }
     for(uint64_t p = 0; p < n_pairs; ++p) {
         PairDesc& d = b->desc[p];
         const uint64_t la = d.la;
-        uint32_t ns = 1, wl = w_main;
+        const uint32_t w_main_p = pair_w[p] != 0 ? std::min<uint32_t>(pair_w[p], w_main) : w_main;
+        uint32_t ns = 1, wl = w_main_p;
         if(plan_l1) {
-            if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main, ns, wl);
+            if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main_p, ns, wl);
         } else {
             ns = std::max(1u, n_strips(d.lb));
         }
         d.v_strips = ns;
-        d.v_wmain = static_cast<uint8_t>(w_main);
+        d.v_wmain = static_cast<uint8_t>(w_main_p);
         d.v_wlast = static_cast<uint8_t>(wl);
         d.flags_off = b->flag_dwords;
         d.bnd_off = b->bnd_floats;
         if(d.la > 0 && d.lb > 0)
-            b->flag_dwords += (ns - 1) * strip_dwords(d.la, w_main) + strip_dwords(d.la, wl);
+            b->flag_dwords += (ns - 1) * strip_dwords(d.la, w_main_p) + strip_dwords(d.la, wl);
         // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
         // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
@@ -341,12 +357,6 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
     B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_queue), sizeof(uint32_t)));
     if(n_pairs > 0) {
         B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
-        // longest-processing-time-first order for the dynamic queue
-        std::vector<uint32_t> order(n_pairs);
-        for(uint64_t p = 0; p < n_pairs; ++p) order[p] = static_cast<uint32_t>(p);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
-        });
         B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
         std::vector<WorkItem> items, fwd_items;
         for(const uint32_t p : order) {
@@ -401,6 +411,14 @@ int coati_hip_batch_sync(coati_hip_batch_t* b) {
     if(b == nullptr) return fail(COATI_HIP_EINVAL, "batch_sync: batch is NULL");
     HIP_TRY(hipSetDevice(b->model->device));
     HIP_TRY(hipStreamSynchronize(b->model->stream));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_wait(coati_hip_batch_t* b) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_wait: batch is NULL");
+    if(!b->launched) return fail(COATI_HIP_ESTATE, "viterbi_wait: nothing was launched");
+    HIP_TRY(hipSetDevice(b->model->device));
+    HIP_TRY(hipEventSynchronize(b->ev[(b->n_launches - 1) % coati_hip_batch::kTimingRing][2]));
     return COATI_HIP_OK;
 }
 

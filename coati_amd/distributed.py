@@ -86,3 +86,47 @@ def gather_results(batch, device, dst: int = 0):
     """The 'final gather over xGMI': every rank's scores / ops / offsets / lengths to rank dst."""
     sc, ops, off, ln = batch_result_tensors(batch, device)
     return tuple(gather_ragged(t, dst) for t in (sc, ops, off, ln))
+
+
+class PackedGather:
+    """Result gather for a loop over the same batch shape: ONE collective per call.
+
+    The four result arrays (scores f32, ops u8, ops_off i64, ops_len i32) are copied device-to-
+    device into one byte buffer and gathered to rank `dst`; sizes are exchanged once at
+    construction, receive buffers are allocated once.  The call only enqueues work on torch's
+    collective stream, so it overlaps with kernels the library runs on its own stream.
+    """
+
+    def __init__(self, tensors, dst: int = 0):
+        self.views = [t.contiguous().view(torch.uint8) if t.dtype != torch.uint8 else t for t in tensors]
+        self.dtypes = [t.dtype for t in tensors]
+        self.sizes = [int(v.numel()) for v in self.views]
+        self.dst = dst
+        world, rank = dist.get_world_size(), dist.get_rank()
+        dev = tensors[0].device
+        mine = torch.tensor(self.sizes, dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        self.all_sizes = [[int(x) for x in e.tolist()] for e in every]
+        self.cap = max(max(sum(self._pad(n) for n in sz) for sz in self.all_sizes), 8)
+        self.packed = torch.zeros(self.cap, dtype=torch.uint8, device=dev)
+        self.bucket = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+
+    @staticmethod
+    def _pad(n: int) -> int:
+        return (n + 7) // 8 * 8  # every segment starts 8-byte aligned (typed views of the buffer)
+
+    def __call__(self, async_op: bool = False):
+        pos = 0
+        for v, n in zip(self.views, self.sizes):
+            self.packed[pos:pos + n].copy_(v)
+            pos += self._pad(n)
+        return dist.gather(self.packed, self.bucket, dst=self.dst, async_op=async_op)
+
+    def unpack(self, rank: int):
+        """On `dst`: rank's (scores, ops, ops_off, ops_len) as typed views of the receive buffer."""
+        out, pos = [], 0
+        for n, dt in zip(self.all_sizes[rank], self.dtypes):
+            out.append(self.bucket[rank][pos:pos + n].view(dt) if dt != torch.uint8 else self.bucket[rank][pos:pos + n])
+            pos += self._pad(n)
+        return tuple(out)

@@ -30,6 +30,7 @@ EXPORTS = (
     "coati_hip_batch_cells",
     "coati_hip_viterbi_launch",
     "coati_hip_batch_sync",
+    "coati_hip_viterbi_wait",
     "coati_hip_viterbi_fetch",
     "coati_hip_viterbi_last_timing",
     "coati_hip_viterbi_timing",
@@ -209,6 +210,10 @@ class Batch:
 
     def sync(self):
         _check(load().coati_hip_batch_sync(self._h))
+
+    def wait(self):
+        """Wait for this batch's last Viterbi launch only (later launches of other batches keep running)."""
+        _check(load().coati_hip_viterbi_wait(self._h))
 
     def viterbi_fetch(self):
         scores = np.zeros(self.n, np.float32)

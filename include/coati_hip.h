@@ -105,8 +105,12 @@ uint64_t coati_hip_batch_cells(const coati_hip_batch_t* batch);
  * fill kernel and the traceback walker on the model's stream and returns
  * without waiting. */
 int coati_hip_viterbi_launch(coati_hip_batch_t* batch);
-/* Wait for everything enqueued for this batch. */
+/* Wait for everything enqueued on the batch's model (its stream). */
 int coati_hip_batch_sync(coati_hip_batch_t* batch);
+/* Wait for THIS batch's most recent Viterbi launch only: launches of other batches of the same
+ * model that were enqueued after it keep running (e.g. fetch or gather the results of batch A
+ * while batch B computes). */
+int coati_hip_viterbi_wait(coati_hip_batch_t* batch);
 
 /* Copy results to host (synchronises first).  Any output may be NULL.
  *   scores[n_pairs]   aln.data.score of traceback (align_pair.cc:265), fp32

@@ -47,6 +47,19 @@ def _worker(rank, world, port, q):
         empty = cd.gather_ragged(torch.zeros(0 if rank else 3, dtype=torch.uint8), dst=0)
         if rank == 0:
             ok = ok and [p.numel() for p in empty] == [3] + [0] * (world - 1)
+        # packed one-collective gather of four typed arrays (what bench.py uses every step)
+        n = 3 + rank
+        arrs = (torch.arange(n, dtype=torch.float32) + rank, torch.arange(7 * n, dtype=torch.uint8) % 3,
+                torch.arange(n, dtype=torch.int64) * (rank + 5), torch.arange(n, dtype=torch.int32) + 9 * rank)
+        pg = cd.PackedGather(arrs, dst=0)
+        for _ in range(2):  # reusable
+            pg()
+        if rank == 0:
+            for r in range(world):
+                m = 3 + r
+                sc, ops, off, ln = pg.unpack(r)
+                ok = ok and sc.tolist() == [float(x + r) for x in range(m)] and ops.tolist() == [x % 3 for x in range(7 * m)]
+                ok = ok and off.tolist() == [x * (r + 5) for x in range(m)] and ln.tolist() == [x + 9 * r for x in range(m)]
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
