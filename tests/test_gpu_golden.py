@@ -81,3 +81,28 @@ def test_long_sample_pairs(key):
     assert (int((got == 0).sum()), int((got == 1).sum()), int((got == 2).sum())) == (case["n_match"], case["n_del"],
                                                                                      case["n_ins"])
     assert "%08x" % zlib.crc32(got.tobytes()) == case["ops_crc32"]
+
+
+def test_full_baseline_workload_checksums():
+    """BASELINE configs[1] at FULL size: all 10 000 synthetic 1 kb pairs through the C ABI; the CRC32
+    of every op of every pair, the CRC32 of the fp32 score bits and the column total equal the CPU
+    oracle's (tools/make_golden_synth.py).  Bit-exact or it fails."""
+    import zlib
+
+    from coati_amd import hip, host
+
+    want = json.loads((GOLD / "synth10k_checksums.json").read_text())
+    table = host.set_subst("mar-mg")
+    assert "%08x" % zlib.crc32(np.ascontiguousarray(table).tobytes()) == want["table_crc32"], "host model drifted"
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, want["pairs"])
+    model = hip.Model(table, host.gap_consts(), 1)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    for _ in range(2):  # a relaunch on the same batch gives the same answer
+        batch.viterbi_launch()
+    scores, ops, off, ln = batch.viterbi_fetch()
+    assert "%08x" % zlib.crc32(scores.tobytes()) == want["scores_crc32"]
+    assert int(ln.sum()) == want["columns"]
+    crc = 0
+    for p in range(want["pairs"]):
+        crc = zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes(), crc)
+    assert "%08x" % crc == want["ops_crc32"]
