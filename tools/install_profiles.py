@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/profile.sh left under gpurun_out/ into profiles/<round>/ (tracked)."""
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = ROOT / "gpurun_out" / "prof_n1", ROOT / "profiles" / rnd
+dst.mkdir(parents=True, exist_ok=True)
+for a, b in (("kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("pmc_summary.csv", "bench_n1_pmc_summary.csv"),
+             ("traffic.json", "bench_n1_traffic.json"), ("bench.json", "bench_n1_under_rocprof.json")):
+    shutil.copy(src / a, dst / b)
+for extra in ("bench_n1.json", "bench_n1_streams2.json", "sample_bench.json", "long_pair.json"):
+    f = ROOT / "gpurun_out" / extra
+    if f.exists():
+        shutil.copy(f, dst / extra)
+t = json.loads((dst / "bench_n1_traffic.json").read_text())["viterbi_l1"]
+(ROOT / "profiles" / "traffic_latest.json").write_text(json.dumps({
+    "viterbi_l1_bytes_per_launch_10000_pairs": t["bytes_per_launch"],
+    "how": "tools/profile.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes of `bench.py --steps 3 "
+           "--warmup 1`; bytes = (WRITE_SIZE + 2*FETCH_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a coalesced "
+           "stream, MI355X_MICROARCH.md section HBM)",
+    "WRITE_SIZE_KB": t["WRITE_SIZE_KB"], "FETCH_SIZE_KB_raw": t["FETCH_SIZE_KB_raw"], "round": int(rnd[1:]),
+    "source": f"profiles/{rnd}/bench_n1_pmc_summary.csv"}, indent=1))
+print(t)

@@ -51,7 +51,7 @@ consumed_ok = (n_m + n_d == la) and (n_m + n_i == lb)
 ps = orc.path_score(table, consts, 1, a_cat[:la], b_cat[:lb], path)
 bit_equal = bool(np.float32(ps).view(np.uint32) == np.float32(scores[0]).view(np.uint32))
 out = {
-    "workload": f"1 pair {la} x {lb} nt (synthetic, configs[2])", "cells": la * lb, "strips": (lb + 1023) // 1024,
+    "workload": f"1 pair {la} x {lb} nt (synthetic, configs[2])", "cells": la * lb,
     "device_bytes": batch.device_bytes, "batch_create_s": round(t_create, 3), "ms_median": float(np.median(ms)),
     "ms_min": float(np.min(ms)), "gcups": la * lb / float(np.median(ms)) / 1e6, "score": float(scores[0]),
     "columns": int(ln[0]), "ops_consume_both_sequences": consumed_ok, "path_score": float(ps),
