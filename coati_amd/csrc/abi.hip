@@ -4,6 +4,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -535,6 +536,183 @@ int coati_hip_debug_forward_matrices(coati_hip_batch_t* b, uint64_t pair, float*
     return COATI_HIP_OK;
 }
 
+namespace {
+// ---- exact-stream sampling in parallel (kernels and rationale: sampleback.hip) ------------------
+// Per chunk and pair: sample j of the chunk is expected to start j * mean draws after the chunk
+// origin; every offset within +-(z * sigma * sqrt(j) + 2) of that is walked as a candidate.  The
+// true chain origin -> sample 0 -> sample 1 ... is then followed through the candidates' draw
+// counts; a sample whose true offset was not a candidate ends the chunk for its pair (it becomes
+// sample 0 of the next chunk, whose offset is always a candidate), so the loop always advances.
+using u128 = unsigned __int128;
+constexpr uint64_t kLehmerMult = 0xda942042e4dd58b5ULL;  // contrib/random/random.hpp:95
+
+u128 lehmer_pow(uint64_t n) {
+    u128 r = 1, bpow = kLehmerMult;
+    for(; n != 0; n >>= 1, bpow *= bpow)
+        if(n & 1u) r *= bpow;
+    return r;
+}
+
+hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const uint64_t* rng_state,
+                                  const std::vector<uint64_t>& base, uint8_t* d_ops, uint64_t* d_start, uint32_t* d_len,
+                                  float* d_lw, uint64_t* states_out) {
+    coati_hip_model* m = b->model;
+    const uint64_t n = b->n_pairs;
+    constexpr uint32_t kChunkMax = 512, kMaxCands = 1u << 18;
+    constexpr double kZ = 5.0;
+    size_t free_b = 0, total_b = 0;
+    hipError_t e = hipMemGetInfo(&free_b, &total_b);
+    if(e != hipSuccess) return e;
+    const uint64_t tmp_budget = std::max<uint64_t>(std::min<uint64_t>(free_b / 4, 1ull << 30), 1ull << 20);
+
+    struct PairState {
+        u128 st0;
+        uint64_t origin = 0;  // draws consumed by the samples resolved so far
+        uint32_t done = 0, cnt = 0;
+        double mean = 0.0, m2 = 0.0;
+    };
+    std::vector<PairState> ps(n);
+    for(uint64_t p = 0; p < n; ++p) ps[p].st0 = (static_cast<u128>(rng_state[2 * p + 1]) << 64) | rng_state[2 * p];
+
+    uint64_t mult_pow[64];
+    {
+        u128 bpow = kLehmerMult;
+        for(int bit = 0; bit < 32; ++bit, bpow *= bpow) {
+            mult_pow[2 * bit] = static_cast<uint64_t>(bpow);
+            mult_pow[2 * bit + 1] = static_cast<uint64_t>(bpow >> 64);
+        }
+    }
+    uint64_t *d_origin = nullptr, *d_pow = nullptr, *d_cstart = nullptr;
+    SpecCandidate* d_cands = nullptr;
+    SpecCommit* d_commits = nullptr;
+    uint8_t* d_tmp = nullptr;
+    uint32_t *d_clen = nullptr, *d_cdraws = nullptr;
+    float* d_clw = nullptr;
+    auto release = [&]() {
+        void* ptrs[] = {d_origin, d_pow, d_cstart, d_cands, d_commits, d_tmp, d_clen, d_cdraws, d_clw};
+        for(void* q : ptrs)
+            if(q != nullptr) (void)hipFree(q);
+    };
+#define S_TRY(expr)                 \
+    do {                            \
+        e = (expr);                 \
+        if(e != hipSuccess) {       \
+            release();              \
+            return e;               \
+        }                           \
+    } while(0)
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_origin), 2 * n * sizeof(uint64_t)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_pow), sizeof(mult_pow)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_cstart), kMaxCands * sizeof(uint64_t)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_cands), kMaxCands * sizeof(SpecCandidate)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_commits), std::max<uint64_t>(std::min<uint64_t>(n * kChunkMax, kMaxCands), 1) * sizeof(SpecCommit)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_tmp), tmp_budget));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_clen), kMaxCands * sizeof(uint32_t)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_cdraws), kMaxCands * sizeof(uint32_t)));
+    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_clw), kMaxCands * sizeof(float)));
+    S_TRY(hipMemcpyAsync(d_pow, mult_pow, sizeof(mult_pow), hipMemcpyHostToDevice, m->stream));
+
+    struct Window {  // candidates of one (pair, sample-in-chunk)
+        uint32_t first_cand, lo, hi;
+    };
+    std::vector<SpecCandidate> cands;
+    std::vector<std::vector<Window>> windows(n);
+    std::vector<uint64_t> origin_states(2 * n);
+    std::vector<uint32_t> draws;
+    std::vector<SpecCommit> commits;
+    const BatchDeviceView view = device_view(b);
+    for(;;) {
+        cands.clear();
+        uint64_t tmp_used = 0;
+        bool any = false;
+        uint64_t active = 0;
+        for(uint64_t p = 0; p < n; ++p) active += ps[p].done < n_samples ? 1 : 0;
+        // every unfinished pair gets an equal share of the candidate and work-arena budget; the chunk
+        // of a pair is as long as its share allows (windows grow with sqrt(j))
+        const uint64_t cand_share = kMaxCands / std::max<uint64_t>(active, 1), tmp_share = tmp_budget / std::max<uint64_t>(active, 1);
+        for(uint64_t p = 0; p < n; ++p) {
+            windows[p].clear();
+            PairState& s = ps[p];
+            if(s.done >= n_samples) continue;
+            any = true;
+            const uint64_t cand_begin = cands.size(), tmp_begin = tmp_used;
+            if(cand_begin + 1 > kMaxCands ||
+               tmp_used + static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb > tmp_budget)
+                continue;  // more unfinished pairs than one round holds: this pair waits for the next round
+            const uint64_t width = static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb;
+            const uint32_t remaining = n_samples - s.done;
+            const uint32_t want = s.cnt == 0 ? 1u : (s.cnt < 4 ? 4u : (s.cnt < 16 ? 16u : kChunkMax));
+            const uint32_t chunk = std::min(remaining, want);
+            // (few observations: widen, a window that is too narrow only ends the chunk early)
+            const double sigma = s.cnt >= 2 ? std::sqrt(s.m2 / (s.cnt - 1)) * (1.0 + 4.0 / s.cnt) + 1.0
+                                            : 0.02 * static_cast<double>(width) + 2.0;
+            for(uint32_t j = 0; j < chunk; ++j) {
+                const int64_t center = std::llround(j * s.mean);
+                const int64_t half = j == 0 ? 0 : static_cast<int64_t>(std::ceil(kZ * sigma * std::sqrt(static_cast<double>(j)))) + 2;
+                const int64_t lo = std::max<int64_t>(center - half, j), hi = std::max<int64_t>(center + half, lo);
+                const uint64_t count = static_cast<uint64_t>(hi - lo + 1);
+                if(j > 0 && (cands.size() - cand_begin + count > cand_share ||
+                            tmp_used - tmp_begin + count * std::max<uint64_t>(width, 1) > tmp_share))
+                    break;
+                windows[p].push_back(Window{static_cast<uint32_t>(cands.size()), static_cast<uint32_t>(lo), static_cast<uint32_t>(hi)});
+                for(int64_t off = lo; off <= hi; ++off) {
+                    cands.push_back(SpecCandidate{static_cast<uint32_t>(p), static_cast<uint32_t>(off), tmp_used});
+                    tmp_used += width;
+                }
+            }
+            const u128 st = s.st0 * lehmer_pow(s.origin);
+            origin_states[2 * p] = static_cast<uint64_t>(st);
+            origin_states[2 * p + 1] = static_cast<uint64_t>(st >> 64);
+        }
+        if(!any) break;
+        if(cands.size() > kMaxCands || tmp_used > tmp_budget) {  // a single sample does not fit the work arena
+            release();
+            return hipErrorOutOfMemory;
+        }
+        const uint32_t nc = static_cast<uint32_t>(cands.size());
+        S_TRY(hipMemcpyAsync(d_origin, origin_states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(hipMemcpyAsync(d_cands, cands.data(), nc * sizeof(SpecCandidate), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_spec_walk(view, d_origin, d_pow, d_cands, nc, d_tmp, d_cstart, d_clen, d_clw, d_cdraws, m->stream));
+        draws.resize(nc);
+        S_TRY(hipMemcpyAsync(draws.data(), d_cdraws, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));
+        // follow the chain of true offsets
+        commits.clear();
+        for(uint64_t p = 0; p < n; ++p) {
+            PairState& s = ps[p];
+            const uint64_t width = static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb;
+            uint64_t off = 0;
+            for(const Window& w : windows[p]) {
+                if(off < w.lo || off > w.hi) break;  // not speculated: first sample of the next chunk
+                const uint32_t cand = w.first_cand + static_cast<uint32_t>(off - w.lo);
+                const uint64_t out_index = p * n_samples + s.done;
+                commits.push_back(SpecCommit{cand, 0u, base[p] + (static_cast<uint64_t>(s.done) + 1) * width, out_index});
+                const double x = static_cast<double>(draws[cand]);
+                s.cnt += 1;  // Welford
+                const double d1 = x - s.mean;
+                s.mean += d1 / s.cnt;
+                s.m2 += d1 * (x - s.mean);
+                off += draws[cand];
+                s.done += 1;
+            }
+            s.origin += off;
+        }
+        const uint32_t ncm = static_cast<uint32_t>(commits.size());
+        S_TRY(hipMemcpyAsync(d_commits, commits.data(), ncm * sizeof(SpecCommit), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_spec_commit(d_commits, ncm, d_tmp, d_cstart, d_clen, d_clw, d_ops, d_start, d_len, d_lw, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));  // `commits`/`cands` are reused by the next round
+    }
+#undef S_TRY
+    for(uint64_t p = 0; p < n; ++p) {
+        const u128 st = ps[p].st0 * lehmer_pow(ps[p].origin);  // where n serial sampleback calls leave the stream
+        states_out[2 * p] = static_cast<uint64_t>(st);
+        states_out[2 * p + 1] = static_cast<uint64_t>(st >> 64);
+    }
+    release();
+    return hipSuccess;
+}
+}  // namespace
+
 int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
                          float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
                          uint64_t* rng_state_out) {
@@ -590,11 +768,19 @@ int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_
         if((e = hipMalloc(reinterpret_cast<void**>(&d_ops), std::max<uint64_t>(total, 16))) != hipSuccess) return e;
         if((e = hipMalloc(reinterpret_cast<void**>(&d_len), n_out * sizeof(uint32_t))) != hipSuccess) return e;
         if((e = hipMalloc(reinterpret_cast<void**>(&d_lw), n_out * sizeof(float))) != hipSuccess) return e;
-        if((e = hipMemcpyAsync(d_states, states.data(), states.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
-        if((e = hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
-        if((e = launch_sampleback(device_view(b), n_samples, independent_streams != 0, d_states, d_base, d_ops, d_start, d_len,
-                                  d_lw, m->stream)) != hipSuccess) return e;
-        if((e = hipStreamSynchronize(m->stream)) != hipSuccess) return e;
+        // exact stream with several samples per pair: walked in parallel by speculating the stream
+        // offsets (identical results); COATI_HIP_SAMPLE_SEQUENTIAL=1 keeps the one-walker-per-pair loop
+        static const bool sequential = std::getenv("COATI_HIP_SAMPLE_SEQUENTIAL") != nullptr;
+        if(!independent_streams && n_samples >= 4 && !sequential) {
+            if((e = sampleback_speculative(b, n_samples, rng_state, base, d_ops, d_start, d_len, d_lw, states.data())) != hipSuccess) return e;
+            if((e = hipMemcpy(d_states, states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        } else {
+            if((e = hipMemcpyAsync(d_states, states.data(), states.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
+            if((e = hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
+            if((e = launch_sampleback(device_view(b), n_samples, independent_streams != 0, d_states, d_base, d_ops, d_start, d_len,
+                                      d_lw, m->stream)) != hipSuccess) return e;
+            if((e = hipStreamSynchronize(m->stream)) != hipSuccess) return e;
+        }
         if(log_weights != nullptr && (e = hipMemcpy(log_weights, d_lw, n_out * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) return e;
         if(ops != nullptr && total > 0 && (e = hipMemcpy(ops, d_ops, total, hipMemcpyDeviceToHost)) != hipSuccess) return e;
         if(ops_off != nullptr && (e = hipMemcpy(ops_off, d_start, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;

@@ -309,5 +309,23 @@ hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool 
                              float* log_weights, hipStream_t stream);
 hipError_t launch_rng_f24(const uint64_t state[2], uint32_t n, float* d_out, hipStream_t stream);
 
+// Speculative exact-stream sampling (sampleback.hip): a walker that assumes its sample starts
+// `offset` draws after the pair's chunk origin, and the record that promotes a candidate to a result.
+struct SpecCandidate {
+    uint32_t pair, offset;
+    uint64_t slot;  // start of its la + lb bytes in the temporary ops arena
+};
+struct SpecCommit {
+    uint32_t cand, pad_;
+    uint64_t slot_end;   // end of the sample's slot in the result ops arena
+    uint64_t out_index;  // pair * n_samples + sample
+};
+hipError_t launch_spec_walk(const BatchDeviceView& v, const uint64_t* origin_state, const uint64_t* mult_pow,
+                            const SpecCandidate* cands, uint32_t n_cands, uint8_t* tmp_ops, uint64_t* c_start,
+                            uint32_t* c_len, float* c_lw, uint32_t* c_draws, hipStream_t stream);
+hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, const uint8_t* tmp_ops,
+                              const uint64_t* c_start, const uint32_t* c_len, const float* c_lw, uint8_t* ops,
+                              uint64_t* ops_start, uint32_t* ops_len, float* log_weights, hipStream_t stream);
+
 }  // namespace coati_hip_detail
 #endif

@@ -107,8 +107,10 @@ __device__ __forceinline__ int sample2(float lm, float li, float p, float& score
 
 // One walk (sampleback, align_pair.cc:401-458).  Ops are written right-to-left into
 // [slot, slot + la + lb); returns the position of the first op.
-__device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restrict__ ops, uint64_t slot, float& score) {
+__device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restrict__ ops, uint64_t slot, float& score,
+                                uint32_t& draws) {
     const uint32_t L = w.L;
+    draws = 1;  // the draw that picks the state of the last cell
     uint32_t i = w.la + L - 1, j = w.lb + L - 1;
     uint64_t pos = slot + w.la + w.lb;
     score = 0.0f;
@@ -117,6 +119,7 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
     float top = fmaxf(fmaxf(m, d), in);
     int st = sample3(m - top, d - top, in - top, rng_f24(rng), score);
     while(j > L - 1 || i > L - 1) {
+        ++draws;
         const bool body = i >= L && j >= L;
         if(st == COATI_HIP_OP_MATCH) {
             ops[--pos] = COATI_HIP_OP_MATCH;
@@ -200,13 +203,77 @@ __global__ __launch_bounds__(64) void sampleback_kernel(const float* __restrict_
         const uint64_t idx = static_cast<uint64_t>(pair) * n_samples + n;
         const uint64_t slot = sample_base[pair] + n * width;
         float score;
-        const uint64_t pos = sample_walk(w, rng, ops, slot, score);
+        uint32_t draws;
+        const uint64_t pos = sample_walk(w, rng, ops, slot, score, draws);
         ops_start[idx] = pos;
         ops_len[idx] = static_cast<uint32_t>(slot + width - pos);
         log_weights[idx] = score;
     }
     rng_states[2 * walker] = rng.lo;  // the stream continues where this launch stopped
     rng_states[2 * walker + 1] = rng.hi;
+}
+
+// ---- exact stream, in parallel --------------------------------------------------------------
+// marg_sample draws its n samples one after the other from ONE Lehmer stream
+// (align_marginal.cc:590-593): sample s starts where sample s-1 stopped, and how many draws a
+// sample takes (1 + its number of moves) is only known once it has been walked.  The host
+// (abi.hip: sampleback_speculative) therefore lets a window of candidate start offsets be walked
+// for every sample of a chunk -- each walker jumps the generator to its assumed offset
+// (state * MULT^offset mod 2^128) and reports how many draws it took -- and then follows the chain
+// of true offsets through the candidates.  Every committed sample is exactly the walk the serial
+// loop would have produced.
+__global__ __launch_bounds__(64) void spec_walk_kernel(const float* __restrict__ table, GapConsts k, uint32_t L,
+                                                       const PairDesc* __restrict__ pairs,
+                                                       const uint8_t* __restrict__ a_cat,
+                                                       const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
+                                                       const uint64_t* __restrict__ origin_state,
+                                                       const uint64_t* __restrict__ mult_pow,
+                                                       const SpecCandidate* __restrict__ cands, uint32_t n_cands,
+                                                       uint8_t* __restrict__ tmp_ops, uint64_t* __restrict__ c_start,
+                                                       uint32_t* __restrict__ c_len, float* __restrict__ c_lw,
+                                                       uint32_t* __restrict__ c_draws) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if(idx >= n_cands) return;
+    const SpecCandidate cd = cands[idx];
+    const PairDesc pd = pairs[cd.pair];
+    // jump: state at the chunk origin times MULT^offset (square-and-multiply over the host's table
+    // of MULT^(2^b)), all modulo 2^128
+    unsigned __int128 st = (static_cast<unsigned __int128>(origin_state[2 * cd.pair + 1]) << 64) | origin_state[2 * cd.pair];
+    for(uint32_t bit = 0, off = cd.offset; off != 0; ++bit, off >>= 1)
+        if(off & 1u) st *= (static_cast<unsigned __int128>(mult_pow[2 * bit + 1]) << 64) | mult_pow[2 * bit];
+    Rng128 rng{static_cast<uint64_t>(st), static_cast<uint64_t>(st >> 64)};
+    const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
+                   table, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
+    float score;
+    uint32_t draws;
+    const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;
+    const uint64_t pos = sample_walk(w, rng, tmp_ops, cd.slot, score, draws);
+    c_start[idx] = pos;
+    c_len[idx] = static_cast<uint32_t>(cd.slot + width - pos);
+    c_lw[idx] = score;
+    c_draws[idx] = draws;
+}
+
+// Copy the candidates that turned out to be the true samples into the result arrays
+// (one workgroup per sample).
+__global__ __launch_bounds__(64) void spec_commit_kernel(const SpecCommit* __restrict__ commits, uint32_t n_commits,
+                                                         const uint8_t* __restrict__ tmp_ops,
+                                                         const uint64_t* __restrict__ c_start,
+                                                         const uint32_t* __restrict__ c_len,
+                                                         const float* __restrict__ c_lw, uint8_t* __restrict__ ops,
+                                                         uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len,
+                                                         float* __restrict__ log_weights) {
+    const uint32_t q = blockIdx.x;
+    if(q >= n_commits) return;
+    const SpecCommit cm = commits[q];
+    const uint32_t len = c_len[cm.cand];
+    const uint64_t src = c_start[cm.cand], dst = cm.slot_end - len;
+    for(uint32_t t = threadIdx.x; t < len; t += blockDim.x) ops[dst + t] = tmp_ops[src + t];
+    if(threadIdx.x == 0) {
+        ops_start[cm.out_index] = dst;
+        ops_len[cm.out_index] = len;
+        log_weights[cm.out_index] = c_lw[cm.cand];
+    }
 }
 
 // Debug/parity: the first n f24() draws of a stream (one thread).
@@ -216,6 +283,25 @@ __global__ void rng_f24_kernel(uint64_t lo, uint64_t hi, uint32_t n, float* __re
 }
 
 }  // namespace
+
+hipError_t launch_spec_walk(const BatchDeviceView& v, const uint64_t* origin_state, const uint64_t* mult_pow,
+                            const SpecCandidate* cands, uint32_t n_cands, uint8_t* tmp_ops, uint64_t* c_start,
+                            uint32_t* c_len, float* c_lw, uint32_t* c_draws, hipStream_t stream) {
+    if(n_cands == 0) return hipSuccess;
+    hipLaunchKernelGGL(spec_walk_kernel, dim3((n_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.gap_len, v.pairs,
+                       v.a_cat, v.b_cat, v.mdi, origin_state, mult_pow, cands, n_cands, tmp_ops, c_start, c_len, c_lw,
+                       c_draws);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, const uint8_t* tmp_ops,
+                              const uint64_t* c_start, const uint32_t* c_len, const float* c_lw, uint8_t* ops,
+                              uint64_t* ops_start, uint32_t* ops_len, float* log_weights, hipStream_t stream) {
+    if(n_commits == 0) return hipSuccess;
+    hipLaunchKernelGGL(spec_commit_kernel, dim3(n_commits), dim3(64), 0, stream, commits, n_commits, tmp_ops, c_start,
+                       c_len, c_lw, ops, ops_start, ops_len, log_weights);
+    return hipGetLastError();
+}
 
 hipError_t launch_rng_f24(const uint64_t state[2], uint32_t n, float* d_out, hipStream_t stream) {
     hipLaunchKernelGGL(rng_f24_kernel, dim3(1), dim3(1), 0, stream, state[0], state[1], n, d_out);

@@ -152,3 +152,44 @@ def test_independent_streams(oracle):
         # both modes sample the same distribution: mean log-weights agree within sampling error
         se = np.sqrt(lw_i[p].var() / n + lw_e[p].var() / n) + 1e-6
         assert abs(lw_i[p].mean() - lw_e[p].mean()) < 6 * se
+
+
+def test_speculative_exact_stream_equals_sequential():
+    """The parallel exact-stream sampler (speculated stream offsets) returns exactly what the
+    one-walker-per-pair loop returns: same ops, same log-weight bits, same final RNG state.
+    The sequential loop is selected with COATI_HIP_SAMPLE_SEQUENTIAL=1 in a child process."""
+    import os
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys, zlib, json, numpy as np
+sys.path.insert(0, %r)
+from coati_amd import hip, host
+from tests import util
+rng = np.random.default_rng(5)
+pairs = util.make_pairs(rng, 10, 20, 150, L=1) + [("", ""), ("ACG", ""), ("", "ACGT")]
+pairs += [host.synth_raw(i) for i in range(3)]
+enc = util.encode_pairs(pairs)
+model = hip.Model(host.set_subst("mar-mg"), host.gap_consts(), 1)
+batch = hip.Batch(model, *hip.pack_pairs(enc))
+batch.forward_launch()
+states = np.stack([host.rng_seed(["42", str(p)]) for p in range(len(enc))])
+lw, ops, off, ln, st = batch.sampleback(150, states, independent=False)
+crc = 0
+for p in range(len(enc)):
+    for s in range(150):
+        crc = zlib.crc32(ops[int(off[p, s]):int(off[p, s]) + int(ln[p, s])].tobytes(), crc)
+print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum()), "st": zlib.crc32(st.tobytes())}))
+''' % str(root)
+    outs = []
+    for seq in (False, True):
+        env = dict(os.environ)
+        env.pop("COATI_HIP_SAMPLE_SEQUENTIAL", None)
+        if seq:
+            env["COATI_HIP_SAMPLE_SEQUENTIAL"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1], outs

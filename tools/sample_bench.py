@@ -60,4 +60,25 @@ for mode, indep in (("exact_stream", False), ("independent_streams", True)):
 out["forward_fill_16_pairs_ms"] = t_fwd * 1e3
 batch.close()
 
+# ---- CPU port beside it (checker library, one thread): Forward with the reference's 11 matrices +
+# sampleback, one pair, scaled to the GPU workload above
+try:
+    from oracle import pyoracle as orc  # baseline only
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 1)
+    a, b = a_cat[:a_off[1]], b_cat[:b_off[1]]
+    t0 = time.perf_counter()
+    M, D, I, E = orc.fill(orc.LOG, table, consts, 1, a, b, edges=True)
+    t_fwd_cpu = time.perf_counter() - t0
+    mats = np.concatenate([np.stack([M, D, I]), E])
+    rng = orc.rng_seed(["42"])
+    t0 = time.perf_counter()
+    n_cpu = 200
+    for _ in range(n_cpu):
+        orc.sampleback(mats, 1, rng)
+    t_s_cpu = (time.perf_counter() - t0) / n_cpu
+    out["cpu_port_1_thread"] = {"forward_ms_per_pair": t_fwd_cpu * 1e3, "forward_gcups": len(a) * len(b) / t_fwd_cpu / 1e9,
+                                "sampleback_us_per_sample": t_s_cpu * 1e6,
+                                "config4_estimate_ms": args.sample_pairs * (t_fwd_cpu + args.samples * t_s_cpu) * 1e3}
+except Exception as exc:  # the baseline never fails the tool
+    out["cpu_port_1_thread"] = {"error": repr(exc)}
 print(json.dumps(out))

@@ -77,19 +77,54 @@ def cell_base(c, parity):
     return L
 
 
+def cell_cmp(c, parity):
+    """22 VALU: the five decisions as v_cmp into SGPR pairs (lane masks), stored by the scalar unit."""
+    xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
+    xout = f"v{XB+c}" if parity == 0 else f"v{YP+2*c+1}"
+    y = f"v{YP+2*c}"
+    t0, t1, t2, t3, t4, t5, x3, zl = "v10", "v11", "v12", "v13", "v14", "v15", "v16", f"v{ZL}"
+    m = 40 + 12 * (c & 1)        # mask registers s[m..m+9], two sets alternate (x4 stores need 4-aligned tuples)
+    pm = 40 + 12 * ((c + 1) & 1)  # the previous cell's set: stored while this cell computes
+    off = (c * 40) % 640
+    L = [f"v_add_f32 {t0}, v{DIAG}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}",
+         f"v_add_f32 {t2}, {GS}, {zl}", f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}",
+         f"s_store_dwordx4 s[{pm}:{pm+3}], s[16:17], {hex(off)}",
+         f"v_max_f32 {zl}, {t3}, {t1}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+         f"v_cmp_gt_f32_e64 s[{m}:{m+1}], {t3}, {t1}",
+         f"v_add_f32 {x3}, {NG}, {t2}", f"v_max_f32 {t3}, {t4}, {t5}",
+         f"s_store_dwordx4 s[{pm+4}:{pm+7}], s[16:17], {hex(off+16)}",
+         f"v_cmp_gt_f32_e64 s[{m+2}:{m+3}], {t5}, {t4}",
+         f"v_mov_b32 v{DIAG}, {xin}",
+         f"v_add_f32 {t1}, {GE}, {y}", f"v_max_f32 {xout}, {t3}, {x3}",
+         f"v_add_f32 {t5}, {GO}, {t0}", f"v_cmp_gt_f32_e64 s[{m+4}:{m+5}], {x3}, {t3}",
+         f"s_store_dwordx2 s[{pm+8}:{pm+9}], s[16:17], {hex(off+32)}",
+         f"v_add_f32 {t4}, {GO}, {t2}", f"v_max_f32 {t0}, {t5}, {t1}",
+         f"v_cmp_gt_f32_e64 s[{m+6}:{m+7}], {t1}, {t5}",
+         f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}", f"v_max_f32 {y}, {t0}, {t4}",
+         f"v_cmp_gt_f32_e64 s[{m+8}:{m+9}], {t4}, {t0}", f"v_xor_b32 v{LDS}, v{LDS}, v{ADDR}"]
+    if c == 15:
+        L.append("s_add_u32 s16, s16, 640")
+        L.append("s_addc_u32 s17, s17, 0")
+    return L
+
+
 def kernel(name, cell):
     body = []
     for parity in (0, 1):
         for c in range(16):
             body += cell(c, parity)
-    n_instr = len(body) // 32
+    n_instr = len([x for x in body if x.startswith("v_")]) // 32
     asm = "\\n\\t\"\n        \"".join(body)
     clobbers = ", ".join(f'"v{i}"' for i in range(2, 120))
     init = "".join('"v_mov_b32 v%d, %%[seed]\\n\\t"' % i for i in range(40, 120))
     return n_instr, f'''
-__global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, float gs, float go, float ge, int iters) {{
+__global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, float gs, float go, float ge, int iters, char* scratch) {{
     float r;
+    const unsigned long long sp = reinterpret_cast<unsigned long long>(scratch) +
+        static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) / 64)) * (1280ull * 400ull);
+    const unsigned sp_lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(sp)), sp_hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(sp >> 32));
     asm volatile(
+        "s_mov_b32 s16, %[splo]\\n\\t s_mov_b32 s17, %[sphi]\\n\\t"
         "s_mov_b32 s4, %[ng]\\n\\t s_mov_b32 s5, %[gs]\\n\\t s_mov_b32 s6, %[go]\\n\\t s_mov_b32 s7, %[ge]\\n\\t"
         "v_mov_b32 v2, s5\\n\\t v_mov_b32 v3, s7\\n\\t v_mov_b32 v4, s6\\n\\t v_mov_b32 v5, s4\\n\\t v_mov_b32 v6, s4\\n\\t v_mov_b32 v7, s6\\n\\t"
         "v_mov_b32 v8, %[seed]\\n\\t v_mov_b32 v9, 0\\n\\t v_mov_b32 v11, 0\\n\\t v_mov_b32 v16, 0\\n\\t v_mov_b32 v29, %[seed]\\n\\t v_mov_b32 v31, 0\\n\\t"
@@ -99,11 +134,12 @@ __global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, 
         "1:\\n\\t"
         "{asm}\\n\\t"
         "s_sub_u32 s8, s8, 1\\n\\t s_cmp_lg_u32 s8, 0\\n\\t s_cbranch_scc1 1b\\n\\t"
+        "s_dcache_wb\\n\\t s_waitcnt lgkmcnt(0)\\n\\t"
         "v_add_f32 %[r], v8, v29\\n\\t v_add_f32 %[r], %[r], v40\\n\\t v_add_f32 %[r], %[r], v41\\n\\t v_add_f32 %[r], %[r], v72\\n\\t"
         "v_xor_b32 %[r], %[r], v32\\n\\t v_xor_b32 %[r], %[r], v33\\n\\t v_xor_b32 %[r], %[r], v34\\n\\t v_xor_b32 %[r], %[r], v31"
         : [r] "=&v"(r)
-        : [seed] "v"(seed + threadIdx.x), [ng] "s"(ng), [gs] "s"(gs), [go] "s"(go), [ge] "s"(ge), [iters] "s"(iters)
-        : "s4", "s5", "s6", "s7", "s8", "scc", {clobbers});
+        : [seed] "v"(seed + threadIdx.x), [ng] "s"(ng), [gs] "s"(gs), [go] "s"(go), [ge] "s"(ge), [iters] "s"(iters), [splo] "s"(sp_lo), [sphi] "s"(sp_hi)
+        : "s4", "s5", "s6", "s7", "s8", "s16", "s17", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "scc", "memory", {clobbers});
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }}
 '''
@@ -111,21 +147,24 @@ __global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, 
 
 nb, kb = kernel("cell_base", cell_base)
 npk, kp = kernel("cell_pk", cell_pk)
+ncm, kc = kernel("cell_cmp", cell_cmp)
 src = f'''// GENERATED by gen_cell_pk.py -- do not edit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CHECK(x) do {{ hipError_t e = (x); if (e != hipSuccess) {{ printf("%s: %s\\n", #x, hipGetErrorString(e)); return 1; }} }} while (0)
 {kb}
 {kp}
+{kc}
 template <typename K> int run(const char* name, K kern, int n_instr) {{
     float* d_out; CHECK(hipMalloc(&d_out, sizeof(float) * 256 * 256 * 8));
+    char* d_scratch; CHECK(hipMalloc(&d_scratch, 256ull * 4 * 4 * 1280 * 400));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int iters = 200;  // x2 steps x16 cells
     for (int wps : {{1, 2, 3, 4}}) {{
         float best = 1e9;
         for (int rep = 0; rep < 3; ++rep) {{
             CHECK(hipEventRecord(e0));
-            hipLaunchKernelGGL(kern, dim3(256 * wps), dim3(256), 0, 0, d_out, 1.0f, -0.001f, -1.79f, -6.9f, -0.18f, iters);
+            hipLaunchKernelGGL(kern, dim3(256 * wps), dim3(256), 0, 0, d_out, 1.0f, -0.001f, -1.79f, -6.9f, -0.18f, iters, d_scratch);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
         }}
@@ -133,12 +172,13 @@ template <typename K> int run(const char* name, K kern, int n_instr) {{
         printf("%-10s %2d instr/cell  waves/SIMD %d: %.3f ms -> %.2f ns per cell per SIMD, %.2f ns/instr\\n", name, n_instr, wps, best,
                best * 1e6 / cells, best * 1e6 / cells / n_instr);
     }}
-    CHECK(hipFree(d_out));
+    CHECK(hipFree(d_out)); CHECK(hipFree(d_scratch));
     return 0;
 }}
 int main() {{
     if (run("base", cell_base, {nb})) return 1;
     if (run("pk", cell_pk, {npk})) return 1;
+    if (run("cmp+sst", cell_cmp, {ncm})) return 1;
     return 0;
 }}
 '''
