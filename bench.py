@@ -157,12 +157,14 @@ def main():
         pend = state["pending"]
         if pend is not None:
             slots[pend][1].wait()  # its own launch only: the launch just issued keeps running
-            gathers[pend]()
+            gathers[pend](async_op=True)
             state["pending"] = None
 
     def fence():
         if multi:
             drain()
+            for g in gathers:
+                g.finish()
             dist.barrier()
         for _, bt in slots:
             bt.sync()

@@ -111,17 +111,31 @@ class PackedGather:
         self.cap = max(max(sum(self._pad(n) for n in sz) for sz in self.all_sizes), 8)
         self.packed = torch.zeros(self.cap, dtype=torch.uint8, device=dev)
         self.bucket = [torch.empty(self.cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+        self.work = None
 
     @staticmethod
     def _pad(n: int) -> int:
         return (n + 7) // 8 * 8  # every segment starts 8-byte aligned (typed views of the buffer)
 
     def __call__(self, async_op: bool = False):
+        if self.work is not None:  # the previous gather of this buffer must be done before it is refilled
+            self.work.wait()
+            self.work = None
         pos = 0
         for v, n in zip(self.views, self.sizes):
             self.packed[pos:pos + n].copy_(v)
             pos += self._pad(n)
-        return dist.gather(self.packed, self.bucket, dst=self.dst, async_op=async_op)
+        work = dist.gather(self.packed, self.bucket, dst=self.dst, async_op=True)
+        if async_op:
+            self.work = work
+            return work
+        work.wait()  # (device-side dependency on NCCL; does not block the host there)
+        return None
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
 
     def unpack(self, rank: int):
         """On `dst`: rank's (scores, ops, ops_off, ops_len) as typed views of the receive buffer."""
