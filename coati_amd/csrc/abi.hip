@@ -558,12 +558,17 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
                                   float* d_lw, uint64_t* states_out) {
     coati_hip_model* m = b->model;
     const uint64_t n = b->n_pairs;
-    constexpr uint32_t kChunkMax = 512, kMaxCands = 1u << 18;
+    constexpr uint32_t kChunkMax = 512;
+    static const uint32_t kMaxCands = [] {
+        const char* e = std::getenv("COATI_HIP_SPEC_CANDS");
+        const long v = e != nullptr ? std::atol(e) : 0;
+        return v >= 1024 && v <= (1 << 22) ? static_cast<uint32_t>(v) : (1u << 17);  // measured best (tools/sample_bench.py)
+    }();
     constexpr double kZ = 5.0;
     size_t free_b = 0, total_b = 0;
     hipError_t e = hipMemGetInfo(&free_b, &total_b);
     if(e != hipSuccess) return e;
-    const uint64_t tmp_budget = std::max<uint64_t>(std::min<uint64_t>(free_b / 4, 1ull << 30), 1ull << 20);
+    const uint64_t tmp_budget = std::max<uint64_t>(std::min<uint64_t>(free_b / 4, 2ull << 30), 1ull << 20);
 
     struct PairState {
         u128 st0;
