@@ -81,7 +81,8 @@ struct coati_hip_model {
     int device = 0;
     int gap_len = 1;
     GapConsts k{};
-    float* d_table = nullptr;
+    uint32_t n_tables = 1;
+    float* d_table = nullptr;  // n_tables * 183*15 floats
     hipStream_t stream = nullptr;
 };
 
@@ -145,9 +146,16 @@ int coati_hip_device_count(void) {
 
 int coati_hip_model_create(const float* table, float no_gap, float gap_stop, float gap_open,
                            float gap_extend, int gap_len, int device, coati_hip_model_t** out) {
+    return coati_hip_model_create_tables(table, 1, no_gap, gap_stop, gap_open, gap_extend, gap_len, device, out);
+}
+
+int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float no_gap, float gap_stop, float gap_open,
+                                  float gap_extend, int gap_len, int device, coati_hip_model_t** out) {
     if(out == nullptr) return fail(COATI_HIP_EINVAL, "model_create: out is NULL");
     *out = nullptr;
     if(table == nullptr) return fail(COATI_HIP_EINVAL, "model_create: table is NULL");
+    if(n_tables < 1 || n_tables > 65535)
+        return fail(COATI_HIP_EINVAL, "model_create: n_tables must be in [1, 65535] (got %u)", n_tables);
     if(gap_len < 1) return fail(COATI_HIP_EINVAL, "model_create: gap_len must be >= 1 (got %d)", gap_len);
     if(gap_len > 8)
         return fail(COATI_HIP_EINVAL, "model_create: gap_len %d not supported by the GPU path (1..8)", gap_len);
@@ -162,6 +170,7 @@ int coati_hip_model_create(const float* table, float no_gap, float gap_stop, flo
     if(m == nullptr) return fail(COATI_HIP_ENOMEM, "model_create: host allocation failed");
     m->device = device;
     m->gap_len = gap_len;
+    m->n_tables = n_tables;
     m->k = GapConsts{no_gap, gap_stop, gap_open, gap_extend};
     auto cleanup = [&](int rc) {
         coati_hip_model_destroy(m);
@@ -172,7 +181,7 @@ int coati_hip_model_create(const float* table, float no_gap, float gap_stop, flo
         return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice: %s", hipGetErrorString(e)));
     if((e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(fail(COATI_HIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)));
-    const size_t bytes = sizeof(float) * kTabRows * kTabCols;
+    const size_t bytes = sizeof(float) * kTabFloats * n_tables;
     if((e = hipMalloc(&m->d_table, bytes)) != hipSuccess)
         return cleanup(fail(COATI_HIP_ENOMEM, "hipMalloc(table): %s", hipGetErrorString(e)));
     if((e = hipMemcpy(m->d_table, table, bytes, hipMemcpyHostToDevice)) != hipSuccess)
@@ -205,6 +214,12 @@ void coati_hip_batch_destroy(coati_hip_batch_t* b) {
 int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                            const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                            coati_hip_batch_t** out) {
+    return coati_hip_batch_create_tables(model, n_pairs, a_cat, a_off, b_cat, b_off, nullptr, out);
+}
+
+int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                                  const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                                  const uint32_t* table_index, coati_hip_batch_t** out) {
     if(out == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: out is NULL");
     *out = nullptr;
     if(model == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: model is NULL");
@@ -255,7 +270,11 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
             if(b_cat[q] >= kTabCols)
                 return cleanup(fail(COATI_HIP_EINVAL, "batch_create: descendant code %u out of range (pair %llu)",
                                     b_cat[q], static_cast<unsigned long long>(p)));
+        if(table_index != nullptr && table_index[p] >= model->n_tables)
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: table index %u of pair %llu out of range [0,%u)",
+                                table_index[p], static_cast<unsigned long long>(p), model->n_tables));
         PairDesc& d = b->desc[p];
+        d.table = static_cast<uint16_t>(table_index != nullptr ? table_index[p] : 0u);
         d.a_off = a_off[p] - a_off[0];
         d.b_off = b_off[p] - b_off[0];
         d.la = static_cast<uint32_t>(la);

@@ -19,6 +19,7 @@ constexpr int kStrip = kWave * kW;           // columns per strip (1024)
 constexpr int kTabRows = COATI_HIP_TABLE_ROWS;
 constexpr int kTabCols = COATI_HIP_TABLE_COLS;
 constexpr int kTabStride = 17;               // LDS row stride in floats (bank spread, measured)
+constexpr int kTabFloats = COATI_HIP_TABLE_ROWS * COATI_HIP_TABLE_COLS;  // one table in HBM (2745)
 constexpr int kPairDwords = 5 * kWave;       // dwords one pair of wavefront steps stores (320)
 constexpr int kFillWaves = 4;                // sequence pairs per workgroup
 constexpr float kLowest = -FLT_MAX;          // semiring zero(), semiring.hpp:83,113
@@ -45,7 +46,8 @@ struct PairDesc {
     // Viterbi strip plan (decision-bit layout): v_strips strips; all but the last are 64*v_wmain
     // columns wide (v_wmain columns per lane), the last one has v_wlast columns per lane.
     uint32_t v_strips;
-    uint8_t v_wmain, v_wlast, pad_[2];
+    uint8_t v_wmain, v_wlast;
+    uint16_t table;  // which of the model's substitution tables this pair uses
 };
 
 // HBM layout of the decision bits of one strip of one pair.  A strip is 64*W descendant

@@ -57,11 +57,7 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
     float* rowbuf = ring + L * 3 * kStrip;             // [2][kRowBufCols]
     float* chunk = rowbuf + 2 * kRowBufCols;           // [64][3 + 2 * kMaxGapLen]
     constexpr int kChunkStride = 3 + 2 * kMaxGapLen;
-    for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
-        const int r = idx / kTabCols, c = idx - r * kTabCols;
-        tab[r * kTabStride + c] = table[idx];
-    }
-    __syncthreads();
+    uint32_t tab_held = 0xffffffffu;  // which of the model's tables the LDS copy holds
     const int lane_id = threadIdx.x;
     const float ext_lm1 = k.ge * static_cast<float>(L - 1), ext_l = k.ge * static_cast<float>(L);  // power(), semiring.hpp:81
 
@@ -78,6 +74,16 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
         const uint32_t pair = order[ticket];
         const PairDesc pd = pairs[pair];
         const uint32_t la = pd.la, lb = pd.lb;
+        if(pd.table != tab_held) {
+            __builtin_amdgcn_s_barrier();  // (single wave: the previous pair's reads are done)
+            const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+            for(int idx = lane; idx < kTabFloats; idx += kWave) {
+                const int r = idx / kTabCols, c = idx - r * kTabCols;
+                tab[r * kTabStride + c] = src[idx];
+            }
+            tab_held = pd.table;
+            __builtin_amdgcn_s_barrier();
+        }
         const uint8_t* __restrict__ a = a_cat + pd.a_off;
         const uint8_t* __restrict__ b = b_cat + pd.b_off;
         float last_m = kLowest, last_d = kLowest, last_i = kLowest;  // unadjusted last cell (in its owner lane)

@@ -172,13 +172,10 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     float* __restrict__ bnd, float* __restrict__ mdi, float* __restrict__ final_mdi) {
-    __shared__ float tab[kTabRows * kTabStride];
-    for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
-        const int r = idx / kTabCols, c = idx - r * kTabCols;
-        tab[r * kTabStride + c] = table[idx];
-    }
-    __syncthreads();
+    __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];  // one table per wavefront (see viterbi_l1.hip)
     const int lane_id = threadIdx.x & (kWave - 1);
+    float* tab = tab_all[threadIdx.x / kWave];
+    uint32_t tab_held = 0xffffffffu;
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     for(;;) {
         int lane = lane_id;  // opaque per iteration (see viterbi_l1.hip)
@@ -190,6 +187,14 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
         const uint32_t pair = item.pair, strip = item.strip;
         const PairDesc pd = pairs[pair];
         const uint32_t la = pd.la, lb = pd.lb;
+        if(pd.table != tab_held) {
+            const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+            for(int idx = lane; idx < kTabFloats; idx += kWave) {
+                const int r = idx / kTabCols, c = idx - r * kTabCols;
+                tab[r * kTabStride + c] = src[idx];
+            }
+            tab_held = pd.table;
+        }
         if(la == 0 || lb == 0) {  // no body cells: the last cell is a margin cell
             float m, d, in;
             margin_mdi(k, 1u, la, lb, m, d, in);

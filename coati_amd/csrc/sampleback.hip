@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void sampleback_kernel(const float* __restrict_
     const uint32_t count = independent ? 1u : n_samples;
     const PairDesc pd = pairs[pair];
     const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
-                   table, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
+                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
     Rng128 rng{rng_states[2 * walker], rng_states[2 * walker + 1]};
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;
     for(uint32_t n = first; n < first + count; ++n) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void spec_walk_kernel(const float* __restrict__
         if(off & 1u) st *= (static_cast<unsigned __int128>(mult_pow[2 * bit + 1]) << 64) | mult_pow[2 * bit];
     Rng128 rng{static_cast<uint64_t>(st), static_cast<uint64_t>(st >> 64)};
     const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
-                   table, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
+                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
     float score;
     uint32_t draws;
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;

@@ -366,14 +366,13 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
     uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
-    __shared__ float tab[kTabRows * kTabStride];
-    for(int idx = threadIdx.x; idx < kTabRows * kTabCols; idx += blockDim.x) {
-        const int r = idx / kTabCols, c = idx - r * kTabCols;
-        tab[r * kTabStride + c] = table[idx];
-    }
-    __syncthreads();
-
+    // One substitution table per WAVEFRONT in LDS (row stride 17): the pairs of a batch may use
+    // different tables (per-leaf branch lengths); a wavefront reloads its copy when the table of
+    // its next item differs from the one it holds (11 KB from L2).
+    __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
+    float* tab = tab_all[threadIdx.x / kWave];
+    uint32_t tab_held = 0xffffffffu;
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
 #ifdef COATI_FILL_TRACE
@@ -400,6 +399,14 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_l1(
         const uint32_t pair = item.pair, strip = item.strip;
         const PairDesc pd = pairs[pair];
         bool handoff_ok = true;
+        if(pd.table != tab_held) {  // (wave-uniform)
+            const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+            for(int idx = lane; idx < kTabFloats; idx += kWave) {
+                const int r = idx / kTabCols, c = idx - r * kTabCols;
+                tab[r * kTabStride + c] = src[idx];
+            }
+            tab_held = pd.table;
+        }
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             const uint8_t* __restrict__ a = a_cat + pd.a_off;
             const uint8_t* __restrict__ b = b_cat + pd.b_off;
@@ -453,8 +460,8 @@ FillShape fill_launch_shape(uint32_t n_items) {
     // 160/(best+1) KB, and `best` of them fit with room for the allocation granule.  (A first
     // version used 160 KB/best minus 512 B: the allocator rounds up, only best-1 blocks fitted and
     // the rest of the grid started after the queue was empty -- seen in the trace build.)
-    constexpr size_t kStatic = kTabRows * kTabStride * sizeof(float);
-    constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 48 * 1024};
+    constexpr size_t kStatic = kFillWaves * kTabRows * kTabStride * sizeof(float);  // 49 776 B
+    constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 52 * 1024};
     const size_t dyn = kPerBlock[best] - ((kStatic + 255) / 256) * 256;
     return {kCUs * static_cast<uint32_t>(best), dyn};
 }

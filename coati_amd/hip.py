@@ -23,8 +23,10 @@ EXPORTS = (
     "coati_hip_device_count",
     "coati_hip_last_error",
     "coati_hip_model_create",
+    "coati_hip_model_create_tables",
     "coati_hip_model_destroy",
     "coati_hip_batch_create",
+    "coati_hip_batch_create_tables",
     "coati_hip_batch_destroy",
     "coati_hip_batch_device_bytes",
     "coati_hip_batch_cells",
@@ -71,6 +73,9 @@ def load() -> C.CDLL:
     lib.coati_hip_device_count.restype = i32
     lib.coati_hip_last_error.restype = C.c_char_p
     lib.coati_hip_model_create.argtypes = [vp, f32, f32, f32, f32, i32, i32, C.POINTER(vp)]
+    if hasattr(lib, "coati_hip_model_create_tables"):  # (older builds in the A/B harness lack the multi-table entries)
+        lib.coati_hip_model_create_tables.argtypes = [vp, C.c_uint32, f32, f32, f32, f32, i32, i32, C.POINTER(vp)]
+        lib.coati_hip_batch_create_tables.argtypes = [vp, u64, vp, vp, vp, vp, vp, C.POINTER(vp)]
     lib.coati_hip_model_destroy.argtypes = [vp]
     lib.coati_hip_model_destroy.restype = None
     lib.coati_hip_batch_create.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(vp)]
@@ -82,6 +87,8 @@ def load() -> C.CDLL:
     lib.coati_hip_batch_cells.restype = u64
     lib.coati_hip_viterbi_launch.argtypes = [vp]
     lib.coati_hip_batch_sync.argtypes = [vp]
+    if hasattr(lib, "coati_hip_viterbi_wait"):
+        lib.coati_hip_viterbi_wait.argtypes = [vp]
     lib.coati_hip_viterbi_fetch.argtypes = [vp, vp, vp, u64, vp, vp]
     lib.coati_hip_viterbi_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
     lib.coati_hip_viterbi_timing.argtypes = [vp, C.c_uint32, C.POINTER(f32), C.POINTER(f32)]
@@ -127,18 +134,26 @@ def pack_pairs(pairs):
 
 
 class Model:
-    """coati_hip_model_t: the 183x15 table + host-computed log gap constants."""
+    """coati_hip_model_t: the 183x15 table (or a stack of n of them, shape (n, 183, 15), for batches
+    whose pairs use different tables) + host-computed log gap constants."""
 
     def __init__(self, table, consts, gap_len: int = 1, device: int = 0):
         table = np.ascontiguousarray(table, np.float32)
-        if table.shape != (TABLE_ROWS, TABLE_COLS):
-            raise ValueError("table must be 183x15")
+        if table.shape == (TABLE_ROWS, TABLE_COLS):
+            table = table[None]
+        if table.ndim != 3 or table.shape[1:] != (TABLE_ROWS, TABLE_COLS):
+            raise ValueError("table must be 183x15 or n x 183 x 15")
         self._h = C.c_void_p()
         self.gap_len = gap_len
         self.device = device
+        self.n_tables = int(table.shape[0])
         c = [float(x) for x in consts]
-        _check(load().coati_hip_model_create(_ptr(table), c[0], c[1], c[2], c[3], gap_len, device,
-                                             C.byref(self._h)))
+        lib = load()
+        if self.n_tables == 1 and not hasattr(lib, "coati_hip_model_create_tables"):
+            _check(lib.coati_hip_model_create(_ptr(table), c[0], c[1], c[2], c[3], gap_len, device, C.byref(self._h)))
+        else:
+            _check(lib.coati_hip_model_create_tables(_ptr(table), self.n_tables, c[0], c[1], c[2], c[3], gap_len, device,
+                                                     C.byref(self._h)))
 
     def close(self):
         if self._h:
@@ -173,7 +188,7 @@ class Model:
 class Batch:
     """coati_hip_batch_t: encoded pairs + workspace resident in HBM."""
 
-    def __init__(self, model: Model, a_cat, a_off, b_cat, b_off):
+    def __init__(self, model: Model, a_cat, a_off, b_cat, b_off, table_index=None):
         self.model = model
         self.n = len(a_off) - 1
         self.ops_total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
@@ -183,8 +198,16 @@ class Batch:
         a_off = np.ascontiguousarray(a_off, np.uint64)
         b_off = np.ascontiguousarray(b_off, np.uint64)
         self.lens = np.stack([np.diff(a_off), np.diff(b_off)], axis=1).astype(np.int64)
-        _check(load().coati_hip_batch_create(model._h, self.n, _ptr(a_cat), _ptr(a_off), _ptr(b_cat),
-                                             _ptr(b_off), C.byref(self._h)))
+        ti = None if table_index is None else np.ascontiguousarray(table_index, np.uint32)
+        if ti is not None and len(ti) != self.n:
+            raise ValueError("table_index needs one entry per pair")
+        lib = load()
+        if ti is None and not hasattr(lib, "coati_hip_batch_create_tables"):
+            _check(lib.coati_hip_batch_create(model._h, self.n, _ptr(a_cat), _ptr(a_off), _ptr(b_cat), _ptr(b_off),
+                                              C.byref(self._h)))
+        else:
+            _check(lib.coati_hip_batch_create_tables(model._h, self.n, _ptr(a_cat), _ptr(a_off), _ptr(b_cat),
+                                                     _ptr(b_off), _ptr(ti) if ti is not None else None, C.byref(self._h)))
 
     def close(self):
         if self._h:

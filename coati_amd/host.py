@@ -184,3 +184,25 @@ def parse_matrix_csv(path) -> np.ndarray:
     out = np.zeros((61, 61), np.float32)
     _check(load().coati_host_parse_matrix_csv(str(path).encode(), _p(out)))
     return out
+
+
+def align_leafs(ref_seq: str, leaves, br_lens, model="mar-mg", omega=0.2, gap_open=0.001, gap_extend=None, gap_len=1):
+    """Batched pairwise step of `coati msa` (coati_amd/host/align.hpp: align_leafs): every leaf aligned
+    to the reference with the table of its own branch length, one GPU launch.
+    Returns [(aligned_ref, aligned_leaf, score), ...]."""
+    ge = float(np.float32(1.0) - np.float32(1.0) / np.float32(6.0)) if gap_extend is None else gap_extend
+    n = len(leaves)
+    slot = len(ref_seq) + max((len(x) for x in leaves), default=0) + 1
+    buf = C.create_string_buffer(max(2 * n * slot, 1))
+    arr = (C.c_char_p * n)(*[x.encode() for x in leaves])
+    bl = np.ascontiguousarray(br_lens, np.float32)
+    scores = np.zeros(n, np.float32)
+    _check(load().coati_host_align_leafs(model.encode(), C.c_float(omega), C.c_float(gap_open), C.c_float(ge),
+                                         C.c_uint(gap_len), ref_seq.encode(), arr, _p(bl), C.c_uint(n), buf,
+                                         C.c_ulonglong(slot), _p(scores)))
+    out = []
+    for p in range(n):
+        a = C.string_at(C.addressof(buf) + (2 * p) * slot).decode()
+        b = C.string_at(C.addressof(buf) + (2 * p + 1) * slot).decode()
+        out.append((a, b, float(scores[p])))
+    return out

@@ -128,6 +128,63 @@ bool marg_alignment(alignment_t& aln) {
     return true;
 }
 
+std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, const std::vector<std::string>& leaf_seqs,
+                                const std::vector<float>& br_lens) {
+    if(leaf_seqs.size() != br_lens.size()) throw std::invalid_argument("One branch length per leaf is required.");
+    const std::size_t n = leaf_seqs.size();
+    std::vector<data_t> out(n);
+    if(n == 0) return out;
+    // one table per distinct branch length (set_subst per leaf, align_msa.cc:297-301)
+    std::vector<float> distinct;
+    std::vector<uint32_t> table_index(n);
+    std::vector<float> tables;
+    for(std::size_t p = 0; p < n; ++p) {
+        std::size_t t = 0;
+        while(t < distinct.size() && distinct[t] != br_lens[p]) ++t;
+        if(t == distinct.size()) {
+            distinct.push_back(br_lens[p]);
+            input.br_len = br_lens[p];
+            set_subst(input);
+            tables.insert(tables.end(), input.subst_matrix.begin(), input.subst_matrix.end());
+        }
+        table_index[p] = static_cast<uint32_t>(t);
+    }
+    std::vector<unsigned char> a_cat, b_cat;
+    std::vector<uint64_t> a_off{0}, b_off{0};
+    for(std::size_t p = 0; p < n; ++p) {
+        const auto enc = marginal_seq_encoding(ref_seq, leaf_seqs[p]);
+        check_descendant_codes(enc[1]);
+        a_cat.insert(a_cat.end(), enc[0].begin(), enc[0].end());
+        b_cat.insert(b_cat.end(), enc[1].begin(), enc[1].end());
+        a_off.push_back(a_cat.size());
+        b_off.push_back(b_cat.size());
+    }
+    if(input.gap.len < 1) throw std::invalid_argument("Gap unit length must be positive.");
+    const auto k = gap_log_consts(input.gap);
+    coati_hip_model* model = nullptr;
+    hip_check(coati_hip_model_create_tables(tables.data(), static_cast<uint32_t>(distinct.size()), k[0], k[1], k[2], k[3],
+                                            static_cast<int>(input.gap.len), input.device, &model));
+    coati_hip_batch* batch = nullptr;
+    int rc = coati_hip_batch_create_tables(model, n, a_cat.data(), a_off.data(), b_cat.data(), b_off.data(),
+                                           table_index.data(), &batch);
+    std::vector<float> scores(n);
+    std::vector<uint8_t> ops(a_cat.size() + b_cat.size() + 1);
+    std::vector<uint64_t> off(n);
+    std::vector<uint32_t> len(n);
+    if(rc == COATI_HIP_OK) rc = coati_hip_viterbi_launch(batch);
+    if(rc == COATI_HIP_OK)
+        rc = coati_hip_viterbi_fetch(batch, scores.data(), ops.data(), a_cat.size() + b_cat.size(), off.data(), len.data());
+    if(batch != nullptr) coati_hip_batch_destroy(batch);
+    coati_hip_model_destroy(model);
+    hip_check(rc);
+    for(std::size_t p = 0; p < n; ++p) {
+        out[p].seqs.assign(2, std::string());
+        ops_to_alignment(ops.data() + off[p], len[p], ref_seq, leaf_seqs[p], out[p].seqs[0], out[p].seqs[1]);
+        out[p].score = scores[p];
+    }
+    return out;
+}
+
 bool marg_alignment_batch(alignment_t& aln) {
     data_t all = read_input(aln.data.path);
     if(all.size() == 0 || all.size() % 2 != 0) throw std::invalid_argument("Batch input needs an even number of sequences.");

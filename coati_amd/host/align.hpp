@@ -86,5 +86,14 @@ void marg_sample(alignment_t& aln, std::size_t sample_size, random_t& rand);
 // (reference first unless rev); writes a JSON array of n alignments.
 bool marg_alignment_batch(alignment_t& aln);
 
+// The pairwise step of `coati msa` (align_leafs, src/lib/align_msa.cc:285-318) for all leaves at
+// once: every leaf is aligned to `ref_seq` with the substitution table of ITS branch length
+// (`input` supplies model, omega, pi, sigma, gaps; its br_len is overwritten per leaf, as the
+// reference does).  One multi-table model, one launch.  Returns, per leaf, the aligned pair
+// (seqs[0] = reference row, seqs[1] = leaf row) and the score.  Sequences are taken as they are
+// (the reference's loop does not trim stop codons either).
+std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, const std::vector<std::string>& leaf_seqs,
+                                const std::vector<float>& br_lens);
+
 }  // namespace coati_amd
 #endif

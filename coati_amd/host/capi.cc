@@ -267,4 +267,28 @@ int coati_host_synth_raw(unsigned long long index, unsigned long long seed_base,
     });
 }
 
+// align_leafs for tests/bindings: leaves are NUL-terminated strings; outputs are written as
+// 2 strings per leaf into `out` (slot = len(ref) + longest leaf + 1 bytes each).
+int coati_host_align_leafs(const char* model, float omega, float gap_open, float gap_extend, unsigned gap_len,
+                           const char* ref_seq, const char* const* leaves, const float* br_lens, unsigned n_leaves,
+                           char* out, unsigned long long slot, float* scores) {
+    return guarded([&] {
+        coati_amd::alignment_t aln;
+        aln.model = model;
+        aln.omega = omega;
+        aln.gap.open = gap_open;
+        aln.gap.extend = gap_extend;
+        aln.gap.len = gap_len;
+        std::vector<std::string> ls(leaves, leaves + n_leaves);
+        std::vector<float> bl(br_lens, br_lens + n_leaves);
+        const auto res = coati_amd::align_leafs(aln, ref_seq, ls, bl);
+        for(unsigned p = 0; p < n_leaves; ++p) {
+            if(res[p].seqs[0].size() + 1 > slot) throw std::invalid_argument("align_leafs: output slot too small");
+            std::strcpy(out + (2ull * p) * slot, res[p].seqs[0].c_str());
+            std::strcpy(out + (2ull * p + 1) * slot, res[p].seqs[1].c_str());
+            scores[p] = res[p].score;
+        }
+    });
+}
+
 }  // extern "C"

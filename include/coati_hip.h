@@ -84,6 +84,13 @@ const char* coati_hip_last_error(void);
 int coati_hip_model_create(const float* table, float no_gap, float gap_stop, float gap_open,
                            float gap_extend, int gap_len, int device,
                            coati_hip_model_t** out);
+/* The same with n_tables substitution tables (tables: n_tables * 183*15 fp32).  What it is
+ * for: `coati msa` aligns every leaf to the reference with the leaf's own branch length, i.e.
+ * its own marginal table (src/lib/align_msa.cc:285-318: set_subst per leaf, then viterbi_mem);
+ * one batch can then carry pairs of different tables (coati_hip_batch_create_tables). */
+int coati_hip_model_create_tables(const float* tables, uint32_t n_tables, float no_gap, float gap_stop,
+                                  float gap_open, float gap_extend, int gap_len, int device,
+                                  coati_hip_model_t** out);
 void coati_hip_model_destroy(coati_hip_model_t* model);
 
 /* ---- batch -------------------------------------------------------------- *
@@ -94,6 +101,10 @@ void coati_hip_model_destroy(coati_hip_model_t* model);
 int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                            const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                            coati_hip_batch_t** out);
+/* The same, pair p using table table_index[p] (< n_tables of the model); NULL = table 0 for all. */
+int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                                  const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                                  const uint32_t* table_index, coati_hip_batch_t** out);
 void coati_hip_batch_destroy(coati_hip_batch_t* batch);
 
 /* Bytes of HBM a batch holds (inputs + workspace + results). */

@@ -4,6 +4,7 @@ import json
 import subprocess
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -115,3 +116,24 @@ def test_sample_doctest_cases(tmp_path):
     one = tmp_path / "one.fasta"
     one.write_text(">A\nCCC\n")
     assert run("coati-sample", one).returncode == 1
+
+
+def test_align_leafs_per_leaf_branch_lengths(oracle):
+    """Host align_leafs (the pairwise step of `coati msa`, align_msa.cc:285-318, batched): each leaf is
+    aligned with the table of its own branch length; equals per-leaf oracle runs bit for bit."""
+    from coati_amd import host
+    from tests import util
+
+    rng = np.random.default_rng(8)
+    ref = util.random_anc(rng, 120)
+    leaves = [util.mutate(rng, ref, sub=0.03 + 0.02 * k, n_indel=2) for k in range(7)]
+    br = [0.0133, 0.05, 0.0133, 0.2, 0.05, 0.8, 0.01]
+    got = host.align_leafs(ref, leaves, br)
+    consts = host.gap_consts()
+    for (aln_ref, aln_leaf, score), leaf, t in zip(got, leaves, br):
+        table = host.set_subst("mar-mg", br_len=t)
+        a, b = util.encode_anc(ref), util.encode_des(leaf)
+        w_ops, w_sc = oracle.viterbi(table, consts, 1, a, b)
+        w_a, w_b = oracle.ops_to_strings(w_ops, ref, leaf)
+        assert (aln_ref, aln_leaf) == (w_a, w_b)
+        assert np.float32(score).view(np.uint32) == np.float32(w_sc).view(np.uint32)

@@ -184,3 +184,35 @@ sys.exit(1 if bad else 0)
     env = dict(os.environ, COATI_HIP_STRIP_W=strip_w)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_per_pair_tables(oracle):
+    """A model with several substitution tables (per-leaf branch lengths of `coati msa`,
+    align_msa.cc:285-318) and a batch whose pairs pick among them: every pair equals the oracle run
+    with ITS table; Viterbi bit-exact, Forward final cell within 1e-5."""
+    from coati_amd import hip
+
+    rng = np.random.default_rng(21)
+    tables = np.stack([util.random_table(rng) for _ in range(5)])
+    consts = oracle.gap_consts()
+    pairs = util.make_pairs(rng, 60, 1, 200, L=1, amb=0.02)
+    enc = util.encode_pairs(pairs)
+    tix = rng.integers(0, 5, len(enc)).astype(np.uint32)
+    model = hip.Model(tables, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc), table_index=tix)
+    batch.viterbi_launch()
+    scores, ops, off, ln = batch.viterbi_fetch()
+    batch.forward_launch()
+    final = batch.forward_final()
+    for p, (a, b) in enumerate(enc):
+        w_ops, w_sc = oracle.viterbi(tables[tix[p]], consts, 1, a, b)
+        got = ops[int(off[p]):int(off[p]) + int(ln[p])]
+        assert len(got) == len(w_ops) and (got == w_ops).all(), p
+        assert np.float32(scores[p]).view(np.uint32) == np.float32(w_sc).view(np.uint32), p
+        M, D, I = oracle.fill(oracle.LOG, tables[tix[p]], consts, 1, a, b)
+        want = np.array([M[-1, -1], D[-1, -1], I[-1, -1]], np.float64)
+        assert (np.abs(final[p] - want) <= 1e-5 * np.maximum(1.0, np.abs(want))).all(), p
+    with pytest.raises(hip.CoatiHipError):
+        hip.Batch(model, *hip.pack_pairs(enc), table_index=np.full(len(enc), 5, np.uint32))
+    batch.close()
+    model.close()
