@@ -217,9 +217,26 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
     return coati_hip_batch_create_tables(model, n_pairs, a_cat, a_off, b_cat, b_off, nullptr, out);
 }
 
+namespace {
+int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
+                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, coati_hip_batch_t** out);
+}
+
 int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                                   const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                                   const uint32_t* table_index, coati_hip_batch_t** out) {
+    try {  // no C++ exception may cross the C ABI (host-side vectors can throw bad_alloc)
+        return batch_create_impl(model, n_pairs, a_cat, a_off, b_cat, b_off, table_index, out);
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
+    } catch(const std::exception& ex) {
+        return fail(COATI_HIP_EHIP, "batch_create: %s", ex.what());
+    }
+}
+
+namespace {
+int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
+                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, coati_hip_batch_t** out) {
     if(out == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: out is NULL");
     *out = nullptr;
     if(model == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: model is NULL");
@@ -233,15 +250,14 @@ int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, co
     if(b == nullptr) return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
     b->model = model;
     b->n_pairs = n_pairs;
-    auto cleanup = [&](int rc) {
-        coati_hip_batch_destroy(b);
-        return rc;
-    };
-    try {
-        b->desc.resize(n_pairs);
-    } catch(const std::bad_alloc&) {
-        return cleanup(fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed"));
-    }
+    struct Owner {  // destroys the half-built batch on every exit but the successful one
+        coati_hip_batch* b;
+        ~Owner() {
+            if(b != nullptr) coati_hip_batch_destroy(b);
+        }
+    } owner{b};
+    auto cleanup = [&](int rc) { return rc; };
+    b->desc.resize(n_pairs);
     const uint64_t L = static_cast<uint64_t>(model->gap_len);
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
@@ -398,9 +414,11 @@ int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, co
     for(auto& trio : b->ev)
         for(auto& e : trio) B_TRY(hipEventCreate(&e));
 #undef B_TRY
+    owner.b = nullptr;
     *out = b;
     return COATI_HIP_OK;
 }
+}  // namespace
 
 uint64_t coati_hip_batch_device_bytes(const coati_hip_batch_t* b) { return b ? b->device_bytes : 0; }
 uint64_t coati_hip_batch_cells(const coati_hip_batch_t* b) { return b ? b->cells : 0; }
@@ -645,6 +663,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     std::vector<uint32_t> draws;
     std::vector<SpecCommit> commits;
     const BatchDeviceView view = device_view(b);
+    try {
     for(;;) {
         cands.clear();
         uint64_t tmp_used = 0;
@@ -726,6 +745,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(launch_spec_commit(d_commits, ncm, d_tmp, d_cstart, d_clen, d_clw, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));  // `commits`/`cands` are reused by the next round
     }
+    } catch(...) {  // host-side allocation failure: free the device work areas, report at the ABI
+        release();
+        throw;
+    }
 #undef S_TRY
     for(uint64_t p = 0; p < n; ++p) {
         const u128 st = ps[p].st0 * lehmer_pow(ps[p].origin);  // where n serial sampleback calls leave the stream
@@ -737,9 +760,29 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
 }
 }  // namespace
 
+namespace {
+int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
+                    float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                    uint64_t* rng_state_out);
+}
+
 int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
                          float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
                          uint64_t* rng_state_out) {
+    try {
+        return sampleback_impl(b, n_samples, rng_state, independent_streams, log_weights, ops, ops_capacity, ops_off, ops_len,
+                               rng_state_out);
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "sampleback: host allocation failed");
+    } catch(const std::exception& ex) {
+        return fail(COATI_HIP_EHIP, "sampleback: %s", ex.what());
+    }
+}
+
+namespace {
+int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
+                    float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                    uint64_t* rng_state_out) {
     if(b == nullptr || rng_state == nullptr) return fail(COATI_HIP_EINVAL, "sampleback: NULL argument");
     if(!b->forward_done) return fail(COATI_HIP_ESTATE, "sampleback: forward was not launched");
     const uint64_t n = b->n_pairs;
@@ -819,6 +862,7 @@ int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_
         return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "sampleback: %s", hipGetErrorString(e));
     return COATI_HIP_OK;
 }
+}  // namespace
 
 int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out) {
     if(model == nullptr || rng_state == nullptr || out == nullptr) return fail(COATI_HIP_EINVAL, "debug_rng_f24: NULL argument");
