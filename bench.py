@@ -28,9 +28,9 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Secondary (and for this recurrence the binding) ceiling, DESIGN.md §4: the gap_len-1 cell is
-# 27 VALU instructions; non-packed fp32 VALU issues 32 lanes/clk/SIMD (measured, tools/ubench):
-# 1024 SIMDs x 32 x 2.4 GHz / 27 = 2.9 TCUPS.
-VALU_PEAK_GCUPS = 1024 * 32 * 2.4 / 27.0
+# 25 VALU instructions; non-packed fp32 VALU issues 32 lanes/clk/SIMD (measured, tools/ubench):
+# 1024 SIMDs x 32 x 2.4 GHz / 25 = 3.1 TCUPS.
+VALU_PEAK_GCUPS = 1024 * 32 * 2.4 / 25.0
 ALGO_BYTES_PER_CELL = 1.0      # 1 B/cell packed traceback written ...
 # ... + (len_a + len_b) B of sequence read per pair (added per pair below)
 

@@ -27,7 +27,8 @@ __global__ void decode_flags(const PairDesc* __restrict__ pairs, uint32_t pair,
         const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
         const CellAddr ca = cell_addr(pd, bi, bj);
         const uint32_t mm = pair_bits(flags, ca, 0), dd = pair_bits(flags, ca, 1), im = im_bit(flags, ca);
-        const uint32_t fm = (mm & 1u) ? 2u : (mm >> 1), fd = (dd & 1u) ? 2u : (dd >> 1);
+        // (bit1: the M argument is not the maximum, bit0: the D argument is not) -> 0 M, 1 D, 2 I
+        const uint32_t fm = !(mm & 2u) ? 0u : ((mm & 1u) ? 2u : 1u), fd = !(dd & 2u) ? 0u : ((dd & 1u) ? 2u : 1u);
         out[idx] = static_cast<uint8_t>(fm | (fd << 2) | ((im ^ 1u) << 4));
     }
 }

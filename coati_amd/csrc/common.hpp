@@ -24,10 +24,11 @@ constexpr int kPairDwords = 5 * kWave;       // dwords one pair of wavefront ste
 constexpr int kFillWaves = 4;                // sequence pairs per workgroup
 constexpr float kLowest = -FLT_MAX;          // semiring zero(), semiring.hpp:83,113
 
-// Decision bits per cell.  Bit = 1 means:
-//   M1: D beats M after a match move     (max_mdi first test,  align_pair.cc:213-216)
-//   M2: I beats max(M,D) after a match   (max_mdi second test, align_pair.cc:217-219)
-//   D1, D2: the same two tests after a deletion move (align_pair.cc:285-287)
+// Decision bits per cell.  max_mdi (align_pair.cc:210-224) is the arg-max of its three
+// arguments with ties M over D over I.  Bit = 1 means:
+//   M1: the M argument is NOT the maximum after a match move   (so the state is D or I)
+//   M2: the D argument is NOT the maximum after a match move   (M1 & M2: the state is I)
+//   D1, D2: the same two facts after a deletion move (align_pair.cc:285-287)
 //   IM: M beats I after an insertion move (max_mi, align_pair.cc:230-232; tie -> I)
 // Three per-lane accumulators: A = (M1,M2) pairs, B = (D1,D2) pairs, C = IM.
 enum : int { ACC_A = 0, ACC_B = 1, ACC_C = 2, kAccs = 3 };
@@ -130,7 +131,7 @@ __device__ __forceinline__ CellAddr cell_addr(const PairDesc& pd, uint32_t bi, u
 // two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
 __device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
     const uint32_t w = flags[ca.group_base + ca.half_off + which * kWave + ca.t];
-    return (w >> ca.sh_ab) & 3u;  // bit1 = first test, bit0 = second test
+    return (w >> ca.sh_ab) & 3u;  // bit1 = M argument is not the maximum, bit0 = D argument is not
 }
 __device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
     const uint32_t w = flags[ca.group_base + 4 * kWave + ca.t];
@@ -142,8 +143,8 @@ __device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, c
     const CellAddr ca = cell_addr(pd, bi, bj);
     if(moved == COATI_HIP_OP_INS) return im_bit(flags, ca) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
     const uint32_t two = pair_bits(flags, ca, moved == COATI_HIP_OP_DEL ? 1 : 0);
-    if(two & 1u) return COATI_HIP_OP_INS;  // second test: I beats max(M,D)
-    return (two & 2u) ? COATI_HIP_OP_DEL : COATI_HIP_OP_MATCH;
+    if(!(two & 2u)) return COATI_HIP_OP_MATCH;  // the M argument is the maximum (ties: M first)
+    return (two & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL;
 }
 
 // ---------------------------------------------------------------------------

@@ -228,8 +228,10 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
                                 // the five decisions of align_pair.cc:275-296 on this cell (common.hpp layout)
                                 const float x1 = (M + k.ng) + k.ng, x2 = D + k.gs, x3 = (I + k.gs) + k.ng;
                                 const float y1 = (M + k.ng) + k.go, y2 = D + k.ge, y3 = (I + k.gs) + k.go;
-                                acc[ACC_A] = (acc[ACC_A] << 2) | (x2 > x1 ? 2u : 0u) | (x3 > fmaxf(x1, x2) ? 1u : 0u);
-                                acc[ACC_B] = (acc[ACC_B] << 2) | (y2 > y1 ? 2u : 0u) | (y3 > fmaxf(y1, y2) ? 1u : 0u);
+                                // max_mdi = arg-max, ties M over D over I: "M is not the max", "D is not the max"
+                                const float xx = fmaxf(fmaxf(x1, x2), x3), yy = fmaxf(fmaxf(y1, y2), y3);
+                                acc[ACC_A] = (acc[ACC_A] << 2) | (x1 < xx ? 2u : 0u) | (x2 < xx ? 1u : 0u);
+                                acc[ACC_B] = (acc[ACC_B] << 2) | (y1 < yy ? 2u : 0u) | (y2 < yy ? 1u : 0u);
                                 acc[ACC_C] = (acc[ACC_C] << 1) | ((M + k.go) > (I + k.ge) ? 1u : 0u);
                             }
                         }

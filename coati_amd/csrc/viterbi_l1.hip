@@ -60,12 +60,15 @@ struct LaneState {
 // so M = X(diagonal cell) + s.
 //
 // The five decisions are max_mdi / max_mi (align_pair.cc:210-232) on the
-// expressions of align_pair.cc:275-296.  Each `p > q` is taken as the sign bit
-// of q - p: exact, because fp32 subtraction of two finite numbers is zero only
-// when they are equal (gradual underflow is on) and no -0.0f occurs here.  On
+// expressions of align_pair.cc:275-296.  max_mdi(x1,x2,x3) is the arg-max with ties
+// M over D over I, so two bits suffice: "x1 is not the maximum" and "x2 is not the
+// maximum" (M if the first is clear, else D if the second is clear, else I).  With
+// X = max3(x1,x2,x3) each of them is the sign bit of x - X: exact, because fp32
+// subtraction of two finite numbers is zero only when they are equal (gradual
+// underflow is on; x - x = +0.0f).  Likewise z1 > z2 is the sign of z2 - z1.  On
 // gfx950 v_sub_f32 issues at twice the rate of v_cmp_f32 and the bit is
 // deposited with a single v_alignbit_b32 (measured: tools/ubench).
-// One DP cell = ONE asm block of 27 VALU instructions with a fixed order and a
+// One DP cell = ONE asm block of 25 VALU instructions with a fixed order and a
 // hand register allocation.  Why not leave it to the compiler (all measured or
 // observed):
 //  * on gfx950 v_add/v_sub_f32 and v_add_u32 issue every 2 cycles, v_max_f32 and
@@ -93,34 +96,32 @@ struct LaneState {
     "v_max_f32 %[zl], %[t3], %[t1]\n\t"       /* S  Z  = max(z1,z2) -> I of next column  */ \
     "v_add_f32 %[t4], %[ng], %[t0]\n\t"       /* F  x1 = m1 + ng                         */ \
     "v_add_f32 %[t5], %[gs], %[y]\n\t"        /* F  x2 = D + gs                          */ \
+    "v_add_f32 %[t6], %[ng], %[t2]\n\t"       /* F  x3 = i1 + ng                         */ \
     "v_sub_f32 %[t1], %[t1], %[t3]\n\t"       /* F  z2 - z1  (sign: z1 > z2)             */ \
-    "v_max_f32 %[t3], %[t4], %[t5]\n\t"       /* S  xm = max(x1,x2)                      */ \
-    "v_add_f32 %[pend], %[ng], %[t2]\n\t"     /* F  x3 = i1 + ng                         */ \
+    "v_max3_f32 %[x], %[t4], %[t5], %[t6]\n\t" /* S  X  = max(x1,x2,x3)                  */ \
+    "v_add_f32 %[t3], %[go], %[t0]\n\t"       /* F  y1 = m1 + go                         */ \
+    "v_add_f32 %[t6], %[ge], %[y]\n\t"        /* F  y2 = D + ge                          */ \
     "v_alignbit_b32 %[aC], %[aC], %[t1], 31\n\t" /* S  IM                                */ \
-    "v_sub_f32 %[t1], %[t4], %[t5]\n\t"       /* F  x1 - x2  (sign: x2 > x1)             */ \
-    "v_max_f32 %[x], %[t3], %[pend]\n\t"      /* S  X  = max(xm,x3)                      */ \
-    "v_sub_f32 %[t4], %[t3], %[pend]\n\t"     /* F  xm - x3  (sign: x3 > xm)             */ \
-    "v_add_f32 %[t5], %[go], %[t0]\n\t"       /* F  y1 = m1 + go                         */ \
-    "v_alignbit_b32 %[aA], %[aA], %[t1], 31\n\t" /* S  M1                                */ \
-    "v_add_f32 %[t1], %[ge], %[y]\n\t"        /* F  y2 = D + ge                          */ \
-    "v_add_f32 %[t3], %[go], %[t2]\n\t"       /* F  y3 = i1 + go                         */ \
-    "v_max_f32 %[t0], %[t5], %[t1]\n\t"       /* S  ym = max(y1,y2)                      */ \
-    "v_sub_f32 %[t2], %[t5], %[t1]\n\t"       /* F  y1 - y2  (sign: y2 > y1)             */ \
-    "v_alignbit_b32 %[aA], %[aA], %[t4], 31\n\t" /* S  M2                                */ \
+    "v_add_f32 %[t2], %[go], %[t2]\n\t"       /* F  y3 = i1 + go                         */ \
+    "v_sub_f32 %[t4], %[t4], %[x]\n\t"        /* F  x1 - X   (sign: x1 is not the max)   */ \
+    "v_sub_f32 %[t5], %[t5], %[x]\n\t"        /* F  x2 - X   (sign: x2 is not the max)   */ \
+    "v_max3_f32 %[y], %[t3], %[t6], %[t2]\n\t" /* S  Y  = max(y1,y2,y3)                  */ \
     "v_add_u32 %[addr], %[lds], %[boff]\n\t"  /* F  LDS address of next step's score     */ \
-    "v_max_f32 %[y], %[t0], %[t3]\n\t"        /* S  Y  = max(ym,y3)                      */ \
-    "v_sub_f32 %[pend], %[t0], %[t3]\n\t"     /* F  ym - y3  (sign: y3 > ym), carried    */ \
-    "v_alignbit_b32 %[aB], %[aB], %[t2], 31"  /* S  D1                                   */
+    "v_alignbit_b32 %[aA], %[aA], %[t4], 31\n\t" /* S  M1                                */ \
+    "v_sub_f32 %[t3], %[t3], %[y]\n\t"        /* F  y1 - Y   (sign: y1 is not the max)   */ \
+    "v_alignbit_b32 %[aA], %[aA], %[t5], 31\n\t" /* S  M2                                */ \
+    "v_sub_f32 %[pend], %[t6], %[y]\n\t"      /* F  y2 - Y, carried into the next cell   */ \
+    "v_alignbit_b32 %[aB], %[aB], %[t3], 31"  /* S  D1                                   */
 
 template <int C, int W>
 __device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState<W>& st, float& diag, float& zl, float& pend,
                                         float& s, uint32_t lds_next_row, uint32_t boff) {
-    float x_new, t0, t1, t2, t3, t4, t5;
+    float x_new, t0, t1, t2, t3, t4, t5, t6;
     uint32_t addr;
 #define COATI_CELL_OPERANDS                                                                              \
     : [x] "=&v"(x_new), [y] "+v"(st.Y[C]), [zl] "+v"(zl), [pend] "+v"(pend), [aA] "+v"(st.acc[ACC_A]),   \
       [aB] "+v"(st.acc[ACC_B]), [aC] "+v"(st.acc[ACC_C]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
-      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [addr] "=&v"(addr)                                  \
+      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [addr] "=&v"(addr)                  \
     : [diag] "v"(diag), [s] "v"(s), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng),          \
       [gs] "s"(k.gs), [go] "s"(k.go), [ge] "s"(k.ge)
     if constexpr(C > 0) {

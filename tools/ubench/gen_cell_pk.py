@@ -77,6 +77,28 @@ def cell_base(c, parity):
     return L
 
 
+def cell_max3(c, parity):
+    """25 VALU: X and Y as v_max3_f32; decisions as sign(x1 - X), sign(x2 - X) (zero iff equal)."""
+    xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
+    xout = f"v{XB+c}" if parity == 0 else f"v{YP+2*c+1}"
+    y = f"v{YP+2*c}"
+    t0, t1, t2, t3, t4, t5, t6, pend, zl = "v10", "v11", "v12", "v13", "v14", "v15", "v17", "v16", f"v{ZL}"
+    L = [f"v_add_f32 {t0}, v{DIAG}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}",
+         f"v_alignbit_b32 v{AB}, v{AB}, {pend}, 31",
+         f"v_add_f32 {t2}, {GS}, {zl}", f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}",
+         f"v_max_f32 {zl}, {t3}, {t1}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+         f"v_add_f32 {t6}, {NG}, {t2}", f"v_sub_f32 {t1}, {t1}, {t3}",
+         f"v_mov_b32 v{DIAG}, {xin}",
+         f"v_max3_f32 {xout}, {t4}, {t5}, {t6}", f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t6}, {GE}, {y}",
+         f"v_alignbit_b32 v{AC}, v{AC}, {t1}, 31", f"v_add_f32 {t2}, {GO}, {t2}",
+         f"v_sub_f32 {t4}, {t4}, {xout}", f"v_sub_f32 {t5}, {t5}, {xout}",
+         f"v_max3_f32 {y}, {t3}, {t6}, {t2}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}",
+         f"v_alignbit_b32 v{AA}, v{AA}, {t4}, 31", f"v_sub_f32 {t3}, {t3}, {y}",
+         f"v_alignbit_b32 v{AA}, v{AA}, {t5}, 31", f"v_sub_f32 {pend}, {t6}, {y}",
+         f"v_alignbit_b32 v{AB}, v{AB}, {t3}, 31", f"v_xor_b32 v{LDS}, v{LDS}, v{ADDR}"]
+    return L
+
+
 def cell_cmp(c, parity):
     """22 VALU: the five decisions as v_cmp into SGPR pairs (lane masks), stored by the scalar unit."""
     xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
@@ -148,6 +170,7 @@ __global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, 
 nb, kb = kernel("cell_base", cell_base)
 npk, kp = kernel("cell_pk", cell_pk)
 ncm, kc = kernel("cell_cmp", cell_cmp)
+nm3, km3 = kernel("cell_max3", cell_max3)
 src = f'''// GENERATED by gen_cell_pk.py -- do not edit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -155,6 +178,7 @@ src = f'''// GENERATED by gen_cell_pk.py -- do not edit.
 {kb}
 {kp}
 {kc}
+{km3}
 template <typename K> int run(const char* name, K kern, int n_instr) {{
     float* d_out; CHECK(hipMalloc(&d_out, sizeof(float) * 256 * 256 * 8));
     char* d_scratch; CHECK(hipMalloc(&d_scratch, 256ull * 4 * 4 * 1280 * 400));
@@ -179,6 +203,7 @@ int main() {{
     if (run("base", cell_base, {nb})) return 1;
     if (run("pk", cell_pk, {npk})) return 1;
     if (run("cmp+sst", cell_cmp, {ncm})) return 1;
+    if (run("max3", cell_max3, {nm3})) return 1;
     return 0;
 }}
 '''
