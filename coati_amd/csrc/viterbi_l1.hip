@@ -185,14 +185,13 @@ struct StripCtx {
 // an s_waitcnt vmcnt(0) -- a wait for the previous step's HBM stores -- into
 // every step).
 template <int W, bool kFirst>
-__device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState<W>& st, uint32_t& arow, float (&s)[W],
-                                          const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk, float bx,
-                                          float bz) {
+__device__ __forceinline__ void one_step(const StripCtx& cx, LaneState<W>& st, uint32_t& arow, float (&s)[W],
+                                         const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk, uint32_t a_chunk,
+                                         float bx, float bz) {
     constexpr uint32_t kMA = 16 / W, kMC = 32 / W;  // wavefront steps per A/B dword and per C dword
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
-    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
-    for(uint32_t kk = 0; kk < kend; ++kk) {
+    {
         const uint32_t kstep = kbase + kk;
         if constexpr(kFirst) {
             if(kk == static_cast<uint32_t>(lane)) {
@@ -239,6 +238,27 @@ __device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState<W>& st, 
             for(int c = 1; c < W; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
             cx.scores[cx.pair] = sc;
         }
+    }
+}
+
+template <int W, bool kFirst>
+__device__ __forceinline__ void run_chunk(const StripCtx& cx, LaneState<W>& st, uint32_t& arow, float (&s)[W],
+                                          const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk, float bx,
+                                          float bz) {
+    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    if constexpr(W == 16 && !kFirst) {
+        // The hot loop, two steps per iteration: the new X of a column must not overwrite the old
+        // one before the next column has taken it as its diagonal input; with two copies of the
+        // body the register allocator ping-pongs X between two register sets instead of copying
+        // 16 values per step (20 v_mov per step in the single-step loop).
+        uint32_t kk = 0;
+        for(; kk + 1 < kend; kk += 2) {
+            one_step<W, kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
+            one_step<W, kFirst>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz);
+        }
+        if(kk < kend) one_step<W, kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
+    } else {
+        for(uint32_t kk = 0; kk < kend; ++kk) one_step<W, kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
     }
 }
 
