@@ -61,13 +61,13 @@ __device__ __forceinline__ void store_through(float* p, float v) {
 // Up to 64 wavefront steps (see viterbi_l1.hip: run_chunk).  ch*: what lane 0 needs at step
 // kbase + l, held by lane l: diagonal cell (M, D, I) and left cell (M, I) of column col0 - 1.
 template <bool kFirst>
-__device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
-                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float chDM,
-                                          float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
+__device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
+                                         const uint32_t (&boff)[kW], uint32_t kbase, uint32_t kk, uint32_t a_chunk,
+                                         float chDM, float chDD, float chDI, float chLM, float chLI,
+                                         const char* tab_bytes) {
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
-    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
-    for(uint32_t kk = 0; kk < kend; ++kk) {
+    {
         const uint32_t kstep = kbase + kk;
         if constexpr(kFirst) {
             if(kk == static_cast<uint32_t>(lane)) {
@@ -151,6 +151,26 @@ __device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_
             f[1] = d + k.gs;
             f[2] = (in + k.gs) + k.ng;
         }
+    }
+}
+
+template <bool kFirst>
+__device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
+                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float chDM,
+                                          float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
+    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    if constexpr(!kFirst) {
+        // two steps per iteration: M/D/I of the row above ping-pong between two register sets
+        // instead of being copied (see viterbi_l1.hip: run_chunk)
+        uint32_t kk = 0;
+        for(; kk + 1 < kend; kk += 2) {
+            fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+        }
+        if(kk < kend) fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+    } else {
+        for(uint32_t kk = 0; kk < kend; ++kk)
+            fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     }
 }
 
