@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Debug aid: per-cell decision bits of the GPU fill against the oracle's decision bytes for a few
+small pairs (this is the script that exposed the SLP-vectoriser v_pk_add_f32 miscompute)."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 from coati_amd import hip
