@@ -25,6 +25,10 @@ __global__ void decode_flags(const PairDesc* __restrict__ pairs, uint32_t pair,
     for(uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; idx < n;
         idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
+        if(pd.v_compact != 0 && (bi % pd.v_compact) != (bj % pd.v_compact)) {
+            out[idx] = 0xffu;  // not a live cell: never stored (viterbi_k.hip)
+            continue;
+        }
         const CellAddr ca = cell_addr(pd, bi, bj);
         const uint32_t mm = pair_bits(flags, ca, 0), dd = pair_bits(flags, ca, 1), im = im_bit(flags, ca);
         // (bit1: the M argument is not the maximum, bit0: the D argument is not) -> 0 M, 1 D, 2 I
@@ -111,6 +115,7 @@ struct coati_hip_batch {
     float *d_bnd = nullptr, *d_scores = nullptr;
     float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward
     bool forward_done = false;
+    bool compact = false;  // Viterbi plan is the live-cell layout of viterbi_k (gap_len 2, 3)
     uint64_t* d_ops_start = nullptr;
     uint32_t* d_ops_len = nullptr;
     static constexpr int kTimingRing = 64;  // launches whose kernel times can still be read back
@@ -341,13 +346,27 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         if(tail_w == 4 || tail_w == 8)
             for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = static_cast<uint8_t>(tail_w);
     }
+    // gap_len 2 and 3: viterbi_k works on the live cells only, in block columns (lb / L), strips of
+    // 16 block columns per lane and a narrow shape (6 for L = 3, 8 for L = 2) for the last strip
+    const bool plan_k = (L == 2 || L == 3) && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;
+    b->compact = plan_k;
     for(uint64_t p = 0; p < n_pairs; ++p) {
         PairDesc& d = b->desc[p];
         const uint64_t la = d.la;
         const uint32_t w_main_p = pair_w[p] != 0 ? std::min<uint32_t>(pair_w[p], w_main) : w_main;
         uint32_t ns = 1, wl = w_main_p;
+        d.v_compact = 0;
+        d.pad_ = 0;
         if(plan_l1) {
             if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main_p, ns, wl);
+        } else if(plan_k) {
+            d.v_compact = static_cast<uint32_t>(L);
+            const uint32_t cols_b = static_cast<uint32_t>(d.lb / L), narrow = L == 3 ? 6u : 8u;
+            if(d.la > 0 && d.lb > 0) {
+                const uint32_t whole = cols_b / kStrip, rem = cols_b % kStrip;
+                ns = whole + (rem != 0 ? 1u : 0u);
+                wl = (rem != 0 && rem <= kWave * narrow) ? narrow : static_cast<uint32_t>(kW);
+            }
         } else {
             ns = std::max(1u, n_strips(d.lb));
         }
@@ -357,13 +376,15 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.flags_off = b->flag_dwords;
         d.bnd_off = b->bnd_floats;
         if(d.la > 0 && d.lb > 0)
-            b->flag_dwords += (ns - 1) * strip_dwords(d.la, w_main_p) + strip_dwords(d.la, wl);
+            b->flag_dwords += plan_k ? ns * compact_strip_dwords(d.la, static_cast<uint32_t>(L))
+                                     : (ns - 1) * strip_dwords(d.la, w_main_p) + strip_dwords(d.la, wl);
         // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
         // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
         const uint64_t nf = n_strips(d.lb);
         const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
-                                                  nf > 1 ? (la + 1) * (3 + 2 * L) : 0});
+                                                  nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
+                                                  plan_k ? (ns - 1) * ((la / L + 1) + la) : 0});
         b->bnd_floats += (need + 31) / 32 * 32;
     }
 
@@ -436,6 +457,8 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
         static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
         if(m->gap_len == 1 && !force_generic)
             HIP_TRY(launch_viterbi_l1(v, m->stream));
+        else if(b->compact)
+            HIP_TRY(launch_viterbi_k(v, m->stream));
         else
             HIP_TRY(launch_dp_generic(v, /*forward=*/false, m->stream));
     }

@@ -49,6 +49,10 @@ struct PairDesc {
     uint32_t v_strips;
     uint8_t v_wmain, v_wlast;
     uint16_t table;  // which of the model's substitution tables this pair uses
+    // 0: one stored cell per matrix cell (layout below).  L (2 or 3): "compact" layout of viterbi_k:
+    // only the live cells (bi - bj) % L == 0 are stored; the plan counts BLOCK columns (lb / L).
+    uint32_t v_compact;
+    uint32_t pad_;
 };
 
 // HBM layout of the decision bits of one strip of one pair.  A strip is 64*W descendant
@@ -67,6 +71,17 @@ struct PairDesc {
 __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
     const uint32_t mc = 32u / w;
     return static_cast<uint64_t>((la + kWave - 1 + mc - 1) / mc) * kPairDwords;
+}
+// Compact layout (gap_len L = 2, 3; viterbi_k.hip): live body cell (bi, bj), bi = p*L + r,
+// bj = q*L + r.  A lane owns W <= 16 block columns q; wavefront step k = p + lane.  Per strip and
+// step S = 2L + (L+1)/2 rows of 64 dwords:
+//   row r          A bits of phase r: column c at bits 31-2c, 30-2c
+//   row L + r      B bits of phase r, same positions
+//   row 2L + h     C bits of phases 2h and 2h+1: column c at bit 31-2c (phase 2h) and 30-2c
+//                  (phase 2h+1); if phase 2h+1 does not exist (L odd) column c is bit 31-c
+__host__ __device__ constexpr uint32_t compact_slots(uint32_t L) { return 2 * L + (L + 1) / 2; }
+__host__ __device__ inline uint64_t compact_strip_dwords(uint32_t la, uint32_t L) {
+    return static_cast<uint64_t>(la / L + kWave - 1) * compact_slots(L) * kWave;
 }
 __host__ __device__ inline uint32_t n_strips(uint32_t lb) { return (lb + kStrip - 1) / kStrip; }
 // Viterbi strip plan of a descendant of lb columns with w_main columns per lane in every strip
@@ -107,11 +122,26 @@ __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) {
 // decision-bit lookups (layout above); (bi, bj) are BODY coordinates
 // ---------------------------------------------------------------------------
 struct CellAddr {
-    uint64_t group_base;          // dword index of the step group
-    uint32_t half_off, t;         // 0 or 128; lane that owns the column
-    uint32_t sh_ab, sh_c;         // shifts that bring the cell's bits to the bottom
+    uint64_t idx_a, idx_b, idx_c;  // dword indices of the cell's A, B and C words
+    uint32_t sh_ab, sh_c;          // shifts that bring the cell's bits to the bottom
 };
 __device__ __forceinline__ CellAddr cell_addr(const PairDesc& pd, uint32_t bi, uint32_t bj) {
+    if(pd.v_compact != 0) {  // viterbi_k: live cells only
+        const uint32_t L = pd.v_compact;
+        const uint32_t q = bj / L, r = bi % L, p = bi / L;
+        const uint32_t full = kWave * pd.v_wmain;
+        uint32_t strip = q / full, w = pd.v_wmain;
+        if(strip + 1 >= pd.v_strips) {
+            strip = pd.v_strips - 1;
+            w = pd.v_wlast;
+        }
+        const uint32_t colin = q - strip * full, t = colin / w, c = colin % w;
+        const uint64_t base = pd.flags_off + strip * compact_strip_dwords(pd.la, L) +
+                              static_cast<uint64_t>(p + t) * (compact_slots(L) * kWave) + t;
+        const bool paired = (r | 1u) < L;  // phase r shares its C word with a partner phase
+        return {base + r * kWave, base + (L + r) * kWave, base + (2 * L + r / 2) * kWave, 30u - 2u * c,
+                paired ? 31u - 2u * c - (r & 1u) : 31u - c};
+    }
     const uint32_t full = kWave * pd.v_wmain;
     uint32_t strip = bj / full, w = pd.v_wmain;
     if(strip + 1 >= pd.v_strips) {
@@ -125,17 +155,17 @@ __device__ __forceinline__ CellAddr cell_addr(const PairDesc& pd, uint32_t bi, u
     const uint32_t lg_mc = 5u - lg, lg_ma = 4u - lg;          // steps per C dword / per A,B dword
     const uint32_t g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
     const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
-    return {pd.flags_off + strip * strip_dwords(pd.la, pd.v_wmain) + static_cast<uint64_t>(g) * kPairDwords,
-            half * (2u * kWave), t, 30u - 2u * ((tt << lg) + c), 31u - ((q << lg) + c)};
+    const uint64_t base = pd.flags_off + strip * strip_dwords(pd.la, pd.v_wmain) + static_cast<uint64_t>(g) * kPairDwords + t;
+    return {base + half * (2u * kWave), base + half * (2u * kWave) + kWave, base + 4u * kWave,
+            30u - 2u * ((tt << lg) + c), 31u - ((q << lg) + c)};
 }
-// two-bit decision (first test, second test) of accumulator A (which = 0) or B (which = 1)
+// two-bit decision of accumulator A (which = 0) or B (which = 1)
 __device__ __forceinline__ uint32_t pair_bits(const uint32_t* __restrict__ flags, const CellAddr& ca, int which) {
-    const uint32_t w = flags[ca.group_base + ca.half_off + which * kWave + ca.t];
+    const uint32_t w = flags[which ? ca.idx_b : ca.idx_a];
     return (w >> ca.sh_ab) & 3u;  // bit1 = M argument is not the maximum, bit0 = D argument is not
 }
 __device__ __forceinline__ uint32_t im_bit(const uint32_t* __restrict__ flags, const CellAddr& ca) {
-    const uint32_t w = flags[ca.group_base + 4 * kWave + ca.t];
-    return (w >> ca.sh_c) & 1u;
+    return (flags[ca.idx_c] >> ca.sh_c) & 1u;
 }
 // state entered after a move of kind `moved` arrives at body cell (bi, bj)
 __device__ __forceinline__ int state_after(const uint32_t* __restrict__ flags, const PairDesc& pd, uint32_t bi,
@@ -307,6 +337,7 @@ struct BatchDeviceView {
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
 hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream);
+hipError_t launch_viterbi_k(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool independent, uint64_t* rng_states,
                              const uint64_t* sample_base, uint8_t* ops, uint64_t* ops_start, uint32_t* ops_len,
                              float* log_weights, hipStream_t stream);

@@ -38,7 +38,15 @@ def viterbi_compare(hip, oracle, table, consts, L, pairs, check_flags=True):
             want = oracle.tb_flags(M, D, I, consts)[L:, L:].copy()
             got_f = batch.debug_flags(p)
             want[-1, -1] = got_f[-1, -1]  # oracle's last cell is terminal-adjusted
-            assert (got_f == want).all(), (L, p, np.argwhere(got_f != want)[:5])
+            # gap_len 2 and 3 store the live cells only ((i - j) % L == 0; the others are `lowest` in the
+            # reference and can never be on a path): the kernel reports 0xff for the rest
+            live = got_f != 0xFF
+            if L in (2, 3) and "COATI_HIP_FORCE_GENERIC" not in os.environ:
+                ii, jj = np.meshgrid(np.arange(len(a)), np.arange(len(b)), indexing="ij")
+                assert (live == ((ii - jj) % L == 0)).all()
+            else:
+                assert live.all()
+            assert (got_f[live] == want[live]).all(), (L, p, np.argwhere((got_f != want) & live)[:5])
     batch.close()
     model.close()
 

@@ -18,10 +18,16 @@ CHILD = r'''
 import sys, json, numpy as np
 sys.path.insert(0, %r)
 from coati_amd import hip, host
-pairs, rounds = %d, %d
+pairs, rounds, gap_len = %d, %d, %d
 table, consts = host.set_subst("mar-mg"), host.gap_consts()
-model = hip.Model(table, consts, 1)
-batch = hip.Batch(model, *host.synth_encoded(0, pairs))
+model = hip.Model(table, consts, gap_len)
+a_cat, a_off, b_cat, b_off = host.synth_encoded(0, pairs)
+if gap_len > 1:  # descendant lengths must be multiples of the gap unit: trim
+    lens = (np.diff(b_off) // gap_len * gap_len).astype(np.uint64)
+    keep = np.concatenate([np.arange(int(b_off[p]), int(b_off[p]) + int(lens[p])) for p in range(pairs)])
+    b_cat = b_cat[keep]
+    b_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
 fills, walks = [], []
 for r in range(rounds + 2):
     batch.viterbi_launch(); batch.sync()
@@ -35,11 +41,12 @@ print(json.dumps({"fill_med": float(np.median(fills)), "fill_min": float(np.min(
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=10000)
 ap.add_argument("--rounds", type=int, default=10)
+ap.add_argument("--gap-len", type=int, default=1)
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 for lib in args.libs:
     env = dict(os.environ, COATI_HIP_LIB=str(Path(lib).resolve()))
-    out = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), args.pairs, args.rounds)], env=env,
+    out = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), args.pairs, args.rounds, args.gap_len)], env=env,
                          capture_output=True, text=True)
     if out.returncode != 0:
         print(f"{lib}: FAILED\n{out.stderr[-2000:]}")
