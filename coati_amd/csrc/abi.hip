@@ -354,6 +354,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         PairDesc& d = b->desc[p];
         const uint64_t la = d.la;
         const uint32_t w_main_p = pair_w[p] != 0 ? std::min<uint32_t>(pair_w[p], w_main) : w_main;
+        uint32_t w_main_q = w_main_p;  // columns per lane of every strip but the last
         uint32_t ns = 1, wl = w_main_p;
         d.v_compact = 0;
         d.pad_ = 0;
@@ -362,16 +363,18 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         } else if(plan_k) {
             d.v_compact = static_cast<uint32_t>(L);
             const uint32_t cols_b = static_cast<uint32_t>(d.lb / L), narrow = L == 3 ? 6u : 8u;
+            w_main_q = L == 3 ? 12u : 16u;  // (viterbi_k.hip: kWMain)
+            wl = w_main_q;
             if(d.la > 0 && d.lb > 0) {
-                const uint32_t whole = cols_b / kStrip, rem = cols_b % kStrip;
+                const uint32_t full = kWave * w_main_q, whole = cols_b / full, rem = cols_b % full;
                 ns = whole + (rem != 0 ? 1u : 0u);
-                wl = (rem != 0 && rem <= kWave * narrow) ? narrow : static_cast<uint32_t>(kW);
+                if(rem != 0 && rem <= kWave * narrow) wl = narrow;
             }
         } else {
             ns = std::max(1u, n_strips(d.lb));
         }
         d.v_strips = ns;
-        d.v_wmain = static_cast<uint8_t>(w_main_p);
+        d.v_wmain = static_cast<uint8_t>(w_main_q);
         d.v_wlast = static_cast<uint8_t>(wl);
         d.flags_off = b->flag_dwords;
         d.bnd_off = b->bnd_floats;

@@ -248,7 +248,9 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void viterbi_k(
     float* tab = tab_all[threadIdx.x / kWave];
     uint32_t tab_held = 0xffffffffu;
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
-    constexpr int kWNarrow = L == 3 ? 6 : 8;  // the narrow strip shape: 1 kb pairs fit one strip (334 / 501 block columns)
+    // strip shapes (block columns per lane): the main one is bounded by registers (L * W values of YL
+    // per lane), the narrow one makes a 1 kb pair one strip (334 / 501 block columns)
+    constexpr int kWMain = L == 3 ? 12 : 16, kWNarrow = L == 3 ? 6 : 8;
     for(;;) {
         int lane = lane_id;  // opaque per iteration (see viterbi_l1.hip)
         asm volatile("" : "+v"(lane));
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void viterbi_k(
             const uint8_t* __restrict__ a = a_cat + pd.a_off;
             const uint8_t* __restrict__ b = b_cat + pd.b_off;
             const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-            if(w == 16)
-                ok = fill_strip_k<L, 16>(k, pd, pair, strip, ticket, lane, tab_bytes, a, b, flags, bnd, scores, progress);
+            if(w == kWMain)
+                ok = fill_strip_k<L, kWMain>(k, pd, pair, strip, ticket, lane, tab_bytes, a, b, flags, bnd, scores, progress);
             else
                 ok = fill_strip_k<L, kWNarrow>(k, pd, pair, strip, ticket, lane, tab_bytes, a, b, flags, bnd, scores, progress);
         }
