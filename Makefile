@@ -13,7 +13,7 @@ all: lib host oracle
 
 lib: $(BUILD)/libcoati_hip.so
 
-HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/viterbi_l1.hip coati_amd/csrc/dp_generic.hip coati_amd/csrc/forward_l1.hip coati_amd/csrc/viterbi_k.hip \
+HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/viterbi_l1.hip coati_amd/csrc/dp_generic.hip coati_amd/csrc/forward_l1.hip coati_amd/csrc/viterbi_k.hip coati_amd/csrc/forward_k.hip \
           coati_amd/csrc/sampleback.hip
 $(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)

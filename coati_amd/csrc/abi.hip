@@ -46,7 +46,8 @@ __global__ void decode_mdi(const PairDesc* __restrict__ pairs, uint32_t pair, co
     for(uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; idx < n;
         idx += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const uint32_t bi = idx / pd.lb, bj = idx % pd.lb;
-        for(int mat = 0; mat < 3; ++mat) out[mat * n + idx] = mdi[mdi_index(pd.mdi_off, pd.la, bi, bj, mat)];
+        for(int mat = 0; mat < 3; ++mat)
+            out[mat * n + idx] = mdi_stored(pd, bi, bj) ? mdi[mdi_index(pd, bi, bj, mat)] : kLowest;  // (not live: lowest)
     }
 }
 
@@ -303,7 +304,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.lb = static_cast<uint32_t>(lb);
         d.ops_off = b->ops_total;
         d.mdi_off = b->mdi_floats;
-        if(la > 0 && lb > 0) b->mdi_floats += n_strips(d.lb) * strip_mdi_floats(d.la);
+        // Forward M/D/I arena: gap_len 2, 3 store the live cells only (forward_k.hip)
+        const bool fwd_k = (L == 2 || L == 3) && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;
+        d.f_compact = fwd_k ? static_cast<uint32_t>(L) : 0u;
+        if(la > 0 && lb > 0)
+            b->mdi_floats += fwd_k ? fwd_compact_strips(d.lb, static_cast<uint32_t>(L)) * fwd_compact_strip_floats(d.la, static_cast<uint32_t>(L))
+                                   : n_strips(d.lb) * strip_mdi_floats(d.la);
         b->ops_total += la + lb;
         b->cells += la * lb;
     }
@@ -357,7 +363,6 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         uint32_t w_main_q = w_main_p;  // columns per lane of every strip but the last
         uint32_t ns = 1, wl = w_main_p;
         d.v_compact = 0;
-        d.pad_ = 0;
         if(plan_l1) {
             if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main_p, ns, wl);
         } else if(plan_k) {
@@ -387,7 +392,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         const uint64_t nf = n_strips(d.lb);
         const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
                                                   nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
-                                                  plan_k ? (ns - 1) * ((la / L + 1) + la) : 0});
+                                                  plan_k ? (ns - 1) * ((la / L + 1) + la) : 0,
+                                                  d.f_compact != 0 && d.lb > 0
+                                                      ? (fwd_compact_strips(d.lb, static_cast<uint32_t>(L)) - 1) * 3 * L * (la / L + 1)
+                                                      : 0});
         b->bnd_floats += (need + 31) / 32 * 32;
     }
 
@@ -422,7 +430,9 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         std::vector<WorkItem> items, fwd_items;
         for(const uint32_t p : order) {
             for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
-            const uint32_t nf = (b->desc[p].la > 0 && b->desc[p].lb > 0) ? n_strips(b->desc[p].lb) : 1u;
+            uint32_t nf = 1;
+            if(b->desc[p].la > 0 && b->desc[p].lb > 0)
+                nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact) : n_strips(b->desc[p].lb);
             for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
         }
         b->n_items = static_cast<uint32_t>(items.size());
@@ -559,6 +569,8 @@ int coati_hip_forward_launch(coati_hip_batch_t* b) {
         static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
         if(m->gap_len == 1 && !force_generic)
             HIP_TRY(launch_forward_l1(device_view(b), m->stream));
+        else if((m->gap_len == 2 || m->gap_len == 3) && !force_generic)
+            HIP_TRY(launch_forward_k(device_view(b), m->stream));
         else
             HIP_TRY(launch_dp_generic(device_view(b), /*forward=*/true, m->stream));
     }

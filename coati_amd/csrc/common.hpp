@@ -52,7 +52,9 @@ struct PairDesc {
     // 0: one stored cell per matrix cell (layout below).  L (2 or 3): "compact" layout of viterbi_k:
     // only the live cells (bi - bj) % L == 0 are stored; the plan counts BLOCK columns (lb / L).
     uint32_t v_compact;
-    uint32_t pad_;
+    // Forward M/D/I layout: 0 = every body cell, 1024-column strips (forward_l1 / dp_generic);
+    // L (2 or 3) = live cells only, forward_k's block-column strips (forward_k.hip)
+    uint32_t f_compact;
 };
 
 // HBM layout of the decision bits of one strip of one pair.  A strip is 64*W descendant
@@ -297,9 +299,44 @@ constexpr int kMdiStepFloats = 3 * kW * kWave;  // 3072
 __host__ __device__ inline uint64_t strip_mdi_floats(uint32_t la) {
     return static_cast<uint64_t>(la + kWave) * kMdiStepFloats;
 }
-__device__ __forceinline__ uint64_t mdi_index(uint64_t base, uint32_t la, uint32_t bi, uint32_t bj, int mat) {
+// Compact Forward layout (gap_len L = 2, 3; forward_k.hip): live cells (p*L + r, q*L + r) only.  A
+// lane owns Wf block columns (one shape per L), step k = p + lane:
+//   float[((k * L + r) * 3 + mat) * Wf + c) * 64 + lane]
+__host__ __device__ constexpr uint32_t fwd_compact_w(uint32_t L) { return L == 3 ? 6u : 8u; }
+__host__ __device__ inline uint64_t fwd_compact_strip_floats(uint32_t la, uint32_t L) {
+    return static_cast<uint64_t>(la / L + kWave - 1) * (3 * L * fwd_compact_w(L)) * kWave;
+}
+__host__ __device__ inline uint32_t fwd_compact_strips(uint32_t lb, uint32_t L) {
+    const uint32_t per = kWave * fwd_compact_w(L);
+    return (lb / L + per - 1) / per;
+}
+__device__ __forceinline__ uint64_t mdi_index(const PairDesc& pd, uint32_t bi, uint32_t bj, int mat) {
+    if(pd.f_compact != 0) {
+        const uint32_t L = pd.f_compact, wf = fwd_compact_w(L), per = kWave * wf;
+        const uint32_t q = bj / L, r = bi % L, p = bi / L;
+        const uint32_t strip = q / per, colin = q % per, t = colin / wf, c = colin % wf;
+        return pd.mdi_off + strip * fwd_compact_strip_floats(pd.la, L) +
+               ((static_cast<uint64_t>(p + t) * L + r) * 3 + mat) * wf * kWave + c * kWave + t;
+    }
     const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
-    return base + strip * strip_mdi_floats(la) + ((static_cast<uint64_t>(bi + t) * 3 + mat) * kW + c) * kWave + t;
+    return pd.mdi_off + strip * strip_mdi_floats(pd.la) + ((static_cast<uint64_t>(bi + t) * 3 + mat) * kW + c) * kWave + t;
+}
+// a live cell of the Forward layout?  (every cell when the layout is not compact)
+__device__ __forceinline__ bool mdi_stored(const PairDesc& pd, uint32_t bi, uint32_t bj) {
+    return pd.f_compact == 0 || (bi % pd.f_compact) == (bj % pd.f_compact);
+}
+
+// log-semiring plus (semiring.hpp:86-121, utils.hpp:134-156) with the hardware exp2/log2; see
+// forward_l1.hip for the derivation and the error bound.
+__device__ __forceinline__ float log_plus(float a, float b) {
+    constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+    const float hi = fmaxf(a, b);
+    const float t = -fabsf(a - b) * kLog2e;        // <= 0 (or -inf); abs/neg are source modifiers
+    const float e = __builtin_amdgcn_exp2f(t);     // v_exp_f32: exp(-|a-b|) in [0, 1]
+    const float u = 1.0f + e;
+    const float resid = e - (u - 1.0f);            // exact
+    const float l2 = __builtin_amdgcn_logf(u);     // v_log_f32: log2(u) in [0, 1]
+    return hi + __builtin_fmaf(l2, kLn2, resid);
 }
 
 // ---------------------------------------------------------------------------
@@ -338,6 +375,7 @@ hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
 hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_viterbi_k(const BatchDeviceView& v, hipStream_t stream);
+hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool independent, uint64_t* rng_states,
                              const uint64_t* sample_base, uint8_t* ops, uint64_t* ops_start, uint32_t* ops_len,
                              float* log_weights, hipStream_t stream);

@@ -28,17 +28,6 @@
 namespace coati_hip_detail {
 namespace {
 
-__device__ __forceinline__ float log_plus(float a, float b) {
-    constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
-    const float hi = fmaxf(a, b);
-    const float t = -fabsf(a - b) * kLog2e;        // <= 0 (or -inf); abs/neg are source modifiers
-    const float e = __builtin_amdgcn_exp2f(t);     // v_exp_f32: exp(-|a-b|) in [0, 1]
-    const float u = 1.0f + e;
-    const float resid = e - (u - 1.0f);            // exact
-    const float l2 = __builtin_amdgcn_logf(u);     // v_log_f32: log2(u) in [0, 1]
-    return hi + __builtin_fmaf(l2, kLn2, resid);
-}
-
 struct FwdLane {
     float M[kW], D[kW], I[kW];     // the lane's 16 columns of the row it processed last
     float oM, oD, oI;              // column 15 of the row before that: the right neighbour's diagonal

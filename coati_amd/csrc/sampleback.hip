@@ -42,15 +42,15 @@ struct Walker {
     const uint8_t* __restrict__ a;
     const uint8_t* __restrict__ b;
     const float* __restrict__ mdi;
-    const uint64_t mdi_off;
+    const PairDesc& pd;
 
     // M/D/I of MATRIX cell (i, j); the last cell carries the terminal adjustment
     // (the reference stores it adjusted, align_pair.cc:130-138).
     __device__ __forceinline__ void cell(uint32_t i, uint32_t j, float& m, float& d, float& in) const {
         if(i >= L && j >= L) {
-            m = mdi[mdi_index(mdi_off, la, i - L, j - L, 0)];
-            d = mdi[mdi_index(mdi_off, la, i - L, j - L, 1)];
-            in = mdi[mdi_index(mdi_off, la, i - L, j - L, 2)];
+            m = mdi[mdi_index(pd, i - L, j - L, 0)];
+            d = mdi[mdi_index(pd, i - L, j - L, 1)];
+            in = mdi[mdi_index(pd, i - L, j - L, 2)];
         } else {
             margin_mdi(k, L, i, j, m, d, in);
         }
@@ -63,9 +63,9 @@ struct Walker {
     // like cell() but never adjusted: the fill's inputs (a predecessor is never the last cell)
     __device__ __forceinline__ void pred(uint32_t i, uint32_t j, float& m, float& d, float& in) const {
         if(i >= L && j >= L) {
-            m = mdi[mdi_index(mdi_off, la, i - L, j - L, 0)];
-            d = mdi[mdi_index(mdi_off, la, i - L, j - L, 1)];
-            in = mdi[mdi_index(mdi_off, la, i - L, j - L, 2)];
+            m = mdi[mdi_index(pd, i - L, j - L, 0)];
+            d = mdi[mdi_index(pd, i - L, j - L, 1)];
+            in = mdi[mdi_index(pd, i - L, j - L, 2)];
         } else {
             margin_mdi(k, L, i, j, m, d, in);
         }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void sampleback_kernel(const float* __restrict_
     const uint32_t count = independent ? 1u : n_samples;
     const PairDesc pd = pairs[pair];
     const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
-                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
+                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd};
     Rng128 rng{rng_states[2 * walker], rng_states[2 * walker + 1]};
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;
     for(uint32_t n = first; n < first + count; ++n) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void spec_walk_kernel(const float* __restrict__
         if(off & 1u) st *= (static_cast<unsigned __int128>(mult_pow[2 * bit + 1]) << 64) | mult_pow[2 * bit];
     Rng128 rng{static_cast<uint64_t>(st), static_cast<uint64_t>(st >> 64)};
     const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
-                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd.mdi_off};
+                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd};
     float score;
     uint32_t draws;
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;
