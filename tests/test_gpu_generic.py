@@ -90,6 +90,18 @@ def test_generic_kernel_equals_l1_kernel():
     assert out.returncode == 0, out.stdout[-3000:]
 
 
+def test_generic_kernel_still_serves_gap_len_2_and_3():
+    """gap_len 2 and 3 normally run on viterbi_k / forward_k (live cells only).  Forced through
+    dp_generic (which fills every cell like the reference) the same tests must pass: two
+    independent implementations, one oracle."""
+    if os.environ.get("COATI_HIP_FORCE_GENERIC"):
+        pytest.skip("already inside the forced run")
+    env = dict(os.environ, COATI_HIP_FORCE_GENERIC="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", str(ROOT / "tests" / "test_gpu_generic.py"),
+                          "-k", "gap_unit_lengths or forward_matrices"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
 def rel_close(got, want, tol=1e-5):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     finite = want > -1e30
