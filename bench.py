@@ -180,7 +180,8 @@ def main():
     elapsed = time.perf_counter() - t0
     # per-kernel device times of the timed launches: HIP events the library recorded on its
     # own stream around each kernel (it keeps the last 64 launches)
-    timed = [bt.viterbi_timing(i) for _, bt in slots for i in range(min(args.steps // len(slots), 64))]
+    n_timed = max(1, min(args.steps // len(slots), 64))
+    timed = [bt.viterbi_timing(i) for _, bt in slots for i in range(n_timed)]
     fill_ms = [t[0] for t in timed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
