@@ -361,9 +361,10 @@ void marg_sample(alignment_t& aln, std::size_t sample_size, random_t& rand) {
     std::vector<uint64_t> off(sample_size);
     std::vector<uint32_t> len(sample_size);
     std::vector<float> lw(sample_size);
-    hip_check(coati_hip_sampleback(work.batch, static_cast<uint32_t>(sample_size), state_in, /*independent_streams=*/0,
-                                   lw.data(), ops.data(), sample_size * width, off.data(), len.data(), state_out));
-    rand.set_state(state_out[0], state_out[1]);
+    hip_check(coati_hip_sampleback(work.batch, static_cast<uint32_t>(sample_size), state_in,
+                                   aln.independent_streams ? 1 : 0, lw.data(), ops.data(), sample_size * width, off.data(),
+                                   len.data(), state_out));
+    if(!aln.independent_streams) rand.set_state(state_out[0], state_out[1]);
     for(std::size_t i = 0; i < sample_size; ++i) {
         aln.data.seqs.assign(2, std::string());
         ops_to_alignment(ops.data() + off[i], len[i], anc, des, aln.data.seqs[0], aln.data.seqs[1]);

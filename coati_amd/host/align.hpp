@@ -44,6 +44,9 @@ class alignment_t {
     AmbiguousNucs amb{AmbiguousNucs::SUM};
     MarginalSubst sub{MarginalSubst::SUM};
     int device{0};  // HIP device ordinal (not in the reference)
+    // coati-sample --independent-streams (not in the reference): every sample draws from its own
+    // jumped-ahead Lehmer stream; all walks run in parallel, sample 0 equals the reference's first
+    bool independent_streams{false};
 
     bool is_marginal() const { return model == "mar-mg" || model == "mar-ecm" || !rate.empty(); }
     std::string& seq(std::size_t i) { return data.seqs[i]; }

@@ -62,6 +62,8 @@ std::string usage(verb_t verb) {
              "  --batch                     Input holds 2n sequences: align consecutive pairs (JSON array out)\n";
     else
         u += "  -n,--sample-size UINT       Sample size\n"
+             "  --independent-streams       Every sample from its own jumped-ahead RNG stream (all walks in parallel;\n"
+             "                              sample 1 equals the default mode's, the rest are equivalent, not identical)\n"
              "  -s,--seed TEXT ...          Space separated list of seed(s) used for sampling\n";
     return u;
 }
@@ -133,6 +135,8 @@ args_t parse_arguments(verb_t verb, int argc, const char* const* argv) {
             aln.score = true;
         } else if(verb == verb_t::alignpair && a == "--batch") {
             args.batch = true;
+        } else if(verb == verb_t::sample && a == "--independent-streams") {
+            args.aln.independent_streams = true;
         } else if(verb == verb_t::sample && (a == "-n" || a == "--sample-size")) {
             const std::string v = need(i, a);
             char* end = nullptr;

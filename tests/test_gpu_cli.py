@@ -137,3 +137,20 @@ def test_align_leafs_per_leaf_branch_lengths(oracle):
         w_a, w_b = oracle.ops_to_strings(w_ops, ref, leaf)
         assert (aln_ref, aln_leaf) == (w_a, w_b)
         assert np.float32(score).view(np.uint32) == np.float32(w_sc).view(np.uint32)
+
+
+def test_sample_independent_streams_flag(tmp_path):
+    """coati-sample --independent-streams (build extension): first sample identical to the default
+    mode's first sample; all samples valid alignments of the input pair."""
+    fasta = tmp_path / "p.fasta"
+    fasta.write_text(">A\nCTCTGGATAGTGACGACG\n>B\nCTATAGTGACGAG\n")
+    outs = []
+    for extra in ([], ["--independent-streams"]):
+        r = subprocess.run([str(BIN / "coati-sample"), str(fasta), "-n", "6", "-s", "42"] + extra, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout))
+    assert outs[0][0] == outs[1][0]
+    for rec in outs[1]:
+        a, b = rec["alignment"]["A"], rec["alignment"]["B"]
+        assert len(a) == len(b) and a.replace("-", "") == "CTCTGGATAGTGACGACG" and b.replace("-", "") == "CTATAGTGACGAG"
