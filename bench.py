@@ -214,6 +214,30 @@ def main():
                 traffic = json.loads(tfile.read_text()).get("viterbi_l1_bytes_per_launch_10000_pairs")
             except Exception:
                 traffic = None
+        # Informational (never `value`): the same K steps alternating between two resident copies of the
+        # batch on two library streams, i.e. how a pipeline of batches runs -- the ragged end of one
+        # launch overlaps the start of the next.  Skipped when --streams 2 is the mode
+        # being measured anyway.
+        pipelined = None
+        if world == 1 and not multi and args.streams == 1:
+            m2 = hip.Model(table, consts, gap_len, device=local_rank)
+            b2 = hip.Batch(m2, a_cat, a_off, b_cat, b_off)
+            pp = [batch, b2]
+            for i in range(4):
+                pp[i % 2].viterbi_launch()
+            for bt in pp:
+                bt.sync()
+            tp = time.perf_counter()
+            for i in range(args.steps):
+                pp[i % 2].viterbi_launch()
+            for bt in pp:
+                bt.sync()
+            tp = time.perf_counter() - tp
+            pipelined = {"gcups": cells * args.steps / tp / 1e9, "ms_per_step": tp / args.steps * 1e3,
+                         "what": "K launches alternating between two resident copies of the batch on two streams "
+                                 "(bench.py --streams 2 measures this mode as `value`)"}
+            b2.close()
+            m2.close()
         # PCIe-inclusive rate of the one-shot ABI call (upload + kernels + download of ops/scores);
         # reported next to `value`, never as `value`
         e2e = 1e30
@@ -245,6 +269,7 @@ def main():
                          "kernel": "viterbi_l1", "algorithmic_bytes_per_launch": algo_bytes,
                          "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
                          "note": "the kernel is VALU-issue bound, not HBM bound: see DESIGN.md §4"},
+            "two_stream_pipeline": pipelined,
             "pcie_inclusive": {"gcups": cells / e2e / 1e9, "pairs_per_s": args.pairs / e2e, "ms": e2e * 1e3,
                                "what": "coati_hip_viterbi_batch on rank 0: H2D of the encoded batch + kernels + D2H of "
                                        "scores/ops, pageable host memory, one call"},
