@@ -356,6 +356,14 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // 16 block columns per lane and a narrow shape (6 for L = 3, 8 for L = 2) for the last strip
     const bool plan_k = (L == 2 || L == 3) && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;
     b->compact = plan_k;
+    uint32_t k_main = L == 3 ? 12u : 16u;  // (viterbi_k.hip: kWMain / kWNarrow)
+    const uint32_t k_narrow = L == 3 ? 6u : 8u;
+    if(plan_k) {  // few long pairs: the narrow shape everywhere puts more wavefronts on each pair
+        uint64_t items_main = 0;
+        for(uint64_t p = 0; p < n_pairs; ++p)
+            items_main += (b->desc[p].la > 0 && b->desc[p].lb > 0) ? (b->desc[p].lb / L + kWave * k_main - 1) / (kWave * k_main) : 1;
+        if(items_main < 1024) k_main = k_narrow;
+    }
     for(uint64_t p = 0; p < n_pairs; ++p) {
         PairDesc& d = b->desc[p];
         const uint64_t la = d.la;
@@ -367,8 +375,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main_p, ns, wl);
         } else if(plan_k) {
             d.v_compact = static_cast<uint32_t>(L);
-            const uint32_t cols_b = static_cast<uint32_t>(d.lb / L), narrow = L == 3 ? 6u : 8u;
-            w_main_q = L == 3 ? 12u : 16u;  // (viterbi_k.hip: kWMain)
+            const uint32_t cols_b = static_cast<uint32_t>(d.lb / L), narrow = k_narrow;
+            w_main_q = k_main;
             wl = w_main_q;
             if(d.la > 0 && d.lb > 0) {
                 const uint32_t full = kWave * w_main_q, whole = cols_b / full, rem = cols_b % full;
