@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=10000, help="pairs per GPU per step")
     ap.add_argument("--model", default="mar-mg", choices=["mar-mg", "mar-ecm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational two_stream_pipeline and pcie_inclusive measurements (their extra "
+                         "launches would be mixed into a rocprofv3 --stats summary of this command)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: consecutive steps alternate between two resident copies of the shard on two library "
                          "streams, so the ragged end of one launch overlaps the start of the next (DESIGN.md 4.1)")
@@ -219,7 +222,7 @@ def main():
         # launch overlaps the start of the next.  Skipped when --streams 2 is the mode
         # being measured anyway.
         pipelined = None
-        if world == 1 and not multi and args.streams == 1:
+        if world == 1 and not multi and args.streams == 1 and not args.no_extras:
             m2 = hip.Model(table, consts, gap_len, device=local_rank)
             b2 = hip.Batch(m2, a_cat, a_off, b_cat, b_off)
             pp = [batch, b2]
@@ -241,7 +244,7 @@ def main():
         # PCIe-inclusive rate of the one-shot ABI call (upload + kernels + download of ops/scores);
         # reported next to `value`, never as `value`
         e2e = 1e30
-        for _ in range(2):
+        for _ in range(0 if args.no_extras else 2):
             t0 = time.perf_counter()
             model.viterbi(a_cat, a_off, b_cat, b_off)
             e2e = min(e2e, time.perf_counter() - t0)
@@ -270,9 +273,10 @@ def main():
                          "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
                          "note": "the kernel is VALU-issue bound, not HBM bound: see DESIGN.md §4"},
             "two_stream_pipeline": pipelined,
-            "pcie_inclusive": {"gcups": cells / e2e / 1e9, "pairs_per_s": args.pairs / e2e, "ms": e2e * 1e3,
-                               "what": "coati_hip_viterbi_batch on rank 0: H2D of the encoded batch + kernels + D2H of "
-                                       "scores/ops, pageable host memory, one call"},
+            "pcie_inclusive": None if args.no_extras else {
+                "gcups": cells / e2e / 1e9, "pairs_per_s": args.pairs / e2e, "ms": e2e * 1e3,
+                "what": "coati_hip_viterbi_batch on rank 0: H2D of the encoded batch + kernels + D2H of scores/ops, "
+                        "pageable host memory, one call"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)

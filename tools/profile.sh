@@ -10,9 +10,9 @@ OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.stderr"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extras "$@" > "$OUT/bench.json" 2> "$OUT/bench.stderr"
 for C in WRITE_SIZE FETCH_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o bench -- \
-        python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench_pmc_$C.json" 2> "$OUT/bench_pmc_$C.stderr"
+        python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_pmc_$C.json" 2> "$OUT/bench_pmc_$C.stderr"
 done
 python3 "$ROOT/tools/summarize_profile.py" "$OUT"
