@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign beyond the committed tests: random batches (lengths 0..~3000, related /
+unrelated / low-complexity pairs, ambiguity codes, coarse "tie" tables, several tables per batch),
+gap_len 1..4, Viterbi bit-exact against the oracle and Forward final cells within 1e-5.
+usage: fuzz.py [seconds] [seed]"""
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from coati_amd import hip
+from oracle import pyoracle as orc
+from tests import util
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+consts_default = orc.gap_consts()
+t_end = time.time() + budget
+rounds = pairs_checked = 0
+while time.time() < t_end:
+    L = int(rng.choice([1, 1, 1, 2, 3, 3, 4]))
+    n_tables = int(rng.integers(1, 4))
+    tables = np.stack([util.tie_table() if rng.random() < 0.3 else util.random_table(rng) for _ in range(n_tables)])
+    g = float(rng.choice([0.001, 0.01, 0.05]))
+    e = float(rng.choice([5 / 6, 0.5, 0.9]))
+    consts = orc.gap_consts(g, e)
+    n = int(rng.integers(1, 40))
+    max_cod = int(rng.choice([20, 120, 400, 1000]))
+    pairs = util.make_pairs(rng, n, 0 if rng.random() < 0.2 else 1, max_cod, L=L, amb=0.03)
+    if rng.random() < 0.3:  # a pair around the strip boundaries
+        nb = int(rng.choice([1020, 1024, 1030, 2050, 3075])) // L * L
+        unit = 3 * L if L % 3 else L
+        anc = util.random_anc(rng, max(unit // 3, (nb // 3) // (unit // 3) * (unit // 3)))
+        pairs.append((anc, "".join(rng.choice(list(util.NT), nb))))
+    enc = util.encode_pairs(pairs)
+    tix = rng.integers(0, n_tables, len(enc)).astype(np.uint32)
+    model = hip.Model(tables, consts, L)
+    batch = hip.Batch(model, *hip.pack_pairs(enc), table_index=tix)
+    batch.viterbi_launch()
+    scores, ops, off, ln = batch.viterbi_fetch()
+    batch.forward_launch()
+    final = batch.forward_final()
+    for p, (a, b) in enumerate(enc):
+        w_ops, w_sc = orc.viterbi(tables[tix[p]], consts, L, a, b, lowmem=len(a) * len(b) > 4_000_000)
+        got = ops[int(off[p]):int(off[p]) + int(ln[p])]
+        ok = len(got) == len(w_ops) and (got == w_ops).all() and np.float32(scores[p]).view(np.uint32) == np.float32(w_sc).view(np.uint32)
+        if ok and len(a) * len(b) <= 2_000_000:
+            M, D, I = orc.fill(orc.LOG, tables[tix[p]], consts, L, a, b)
+            want = np.array([M[-1, -1], D[-1, -1], I[-1, -1]], np.float64)
+            fin = want > -1e30
+            ok = bool((np.abs(final[p][fin] - want[fin]) <= 1e-5 * np.maximum(1.0, np.abs(want[fin]))).all() and (final[p][~fin] < -1e30).all())
+        if not ok:
+            print("MISMATCH", dict(seed=seed, round=rounds, L=L, pair=p, la=len(a), lb=len(b), g=g, e=e))
+            sys.exit(1)
+        pairs_checked += 1
+    batch.close(); model.close()
+    rounds += 1
+print(f"fuzz ok: {rounds} batches, {pairs_checked} pairs, seed {seed}")
