@@ -117,6 +117,7 @@ struct coati_hip_batch {
     float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward
     bool forward_done = false;
     bool compact = false;  // Viterbi plan is the live-cell layout of viterbi_k (gap_len 2, 3)
+    bool compact_narrow_only = false;  // ... and every strip has the narrow shape
     uint64_t* d_ops_start = nullptr;
     uint32_t* d_ops_len = nullptr;
     static constexpr int kTimingRing = 64;  // launches whose kernel times can still be read back
@@ -364,6 +365,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             items_main += (b->desc[p].la > 0 && b->desc[p].lb > 0) ? (b->desc[p].lb / L + kWave * k_main - 1) / (kWave * k_main) : 1;
         if(items_main < 1024) k_main = k_narrow;
     }
+    bool all_narrow = plan_k;
     for(uint64_t p = 0; p < n_pairs; ++p) {
         PairDesc& d = b->desc[p];
         const uint64_t la = d.la;
@@ -389,6 +391,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.v_strips = ns;
         d.v_wmain = static_cast<uint8_t>(w_main_q);
         d.v_wlast = static_cast<uint8_t>(wl);
+        if(plan_k && d.la > 0 && d.lb > 0 && (wl != k_narrow || (ns > 1 && w_main_q != k_narrow))) all_narrow = false;
         d.flags_off = b->flag_dwords;
         d.bnd_off = b->bnd_floats;
         if(d.la > 0 && d.lb > 0)
@@ -406,6 +409,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                                                       : 0});
         b->bnd_floats += (need + 31) / 32 * 32;
     }
+    b->compact_narrow_only = plan_k && all_narrow;
 
     if(hipSetDevice(model->device) != hipSuccess)
         return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice failed"));
@@ -479,7 +483,7 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
         if(m->gap_len == 1 && !force_generic)
             HIP_TRY(launch_viterbi_l1(v, m->stream));
         else if(b->compact)
-            HIP_TRY(launch_viterbi_k(v, m->stream));
+            HIP_TRY(launch_viterbi_k(v, b->compact_narrow_only, m->stream));
         else
             HIP_TRY(launch_dp_generic(v, /*forward=*/false, m->stream));
     }

@@ -374,7 +374,7 @@ struct BatchDeviceView {
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
 hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream);
-hipError_t launch_viterbi_k(const BatchDeviceView& v, hipStream_t stream);
+hipError_t launch_viterbi_k(const BatchDeviceView& v, bool narrow_only, hipStream_t stream);
 hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool independent, uint64_t* rng_states,
                              const uint64_t* sample_base, uint8_t* ops, uint64_t* ops_start, uint32_t* ops_len,

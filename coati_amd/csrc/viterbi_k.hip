@@ -236,8 +236,10 @@ __device__ __forceinline__ bool fill_strip_k(const GapConsts& k, const PairDesc&
     return ok;
 }
 
-template <int L>
-__global__ __launch_bounds__(kFillWaves* kWave, 2) void viterbi_k(
+// kNarrowOnly: every strip of the batch has the narrow shape (the common case: descendants up to
+// 1 152 / 1 024 nt) -- fewer registers, three wavefronts per SIMD.
+template <int L, bool kNarrowOnly>
+__global__ __launch_bounds__(kFillWaves* kWave, kNarrowOnly ? 3 : 2) void viterbi_k(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void viterbi_k(
             const uint8_t* __restrict__ a = a_cat + pd.a_off;
             const uint8_t* __restrict__ b = b_cat + pd.b_off;
             const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-            if(w == kWMain)
+            if(!kNarrowOnly && w == kWMain)
                 ok = fill_strip_k<L, kWMain>(k, pd, pair, strip, ticket, lane, tab_bytes, a, b, flags, bnd, scores, progress);
             else
                 ok = fill_strip_k<L, kWNarrow>(k, pd, pair, strip, ticket, lane, tab_bytes, a, b, flags, bnd, scores, progress);
@@ -288,22 +290,24 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void viterbi_k(
 
 }  // namespace
 
-hipError_t launch_viterbi_k(const BatchDeviceView& v, hipStream_t stream) {
+hipError_t launch_viterbi_k(const BatchDeviceView& v, bool narrow_only, hipStream_t stream) {
     if(v.gap_len != 2 && v.gap_len != 3) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
     if(e != hipSuccess) return e;
     e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);
     if(e != hipSuccess) return e;
-    // up to two workgroups (8 wavefronts) per CU, no more wavefronts than items
-    const uint32_t blocks = std::min<uint32_t>(512u, std::max<uint32_t>(1u, (v.n_items + kFillWaves - 1) / kFillWaves));
-    if(v.gap_len == 2)
-        hipLaunchKernelGGL(viterbi_k<2>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.items,
-                           v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops, v.ops_start,
-                           v.ops_len);
-    else
-        hipLaunchKernelGGL(viterbi_k<3>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.items,
-                           v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops, v.ops_start,
-                           v.ops_len);
+    // two (three for the narrow-only kernel) workgroups per CU, no more wavefronts than items
+    const uint32_t blocks = std::min<uint32_t>(narrow_only ? 768u : 512u, std::max<uint32_t>(1u, (v.n_items + kFillWaves - 1) / kFillWaves));
+#define COATI_LAUNCH_K(LL, NN)                                                                                          \
+    hipLaunchKernelGGL((viterbi_k<LL, NN>), dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,   \
+                       v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops,      \
+                       v.ops_start, v.ops_len)
+    if(v.gap_len == 2) {
+        if(narrow_only) COATI_LAUNCH_K(2, true); else COATI_LAUNCH_K(2, false);
+    } else {
+        if(narrow_only) COATI_LAUNCH_K(3, true); else COATI_LAUNCH_K(3, false);
+    }
+#undef COATI_LAUNCH_K
     return hipGetLastError();
 }
 
