@@ -26,12 +26,12 @@ $(BUILD)/libcoati_hip_trace.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coa
 	$(HIPCC) $(HIPFLAGS) -DCOATI_FILL_TRACE -shared -o $@ $(HIP_SRC)
 
 HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc coati_amd/host/io.cc \
-           coati_amd/host/align.cc coati_amd/host/cli.cc coati_amd/host/format.cc coati_amd/host/capi.cc
+           coati_amd/host/align.cc coati_amd/host/cli.cc coati_amd/host/format.cc coati_amd/host/tree.cc coati_amd/host/insertions.cc coati_amd/host/msa.cc coati_amd/host/capi.cc
 HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc
 CXX      ?= g++
 HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -Icoati_amd/host
 
-host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample $(BUILD)/coati-format
+host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample $(BUILD)/coati-format $(BUILD)/coati-msa
 
 # the host layer calls the DP through the C ABI of libcoati_hip.so only
 $(BUILD)/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so

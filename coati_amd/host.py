@@ -206,3 +206,30 @@ def align_leafs(ref_seq: str, leaves, br_lens, model="mar-mg", omega=0.2, gap_op
         b = C.string_at(C.addressof(buf) + (2 * p + 1) * slot).decode()
         out.append((a, b, float(scores[p])))
     return out
+
+
+def newick(text: str, reroot: str = ""):
+    """[(index, label, length, is_leaf, parent)] of the parsed (optionally re-rooted) guide tree."""
+    buf = C.create_string_buffer(1 << 20)
+    _check(load().coati_host_newick(text.encode(), reroot.encode(), buf, C.c_ulonglong(len(buf))))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        i, label, length, leaf, parent = line.split("\t")
+        rows.append((int(i), label, float(length), leaf == "1", int(parent)))
+    return rows
+
+
+def tree_distance(text: str, ref: str, node: str, reroot: bool = False) -> float:
+    out = C.c_float()
+    _check(load().coati_host_tree_distance(text.encode(), ref.encode(), node.encode(), int(reroot), C.byref(out)))
+    return float(out.value)
+
+
+def merge_indels(sets):
+    """sets: [(names, seqs, flag_length, {pos: flag})].  Returns (names, seqs, {pos: flag})."""
+    spec = "\n".join(f"{','.join(n)};{','.join(s)};{cap};{','.join(f'{k}={v}' for k, v in sorted(fl.items()))}"
+                     for n, s, cap, fl in sets)
+    buf = C.create_string_buffer(1 << 20)
+    _check(load().coati_host_merge_indels(spec.encode(), buf, C.c_ulonglong(len(buf))))
+    names, seqs, flags = buf.value.decode().split(";")
+    return names.split(","), seqs.split(","), {int(kv.split("=")[0]): int(kv.split("=")[1]) for kv in flags.split(",") if kv}

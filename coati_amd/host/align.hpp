@@ -34,6 +34,7 @@ class alignment_t {
     float omega{0.2};      // NOLINT
     std::array<float, 4> pi{0.308, 0.185, 0.199, 0.308};  // NOLINT
     std::string refs;
+    std::string tree;  // msa: path of the Newick guide tree
     bool rev{false};
     std::string rate;  // --sub: CSV rate matrix
     gap_t gap;
@@ -97,6 +98,12 @@ bool marg_alignment_batch(alignment_t& aln);
 // (the reference's loop does not trim stop codons either).
 std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, const std::vector<std::string>& leaf_seqs,
                                 const std::vector<float>& br_lens);
+
+// `coati msa` (ref_indel_alignment, src/lib/align_msa.cc:45-120): every leaf of the guide tree is
+// aligned to the reference (one batched GPU launch, align_leafs), then the pairwise alignments are
+// merged up the tree re-rooted at the reference's parent (merge_alignments, align_msa.cc:337-374;
+// insertions.hpp).  Reads input.data.path and input.tree, writes input.output.
+bool ref_indel_alignment(alignment_t& input);
 
 }  // namespace coati_amd
 #endif

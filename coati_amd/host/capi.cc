@@ -8,6 +8,8 @@
 #include <string>
 
 #include "align.hpp"
+#include "insertions.hpp"
+#include "tree.hpp"
 #include "io.hpp"
 #include "model.hpp"
 #include "random.hpp"
@@ -288,6 +290,82 @@ int coati_host_align_leafs(const char* model, float omega, float gap_open, float
             std::strcpy(out + (2ull * p + 1) * slot, res[p].seqs[1].c_str());
             scores[p] = res[p].score;
         }
+    });
+}
+
+// ---- msa host pieces, for the unit tests (text in, text out) ---------------------------------
+// Parsed (optionally re-rooted at reroot_label's parent) guide tree, one node per line:
+//   index <TAB> label <TAB> length <TAB> is_leaf <TAB> parent
+int coati_host_newick(const char* text, const char* reroot_label, char* out, unsigned long long cap) {
+    return guarded([&] {
+        std::string content(text);
+        coati_amd::tree::tree_t tree = coati_amd::tree::parse_newick(content);
+        if(reroot_label != nullptr && reroot_label[0] != '\0') coati_amd::tree::reroot(tree, reroot_label);
+        std::string res;
+        for(std::size_t i = 0; i < tree.size(); ++i) {
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "%.9g", static_cast<double>(tree[i].length));
+            res += std::to_string(i) + "\t" + tree[i].label + "\t" + buf + "\t" + (tree[i].is_leaf ? "1" : "0") + "\t" +
+                   std::to_string(tree[i].parent) + "\n";
+        }
+        if(res.size() + 1 > cap) throw std::invalid_argument("newick: output buffer too small");
+        std::memcpy(out, res.c_str(), res.size() + 1);
+    });
+}
+
+int coati_host_tree_distance(const char* text, const char* ref_label, const char* node_label, int do_reroot, float* out) {
+    return guarded([&] {
+        std::string content(text);
+        coati_amd::tree::tree_t tree = coati_amd::tree::parse_newick(content);
+        if(do_reroot) coati_amd::tree::reroot(tree, ref_label);
+        *out = coati_amd::tree::distance_ref(tree, coati_amd::tree::find_node(tree, ref_label),
+                                             coati_amd::tree::find_node(tree, node_label));
+    });
+}
+
+// merge_indels on sets given one per line as  names;seqs;flag_length;pos=flag,pos=flag,...
+// (names and seqs comma separated).  Output: one line in the same format (flag_length omitted).
+int coati_host_merge_indels(const char* spec, char* out, unsigned long long cap) {
+    return guarded([&] {
+        auto split = [](const std::string& s, char sep) {
+            std::vector<std::string> parts;
+            std::size_t from = 0;
+            for(;;) {
+                const std::size_t at = s.find(sep, from);
+                parts.push_back(s.substr(from, at == std::string::npos ? std::string::npos : at - from));
+                if(at == std::string::npos) break;
+                from = at + 1;
+            }
+            return parts;
+        };
+        coati_amd::insertion_vector sets;
+        for(const std::string& line : split(spec, '\n')) {
+            if(line.empty()) continue;
+            const auto f = split(line, ';');
+            if(f.size() != 4) throw std::invalid_argument("merge_indels: bad set line");
+            coati_amd::flag_vector flags(static_cast<std::size_t>(std::stoul(f[2])), 0);
+            if(!f[3].empty())
+                for(const std::string& kv : split(f[3], ',')) {
+                    const auto pv = split(kv, '=');
+                    flags.at(std::stoul(pv.at(0))) = std::stoi(pv.at(1));
+                }
+            sets.emplace_back(split(f[1], ','), split(f[0], ','), flags);
+        }
+        coati_amd::insertion_data_t merged;
+        coati_amd::merge_indels(sets, merged);
+        std::string res;
+        for(std::size_t i = 0; i < merged.names.size(); ++i) res += (i ? "," : "") + merged.names[i];
+        res += ";";
+        for(std::size_t i = 0; i < merged.sequences.size(); ++i) res += (i ? "," : "") + merged.sequences[i];
+        res += ";";
+        bool first = true;
+        for(std::size_t i = 0; i < merged.insertions.size(); ++i)
+            if(merged.insertions[i] != 0) {
+                res += (first ? "" : ",") + std::to_string(i) + "=" + std::to_string(merged.insertions[i]);
+                first = false;
+            }
+        if(res.size() + 1 > cap) throw std::invalid_argument("merge_indels: output buffer too small");
+        std::memcpy(out, res.c_str(), res.size() + 1);
     });
 }
 

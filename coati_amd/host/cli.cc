@@ -1,6 +1,7 @@
 #include "cli.hpp"
 
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -37,6 +38,22 @@ std::string upper(std::string s) {
 }  // namespace
 
 std::string usage(verb_t verb) {
+    if(verb == verb_t::msa)
+        return "coati msa - multiple sequence alignment of nucleotide sequences\n"
+               "Usage: coati-msa [OPTIONS] input tree reference\n"
+               "  input                       Input file (FASTA/PHYLIP/JSON accepted)\n"
+               "  tree                        Newick phylogenetic tree\n"
+               "  reference                   Name of reference sequence\n"
+               "  -m,--model TEXT             Substitution model (mar-mg mar-ecm)\n"
+               "  -o,--output TEXT            Alignment output file\n"
+               "  -g,--gap-open FLOAT         Gap opening score\n"
+               "  -e,--gap-extend FLOAT       Gap extension score\n"
+               "  -w,--omega FLOAT            Nonsynonymous-synonymous bias\n"
+               "  -p,--pi FLOAT x 4           Nucleotide frequencies (A C G T)\n"
+               "  -k,--gap-len UINT           Gap unit length\n"
+               "  -x,--sigma FLOAT x 6        GTR sigma parameters (AC AG AT CG CT GT)\n"
+               "  -a,--ambiguous SUM|BEST     Ambiguous nucleotides model\n"
+               "  --device INT                HIP device ordinal (default 0)\n";
     std::string u = verb == verb_t::alignpair ? "coati alignpair - pairwise alignment of nucleotide sequences\n"
                                                 "Usage: coati-alignpair [OPTIONS] input\n"
                                               : "coati sample - align two sequences and sample alignments\n"
@@ -72,6 +89,7 @@ args_t parse_arguments(verb_t verb, int argc, const char* const* argv) {
     args_t args;
     alignment_t& aln = args.aln;
     bool have_input = false, have_model = false, have_ref = false, seeds_given = false;
+    int msa_positionals = 0;  // msa: input, tree, reference
     auto need = [&](int& i, const std::string& flag) -> std::string {
         if(i + 1 >= argc) throw std::invalid_argument(flag + ": 1 required TEXT missing");
         return argv[++i];
@@ -153,12 +171,27 @@ args_t parse_arguments(verb_t verb, int argc, const char* const* argv) {
         } else if(!have_input) {
             aln.data.path = a;
             have_input = true;
+            msa_positionals = 1;
+        } else if(verb == verb_t::msa && msa_positionals == 1) {
+            aln.tree = a;
+            msa_positionals = 2;
+        } else if(verb == verb_t::msa && msa_positionals == 2) {
+            aln.refs = a;
+            msa_positionals = 3;
         } else {
             throw std::invalid_argument("The following argument was not expected: " + a);
         }
     }
     if(args.help) return args;
     if(!have_input) throw std::invalid_argument("input is required");
+    if(verb == verb_t::msa) {
+        if(msa_positionals < 2) throw std::invalid_argument("tree is required");
+        if(msa_positionals < 3) throw std::invalid_argument("reference is required");
+        if(FILE* f = std::fopen(aln.tree.c_str(), "r"))
+            std::fclose(f);
+        else
+            throw std::invalid_argument("tree: File does not exist: " + aln.tree);  // CLI::ExistingFile
+    }
     if(have_model && !aln.rate.empty()) throw std::invalid_argument("--sub excludes --model");
     if(have_ref && aln.rev) throw std::invalid_argument("--rev-ref excludes --ref");
     return args;

@@ -1,5 +1,5 @@
-// Command-line surface of `coati alignpair` / `coati sample`
-// (set_options_alignpair / set_options_sample, src/lib/utils.cc:93-161,328-380):
+// Command-line surface of `coati alignpair` / `coati sample` / `coati msa`
+// (set_options_alignpair / set_options_sample / set_options_msa, src/lib/utils.cc:93-161,224-268,328-380):
 // same flags, defaults and value checks, parsed by a small hand-written parser
 // (the reference uses the vendored CLI11).
 #ifndef COATI_AMD_HOST_CLI_HPP
@@ -20,7 +20,7 @@ struct args_t {
     bool help{false};
 };
 
-enum class verb_t { alignpair, sample };
+enum class verb_t { alignpair, sample, msa };
 
 // Throws std::invalid_argument with a CLI-style message on bad usage.
 args_t parse_arguments(verb_t verb, int argc, const char* const* argv);

@@ -154,3 +154,43 @@ def test_sample_independent_streams_flag(tmp_path):
     for rec in outs[1]:
         a, b = rec["alignment"]["A"], rec["alignment"]["B"]
         assert len(a) == len(b) and a.replace("-", "") == "CTCTGGATAGTGACGACG" and b.replace("-", "") == "CTATAGTGACGAG"
+
+
+MSA_SEQS = ">A\nTCATCG\n>B\nTCAGTCG\n>C\nTATCG\n>D\nTCACTCG\n>E\nTCATC\n"
+MSA_WANT = {"A": "TCA--TCG", "B": "TCA-GTCG", "C": "T-A--TCG", "D": "TCAC-TCG", "E": "TCA--TC-"}
+
+
+def run_msa(tmp_path, fasta, newick, ref, extra=()):
+    (tmp_path / "in.fasta").write_text(fasta)
+    (tmp_path / "tree.newick").write_text(newick)
+    out = tmp_path / "msa.fasta"
+    r = subprocess.run([str(BIN / "coati-msa"), str(tmp_path / "in.fasta"), str(tmp_path / "tree.newick"), ref, "-o", str(out),
+                        *extra], capture_output=True, text=True, timeout=300)
+    return r, out
+
+
+@pytest.mark.parametrize("model", ["mar-mg", "mar-ecm"])
+def test_msa_known_answer(tmp_path, model):
+    """ref_indel_alignment doctests (align_msa.cc:135-195): 5 leaves, ladder tree."""
+    r, out = run_msa(tmp_path, MSA_SEQS, "((((A:0.1,B:0.1):0.1,C:0.1):0.1,D:0.1):0.1,E:0.1);", "A", ["-m", model])
+    assert r.returncode == 0, r.stderr
+    toks = out.read_text().split()
+    assert dict(zip([t[1:] for t in toks[0::2]], toks[1::2])) == MSA_WANT
+    assert [t[1:] for t in toks[0::2]] == ["A", "B", "C", "D", "E"]  # input order
+
+
+def test_msa_more_complex_tree(tmp_path):
+    """align_msa.cc:217-258"""
+    r, out = run_msa(tmp_path, MSA_SEQS + ">F\nTCATCG", "((A:0.1,B:0.1):0.1,(C:0.1,(D:0.1,E:0.1):0.1):0.1,F:0.1);\n", "A")
+    assert r.returncode == 0, r.stderr
+    toks = out.read_text().split()
+    assert dict(zip([t[1:] for t in toks[0::2]], toks[1::2])) == dict(MSA_WANT, F="TCA--TCG")
+
+
+def test_msa_errors(tmp_path):
+    r, _ = run_msa(tmp_path, ">A\nTCATCG\n>B\nTCAGTCG\n", "(A:0.1,B:0.1);\n", "A")
+    assert r.returncode != 0 and "At least three sequences required." in r.stderr  # align_msa.cc:197-215
+    r, _ = run_msa(tmp_path, MSA_SEQS, "((((A:0.1,B:0.1):0.1,C:0.1):0.1,D:0.1):0.1,E:0.1);", "A", ["-m", "tri-mg"])
+    assert r.returncode != 0 and "MSA only supports marginal models." in r.stderr  # align_msa.cc:260-265
+    r, _ = run_msa(tmp_path, MSA_SEQS, "((((A:0.1,B:0.1):0.1,C:0.1):0.1,D:0.1):0.1,E:0.1);", "Z")
+    assert r.returncode != 0 and "not found" in r.stderr
