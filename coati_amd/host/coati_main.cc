@@ -1,0 +1,57 @@
+// coati: the verb dispatcher (`coati alignpair ...` runs `coati-alignpair ...`), the reference's
+// git-style front end (src/coati.cc.in).  The verb executables are looked up next to this binary.
+// It never touches the GPU itself, so replacing the process image here is safe.
+#include <unistd.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+int main(int argc, char* argv[]) {
+    struct verb_t {
+        const char* name;
+        const char* what;
+        bool built;
+    };
+    static const verb_t verbs[] = {
+        {"help", "display this message", true},
+        {"version", "version information", true},
+        {"alignpair", "pairwise alignment of nucleotide sequences (marginal models, MI355X)", true},
+        {"msa", "multiple sequence alignment of nucleotide sequences (marginal models, MI355X)", true},
+        {"sample", "align two sequences and sample alignments (MI355X)", true},
+        {"format", "convert between formats, extract and/or reorder sequences", true},
+        {"genseed", "generate a random seed (not part of this build)", false},
+    };
+    const verb_t* chosen = nullptr;
+    if(argc >= 2)
+        for(const verb_t& v : verbs)
+            if(std::strcmp(argv[1], v.name) == 0) chosen = &v;
+    if(chosen == nullptr || std::strcmp(chosen->name, "help") == 0) {
+        std::cout << "Usage:   coati command [options]\n\nCommands available:\n";
+        for(const verb_t& v : verbs) std::cout << "    " << v.name << std::string(12 - std::strlen(v.name), ' ') << "- " << v.what << "\n";
+        return EXIT_SUCCESS;
+    }
+    if(std::strcmp(chosen->name, "version") == 0) {
+        std::cout << "coati (coati_amd: marginal pairwise path on MI355X)" << std::endl;
+        return EXIT_SUCCESS;
+    }
+    if(!chosen->built) {
+        std::cerr << "ERROR: the " << chosen->name << " verb is not part of this build." << std::endl;
+        return EXIT_FAILURE;
+    }
+    // directory of this executable
+    std::string self(4096, '\0');
+    const ssize_t n = ::readlink("/proc/self/exe", self.data(), self.size() - 1);
+    std::string dir = n > 0 ? std::string(self.data(), static_cast<std::size_t>(n)) : std::string(argv[0]);
+    const std::size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    std::string exe = dir + "/coati-" + chosen->name;
+    std::vector<char*> next{exe.data()};
+    for(int i = 2; i < argc; ++i) next.push_back(argv[i]);
+    next.push_back(nullptr);
+    ::execv(next[0], next.data());
+    std::cerr << "ERROR: command " << chosen->name << " failed: cannot run " << exe << std::endl;
+    return EXIT_FAILURE;
+}

@@ -85,3 +85,15 @@ def test_format_converts_to_json(tmp_path):
     assert r.returncode == 0, r.stderr
     doc = json.loads(out.read_text())
     assert doc["alignment"] == {"1": "CTCTGGATAGTG", "2": "CT----ATAGTG"}
+
+
+def test_dispatcher_runs_a_verb(tmp_path):
+    """`coati format ...` == `coati-format ...` (src/coati.cc.in)."""
+    src = tmp_path / "in.fasta"
+    src.write_text(">A\nA--GT\n>B\nACCGT\n")
+    out = tmp_path / "o.fa"
+    r = subprocess.run([str(BIN.parent / "coati"), "format", str(src), "-p", "-o", str(out)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert out.read_text().split() == [">A", "A--?GT", ">B", "ACC?GT"]
+    r = subprocess.run([str(BIN.parent / "coati")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "alignpair" in r.stdout and "msa" in r.stdout
