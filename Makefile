@@ -31,7 +31,7 @@ HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc
 CXX      ?= g++
 HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -Icoati_amd/host
 
-host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample $(BUILD)/coati-format $(BUILD)/coati-msa $(BUILD)/coati
+host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample $(BUILD)/coati-format $(BUILD)/coati-msa $(BUILD)/coati-genseed $(BUILD)/coati
 
 # the host layer calls the DP through the C ABI of libcoati_hip.so only
 $(BUILD)/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so

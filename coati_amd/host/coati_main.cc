@@ -22,7 +22,7 @@ int main(int argc, char* argv[]) {
         {"msa", "multiple sequence alignment of nucleotide sequences (marginal models, MI355X)", true},
         {"sample", "align two sequences and sample alignments (MI355X)", true},
         {"format", "convert between formats, extract and/or reorder sequences", true},
-        {"genseed", "generate a random seed (not part of this build)", false},
+        {"genseed", "generate a random seed", true},
     };
     const verb_t* chosen = nullptr;
     if(argc >= 2)

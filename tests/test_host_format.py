@@ -97,3 +97,30 @@ def test_dispatcher_runs_a_verb(tmp_path):
     assert out.read_text().split() == [">A", "A--?GT", ">B", "ACC?GT"]
     r = subprocess.run([str(BIN.parent / "coati")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "alignpair" in r.stdout and "msa" in r.stdout
+
+
+def test_genseed_encodes_the_seeded_state():
+    """coati-genseed (src/coati-genseed.cc): four base-58 words of the generator state after
+    Seed(string_seed_seq(args)) (random.hpp:416-441); the state itself is pinned bit for bit against
+    the reference by the RNG stream tests."""
+    from coati_amd import host
+
+    alphabet = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
+
+    def word(u):
+        w = [alphabet[0]] * 6
+        for i in range(6):
+            if u == 0:
+                break
+            w[5 - i] = alphabet[u % 58]
+            u //= 58
+        return "".join(w)
+
+    for seeds in (["42"], ["random42", "7"], [""]):
+        st = host.rng_seed(seeds)
+        lo, hi = int(st[0]), int(st[1])
+        want = "-".join(word(x) for x in (lo & 0xFFFFFFFF, lo >> 32, hi & 0xFFFFFFFF, hi >> 32))
+        r = subprocess.run([str(BIN.parent / "coati-genseed")] + seeds, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout.strip() == want
+    a = subprocess.run([str(BIN.parent / "coati-genseed")], capture_output=True, text=True, timeout=60).stdout.strip()
+    assert len(a) == 27 and a.count("-") == 3  # no arguments: machine entropy
