@@ -38,6 +38,18 @@ __global__ void decode_flags(const PairDesc* __restrict__ pairs, uint32_t pair,
 }
 
 
+// Debug: the libm restatements element-wise (glibc_math.hpp).
+__global__ void libm_kernel(int op, const float* __restrict__ in, uint64_t n, float* __restrict__ out) {
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
+    for(uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < n;
+        i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const float x = in[i];
+        out[i] = op == 0 ? libm::expf_nonpos(x, exp_tab) : (op == 1 ? libm::log1pf_unit(x) : libm::logf_pos(x));
+    }
+}
+
 // Debug: gather one pair's Forward M/D/I into three row-major la x lb matrices.
 __global__ void decode_mdi(const PairDesc* __restrict__ pairs, uint32_t pair, const float* __restrict__ mdi,
                            float* __restrict__ out) {
@@ -52,6 +64,16 @@ __global__ void decode_mdi(const PairDesc* __restrict__ pairs, uint32_t pair, co
 }
 
 }  // namespace
+
+namespace coati_hip_detail {
+bool forward_fast_math() {
+    static const bool fast = [] {
+        const char* e = std::getenv("COATI_HIP_FORWARD_FAST");
+        return e != nullptr && e[0] != '\0' && e[0] != '0';
+    }();
+    return fast;
+}
+}  // namespace coati_hip_detail
 
 namespace {
 
@@ -914,6 +936,26 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
     return COATI_HIP_OK;
 }
 }  // namespace
+
+int coati_hip_debug_libm(coati_hip_model_t* model, int op, const float* in, uint64_t n, float* out) {
+    if(model == nullptr || in == nullptr || out == nullptr) return fail(COATI_HIP_EINVAL, "debug_libm: NULL argument");
+    if(op < 0 || op > 2) return fail(COATI_HIP_EINVAL, "debug_libm: op %d unknown", op);
+    if(n == 0) return COATI_HIP_OK;
+    HIP_TRY(hipSetDevice(model->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), n * sizeof(float));
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(float));
+    if(e == hipSuccess) e = hipMemcpy(d_in, in, n * sizeof(float), hipMemcpyHostToDevice);
+    if(e == hipSuccess) {
+        hipLaunchKernelGGL(libm_kernel, dim3(2048), dim3(256), 0, model->stream, op, d_in, n, d_out);
+        e = hipStreamSynchronize(model->stream);
+    }
+    if(e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+    if(d_in != nullptr) (void)hipFree(d_in);
+    if(d_out != nullptr) (void)hipFree(d_out);
+    if(e != hipSuccess) return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "debug_libm: %s", hipGetErrorString(e));
+    return COATI_HIP_OK;
+}
 
 int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out) {
     if(model == nullptr || rng_state == nullptr || out == nullptr) return fail(COATI_HIP_EINVAL, "debug_rng_f24: NULL argument");

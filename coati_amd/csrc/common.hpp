@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "glibc_math.hpp"
+
 #include <cfloat>
 #include <cstdint>
 
@@ -326,8 +328,22 @@ __device__ __forceinline__ bool mdi_stored(const PairDesc& pd, uint32_t bi, uint
     return pd.f_compact == 0 || (bi % pd.f_compact) == (bj % pd.f_compact);
 }
 
-// log-semiring plus (semiring.hpp:86-121, utils.hpp:134-156) with the hardware exp2/log2; see
-// forward_l1.hip for the derivation and the error bound.
+// log-semiring plus = log_sum_exp (semiring.hpp:86-121, utils.hpp:134-156), BIT-EXACT: glibc's expf and
+// log1pf restated in glibc_math.hpp, the reference's branch at y <= -16 included.  `exp_tab` is the
+// 32-entry table of expf (kernels keep a copy in LDS, see load_exp_table).
+__device__ __forceinline__ float log_plus_exact(float a, float b, const uint64_t* exp_tab) {
+    const float hi = fmaxf(a, b);
+    const float y = -fabsf(a - b);
+    const float e = libm::expf_nonpos(y, exp_tab);
+    return hi + (y <= -16.0f ? e : libm::log1pf_unit(e));
+}
+__device__ __forceinline__ void load_exp_table(uint64_t* lds_tab, int tid) {
+    constexpr uint64_t kTab[32] = {COATI_EXP2F_TABLE};
+    if(tid < 32) lds_tab[tid] = kTab[tid];
+}
+
+// The same with the hardware exp2/log2 instead (opt-in, COATI_HIP_FORWARD_FAST=1: ~3x faster, not
+// bit-identical to the CPU); see forward_l1.hip for the derivation and the error bound.
 __device__ __forceinline__ float log_plus(float a, float b) {
     constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
     const float hi = fmaxf(a, b);
@@ -376,6 +392,9 @@ hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t
 hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_viterbi_k(const BatchDeviceView& v, bool narrow_only, hipStream_t stream);
 hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream);
+// COATI_HIP_FORWARD_FAST=1: Forward with the hardware exp2/log2 (fast, within 1e-5 of the CPU) instead
+// of the bit-exact libm restatements (read once).
+bool forward_fast_math();
 hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool independent, uint64_t* rng_states,
                              const uint64_t* sample_base, uint8_t* ops, uint64_t* ops_start, uint32_t* ops_len,
                              float* log_weights, hipStream_t stream);

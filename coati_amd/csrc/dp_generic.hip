@@ -24,16 +24,11 @@ namespace {
 constexpr int kMaxGapLen = 8;
 constexpr int kRowBufCols = kStrip + 16;
 
-// utils.hpp:134-156 (y = -|a-b| <= 0, so only the first two branches are reachable)
-__device__ __forceinline__ float log_sum_exp(float a, float b) {
-    const float hi = fmaxf(a, b);
-    const float y = -fabsf(a - b);
-    const float e = expf(y);
-    return hi + (y <= -16.0f ? e : log1pf(e));
-}
+// utils.hpp:134-156 (y = -|a-b| <= 0, so only the first two branches are reachable), bit-exact
+// (common.hpp: log_plus_exact)
 template <bool kLog>
-__device__ __forceinline__ float plus(float a, float b) {
-    if constexpr(kLog) return log_sum_exp(a, b);
+__device__ __forceinline__ float plus(float a, float b, const uint64_t* exp_tab) {
+    if constexpr(kLog) return log_plus_exact(a, b, exp_tab);
     return fmaxf(a, b);
 }
 
@@ -58,6 +53,9 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
     float* chunk = rowbuf + 2 * kRowBufCols;           // [64][3 + 2 * kMaxGapLen]
     constexpr int kChunkStride = 3 + 2 * kMaxGapLen;
     uint32_t tab_held = 0xffffffffu;  // which of the model's tables the LDS copy holds
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
     const int lane_id = threadIdx.x;
     const float ext_lm1 = k.ge * static_cast<float>(L - 1), ext_l = k.ge * static_cast<float>(L);  // power(), semiring.hpp:81
 
@@ -205,9 +203,9 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
                             const float d2d = upD + ext_l;
                             const float m2i = (lfM + k.go) + ext_lm1;
                             const float i2i = lfI + ext_l;
-                            const float M = plus<kLog>(plus<kLog>(m2m, d2m), i2m);
-                            const float D = plus<kLog>(plus<kLog>(m2d, d2d), i2d);
-                            const float I = plus<kLog>(m2i, i2i);
+                            const float M = plus<kLog>(plus<kLog>(m2m, d2m, exp_tab), i2m, exp_tab);
+                            const float D = plus<kLog>(plus<kLog>(m2d, d2d, exp_tab), i2d, exp_tab);
+                            const float I = plus<kLog>(m2i, i2i, exp_tab);
                             dgM = Mp[c];
                             dgD = Dp[c];
                             dgI = Ip[c];

@@ -9,7 +9,8 @@
 // order (align_pair.cc:97-119), e1 = ge*float(L-1), eL = ge*float(L):
 //   diagonal  = phase r-1 of the same block, or phase L-1 of block (p-1, q-1) for r = 0
 //   up        = phase r of block (p-1, q);   left = phase r of block (p, q-1)
-// `plus` is common.hpp: log_plus (hardware exp2/log2, < 1e-7 absolute per call).
+// `plus` is common.hpp: log_plus_exact (bit-exact libm restatements; COATI_HIP_FORWARD_FAST=1 selects the
+// hardware exp2/log2 version).
 // Output: fp32 M/D/I of every live cell (12 B per live cell = 12/L B per matrix cell; layout
 // common.hpp: mdi_index, "compact") and the terminal-adjusted last cell per pair.
 #include "common.hpp"
@@ -35,14 +36,21 @@ __device__ __forceinline__ bool wait_rows(const uint32_t* word, uint32_t need) {
     return true;
 }
 
-template <int L>
-__global__ __launch_bounds__(kFillWaves* kWave, 3) void forward_k(
+template <int L, bool kFast>
+__global__ __launch_bounds__(kFillWaves* kWave, kFast ? 3 : 2) void forward_k(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     float* __restrict__ bnd, float* __restrict__ mdi, float* __restrict__ final_mdi) {
     constexpr int W = fwd_compact_w(L);
     __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];  // one table per wavefront (see viterbi_l1.hip)
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
+    auto plus2 = [&](float x, float y) -> float {
+        if constexpr(kFast) return log_plus(x, y);
+        return log_plus_exact(x, y, exp_tab);
+    };
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[threadIdx.x / kWave];
     uint32_t tab_held = 0xffffffffu;
@@ -200,9 +208,9 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void forward_k(
                         const float d2d = upD + eL;
                         const float m2i = (lfM[r] + k.go) + e1;
                         const float i2i = lfI[r] + eL;
-                        const float M = log_plus(log_plus(m2m, d2m), i2m);
-                        const float D = log_plus(log_plus(m2d, d2d), i2d);
-                        const float I = log_plus(m2i, i2i);
+                        const float M = plus2(plus2(m2m, d2m), i2m);
+                        const float D = plus2(plus2(m2d, d2d), i2d);
+                        const float I = plus2(m2i, i2i);
                         P[r][0][c] = M;
                         P[r][1][c] = D;
                         P[r][2][c] = I;
@@ -258,12 +266,16 @@ hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream) {
     if(e != hipSuccess) return e;
     // up to three workgroups (12 wavefronts) per CU, no more wavefronts than items
     const uint32_t blocks = std::min<uint32_t>(768u, std::max<uint32_t>(1u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
-    if(v.gap_len == 2)
-        hipLaunchKernelGGL(forward_k<2>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.fwd_items,
-                           v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
-    else
-        hipLaunchKernelGGL(forward_k<3>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.fwd_items,
-                           v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+#define COATI_LAUNCH_FK(LL, FF)                                                                                        \
+    hipLaunchKernelGGL((forward_k<LL, FF>), dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,   \
+                       v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi)
+    const bool fast = forward_fast_math();
+    if(v.gap_len == 2) {
+        if(fast) COATI_LAUNCH_FK(2, true); else COATI_LAUNCH_FK(2, false);
+    } else {
+        if(fast) COATI_LAUNCH_FK(3, true); else COATI_LAUNCH_FK(3, false);
+    }
+#undef COATI_LAUNCH_FK
     return hipGetLastError();
 }
 

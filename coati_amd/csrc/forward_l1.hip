@@ -41,7 +41,14 @@ struct FwdCtx {
     float* mout;
     float* bnd_out;   // [la + 1][3]: M, D, I of this strip's last column; entry 0 = the margin row
     float* final_mdi;
+    const uint64_t* exp_tab;  // LDS copy of expf's table (glibc_math.hpp)
 };
+
+template <bool kFast>
+__device__ __forceinline__ float plus2(const FwdCtx& cx, float a, float b) {
+    if constexpr(kFast) return log_plus(a, b);
+    return log_plus_exact(a, b, cx.exp_tab);
+}
 
 __device__ __forceinline__ void store_through(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -49,7 +56,7 @@ __device__ __forceinline__ void store_through(float* p, float v) {
 
 // Up to 64 wavefront steps (see viterbi_l1.hip: run_chunk).  ch*: what lane 0 needs at step
 // kbase + l, held by lane l: diagonal cell (M, D, I) and left cell (M, I) of column col0 - 1.
-template <bool kFirst>
+template <bool kFirst, bool kFast>
 __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t kk, uint32_t a_chunk,
                                          float chDM, float chDD, float chDI, float chLM, float chLI,
@@ -103,9 +110,9 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
             const float d2d = upD + k.ge;
             const float m2i = lfM + k.go;
             const float i2i = lfI + k.ge;
-            const float M = log_plus(log_plus(m2m, d2m), i2m);
-            const float D = log_plus(log_plus(m2d, d2d), i2d);
-            const float I = log_plus(m2i, i2i);
+            const float M = plus2<kFast>(cx, plus2<kFast>(cx, m2m, d2m), i2m);
+            const float D = plus2<kFast>(cx, plus2<kFast>(cx, m2d, d2d), i2d);
+            const float I = plus2<kFast>(cx, m2i, i2i);
             dgM = upM;
             dgD = upD;
             dgI = upI;
@@ -143,7 +150,7 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
     }
 }
 
-template <bool kFirst>
+template <bool kFirst, bool kFast>
 __device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
                                           const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float chDM,
                                           float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
@@ -153,13 +160,13 @@ __device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_
         // instead of being copied (see viterbi_l1.hip: run_chunk)
         uint32_t kk = 0;
         for(; kk + 1 < kend; kk += 2) {
-            fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
-            fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
         }
-        if(kk < kend) fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+        if(kk < kend) fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     } else {
         for(uint32_t kk = 0; kk < kend; ++kk)
-            fwd_step<kFirst>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     }
 }
 
@@ -176,12 +183,16 @@ __device__ __forceinline__ bool wait_rows(const uint32_t* word, uint32_t need) {
     return true;
 }
 
+template <bool kFast>
 __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     float* __restrict__ bnd, float* __restrict__ mdi, float* __restrict__ final_mdi) {
     __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];  // one table per wavefront (see viterbi_l1.hip)
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[threadIdx.x / kWave];
     uint32_t tab_held = 0xffffffffu;
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
         }
         const FwdCtx cx{k, la, col0, nsteps, pair, lane,
                         static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
-                        last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats(la) + lane, bnd_out, final_mdi};
+                        last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats(la) + lane, bnd_out, final_mdi, exp_tab};
         FwdLane st;
 #pragma unroll
         for(int c = 0; c < kW; ++c) st.M[c] = st.D[c] = st.I[c] = kLowest;
@@ -268,9 +279,9 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
             }
             asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
             if(kbase == 0)
-                fwd_chunk<true>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+                fwd_chunk<true, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
             else
-                fwd_chunk<false>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+                fwd_chunk<false, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
             if(!last_strip) {
                 const uint32_t done = min(kbase + kWave, nsteps);
                 if(done > kWave - 1) publish(progress + ticket, min(la, done - (kWave - 1)), lane == kWave - 1);
@@ -290,8 +301,12 @@ hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream) {
     if(e != hipSuccess) return e;
     // two workgroups (8 wavefronts) per CU; fewer when there are fewer items than wavefronts
     const uint32_t blocks = std::min<uint32_t>(512u, std::max<uint32_t>(256u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
-    hipLaunchKernelGGL(forward_l1, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.fwd_items,
-                       v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+    if(forward_fast_math())
+        hipLaunchKernelGGL(forward_l1<true>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,
+                           v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+    else
+        hipLaunchKernelGGL(forward_l1<false>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,
+                           v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
     return hipGetLastError();
 }
 

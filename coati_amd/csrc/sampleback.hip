@@ -15,8 +15,8 @@
 //     starts from the pair's state advanced by n * 2^32 draws (host: jump-ahead),
 //     so sample 0 is the reference's first sample and the rest are statistically
 //     equivalent but not the same draws.
-// fp32 throughout; device expf/logf differ from glibc by ulps (log-weights agree
-// to ~1e-6 relative; tests allow the 1e-5 north_star states).
+// fp32 throughout; expf and logf are the bit-exact restatements of glibc_math.hpp, so with a bit-exact
+// Forward fill every draw, path and log-weight equals the CPU's.
 #include "common.hpp"
 
 namespace coati_hip_detail {
@@ -43,6 +43,7 @@ struct Walker {
     const uint8_t* __restrict__ b;
     const float* __restrict__ mdi;
     const PairDesc& pd;
+    const uint64_t* exp_tab;  // LDS copy of expf's table (glibc_math.hpp)
 
     // M/D/I of MATRIX cell (i, j); the last cell carries the terminal adjustment
     // (the reference stores it adjusted, align_pair.cc:130-138).
@@ -76,8 +77,8 @@ struct Walker {
 };
 
 // sample_mdi (align_pair.cc:336-358): returns the state, adds log(x) - log(scale) to score
-__device__ __forceinline__ int sample3(float lm, float ld, float li, float p, float& score) {
-    const float m = expf(lm), d = expf(ld), i = expf(li);
+__device__ __forceinline__ int sample3(float lm, float ld, float li, float p, float& score, const uint64_t* exp_tab) {
+    const float m = libm::expf_nonpos(lm, exp_tab), d = libm::expf_nonpos(ld, exp_tab), i = libm::expf_nonpos(li, exp_tab);
     const float scale = m + d + i;
     p *= scale;
     int st;
@@ -92,16 +93,16 @@ __device__ __forceinline__ int sample3(float lm, float ld, float li, float p, fl
         st = COATI_HIP_OP_INS;
         lx = li;
     }
-    score += lx - logf(scale);
+    score += lx - libm::logf_pos(scale);
     return st;
 }
 // sample_mi (align_pair.cc:370-385)
-__device__ __forceinline__ int sample2(float lm, float li, float p, float& score) {
-    const float m = expf(lm), i = expf(li);
+__device__ __forceinline__ int sample2(float lm, float li, float p, float& score, const uint64_t* exp_tab) {
+    const float m = libm::expf_nonpos(lm, exp_tab), i = libm::expf_nonpos(li, exp_tab);
     const float scale = m + i;
     p *= scale;
     const bool pick_m = p < m;
-    score += (pick_m ? lm : li) - logf(scale);
+    score += (pick_m ? lm : li) - libm::logf_pos(scale);
     return pick_m ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
 }
 
@@ -117,7 +118,7 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
     float m, d, in;
     w.cell(i, j, m, d, in);
     float top = fmaxf(fmaxf(m, d), in);
-    int st = sample3(m - top, d - top, in - top, rng_f24(rng), score);
+    int st = sample3(m - top, d - top, in - top, rng_f24(rng), score, w.exp_tab);
     while(j > L - 1 || i > L - 1) {
         ++draws;
         const bool body = i >= L && j >= L;
@@ -134,7 +135,7 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
                 dm = (pdd + w.k.gs) + s;
                 im = ((pi + w.k.gs) + w.k.ng) + s;
             }
-            st = sample3(mm - top, dm - top, im - top, rng_f24(rng), score);
+            st = sample3(mm - top, dm - top, im - top, rng_f24(rng), score, w.exp_tab);
             --i;
             --j;
         } else if(st == COATI_HIP_OP_DEL) {
@@ -155,7 +156,7 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
                 margin_mdi(w.k, L, i, j, mm0, dm0, im0);
                 dd = dm0;
             }
-            st = sample3(md - top, dd - top, id - top, rng_f24(rng), score);
+            st = sample3(md - top, dd - top, id - top, rng_f24(rng), score, w.exp_tab);
             i -= L;
         } else {
             for(uint32_t q = 0; q < L; ++q) ops[--pos] = COATI_HIP_OP_INS;
@@ -172,7 +173,7 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
                 margin_mdi(w.k, L, i, j, mm0, dm0, im0);
                 ii = im0;
             }
-            st = sample2(mi - top, ii - top, rng_f24(rng), score);
+            st = sample2(mi - top, ii - top, rng_f24(rng), score, w.exp_tab);
             j -= L;
         }
     }
@@ -188,6 +189,9 @@ __global__ __launch_bounds__(64) void sampleback_kernel(const float* __restrict_
                                                         const uint64_t* __restrict__ sample_base, uint8_t* __restrict__ ops,
                                                         uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len,
                                                         float* __restrict__ log_weights) {
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
     const uint64_t walker = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
     const uint64_t n_walkers = independent ? static_cast<uint64_t>(n_pairs) * n_samples : n_pairs;
     if(walker >= n_walkers) return;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(64) void sampleback_kernel(const float* __restrict_
     const uint32_t count = independent ? 1u : n_samples;
     const PairDesc pd = pairs[pair];
     const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
-                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd};
+                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd, exp_tab};
     Rng128 rng{rng_states[2 * walker], rng_states[2 * walker + 1]};
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;
     for(uint32_t n = first; n < first + count; ++n) {
@@ -232,6 +236,9 @@ __global__ __launch_bounds__(64) void spec_walk_kernel(const float* __restrict__
                                                        uint8_t* __restrict__ tmp_ops, uint64_t* __restrict__ c_start,
                                                        uint32_t* __restrict__ c_len, float* __restrict__ c_lw,
                                                        uint32_t* __restrict__ c_draws) {
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if(idx >= n_cands) return;
     const SpecCandidate cd = cands[idx];
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(64) void spec_walk_kernel(const float* __restrict__
         if(off & 1u) st *= (static_cast<unsigned __int128>(mult_pow[2 * bit + 1]) << 64) | mult_pow[2 * bit];
     Rng128 rng{static_cast<uint64_t>(st), static_cast<uint64_t>(st >> 64)};
     const Walker w{k, L, pd.la, pd.lb, k.ge * static_cast<float>(L - 1), k.ge * static_cast<float>(L),
-                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd};
+                   table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off, mdi, pd, exp_tab};
     float score;
     uint32_t draws;
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb;

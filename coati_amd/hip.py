@@ -42,6 +42,7 @@ EXPORTS = (
     "coati_hip_debug_forward_matrices",
     "coati_hip_sampleback",
     "coati_hip_debug_rng_f24",
+    "coati_hip_debug_libm",
     "coati_hip_viterbi_batch",
     "coati_hip_debug_viterbi_flags",
 )
@@ -99,6 +100,8 @@ def load() -> C.CDLL:
     lib.coati_hip_debug_forward_matrices.argtypes = [vp, u64, vp, vp, vp, u64]
     lib.coati_hip_sampleback.argtypes = [vp, C.c_uint32, vp, i32, vp, vp, u64, vp, vp, vp]
     lib.coati_hip_debug_rng_f24.argtypes = [vp, vp, C.c_uint32, vp]
+    if hasattr(lib, "coati_hip_debug_libm"):
+        lib.coati_hip_debug_libm.argtypes = [vp, i32, vp, u64, vp]
     lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_debug_viterbi_flags.argtypes = [vp, u64, vp, u64]
     _lib = lib
@@ -165,6 +168,13 @@ class Model:
             self.close()
         except Exception:
             pass
+
+    def debug_libm(self, op: int, x):
+        """Device restatement of expf (op 0), log1pf (1) or logf (2) applied to a float32 array."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros_like(x)
+        _check(load().coati_hip_debug_libm(self._h, op, _ptr(x), C.c_uint64(x.size), _ptr(out)))
+        return out
 
     def debug_rng_f24(self, state, n: int):
         st = np.ascontiguousarray(state, np.uint64)

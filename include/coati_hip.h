@@ -184,6 +184,12 @@ int coati_hip_debug_forward_matrices(coati_hip_batch_t* batch, uint64_t pair, fl
 int coati_hip_sampleback(coati_hip_batch_t* batch, uint32_t n_samples, const uint64_t* rng_state,
                          int independent_streams, float* log_weights, uint8_t* ops, uint64_t ops_capacity,
                          uint64_t* ops_off, uint32_t* ops_len, uint64_t* rng_state_out);
+/* Parity/debug: the device's bit-exact restatements of the libm functions the log-semiring path
+ * calls (glibc 2.35; coati_amd/csrc/glibc_math.hpp), applied element-wise.
+ *   op 0: expf(x), x <= 0      (log1p_exp, utils.hpp:134-146; sample_mdi, align_pair.cc:336-358)
+ *   op 1: log1pf(x), 0 <= x <= 1
+ *   op 2: logf(x), x > 0 */
+int coati_hip_debug_libm(coati_hip_model_t* model, int op, const float* in, uint64_t n, float* out);
 /* Parity/debug: the first n f24() draws (random.hpp:213-216) of a stream, computed on the device. */
 int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out);
 

@@ -626,6 +626,10 @@ float oracle_path_score(const float* table, const float consts[4], int gap_len, 
     return (v + k.gap_stop) + k.no_gap;
 }
 
+void oracle_libm(int op, const float* in, uint64_t n, float* out) {
+    for(uint64_t i = 0; i < n; ++i) out[i] = op == 0 ? ::expf(in[i]) : (op == 1 ? ::log1pf(in[i]) : ::logf(in[i]));
+}
+
 double oracle_viterbi_batch_timed(const float* table, const float consts[4], int gap_len,
                                   uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                                   const uint8_t* b_cat, const uint64_t* b_off, int threads,

@@ -111,6 +111,9 @@ float oracle_path_score(const float* table, const float consts[4], int gap_len, 
                         uint64_t len_a, const uint8_t* b, uint64_t len_b, const uint8_t* ops,
                         int64_t n_ops);
 
+/* The host libm itself, element-wise (what the reference calls): op 0 expf, 1 log1pf, 2 logf. */
+void oracle_libm(int op, const float* in, uint64_t n, float* out);
+
 /* Timed CPU baseline: run oracle_viterbi (reference data layout: three fp32
  * matrices incl. their fill) over a batch on `threads` host threads, one pair
  * per thread at a time.  Returns wall seconds. */

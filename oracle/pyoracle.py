@@ -170,6 +170,14 @@ def path_score(table, consts, L, a, b, ops):
                                                C.c_int64(len(ops))))
 
 
+def libm(op: int, x):
+    """The host libm (expf / log1pf / logf for op 0 / 1 / 2) applied to a float32 array."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    lib().oracle_libm(op, _p(x), _u64(x.size), _p(out))
+    return out
+
+
 def viterbi_batch_timed(table, consts, L, a_cat, a_off, b_cat, b_off, threads=1):
     n = len(a_off) - 1
     scores = np.zeros(n, np.float32)

@@ -51,6 +51,8 @@ def run_exact(hip, host, oracle, table, consts, L, pairs, seeds, n_samples):
                 if len(w_ops) == len(got) and (w_ops == got).all():
                     identical += 1
                     assert rel_close(lw[p, s], w_lw)
+                    if util.forward_exact():
+                        assert util.same_bits(lw[p, s], np.float32(w_lw)), (p, s, lw[p, s], w_lw)
                 else:
                     in_sync = False
         if in_sync:  # the stream was consumed draw for draw
@@ -69,6 +71,8 @@ def test_exact_stream_matches_oracle(oracle, L):
     consts = oracle.gap_consts()
     pairs = util.make_pairs(rng, 24, 1, 40, L=L) + [("", ""), ("ACGACG" if L == 3 else "ACG", "")]
     identical, total = run_exact(hip, host, oracle, table, consts, L, pairs, ["42"], 20)
+    if util.forward_exact():  # same libm arithmetic as the reference: never a flipped draw
+        assert identical == total, (identical, total)
     assert identical >= 0.98 * total, (identical, total)
 
 
@@ -118,10 +122,14 @@ def test_golden_sample_cases_exact_stream(oracle):
                 same += 1
                 w = np.array([int(want["score_bits"], 16)], np.uint32).view(np.float32)[0]
                 assert rel_close(lw[0, s], w), (c["name"], s)
+                if util.forward_exact():
+                    assert util.same_bits(lw[0, s], w), (c["name"], s, lw[0, s], w)
             else:
                 break  # the stream shifted; later samples of this case are different draws
         batch.close()
         model.close()
+    if util.forward_exact():
+        assert same == total, (same, total)
     assert same >= 0.97 * total, (same, total)
 
 

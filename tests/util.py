@@ -121,3 +121,18 @@ def load_long_pair(key: str):
     c61 = cod - sum((cod > s).astype(np.int32) for s in STOPS64)
     a = (c61[:, None] * 3 + np.arange(3)[None, :]).reshape(-1).astype(np.uint8)
     return a, des_nt, case, doc
+
+
+def forward_exact() -> bool:
+    """The Forward / sampling kernels run the bit-exact libm restatement unless the
+    fast log-plus was asked for (COATI_HIP_FORWARD_FAST=1, 1e-5 relative)."""
+    import os
+
+    v = os.environ.get("COATI_HIP_FORWARD_FAST", "")
+    return v in ("", "0")
+
+
+def same_bits(got, want) -> bool:
+    got = np.ascontiguousarray(got, np.float32)
+    want = np.ascontiguousarray(want, np.float32)
+    return got.shape == want.shape and bool((got.view(np.uint32) == want.view(np.uint32)).all())
