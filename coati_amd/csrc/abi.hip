@@ -46,7 +46,10 @@ __global__ void libm_kernel(int op, const float* __restrict__ in, uint64_t n, fl
     for(uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < n;
         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const float x = in[i];
-        out[i] = op == 0 ? libm::expf_nonpos(x, exp_tab) : (op == 1 ? libm::log1pf_unit(x) : libm::logf_pos(x));
+        out[i] = op == 0   ? libm::expf_nonpos(x, exp_tab)
+                 : op == 1 ? libm::log1pf_unit(x)
+                 : op == 2 ? libm::logf_pos(x)
+                           : libm::log1pf_mid(x);  // op 3: the straight-line log1pf of [2^-29, 1]
     }
 }
 
@@ -939,7 +942,7 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
 
 int coati_hip_debug_libm(coati_hip_model_t* model, int op, const float* in, uint64_t n, float* out) {
     if(model == nullptr || in == nullptr || out == nullptr) return fail(COATI_HIP_EINVAL, "debug_libm: NULL argument");
-    if(op < 0 || op > 2) return fail(COATI_HIP_EINVAL, "debug_libm: op %d unknown", op);
+    if(op < 0 || op > 3) return fail(COATI_HIP_EINVAL, "debug_libm: op %d unknown", op);
     if(n == 0) return COATI_HIP_OK;
     HIP_TRY(hipSetDevice(model->device));
     float *d_in = nullptr, *d_out = nullptr;

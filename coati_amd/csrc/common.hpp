@@ -335,7 +335,7 @@ __device__ __forceinline__ float log_plus_exact(float a, float b, const uint64_t
     const float hi = fmaxf(a, b);
     const float y = -fabsf(a - b);
     const float e = libm::expf_nonpos(y, exp_tab);
-    return hi + (y <= -16.0f ? e : libm::log1pf_unit(e));
+    return hi + (y <= -16.0f ? e : libm::log1pf_mid(e));  // (e >= expf(-16) = 1.1e-7 on the log1pf side)
 }
 __device__ __forceinline__ void load_exp_table(uint64_t* lds_tab, int tid) {
     constexpr uint64_t kTab[32] = {COATI_EXP2F_TABLE};

@@ -155,7 +155,7 @@ __device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_
                                           const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float chDM,
                                           float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
     const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
-    if constexpr(!kFirst) {
+    if constexpr(!kFirst && kFast) {
         // two steps per iteration: M/D/I of the row above ping-pong between two register sets
         // instead of being copied (see viterbi_l1.hip: run_chunk)
         uint32_t kk = 0;

@@ -50,7 +50,6 @@ COATI_MATH_FN double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 // expf for x <= 0 (the only arguments the path produces: -|a-b| and lx - max <= 0).
 // `tab` is the 32-entry table above (callers keep it in LDS or constant memory).
 COATI_MATH_FN float expf_nonpos(float x, const uint64_t* tab) {
-    if(x < -0x1.9fe368p6f) return 0.0f;  // < log(2^-150): underflows to +0 (also -inf, -FLT_MAX)
     constexpr double kInvLn2N = 0x1.71547652b82fep+0 * 32, kShift = 0x1.8p+52;
     constexpr double kC0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, kC1 = 0x1.ebfce50fac4f3p-3 / 32 / 32,
                      kC2 = 0x1.62e42ff0c52d6p-1 / 32;
@@ -66,7 +65,9 @@ COATI_MATH_FN float expf_nonpos(float x, const uint64_t* tab) {
     const double r2 = r * r;
     double y = __builtin_fma(r, kC2, 1.0);
     y = __builtin_fma(z, r2, y);
-    return static_cast<float>(y * s);
+    // x < log(2^-150) underflows to +0 (also -inf, -FLT_MAX; whatever the lines above made of those
+    // is discarded -- a select, not a branch, so wavefronts stay converged)
+    return x < -0x1.9fe368p6f ? 0.0f : static_cast<float>(y * s);
 }
 
 // log1pf for 0 <= x <= 1 (x = expf(y), -16 < y <= 0).  fdlibm: 1+x = 2^k (1+f), log(1+f) by a
@@ -120,6 +121,72 @@ COATI_MATH_FN float log1pf_unit(float x) {
     const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
     if(k == 0) return f - (hfsq - s * (hfsq + R));
     return kf * ln2_hi - ((hfsq - (s * (hfsq + R) + (kf * ln2_lo + c))) - f);
+}
+
+// ---- log1pf on [2^-29, 1], straight-line -------------------------------------------------------
+// The Forward fill only ever asks for log1pf(e), e = expf(y) with -16 < y <= 0, i.e. e >= 1.1e-7.
+// On that range log1pf_unit above takes one of two main routes (k = 0: f = x; k = 1: f = u/2 - 1),
+// which are evaluated side by side here and selected, so a wavefront never diverges; the handful of
+// inputs on other routes (u = 1+x rounding to 2, or to within 3 ulp of it) branch to log1pf_near2.
+// The two divisions are replaced by reciprocal + Newton + Markstein correction (operands are
+// normal and no intermediate can over/underflow: f/(2+f) with |f| in [2^-29, 0.42]; c/u with c zero
+// or +-2^-24, +-2^-25, where RN(c/u) = c * RN(1/u) exactly).  Same bits as log1pf_unit -- and so as
+// glibc -- on EVERY float of [2^-29, 1]: tools/libm_check.cc (host build, 1/d for the estimate) and
+// tools/libm_device_check.py (the device code with v_rcp_f32) both sweep the whole range.
+COATI_MATH_FN float rcp_estimate(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(d);  // v_rcp_f32, 1 ulp
+#else
+    return 1.0f / d;
+#endif
+}
+COATI_MATH_FN float recip_rn(float d) {
+    const float y0 = rcp_estimate(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+COATI_MATH_FN float div_rn(float n, float d) {
+    const float y = recip_rn(d);
+    const float q = n * y;
+    const float r = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(r, y, q);
+}
+
+// x in [0.41422, 1] whose u = fl(1+x) has a zero mantissa (u = 2) or lies within 3 ulp below 2:
+// log1pf_unit's |f| < 2^-20 routes.
+COATI_MATH_FN float log1pf_near2(float x, float u, uint32_t mant) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    if(mant == 0) {  // u == 2: k = 1, f = 0
+        const float c = (1.0f - (u - x)) / u;
+        return ln2_hi + (c + ln2_lo);
+    }
+    const float c = (x - (u - 1.0f)) / u;
+    const float f = u * 0.5f - 1.0f;
+    const float hfsq = 0.5f * f * f;
+    const float R = hfsq * (1.0f - 0.66666666666666666f * f);
+    return ln2_hi - ((R - (ln2_lo + c)) - f);
+}
+
+COATI_MATH_FN float log1pf_mid(float x) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, Lp1 = 6.6666668653e-01f,
+                    Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f, Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f,
+                    Lp6 = 1.5313838422e-01f, Lp7 = 1.4798198640e-01f;
+    const bool small = x < u2f(0x3ed413d7u);  // 1+x < sqrt(2): k = 0, f = x
+    const float u = 1.0f + x;
+    const uint32_t mant = f2u(u) & 0x007fffffu;
+    const bool halve = !small && mant >= 0x3504f7u;  // k = 1, f = u/2 - 1 (else k = 0, f = u - 1)
+    const float f = small ? x : __builtin_fmaf(u, halve ? 0.5f : 1.0f, -1.0f);  // (u/2 is exact)
+    const float c = (x - (u - 1.0f)) * recip_rn(u);  // rounding error of 1+x, relative
+    const float hfsq = 0.5f * f * f;
+    const float s = div_rn(f, 2.0f + f);
+    const float z = s * s;
+    const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    const float t = s * (hfsq + R);
+    const float r0 = f - (hfsq - t);
+    const float r1 = ln2_hi - ((hfsq - (t + (ln2_lo + c))) - f);
+    float res = halve ? r1 : r0;
+    if(__builtin_expect(!small && mant - 1u >= 0x7ffffcu, 0)) res = log1pf_near2(x, u, mant);
+    return res;
 }
 
 // logf for normal positive x (x = sum of up to three expf values in (0, 3]).

@@ -188,7 +188,8 @@ int coati_hip_sampleback(coati_hip_batch_t* batch, uint32_t n_samples, const uin
  * calls (glibc 2.35; coati_amd/csrc/glibc_math.hpp), applied element-wise.
  *   op 0: expf(x), x <= 0      (log1p_exp, utils.hpp:134-146; sample_mdi, align_pair.cc:336-358)
  *   op 1: log1pf(x), 0 <= x <= 1
- *   op 2: logf(x), x > 0 */
+ *   op 2: logf(x), x > 0
+ *   op 3: log1pf(x), 2^-29 <= x <= 1: the straight-line form the Forward fill uses (same bits as op 1) */
 int coati_hip_debug_libm(coati_hip_model_t* model, int op, const float* in, uint64_t n, float* out);
 /* Parity/debug: the first n f24() draws (random.hpp:213-216) of a stream, computed on the device. */
 int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out);
