@@ -5,7 +5,9 @@ equal state * MULT^(total draws).  Log-weights are compared with the oracle's ev
 path: with MODEL tables (mar-mg / mar-ecm at random branch lengths and omega) the 1e-5 relative bound
 is asserted; with uniform random tables (scores -8..2: near-ties everywhere at magnitudes of several
 hundred, where one fp32 ulp of M/D/I is 3e-5) the deviations are only recorded -- there the bound
-depends on glibc's and the GPU's log1p(exp()) agreeing in the last bit.
+depends on glibc's and the GPU's log1p(exp()) agreeing in the last bit.  In the default (bit-exact)
+build every exact-stream sample is also compared with the oracle's own sample: same ops, same
+log-weight bits.
 usage: fuzz_sample.py [seconds] [seed]"""
 import sys, time
 from pathlib import Path
@@ -21,7 +23,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
 rng = np.random.default_rng(seed)
 MULT = 0xda942042e4dd58b5
 t_end = time.time() + budget
-rounds = samples = samples_random = over_random = 0
+exact = util.forward_exact()
+rounds = samples = samples_random = over_random = identical = 0
 worst = worst_random = 0.0
 while time.time() < t_end:
     L = int(rng.choice([1, 1, 2, 3]))
@@ -46,8 +49,14 @@ while time.time() < t_end:
     for p, (a, b) in enumerate(enc):
         M, D, I = orc.fill(orc.LOG, tables[tix[p]], consts, L, a, b)
         draws = 0
+        ref_rng = orc.rng_seed([str(seed), str(rounds), str(p)]) if (exact and not indep) else None
         for s in range(n_s):
             got = ops[int(off[p, s]):int(off[p, s]) + int(ln[p, s])]
+            if ref_rng is not None:  # default build: the oracle's own sample, draw for draw
+                w_ops, w_lw = orc.sampleback_mdi(M, D, I, tables[tix[p]], consts, L, a, b, ref_rng)
+                assert len(w_ops) == len(got) and (w_ops == got).all(), ("sample differs", seed, rounds, p, s)
+                assert np.float32(lw[p, s]).view(np.uint32) == np.float32(w_lw).view(np.uint32), ("lw bits", seed, rounds, p, s)
+                identical += 1
             nm, nd, ni = int((got == 0).sum()), int((got == 1).sum()), int((got == 2).sum())
             assert nm + nd == len(a) and nm + ni == len(b), ("invalid path", seed, rounds, p, s)
             want = float(orc.path_logweight(M, D, I, tables[tix[p]], consts, L, a, b, got))
@@ -68,4 +77,5 @@ while time.time() < t_end:
     batch.close(); model.close()
     rounds += 1
 print(f"fuzz_sample ok: {rounds} batches, {samples} samples, seed {seed}; model tables: worst relative log-weight deviation "
-      f"{worst:.2e}; uniform random tables: {samples_random} samples, worst {worst_random:.2e}, {over_random} above 1e-5")
+      f"{worst:.2e}; uniform random tables: {samples_random} samples, worst {worst_random:.2e}, {over_random} above 1e-5; {identical} exact-stream samples "
+      f"identical to the oracle's (ops and log-weight bits)" + ("" if exact else " [fast build: not compared]"))
