@@ -45,6 +45,14 @@ $(BUILD)/coati: coati_amd/host/coati_main.cc
 $(BUILD)/coati-%: coati_amd/host/coati_%.cc $(BUILD)/libcoati_host.so
 	$(CXX) $(HOSTFLAGS) -o $@ $< -L$(BUILD) -lcoati_host -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm
 
+# sanitizer build of the host layer (CPU only; GPU ASan is not available on the pool):
+# run the CPU tests / tools/fuzz_host_io.py against it with COATI_HOST_LIB + LD_PRELOAD (see the tool)
+asan: $(BUILD)/asan/libcoati_host.so
+$(BUILD)/asan/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so
+	@mkdir -p $(BUILD)/asan
+	$(CXX) -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer \
+	    -Iinclude -Icoati_amd/host -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN/..' -lm
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -55,4 +63,4 @@ clean:
 	rm -rf $(BUILD)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host oracle ref clean
+.PHONY: all lib host oracle ref clean asan trace

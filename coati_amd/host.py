@@ -88,10 +88,11 @@ def set_subst(model="mar-mg", br_len=0.0133, omega=0.2, pi=DEFAULT_PI, sigma=Non
 
 
 def encode(anc: str, des: str):
-    a = np.zeros(max(len(anc), 1), np.uint8)
-    b = np.zeros(max(len(des), 1), np.uint8)
-    _check(load().coati_host_encode(anc.encode(), des.encode(), _p(a), _p(b)))
-    return a[:len(anc)].copy(), b[:len(des)].copy()
+    ab, db = anc.encode(), des.encode()  # (buffers sized by BYTES: non-ASCII input must fail in the library, not overflow here)
+    a = np.zeros(max(len(ab), 1), np.uint8)
+    b = np.zeros(max(len(db), 1), np.uint8)
+    _check(load().coati_host_encode(ab, db, _p(a), _p(b)))
+    return a[:len(ab)].copy(), b[:len(db)].copy()
 
 
 def synth_encoded(first: int, n: int, seed_base: int = 0xC0A71, n_codons: int = 334):
@@ -118,7 +119,7 @@ def synth_raw(index: int, seed_base: int = 0xC0A71, n_codons: int = 334):
 
 
 def trim_end_stops(s0: str, s1: str):
-    cap = max(len(s0), len(s1)) + 8
+    cap = max(len(s0.encode()), len(s1.encode())) + 8
     bufs = [C.create_string_buffer(cap) for _ in range(4)]
     _check(load().coati_host_trim_end_stops(s0.encode(), s1.encode(), *bufs, C.c_ulonglong(cap)))
     t0, t1, st0, st1 = (b.value.decode() for b in bufs)

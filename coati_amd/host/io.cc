@@ -270,6 +270,8 @@ void write_fasta(const data_t& data, std::ostream& out) {
 }
 
 void write_phylip(const data_t& data, std::ostream& out) {
+    // (phylip.cc:194-215 reads seqs[0] unconditionally: undefined behaviour for an empty set)
+    if(data.seqs.empty() || data.names.size() < data.seqs.size()) throw std::invalid_argument("PHYLIP output needs at least one named sequence.");
     out << data.size() << " " << data.seqs[0].length() << std::endl;
     std::size_t i = 50;
     for(std::size_t j = 0; j < data.size(); ++j) {

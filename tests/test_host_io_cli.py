@@ -148,3 +148,20 @@ def test_cli_usage_errors(tmp_path):
     assert r.returncode == 1 and "ERROR" in r.stderr
     r = run("coati-sample", str(fa), "-m", "dna")
     assert r.returncode == 1 and "Sampling only available" in r.stderr
+
+
+def test_writers_reject_degenerate_input_cleanly(tmp_path):
+    """Inputs on which the reference's writers index out of range (phylip.cc:194-215 reads seqs[0] of
+    an empty set; ragged blocks call substr past the end) must come back as errors, not crashes."""
+    empty = tmp_path / "empty.fa"
+    empty.write_text("; nothing but a comment\n")
+    with pytest.raises(host.CoatiHostError):
+        host.convert(str(empty), str(tmp_path / "out.phy"))
+    ragged = tmp_path / "ragged.fa"
+    ragged.write_text(">a\n" + "ACGT" * 30 + "\n>b\nACG\n")
+    with pytest.raises(host.CoatiHostError):
+        host.convert(str(ragged), str(tmp_path / "out2.phy"))
+    # non-ASCII bytes in a descendant encode as the invalid code 16 (the reference indexes past its
+    # 128-entry table there, utils.cc:496-528); coati_hip_batch_create rejects codes 15/16
+    _, des = host.encode("ACG", "ACé")
+    assert des.tolist() == [0, 1, 16, 16]
