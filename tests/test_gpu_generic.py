@@ -122,18 +122,19 @@ def rel_close(got, want, tol=1e-5):
     return np.abs(got[finite] - want[finite]) <= tol * np.maximum(1.0, np.abs(want[finite]))
 
 
-@pytest.mark.parametrize("L", [1, 3])
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
 def test_forward_matrices_vs_oracle(oracle, L):
     from coati_amd import hip
 
     rng = np.random.default_rng(40 + L)
     table = util.random_table(rng)
     consts = oracle.gap_consts()
-    pairs = util.make_pairs(rng, 30, 1, 60, L=L, amb=0.03) + [("", ""), ("ACGACG" if L == 3 else "ACG", "")]
+    unit = 3 * L if L % 3 else L  # ancestor lengths are multiples of 3 and of L
+    pairs = util.make_pairs(rng, 30, 1, 60, L=L, amb=0.03) + [("", ""), ("ACG" * (unit // 3), "")]
     a_long = util.random_anc(rng, 120 * (1 if L == 1 else L))
     d_long = util.mutate(rng, a_long)
     pairs.append((a_long, d_long[: len(d_long) // L * L]))
-    big = util.random_anc(rng, 345)
+    big = util.random_anc(rng, 348)
     pairs.append((big, (util.mutate(rng, big) + "ACGT" * 30)[: 1032 // L * L]))  # crosses the strip boundary
     enc = util.encode_pairs(pairs)
     model = hip.Model(table, consts, L)

@@ -62,14 +62,15 @@ def run_exact(hip, host, oracle, table, consts, L, pairs, seeds, n_samples):
     return identical, total
 
 
-@pytest.mark.parametrize("L", [1, 3])
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
 def test_exact_stream_matches_oracle(oracle, L):
     from coati_amd import hip, host
 
     rng = np.random.default_rng(50 + L)
     table = util.random_table(rng)
     consts = oracle.gap_consts()
-    pairs = util.make_pairs(rng, 24, 1, 40, L=L) + [("", ""), ("ACGACG" if L == 3 else "ACG", "")]
+    unit = 3 * L if L % 3 else L
+    pairs = util.make_pairs(rng, 24, 1, 40, L=L) + [("", ""), ("ACG" * (unit // 3), "")]
     identical, total = run_exact(hip, host, oracle, table, consts, L, pairs, ["42"], 20)
     if util.forward_exact():  # same libm arithmetic as the reference: never a flipped draw
         assert identical == total, (identical, total)
