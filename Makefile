@@ -29,7 +29,7 @@ HOST_SRC = coati_amd/host/model.cc coati_amd/host/seq.cc coati_amd/host/synth.cc
            coati_amd/host/align.cc coati_amd/host/cli.cc coati_amd/host/format.cc coati_amd/host/tree.cc coati_amd/host/insertions.cc coati_amd/host/msa.cc coati_amd/host/capi.cc
 HOST_HDR = $(wildcard coati_amd/host/*.hpp) coati_amd/host/ecm_kosiol2007.inc
 CXX      ?= g++
-HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -Icoati_amd/host
+HOSTFLAGS = -std=c++17 -O2 -fPIC -pthread -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -Icoati_amd/host
 
 host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample $(BUILD)/coati-format $(BUILD)/coati-msa $(BUILD)/coati-genseed $(BUILD)/coati
 
@@ -50,7 +50,7 @@ $(BUILD)/coati-%: coati_amd/host/coati_%.cc $(BUILD)/libcoati_host.so
 asan: $(BUILD)/asan/libcoati_host.so
 $(BUILD)/asan/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so
 	@mkdir -p $(BUILD)/asan
-	$(CXX) -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer \
+	$(CXX) -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer -pthread \
 	    -Iinclude -Icoati_amd/host -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN/..' -lm
 
 oracle:

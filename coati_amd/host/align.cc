@@ -1,10 +1,16 @@
 #include "align.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <exception>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "coati_hip.h"
 #include "codon.hpp"
@@ -46,6 +52,49 @@ void make_pair_batch(align_pair_work_mem_t& work, const seq_view_t& a, const seq
 }  // namespace
 
 align_pair_work_mem_t::~align_pair_work_mem_t() { release(*this); }
+
+namespace {
+// fn(i) for i in [0, n) on up to 16 host threads (the per-pair host work either side of a batched
+// launch: tables, encoding, gapped strings).  The exception of the lowest failing index is rethrown on
+// the caller's thread.
+template <typename Fn>
+void parallel_for(std::size_t n, std::size_t min_per_thread, Fn&& fn) {
+    const std::size_t want = std::max<std::size_t>(1, n / std::max<std::size_t>(1, min_per_thread));
+    const std::size_t n_threads = std::min<std::size_t>({want, std::max(1u, std::thread::hardware_concurrency()), 16});
+    if(n_threads <= 1) {
+        for(std::size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    const std::size_t chunk = std::max<std::size_t>(1, std::min<std::size_t>(min_per_thread, n / (4 * n_threads) + 1));
+    std::atomic<std::size_t> next{0};
+    std::exception_ptr failure;
+    std::size_t failure_at = n;  // the LOWEST failing index wins, as in a serial loop: chunks are handed
+    std::mutex failure_lock;     // out in ascending order and a started chunk always runs to its end
+    auto worker = [&]() {
+        for(;;) {
+            const std::size_t lo = next.fetch_add(chunk);
+            if(lo >= n) return;
+            std::size_t i = lo;
+            try {
+                for(; i < std::min(n, lo + chunk); ++i) fn(i);
+            } catch(...) {
+                std::lock_guard<std::mutex> hold(failure_lock);
+                if(i < failure_at) {
+                    failure_at = i;
+                    failure = std::current_exception();
+                }
+                next.store(n);
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for(std::size_t w = 1; w < n_threads; ++w) pool.emplace_back(worker);
+    worker();
+    for(auto& th : pool) th.join();
+    if(failure) std::rethrow_exception(failure);
+}
+}  // namespace
 
 void set_subst(alignment_t& aln) {
     if(!aln.rate.empty()) {
@@ -132,34 +181,69 @@ std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, 
                                 const std::vector<float>& br_lens) {
     if(leaf_seqs.size() != br_lens.size()) throw std::invalid_argument("One branch length per leaf is required.");
     const std::size_t n = leaf_seqs.size();
+    // COATI_HOST_TIMING=1: stage times on stderr (tables / encode / device / strings)
+    const bool timing = std::getenv("COATI_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto stage = [&](const char* what) {
+        if(!timing) return;
+        const auto t = now();
+        std::cerr << "align_leafs: " << what << " " << std::chrono::duration<double, std::milli>(t - t_prev).count() << " ms\n";
+        t_prev = t;
+    };
     std::vector<data_t> out(n);
     if(n == 0) return out;
-    // one table per distinct branch length (set_subst per leaf, align_msa.cc:297-301)
+    // one table per distinct branch length (set_subst per leaf, align_msa.cc:297-301); a table costs
+    // ~3 ms of host time (61x61 matrix exponential), so distinct lengths are built on several threads
     std::vector<float> distinct;
     std::vector<uint32_t> table_index(n);
-    std::vector<float> tables;
     for(std::size_t p = 0; p < n; ++p) {
         std::size_t t = 0;
         while(t < distinct.size() && distinct[t] != br_lens[p]) ++t;
-        if(t == distinct.size()) {
-            distinct.push_back(br_lens[p]);
-            input.br_len = br_lens[p];
-            set_subst(input);
-            tables.insert(tables.end(), input.subst_matrix.begin(), input.subst_matrix.end());
-        }
+        if(t == distinct.size()) distinct.push_back(br_lens[p]);
         table_index[p] = static_cast<uint32_t>(t);
     }
-    std::vector<unsigned char> a_cat, b_cat;
-    std::vector<uint64_t> a_off{0}, b_off{0};
-    for(std::size_t p = 0; p < n; ++p) {
-        const auto enc = marginal_seq_encoding(ref_seq, leaf_seqs[p]);
-        check_descendant_codes(enc[1]);
-        a_cat.insert(a_cat.end(), enc[0].begin(), enc[0].end());
-        b_cat.insert(b_cat.end(), enc[1].begin(), enc[1].end());
-        a_off.push_back(a_cat.size());
-        b_off.push_back(b_cat.size());
+    constexpr std::size_t kTable = 183 * 15;
+    std::vector<float> tables(distinct.size() * kTable);
+    auto store = [&](std::size_t t, const table_t& tab) { std::copy(tab.begin(), tab.end(), tables.begin() + t * kTable); };
+    if(!input.rate.empty()) {  // user matrix: the file fixes the branch length, every leaf shares one table
+        set_subst(input);
+        for(std::size_t t = 0; t < distinct.size(); ++t) store(t, input.subst_matrix);
+    } else {
+        model_params_t prm;
+        prm.model = input.model;
+        prm.omega = input.omega;
+        prm.pi = input.pi;
+        prm.sigma = input.sigma;
+        prm.amb = input.amb;
+        prm.sub = input.sub;
+        parallel_for(distinct.size(), 1, [&](std::size_t t) {
+            model_params_t mine = prm;
+            mine.br_len = distinct[t];
+            store(t, set_subst(mine));
+        });
+        // leave `input` as the serial loop of the reference does: the last leaf's model
+        input.br_len = br_lens.back();
+        const table_t last(tables.begin() + table_index[n - 1] * kTable, tables.begin() + (table_index[n - 1] + 1) * kTable);
+        input.subst_matrix = last;
     }
+    stage("tables");
+    const encoded_t ref_codes = marginal_seq_encoding(ref_seq, std::string_view())[0];  // the same ancestor for every leaf
+    std::vector<uint64_t> a_off(n + 1, 0), b_off(n + 1, 0);
+    for(std::size_t p = 0; p < n; ++p) {
+        a_off[p + 1] = a_off[p] + ref_codes.size();
+        b_off[p + 1] = b_off[p] + leaf_seqs[p].size();
+    }
+    std::vector<unsigned char> a_cat(a_off[n]), b_cat(b_off[n]);
+    parallel_for(n, 256, [&](std::size_t p) {
+        std::copy(ref_codes.begin(), ref_codes.end(), a_cat.begin() + static_cast<std::ptrdiff_t>(a_off[p]));
+        unsigned char* des = b_cat.data() + b_off[p];
+        encode_descendant(leaf_seqs[p], des);
+        for(std::size_t i = 0; i < leaf_seqs[p].size(); ++i)
+            if(des[i] >= kTableCols) throw std::invalid_argument("Invalid character in descendant sequence.");
+    });
     if(input.gap.len < 1) throw std::invalid_argument("Gap unit length must be positive.");
+    stage("encode");
     const auto k = gap_log_consts(input.gap);
     coati_hip_model* model = nullptr;
     hip_check(coati_hip_model_create_tables(tables.data(), static_cast<uint32_t>(distinct.size()), k[0], k[1], k[2], k[3],
@@ -177,11 +261,13 @@ std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, 
     if(batch != nullptr) coati_hip_batch_destroy(batch);
     coati_hip_model_destroy(model);
     hip_check(rc);
-    for(std::size_t p = 0; p < n; ++p) {
+    stage("device (upload, plan, launch, fetch)");
+    parallel_for(n, 256, [&](std::size_t p) {
         out[p].seqs.assign(2, std::string());
         ops_to_alignment(ops.data() + off[p], len[p], ref_seq, leaf_seqs[p], out[p].seqs[0], out[p].seqs[1]);
         out[p].score = scores[p];
-    }
+    });
+    stage("gapped strings");
     return out;
 }
 
@@ -192,21 +278,26 @@ bool marg_alignment_batch(alignment_t& aln) {
     const std::size_t n = all.size() / 2;
     std::vector<data_t> pairs(n);
     std::vector<std::string> ancs(n), dess(n);
-    std::vector<unsigned char> a_cat, b_cat;
-    std::vector<uint64_t> a_off{0}, b_off{0};
-    for(std::size_t p = 0; p < n; ++p) {
+    parallel_for(n, 256, [&](std::size_t p) {
         pairs[p].names = {all.names[2 * p], all.names[2 * p + 1]};
         pairs[p].seqs = {all.seqs[2 * p], all.seqs[2 * p + 1]};
         process_marginal(pairs[p], aln.gap, std::string(), aln.rev);
         ancs[p] = pairs[p].seqs[0];
         dess[p] = pairs[p].seqs[1];
-        const auto enc = marginal_seq_encoding(ancs[p], dess[p]);
-        check_descendant_codes(enc[1]);
-        a_cat.insert(a_cat.end(), enc[0].begin(), enc[0].end());
-        b_cat.insert(b_cat.end(), enc[1].begin(), enc[1].end());
-        a_off.push_back(a_cat.size());
-        b_off.push_back(b_cat.size());
+    });
+    std::vector<uint64_t> a_off(n + 1, 0), b_off(n + 1, 0);
+    for(std::size_t p = 0; p < n; ++p) {
+        a_off[p + 1] = a_off[p] + ancs[p].size();
+        b_off[p + 1] = b_off[p] + dess[p].size();
     }
+    std::vector<unsigned char> a_cat(a_off[n]), b_cat(b_off[n]);
+    parallel_for(n, 256, [&](std::size_t p) {
+        encode_ancestor(ancs[p], a_cat.data() + a_off[p]);
+        unsigned char* des = b_cat.data() + b_off[p];
+        encode_descendant(dess[p], des);
+        for(std::size_t i = 0; i < dess[p].size(); ++i)
+            if(des[i] >= kTableCols) throw std::invalid_argument("Invalid character in descendant sequence.");
+    });
     coati_hip_model* model = make_model(aln);
     std::vector<float> scores(n);
     std::vector<uint8_t> ops(a_cat.size() + b_cat.size() + 1);

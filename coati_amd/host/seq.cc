@@ -12,18 +12,26 @@ std::size_t data_t::size() const {
     return names.size();
 }
 
-std::vector<encoded_t> marginal_seq_encoding(std::string_view anc, std::string_view des) {
-    std::vector<encoded_t> ret(2);
-    ret[0].reserve(anc.size());
-    ret[1].reserve(des.size());
+void encode_ancestor(std::string_view anc, unsigned char* out) {
     for(std::size_t i = 0; i < anc.size(); i += 3) {
-        const int cod = cod_int(anc.substr(i, 3));
+        const int cod = cod_int(anc.substr(i, 3));  // (-1 also for a trailing partial codon)
         if(cod == -1) throw std::invalid_argument("Ambiguous nucleotides in ancestor/reference.");
         if(is_stop64(cod)) throw std::invalid_argument("Early stop codon in ancestor/reference.");
         const int base = cod64_to_61(cod) * 3;
-        for(int phase = 0; phase < 3; ++phase) ret[0].push_back(static_cast<unsigned char>(base + phase));
+        for(int phase = 0; phase < 3; ++phase) out[i + static_cast<std::size_t>(phase)] = static_cast<unsigned char>(base + phase);
     }
-    for(const char ch : des) ret[1].push_back(nt16(static_cast<unsigned char>(ch)));
+}
+
+void encode_descendant(std::string_view des, unsigned char* out) {
+    for(std::size_t i = 0; i < des.size(); ++i) out[i] = nt16(static_cast<unsigned char>(des[i]));
+}
+
+std::vector<encoded_t> marginal_seq_encoding(std::string_view anc, std::string_view des) {
+    std::vector<encoded_t> ret(2);
+    ret[0].resize(anc.size());
+    ret[1].resize(des.size());
+    encode_ancestor(anc, ret[0].data());
+    encode_descendant(des, ret[1].data());
     return ret;
 }
 

@@ -34,6 +34,9 @@ using encoded_t = std::basic_string<unsigned char>;
 // character -> 16, exactly as upstream).  Throws std::invalid_argument for
 // ambiguous nucleotides or a stop codon in the ancestor (upstream messages).
 std::vector<encoded_t> marginal_seq_encoding(std::string_view anc, std::string_view des);
+// the two halves of it, writing into caller storage (anc.size() resp. des.size() bytes); same errors
+void encode_ancestor(std::string_view anc, unsigned char* out);
+void encode_descendant(std::string_view des, unsigned char* out);
 
 // Upstream lets descendant codes 15 ('-') and 16 (invalid) index past the 15
 // table columns (only a debug assert, matrix.hpp:73-80).  The drivers here call
