@@ -4,11 +4,13 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -115,6 +117,16 @@ struct coati_hip_model {
     uint32_t n_tables = 1;
     float* d_table = nullptr;  // n_tables * 183*15 floats
     hipStream_t stream = nullptr;
+    // Workspaces of destroyed batches, kept for the next batch_create (hipMalloc of a multi-GB
+    // workspace was measured at 0.4 ms when the driver still had the pages and 250-550 ms when it
+    // did not).  At most kCachedArenas are kept; coati_hip_model_trim / model_destroy free them.
+    struct Arena {
+        void* ptr;
+        uint64_t bytes;
+    };
+    static constexpr size_t kCachedArenas = 2;
+    std::vector<Arena> free_arenas;
+    std::mutex arena_lock;
 };
 
 struct coati_hip_batch {
@@ -127,7 +139,9 @@ struct coati_hip_batch {
     uint64_t mdi_floats = 0;   // floats the Forward M/D/I arena needs (allocated on first use)
     uint64_t device_bytes = 0;
     std::vector<PairDesc> desc;
-    // device
+    // device: one workspace allocation, everything below except d_mdi / d_final_mdi points into it
+    void* arena = nullptr;
+    uint64_t arena_bytes = 0;
     PairDesc* d_desc = nullptr;
     uint32_t* d_order = nullptr;   // pair indices, most cells first
     uint32_t* d_queue = nullptr;   // ticket counter of the persistent fill kernel
@@ -226,6 +240,7 @@ int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float n
 void coati_hip_model_destroy(coati_hip_model_t* m) {
     if(m == nullptr) return;
     (void)hipSetDevice(m->device);
+    for(const auto& a : m->free_arenas) (void)hipFree(a.ptr);
     if(m->d_table != nullptr) (void)hipFree(m->d_table);
     if(m->stream != nullptr) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -233,15 +248,44 @@ void coati_hip_model_destroy(coati_hip_model_t* m) {
 
 void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(b == nullptr) return;
-    if(b->model != nullptr) (void)hipSetDevice(b->model->device);
-    void* ptrs[] = {b->d_items, b->d_fwd_items, b->d_progress, b->d_mdi, b->d_final_mdi, b->d_order, b->d_queue, b->d_desc, b->d_a,      b->d_b,         b->d_ops,    b->d_flags,
-                    b->d_bnd,  b->d_scores, b->d_ops_start, b->d_ops_len};
-    for(void* p : ptrs)
+    coati_hip_model* m = b->model;
+    if(m != nullptr) (void)hipSetDevice(m->device);
+    for(void* p : {static_cast<void*>(b->d_mdi), static_cast<void*>(b->d_final_mdi)})
         if(p != nullptr) (void)hipFree(p);
+    if(b->arena != nullptr) {
+        // the workspace goes back to the model once nothing on the stream can still touch it
+        bool keep = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
+        void* drop = b->arena;
+        if(keep) {
+            std::lock_guard<std::mutex> hold(m->arena_lock);
+            m->free_arenas.push_back({b->arena, b->arena_bytes});
+            drop = nullptr;
+            if(m->free_arenas.size() > coati_hip_model::kCachedArenas) {  // evict the smallest
+                size_t k = 0;
+                for(size_t i = 1; i < m->free_arenas.size(); ++i)
+                    if(m->free_arenas[i].bytes < m->free_arenas[k].bytes) k = i;
+                drop = m->free_arenas[k].ptr;
+                m->free_arenas.erase(m->free_arenas.begin() + static_cast<std::ptrdiff_t>(k));
+            }
+        }
+        if(drop != nullptr) (void)hipFree(drop);
+    }
     for(auto& trio : b->ev)
         for(hipEvent_t e : trio)
             if(e != nullptr) (void)hipEventDestroy(e);
     delete b;
+}
+
+int coati_hip_model_trim(coati_hip_model_t* m) {
+    if(m == nullptr) return fail(COATI_HIP_EINVAL, "model_trim: model is NULL");
+    HIP_TRY(hipSetDevice(m->device));
+    std::vector<coati_hip_model::Arena> drop;
+    {
+        std::lock_guard<std::mutex> hold(m->arena_lock);
+        drop.swap(m->free_arenas);
+    }
+    for(const auto& a : drop) (void)hipFree(a.ptr);
+    return COATI_HIP_OK;
 }
 
 int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
@@ -268,6 +312,12 @@ int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, co
 }
 
 namespace {
+inline uint8_t max_byte(const uint8_t* p, uint64_t n) {
+    uint8_t m = 0;
+    for(uint64_t i = 0; i < n; ++i) m = p[i] > m ? p[i] : m;
+    return m;
+}
+
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                       const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, coati_hip_batch_t** out) {
     if(out == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: out is NULL");
@@ -290,8 +340,18 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         }
     } owner{b};
     auto cleanup = [&](int rc) { return rc; };
+    // COATI_HIP_TIMING=1: host-side stage times of this call on stderr
+    static const bool timing = std::getenv("COATI_HIP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if(!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "batch_create: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     b->desc.resize(n_pairs);
     const uint64_t L = static_cast<uint64_t>(model->gap_len);
+    static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
             return cleanup(fail(COATI_HIP_EINVAL, "batch_create: offsets of pair %llu decrease",
@@ -311,14 +371,19 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                                 "Length of descendant sequence must be multiple of gap unit length. "
                                 "(pair %llu)",
                                 static_cast<unsigned long long>(p)));
-        for(uint64_t q = a_off[p]; q < a_off[p + 1]; ++q)
-            if(a_cat[q] >= kTabRows)
-                return cleanup(fail(COATI_HIP_EINVAL, "batch_create: ancestor code %u out of range (pair %llu)",
-                                    a_cat[q], static_cast<unsigned long long>(p)));
-        for(uint64_t q = b_off[p]; q < b_off[p + 1]; ++q)
-            if(b_cat[q] >= kTabCols)
-                return cleanup(fail(COATI_HIP_EINVAL, "batch_create: descendant code %u out of range (pair %llu)",
-                                    b_cat[q], static_cast<unsigned long long>(p)));
+        // code ranges: a branch-free max over the bytes (vectorises); the offender is only looked up on failure
+        if(max_byte(a_cat + a_off[p], la) >= kTabRows) {
+            uint64_t q = a_off[p];
+            while(a_cat[q] < kTabRows) ++q;
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: ancestor code %u out of range (pair %llu)", a_cat[q],
+                                static_cast<unsigned long long>(p)));
+        }
+        if(max_byte(b_cat + b_off[p], lb) >= kTabCols) {
+            uint64_t q = b_off[p];
+            while(b_cat[q] < kTabCols) ++q;
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: descendant code %u out of range (pair %llu)", b_cat[q],
+                                static_cast<unsigned long long>(p)));
+        }
         if(table_index != nullptr && table_index[p] >= model->n_tables)
             return cleanup(fail(COATI_HIP_EINVAL, "batch_create: table index %u of pair %llu out of range [0,%u)",
                                 table_index[p], static_cast<unsigned long long>(p), model->n_tables));
@@ -331,7 +396,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.ops_off = b->ops_total;
         d.mdi_off = b->mdi_floats;
         // Forward M/D/I arena: gap_len 2, 3 store the live cells only (forward_k.hip)
-        const bool fwd_k = (L == 2 || L == 3) && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;
+        const bool fwd_k = (L == 2 || L == 3) && !force_generic;
         d.f_compact = fwd_k ? static_cast<uint32_t>(L) : 0u;
         if(la > 0 && lb > 0)
             b->mdi_floats += fwd_k ? fwd_compact_strips(d.lb, static_cast<uint32_t>(L)) * fwd_compact_strip_floats(d.la, static_cast<uint32_t>(L))
@@ -436,13 +501,9 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     }
     b->compact_narrow_only = plan_k && all_narrow;
 
+    stage("plan");
     if(hipSetDevice(model->device) != hipSuccess)
         return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice failed"));
-    auto dmalloc = [&](void** p, uint64_t bytes) -> hipError_t {
-        if(bytes == 0) bytes = 16;
-        b->device_bytes += bytes;
-        return hipMalloc(p, bytes);
-    };
 #define B_TRY(expr)                                                                             \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -450,41 +511,92 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             return cleanup(fail(e_ == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,  \
                                 "%s failed: %s", #expr, hipGetErrorString(e_)));                \
     } while(0)
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_desc), n_pairs * sizeof(PairDesc)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_a), a_total));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_b), b_total));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops), b->ops_total));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_flags), b->flag_dwords * sizeof(uint32_t)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_bnd), b->bnd_floats * sizeof(float)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_scores), n_pairs * sizeof(float)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops_start), n_pairs * sizeof(uint64_t)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_ops_len), n_pairs * sizeof(uint32_t)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_order), n_pairs * sizeof(uint32_t)));
-    B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_queue), sizeof(uint32_t)));
+    // work lists: one item per strip, pairs in LPT order
+    std::vector<WorkItem> items, fwd_items;
+    for(const uint32_t p : order) {
+        for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
+        uint32_t nf = 1;
+        if(b->desc[p].la > 0 && b->desc[p].lb > 0)
+            nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact) : n_strips(b->desc[p].lb);
+        for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
+    }
+    b->n_items = static_cast<uint32_t>(items.size());
+    b->n_fwd_items = static_cast<uint32_t>(fwd_items.size());
+    // ONE workspace for everything but the Forward M/D/I arena, carved into 256-byte aligned parts
+    uint64_t arena_need = 0;
+    auto carve = [&](uint64_t bytes) {
+        const uint64_t at = arena_need;
+        arena_need += (std::max<uint64_t>(bytes, 16) + 255) / 256 * 256;
+        return at;
+    };
+    const uint64_t o_desc = carve(n_pairs * sizeof(PairDesc)), o_a = carve(a_total), o_b = carve(b_total),
+                   o_ops = carve(b->ops_total), o_flags = carve(b->flag_dwords * sizeof(uint32_t)),
+                   o_bnd = carve(b->bnd_floats * sizeof(float)), o_scores = carve(n_pairs * sizeof(float)),
+                   o_start = carve(n_pairs * sizeof(uint64_t)), o_len = carve(n_pairs * sizeof(uint32_t)),
+                   o_order = carve(n_pairs * sizeof(uint32_t)), o_queue = carve(sizeof(uint32_t)),
+                   o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
+                   o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t));
+    {
+        // a workspace a destroyed batch of this model left behind, unless it is far too large
+        std::lock_guard<std::mutex> hold(model->arena_lock);
+        size_t best = model->free_arenas.size();
+        for(size_t i = 0; i < model->free_arenas.size(); ++i) {
+            const uint64_t have = model->free_arenas[i].bytes;
+            if(have >= arena_need && have <= 2 * arena_need + (64ull << 20) &&
+               (best == model->free_arenas.size() || have < model->free_arenas[best].bytes))
+                best = i;
+        }
+        if(best != model->free_arenas.size()) {
+            b->arena = model->free_arenas[best].ptr;
+            b->arena_bytes = model->free_arenas[best].bytes;
+            model->free_arenas.erase(model->free_arenas.begin() + static_cast<std::ptrdiff_t>(best));
+        }
+    }
+    if(b->arena == nullptr) {
+        hipError_t e = hipMalloc(&b->arena, arena_need);
+        if(e == hipErrorOutOfMemory) {  // give the cached workspaces back and try once more
+            (void)hipGetLastError();
+            (void)coati_hip_model_trim(model);
+            e = hipMalloc(&b->arena, arena_need);
+        }
+        if(e != hipSuccess) {
+            b->arena = nullptr;
+            return cleanup(fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,
+                                "hipMalloc(workspace, %llu bytes) failed: %s", static_cast<unsigned long long>(arena_need),
+                                hipGetErrorString(e)));
+        }
+        b->arena_bytes = arena_need;
+    }
+    b->device_bytes += arena_need;
+    auto at = [&](uint64_t off) { return static_cast<char*>(b->arena) + off; };
+    b->d_desc = reinterpret_cast<PairDesc*>(at(o_desc));
+    b->d_a = reinterpret_cast<uint8_t*>(at(o_a));
+    b->d_b = reinterpret_cast<uint8_t*>(at(o_b));
+    b->d_ops = reinterpret_cast<uint8_t*>(at(o_ops));
+    b->d_flags = reinterpret_cast<uint32_t*>(at(o_flags));
+    b->d_bnd = reinterpret_cast<float*>(at(o_bnd));
+    b->d_scores = reinterpret_cast<float*>(at(o_scores));
+    b->d_ops_start = reinterpret_cast<uint64_t*>(at(o_start));
+    b->d_ops_len = reinterpret_cast<uint32_t*>(at(o_len));
+    b->d_order = reinterpret_cast<uint32_t*>(at(o_order));
+    b->d_queue = reinterpret_cast<uint32_t*>(at(o_queue));
+    b->d_items = reinterpret_cast<WorkItem*>(at(o_items));
+    b->d_fwd_items = reinterpret_cast<WorkItem*>(at(o_fwd));
+    b->d_progress = reinterpret_cast<uint32_t*>(at(o_progress));
+    stage("workspace");
     if(n_pairs > 0) {
         B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
         B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
-        std::vector<WorkItem> items, fwd_items;
-        for(const uint32_t p : order) {
-            for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
-            uint32_t nf = 1;
-            if(b->desc[p].la > 0 && b->desc[p].lb > 0)
-                nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact) : n_strips(b->desc[p].lb);
-            for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
-        }
-        b->n_items = static_cast<uint32_t>(items.size());
-        b->n_fwd_items = static_cast<uint32_t>(fwd_items.size());
-        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_items), items.size() * sizeof(WorkItem)));
-        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_fwd_items), fwd_items.size() * sizeof(WorkItem)));
-        B_TRY(dmalloc(reinterpret_cast<void**>(&b->d_progress),
-                      std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)));
         B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         B_TRY(hipMemcpy(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
     }
+    stage("descriptors + work items upload");
     if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
     if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));
+    stage("sequences upload");
     for(auto& trio : b->ev)
         for(auto& e : trio) B_TRY(hipEventCreate(&e));
+    stage("events");
 #undef B_TRY
     owner.b = nullptr;
     *out = b;

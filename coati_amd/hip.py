@@ -25,6 +25,7 @@ EXPORTS = (
     "coati_hip_model_create",
     "coati_hip_model_create_tables",
     "coati_hip_model_destroy",
+    "coati_hip_model_trim",
     "coati_hip_batch_create",
     "coati_hip_batch_create_tables",
     "coati_hip_batch_destroy",
@@ -79,6 +80,8 @@ def load() -> C.CDLL:
         lib.coati_hip_batch_create_tables.argtypes = [vp, u64, vp, vp, vp, vp, vp, C.POINTER(vp)]
     lib.coati_hip_model_destroy.argtypes = [vp]
     lib.coati_hip_model_destroy.restype = None
+    if hasattr(lib, "coati_hip_model_trim"):
+        lib.coati_hip_model_trim.argtypes = [vp]
     lib.coati_hip_batch_create.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(vp)]
     lib.coati_hip_batch_destroy.argtypes = [vp]
     lib.coati_hip_batch_destroy.restype = None
@@ -157,6 +160,10 @@ class Model:
         else:
             _check(lib.coati_hip_model_create_tables(_ptr(table), self.n_tables, c[0], c[1], c[2], c[3], gap_len, device,
                                                      C.byref(self._h)))
+
+    def trim(self):
+        """Free the workspaces the model cached from destroyed batches."""
+        _check(load().coati_hip_model_trim(self._h))
 
     def close(self):
         if self._h:

@@ -92,6 +92,12 @@ int coati_hip_model_create_tables(const float* tables, uint32_t n_tables, float 
                                   float gap_open, float gap_extend, int gap_len, int device,
                                   coati_hip_model_t** out);
 void coati_hip_model_destroy(coati_hip_model_t* model);
+/* A model keeps the HBM workspaces of its last (at most two) destroyed batches and hands them to
+ * the next coati_hip_batch_create whose needs they fit (the reference has no counterpart: its work
+ * matrices are std::vectors that die with align_pair_work_mem_t, align_pair.hpp:45-62; here a
+ * multi-GB hipMalloc costs between 0.4 and 500 ms, which a loop over batches should not pay per
+ * batch).  This call frees what is cached; coati_hip_model_destroy does it too. */
+int coati_hip_model_trim(coati_hip_model_t* model);
 
 /* ---- batch -------------------------------------------------------------- *
  * Validates and uploads n_pairs encoded pairs (host pointers) and reserves the

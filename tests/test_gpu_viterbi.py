@@ -112,6 +112,40 @@ def test_one_shot_chunked_equals_resident(hip, oracle):
         assert bits(scores[p]) == bits(want_score) and (got == want_ops).all()
 
 
+def test_workspace_reuse_across_batches(hip, oracle):
+    """A model hands the HBM workspace of a destroyed batch to the next one (coati_hip.h:
+    coati_hip_model_trim).  Batches of different shapes created, run and destroyed in turn on ONE
+    model -- larger after smaller, smaller into a larger leftover, Forward + samples in between --
+    must give what a fresh model gives; the stale contents of a reused workspace must never show."""
+    from coati_amd import host
+
+    rng = np.random.default_rng(19)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    model = hip.Model(table, consts, 1)
+    shapes = [(30, 60), (8, 20), (3, 400), (40, 90), (1, 5), (25, 60)]
+    for round_no, (n, max_cod) in enumerate(shapes):
+        enc = util.encode_pairs(util.make_pairs(rng, n, 1, max_cod) + [("", ""), ("ACG", "")])
+        batch = hip.Batch(model, *hip.pack_pairs(enc))
+        batch.viterbi_launch()
+        scores, ops, off, ln = batch.viterbi_fetch()
+        if round_no % 2 == 1:  # Forward on the same (reused) workspace
+            batch.forward_launch()
+            final = batch.forward_final()
+        for p, (a, b) in enumerate(enc):
+            want_ops, want_score = oracle.viterbi(table, consts, 1, a, b)
+            got = ops[int(off[p]):int(off[p]) + int(ln[p])]
+            assert bits(scores[p]) == bits(want_score) and len(got) == len(want_ops) and (got == want_ops).all(), (round_no, p)
+            if round_no % 2 == 1 and util.forward_exact():
+                M, D, I = oracle.fill(oracle.LOG, table, consts, 1, a, b)
+                assert util.same_bits(final[p], np.array([M[-1, -1], D[-1, -1], I[-1, -1]], np.float32)), (round_no, p)
+        batch.close()
+        if round_no == 3:
+            model.trim()  # drop the cache in the middle: the next batch allocates afresh
+    model.trim()
+    model.close()
+
+
 def test_invalid_inputs_rejected(hip, oracle):
     table = util.random_table(np.random.default_rng(1))
     consts = oracle.gap_consts()
