@@ -294,7 +294,7 @@ def main():
             "pcie_inclusive": None if args.no_extras else {
                 "gcups": cells / e2e / 1e9, "pairs_per_s": args.pairs / e2e, "ms": e2e * 1e3,
                 "what": "coati_hip_viterbi_batch on rank 0: H2D of the encoded batch + kernels + D2H of scores/ops, "
-                        "pageable host memory, one call"},
+                        "pageable host memory, one call (best of 2; the second reuses the workspace the model cached)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)
