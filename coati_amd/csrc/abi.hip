@@ -417,31 +417,45 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
     });
-    // Experimental: the last `tail_pairs` pairs of the queue in narrow strips (finer items at the
-    // ragged end of a batch).  COATI_HIP_TAIL_PAIRS / COATI_HIP_TAIL_W.
+    // Ragged end of the queue.  The persistent kernel runs kFillSlots wavefronts whose speeds differ
+    // by +-15 % (trace build: wavefronts of one launch finish between 5.2 and 6.8 ms), so a batch of
+    // equal pairs ends raggedly however many rounds it has: slow wavefronts are still on their last
+    // 1.7 ms item while the fast ones have nothing left to draw.  The last quarter round of such a
+    // batch (the end of the LPT order) therefore gets 8-column-per-lane strips -- twice as many,
+    // half as long items that the early finishers pick up.  Measured (tools/ab_fill.py, 1 kb pairs):
+    // 9 216 pairs +11 %, 6 644 +6 %, 10 000 +3.7 %, 20 000 and 40 000 +2.3 %, 12 000 and 125 000 +-0.5 %; narrowing more
+    // than ~1 000 pairs, or to 4 columns, loses (W = 8 runs at ~85 %, W = 4 at ~57 % of the W = 16
+    // rate per cell).  A mixed bag needs none of it: its short pairs already end the queue.
+    // COATI_HIP_TAIL_PAIRS=<n> overrides the count (0: off).
     std::vector<uint8_t> pair_w(n_pairs, 0);
     if(plan_l1) {
+        auto items_of = [&](uint64_t p, uint32_t w) {
+            uint32_t ns = 1, wl = w;
+            if(b->desc[p].la > 0 && b->desc[p].lb > 0) viterbi_strip_plan(b->desc[p].lb, w, ns, wl);
+            return static_cast<uint64_t>(ns);
+        };
         auto count_items = [&](uint32_t w) {
             uint64_t items = 0;
-            for(uint64_t p = 0; p < n_pairs; ++p) {
-                uint32_t ns = 1, wl = w;
-                if(b->desc[p].la > 0 && b->desc[p].lb > 0) viterbi_strip_plan(b->desc[p].lb, w, ns, wl);
-                items += ns;
-            }
+            for(uint64_t p = 0; p < n_pairs; ++p) items += items_of(p, w);
             return items;
         };
-        constexpr uint64_t kSimds = 1024;
+        constexpr uint64_t kSimds = 1024, kFillSlots = 3 * kSimds;
         while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
         if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
             const int w = std::atoi(e);
             if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
         }
-        const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS");
-        const char* tw = std::getenv("COATI_HIP_TAIL_W");
-        const uint64_t tail_pairs = tp != nullptr ? std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10)) : 0;
-        const int tail_w = tw != nullptr ? std::atoi(tw) : 4;
-        if(tail_w == 4 || tail_w == 8)
-            for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = static_cast<uint8_t>(tail_w);
+        uint64_t tail_pairs = 0;
+        if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {
+            tail_pairs = std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10));
+        } else if(w_main == kW && n_pairs > 0) {
+            // "equal pairs": the smallest has at least half the cells of the largest (LPT order);
+            // and the batch must be clearly longer than one round (3 500 pairs: -1 %, 6 644: +6 %)
+            auto cells_of = [&](uint64_t p) { return static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb; };
+            const bool homogeneous = cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]);
+            if(homogeneous && n_pairs > kFillSlots * 3 / 2) tail_pairs = kFillSlots / 4;
+        }
+        for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = 8;
     }
     // gap_len 2 and 3: viterbi_k works on the live cells only, in block columns (lb / L), strips of
     // 16 block columns per lane and a narrow shape (6 for L = 3, 8 for L = 2) for the last strip
