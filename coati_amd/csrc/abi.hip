@@ -417,10 +417,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
     });
-    // Ragged end of the queue.  The persistent kernel runs kFillSlots wavefronts whose speeds differ
-    // by +-15 % (trace build: wavefronts of one launch finish between 5.2 and 6.8 ms), so a batch of
-    // equal pairs ends raggedly however many rounds it has: slow wavefronts are still on their last
-    // 1.7 ms item while the fast ones have nothing left to draw.  The last quarter round of such a
+    // Ragged end of the queue.  The persistent kernel runs kFillSlots wavefronts, three per SIMD, and
+    // the SIMD's issue arbitration favours the oldest: in the trace build one 1 kb item takes a
+    // wavefront between 1.15 and 3.4 ms (mean 2.1; `make trace`, tools/trace_fill.py).  The SIMD as a
+    // whole is work-conserving, but when the queue runs empty every SIMD still holds up to three
+    // items in different states of progress and drains them alone -- a batch of equal pairs ends
+    // raggedly however many rounds it has.  The last quarter round of such a
     // batch (the end of the LPT order) therefore gets 8-column-per-lane strips -- twice as many,
     // half as long items that the early finishers pick up.  Measured (tools/ab_fill.py, 1 kb pairs):
     // 9 216 pairs +11 %, 6 644 +6 %, 10 000 +3.7 %, 20 000 and 40 000 +2.3 %, 12 000 and 125 000 +-0.5 %; narrowing more
