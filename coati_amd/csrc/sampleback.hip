@@ -96,18 +96,26 @@ __device__ __forceinline__ int sample3(float lm, float ld, float li, float p, fl
     score += lx - libm::logf_pos(scale);
     return st;
 }
-// sample_mi (align_pair.cc:370-385)
-__device__ __forceinline__ int sample2(float lm, float li, float p, float& score, const uint64_t* exp_tab) {
-    const float m = libm::expf_nonpos(lm, exp_tab), i = libm::expf_nonpos(li, exp_tab);
-    const float scale = m + i;
-    p *= scale;
-    const bool pick_m = p < m;
-    score += (pick_m ? lm : li) - libm::logf_pos(scale);
-    return pick_m ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
-}
+// sample_mi (align_pair.cc:370-385) is sample3 with a middle term of weight exactly zero (ld = -inf):
+// scale = (m + 0) + i, `p < 0 + m` is the test that already failed, and the picked log-term and
+// logf(scale) are the same floats -- so the walk below calls sample3 for all three states.
 
 // One walk (sampleback, align_pair.cc:401-458).  Ops are written right-to-left into
 // [slot, slot + la + lb); returns the position of the first op.
+//
+// Shape of the loop.  A step at cell (i, j) in state st needs M/D/I of ONE predecessor cell --
+// (i-1, j-1), (i-L, j) or (i, j-L) for st = M, D, I -- and the draw then picks the state st' the
+// walk is in at that cell.  The step is branch-free so that the 64 independent walks of a wavefront
+// do not serialise three code paths: the states differ in a handful of selects, then ONE sample_mdi
+// runs for all lanes.  The triple loaded for the step is also M/D/I of the cell the walk arrives
+// at, so nothing is loaded twice (3 loads per step).  Requesting the predecessors of the NEXT cell
+// ahead of the arithmetic was tried and is slower: with 10^5 walks in flight the walk is bound by
+// memory transactions, not by latency, and the speculative requests triple them (16 x 1 000 samples:
+// 71 ms against 51).  The values and the order of every float operation are those of the reference.
+struct Triple {
+    float m, d, in;
+};
+
 __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restrict__ ops, uint64_t slot, float& score,
                                 uint32_t& draws) {
     const uint32_t L = w.L;
@@ -115,67 +123,52 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
     uint32_t i = w.la + L - 1, j = w.lb + L - 1;
     uint64_t pos = slot + w.la + w.lb;
     score = 0.0f;
-    float m, d, in;
-    w.cell(i, j, m, d, in);
-    float top = fmaxf(fmaxf(m, d), in);
-    int st = sample3(m - top, d - top, in - top, rng_f24(rng), score, w.exp_tab);
+    Triple cur;  // M/D/I of the cell the walk is at (terminal-adjusted at the last cell)
+    w.cell(i, j, cur.m, cur.d, cur.in);
+    int st;
+    {
+        const float top = fmaxf(fmaxf(cur.m, cur.d), cur.in);
+        st = sample3(cur.m - top, cur.d - top, cur.in - top, rng_f24(rng), score, w.exp_tab);
+    }
     while(j > L - 1 || i > L - 1) {
         ++draws;
         const bool body = i >= L && j >= L;
-        if(st == COATI_HIP_OP_MATCH) {
-            ops[--pos] = COATI_HIP_OP_MATCH;
-            w.cell(i, j, m, d, in);
-            top = m;
-            float mm = kLowest, dm = kLowest, im = kLowest;
-            if(body) {
-                float pm, pdd, pi;
-                w.pred(i - 1, j - 1, pm, pdd, pi);
-                const float s = w.subst(i, j);
-                mm = ((pm + w.k.ng) + w.k.ng) + s;
-                dm = (pdd + w.k.gs) + s;
-                im = ((pi + w.k.gs) + w.k.ng) + s;
-            }
-            st = sample3(mm - top, dm - top, im - top, rng_f24(rng), score, w.exp_tab);
-            --i;
-            --j;
-        } else if(st == COATI_HIP_OP_DEL) {
-            for(uint32_t q = 0; q < L; ++q) ops[--pos] = COATI_HIP_OP_DEL;
-            w.cell(i, j, m, d, in);
-            top = d;
-            float md = kLowest, dd = kLowest, id = kLowest;
-            if(body) {
-                float pm, pdd, pi;
-                w.pred(i - L, j, pm, pdd, pi);
-                md = ((pm + w.k.ng) + w.k.go) + w.ext_lm1;
-                dd = pdd + w.ext_l;
-                id = ((pi + w.k.gs) + w.k.go) + w.ext_lm1;
-            } else {
-                // margins: del_del is a copy of the margin D made BEFORE the terminal adjustment
-                // (init_margins, align_pair.hpp:108-111)
-                float mm0, dm0, im0;
-                margin_mdi(w.k, L, i, j, mm0, dm0, im0);
-                dd = dm0;
-            }
-            st = sample3(md - top, dd - top, id - top, rng_f24(rng), score, w.exp_tab);
-            i -= L;
-        } else {
-            for(uint32_t q = 0; q < L; ++q) ops[--pos] = COATI_HIP_OP_INS;
-            w.cell(i, j, m, d, in);
-            top = in;
-            float mi = kLowest, ii = kLowest;
-            if(body) {
-                float pm, pdd, pi;
-                w.pred(i, j - L, pm, pdd, pi);
-                mi = (pm + w.k.go) + w.ext_lm1;
-                ii = pi + w.ext_l;
-            } else {
-                float mm0, dm0, im0;
-                margin_mdi(w.k, L, i, j, mm0, dm0, im0);
-                ii = im0;
-            }
-            st = sample2(mi - top, ii - top, rng_f24(rng), score, w.exp_tab);
-            j -= L;
+        const bool is_m = st == COATI_HIP_OP_MATCH, is_d = st == COATI_HIP_OP_DEL;
+        // where this step goes, and M/D/I there (a walk that would leave the matrix -- impossible
+        // with non-zero probability -- reads nothing)
+        const uint32_t pi = is_m ? i - 1 : (is_d ? i - L : i), pj = is_m ? j - 1 : (is_d ? j : j - L);
+        Triple t{kLowest, kLowest, kLowest};
+        if(pi <= i && pj <= j) w.pred(pi, pj, t.m, t.d, t.in);
+        const float top = is_m ? cur.m : (is_d ? cur.d : cur.in);
+        // the emitted columns: one match, or L gap columns
+        const uint32_t n_emit = is_m ? 1u : L;
+        for(uint32_t q = 0; q < n_emit; ++q) ops[--pos] = static_cast<uint8_t>(st);
+        // the edge values of the fill (align_pair.cc:97-119) at (i, j) for the current state
+        float e0 = kLowest, e1 = kLowest, e2 = kLowest;
+        if(body) {
+            const float s = w.subst(i, j);
+            // st = M: mch_mch, del_mch, ins_mch;  D: mch_del, del_del, ins_del;  I: mch_ins, -, ins_ins
+            const float m1 = t.m + (is_m || is_d ? w.k.ng : w.k.go);  // (M+ng) | (M+ng) | (M+go)
+            e0 = is_m ? (m1 + w.k.ng) + s : (is_d ? (m1 + w.k.go) + w.ext_lm1 : m1 + w.ext_lm1);
+            e1 = is_m ? (t.d + w.k.gs) + s : t.d + w.ext_l;
+            const float i1 = t.in + w.k.gs;
+            e2 = is_m ? (i1 + w.k.ng) + s : (is_d ? (i1 + w.k.go) + w.ext_lm1 : t.in + w.ext_l);
+        } else if(!is_m) {
+            // margins: del_del / ins_ins are copies of the margin D / I made BEFORE the terminal
+            // adjustment (init_margins, align_pair.hpp:108-111); everything else stays `lowest`
+            float mm0, dm0, im0;
+            margin_mdi(w.k, L, i, j, mm0, dm0, im0);
+            if(is_d)
+                e1 = dm0;
+            else
+                e2 = im0;
         }
+        // state I draws among two terms (sample_mi): a middle term of exactly zero weight
+        const float l1 = (is_m || is_d) ? e1 - top : -__builtin_inff();
+        st = sample3(e0 - top, l1, e2 - top, rng_f24(rng), score, w.exp_tab);
+        i = pi;
+        j = pj;
+        cur = t;
     }
     return pos;
 }
