@@ -294,16 +294,16 @@ __device__ __forceinline__ void viterbi_finish(int lane, const GapConsts& k, uin
 }
 
 // Forward: HBM layout of the fp32 M/D/I of the body cells of one strip of one pair:
-//   float[((k * 3 + mat) * 16 + c) * 64 + lane], k = wavefront step = body_row + lane,
-//   mat 0/1/2 = M/D/I, c = the lane's column.  Every (k, mat, c) is one coalesced
-//   256-byte row.  12 bytes per cell.
+//   float[(((k * 16 + c) * 64 + lane) * 3 + mat], k = wavefront step = body_row + lane,
+//   mat 0/1/2 = M/D/I, c = the lane's column.  Every (k, c) is one coalesced 768-byte row
+//   written by one 12-byte store per lane.  12 bytes per cell.
 constexpr int kMdiStepFloats = 3 * kW * kWave;  // 3072
 __host__ __device__ inline uint64_t strip_mdi_floats(uint32_t la) {
     return static_cast<uint64_t>(la + kWave) * kMdiStepFloats;
 }
 // Compact Forward layout (gap_len L = 2, 3; forward_k.hip): live cells (p*L + r, q*L + r) only.  A
 // lane owns Wf block columns (one shape per L), step k = p + lane:
-//   float[((k * L + r) * 3 + mat) * Wf + c) * 64 + lane]
+//   float[((((k * L + r) * Wf + c) * 64 + lane) * 3 + mat]
 __host__ __device__ constexpr uint32_t fwd_compact_w(uint32_t L) { return L == 3 ? 6u : 8u; }
 __host__ __device__ inline uint64_t fwd_compact_strip_floats(uint32_t la, uint32_t L) {
     return static_cast<uint64_t>(la / L + kWave - 1) * (3 * L * fwd_compact_w(L)) * kWave;
@@ -312,16 +312,21 @@ __host__ __device__ inline uint32_t fwd_compact_strips(uint32_t lb, uint32_t L) 
     const uint32_t per = kWave * fwd_compact_w(L);
     return (lb / L + per - 1) / per;
 }
+// M, D, I of one cell are adjacent (12 bytes): the fill writes them with one 12-byte store per lane (a
+// wavefront's store covers 768 contiguous bytes) and a sampler step reads them with one load.
+struct Mdi {
+    float m, d, in;
+};
 __device__ __forceinline__ uint64_t mdi_index(const PairDesc& pd, uint32_t bi, uint32_t bj, int mat) {
     if(pd.f_compact != 0) {
         const uint32_t L = pd.f_compact, wf = fwd_compact_w(L), per = kWave * wf;
         const uint32_t q = bj / L, r = bi % L, p = bi / L;
         const uint32_t strip = q / per, colin = q % per, t = colin / wf, c = colin % wf;
         return pd.mdi_off + strip * fwd_compact_strip_floats(pd.la, L) +
-               ((static_cast<uint64_t>(p + t) * L + r) * 3 + mat) * wf * kWave + c * kWave + t;
+               (((static_cast<uint64_t>(p + t) * L + r) * wf + c) * kWave + t) * 3 + mat;
     }
     const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
-    return pd.mdi_off + strip * strip_mdi_floats(pd.la) + ((static_cast<uint64_t>(bi + t) * 3 + mat) * kW + c) * kWave + t;
+    return pd.mdi_off + strip * strip_mdi_floats(pd.la) + ((static_cast<uint64_t>(bi + t) * kW + c) * kWave + t) * 3 + mat;
 }
 // a live cell of the Forward layout?  (every cell when the layout is not compact)
 __device__ __forceinline__ bool mdi_stored(const PairDesc& pd, uint32_t bi, uint32_t bj) {

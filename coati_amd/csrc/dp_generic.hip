@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
                 const bool last_strip = strip + 1 == strips;
                 const int last_lane = static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), last_c = (lb - 1) & (kW - 1);
                 uint32_t* __restrict__ fout = flags + pd.flags_off + strip * strip_dwords(la) + lane;
-                float* __restrict__ mout = mdi + pd.mdi_off + strip * strip_mdi_floats(la) + lane;
+                float* __restrict__ mout = mdi + pd.mdi_off + strip * strip_mdi_floats(la) + 3 * lane;
 
                 uint32_t bcode[kW];
 #pragma unroll
@@ -218,10 +218,7 @@ __global__ __launch_bounds__(kWave) void dp_generic(const float* __restrict__ ta
                             rowbuf[col + L] = M;
                             rowbuf[kRowBufCols + col + L] = I;
                             if constexpr(kLog) {
-                                float* dst = mout + (static_cast<uint64_t>(kstep) * 3 * kW + c) * kWave;
-                                dst[0] = M;
-                                dst[kW * kWave] = D;
-                                dst[2 * kW * kWave] = I;
+                                *reinterpret_cast<Mdi*>(mout + (static_cast<uint64_t>(kstep) * kW + c) * (3 * kWave)) = Mdi{M, D, I};
                             } else {
                                 // the five decisions of align_pair.cc:275-296 on this cell (common.hpp layout)
                                 const float x1 = (M + k.ng) + k.ng, x2 = D + k.gs, x3 = (I + k.gs) + k.ng;

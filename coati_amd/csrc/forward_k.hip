@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 3 : 2) void forward_k(
         const uint32_t nlanes = (ncol + W - 1) / W;
         const uint32_t nsteps = rows_b + nlanes - 1;
         const bool last_strip = strip + 1 == strips;
-        float* __restrict__ mout = mdi + pd.mdi_off + strip * fwd_compact_strip_floats(pd.la, L) + lane;
+        float* __restrict__ mout = mdi + pd.mdi_off + strip * fwd_compact_strip_floats(pd.la, L) + 3 * lane;
         // strip boundary: per block row (entry p + 1; entry 0 = the margin row) M, D, I of every phase
         // of the strip's last block column
         const uint64_t bstride = 3ull * L * (static_cast<uint64_t>(rows_b) + 1);
@@ -219,9 +219,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 3 : 2) void forward_k(
                         dM = M;  // the next phase's diagonal
                         dD = D;
                         dI = I;
-                        dst[((r * 3 + 0) * W + c) * kWave] = M;
-                        dst[((r * 3 + 1) * W + c) * kWave] = D;
-                        dst[((r * 3 + 2) * W + c) * kWave] = I;
+                        *reinterpret_cast<Mdi*>(dst + (r * W + c) * (3 * kWave)) = Mdi{M, D, I};
                     }
                 }
                 const int p = static_cast<int>(kstep) - lane;  // block row this lane just did

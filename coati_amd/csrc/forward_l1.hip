@@ -121,9 +121,7 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
             st.M[c] = M;
             st.D[c] = D;
             st.I[c] = I;
-            dst[c * kWave] = M;
-            dst[(kW + c) * kWave] = D;
-            dst[(2 * kW + c) * kWave] = I;
+            *reinterpret_cast<Mdi*>(dst + c * (3 * kWave)) = Mdi{M, D, I};
         }
         arow = arow_next;
         const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
         }
         const FwdCtx cx{k, la, col0, nsteps, pair, lane,
                         static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
-                        last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats(la) + lane, bnd_out, final_mdi, exp_tab};
+                        last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats(la) + 3 * lane, bnd_out, final_mdi, exp_tab};
         FwdLane st;
 #pragma unroll
         for(int c = 0; c < kW; ++c) st.M[c] = st.D[c] = st.I[c] = kLowest;

@@ -49,9 +49,10 @@ struct Walker {
     // (the reference stores it adjusted, align_pair.cc:130-138).
     __device__ __forceinline__ void cell(uint32_t i, uint32_t j, float& m, float& d, float& in) const {
         if(i >= L && j >= L) {
-            m = mdi[mdi_index(pd, i - L, j - L, 0)];
-            d = mdi[mdi_index(pd, i - L, j - L, 1)];
-            in = mdi[mdi_index(pd, i - L, j - L, 2)];
+            const Mdi v = *reinterpret_cast<const Mdi*>(mdi + mdi_index(pd, i - L, j - L, 0));  // one 12-byte load
+            m = v.m;
+            d = v.d;
+            in = v.in;
         } else {
             margin_mdi(k, L, i, j, m, d, in);
         }
@@ -64,9 +65,10 @@ struct Walker {
     // like cell() but never adjusted: the fill's inputs (a predecessor is never the last cell)
     __device__ __forceinline__ void pred(uint32_t i, uint32_t j, float& m, float& d, float& in) const {
         if(i >= L && j >= L) {
-            m = mdi[mdi_index(pd, i - L, j - L, 0)];
-            d = mdi[mdi_index(pd, i - L, j - L, 1)];
-            in = mdi[mdi_index(pd, i - L, j - L, 2)];
+            const Mdi v = *reinterpret_cast<const Mdi*>(mdi + mdi_index(pd, i - L, j - L, 0));  // one 12-byte load
+            m = v.m;
+            d = v.d;
+            in = v.in;
         } else {
             margin_mdi(k, L, i, j, m, d, in);
         }
