@@ -110,10 +110,13 @@ __device__ __forceinline__ int sample3(float lm, float ld, float li, float p, fl
 // walk is in at that cell.  The step is branch-free so that the 64 independent walks of a wavefront
 // do not serialise three code paths: the states differ in a handful of selects, then ONE sample_mdi
 // runs for all lanes.  The triple loaded for the step is also M/D/I of the cell the walk arrives
-// at, so nothing is loaded twice (3 loads per step).  Requesting the predecessors of the NEXT cell
-// ahead of the arithmetic was tried and is slower: with 10^5 walks in flight the walk is bound by
-// memory transactions, not by latency, and the speculative requests triple them (16 x 1 000 samples:
-// 71 ms against 51).  The values and the order of every float operation are those of the reference.
+// at, so nothing is loaded twice (one 12-byte load per step).  Requesting the three possible
+// predecessors of the NEXT cell ahead of the arithmetic was tried twice (matrix-by-matrix layout:
+// 9 loads per step, 71 ms against 51 for 16 x 1 000 samples; interleaved layout: 3 loads, 63 ms
+// against 40) and loses both times: at 2 wavefronts per SIMD a wavefront issues one instruction
+// per ~4.4 cycles, so the ~100 instructions of extra index arithmetic and selects cost more than
+// the load latency they hide.  The values and the order of every float operation are those of the
+// reference.
 struct Triple {
     float m, d, in;
 };
