@@ -4,6 +4,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -127,6 +128,9 @@ struct coati_hip_model {
     static constexpr size_t kCachedArenas = 2;
     std::vector<Arena> free_arenas;
     std::mutex arena_lock;
+    // the handle itself + one per live batch: coati_hip_model_destroy while batches are alive only
+    // marks the model; the last batch_destroy releases it (a batch keeps launching on m->stream)
+    std::atomic<int> refs{1};
 };
 
 struct coati_hip_batch {
@@ -237,13 +241,20 @@ int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float n
     return COATI_HIP_OK;
 }
 
-void coati_hip_model_destroy(coati_hip_model_t* m) {
-    if(m == nullptr) return;
+namespace {
+void model_release(coati_hip_model* m) {
+    if(m->refs.fetch_sub(1) != 1) return;  // batches (or the handle) still hold it
     (void)hipSetDevice(m->device);
     for(const auto& a : m->free_arenas) (void)hipFree(a.ptr);
     if(m->d_table != nullptr) (void)hipFree(m->d_table);
     if(m->stream != nullptr) (void)hipStreamDestroy(m->stream);
     delete m;
+}
+}  // namespace
+
+void coati_hip_model_destroy(coati_hip_model_t* m) {
+    if(m == nullptr) return;
+    model_release(m);
 }
 
 void coati_hip_batch_destroy(coati_hip_batch_t* b) {
@@ -274,6 +285,7 @@ void coati_hip_batch_destroy(coati_hip_batch_t* b) {
         for(hipEvent_t e : trio)
             if(e != nullptr) (void)hipEventDestroy(e);
     delete b;
+    if(m != nullptr) model_release(m);
 }
 
 int coati_hip_model_trim(coati_hip_model_t* m) {
@@ -332,6 +344,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     auto* b = new(std::nothrow) coati_hip_batch;
     if(b == nullptr) return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
     b->model = model;
+    model->refs.fetch_add(1);  // released by coati_hip_batch_destroy
     b->n_pairs = n_pairs;
     struct Owner {  // destroys the half-built batch on every exit but the successful one
         coati_hip_batch* b;

@@ -91,6 +91,9 @@ int coati_hip_model_create(const float* table, float no_gap, float gap_stop, flo
 int coati_hip_model_create_tables(const float* tables, uint32_t n_tables, float no_gap, float gap_stop,
                                   float gap_open, float gap_extend, int gap_len, int device,
                                   coati_hip_model_t** out);
+/* Batches created from a model keep it alive: destroying the model first is allowed (its
+ * batches stay usable, the model's memory is released with the last of them); creating new
+ * batches from a destroyed handle is not. */
 void coati_hip_model_destroy(coati_hip_model_t* model);
 /* A model keeps the HBM workspaces of its last (at most two) destroyed batches and hands them to
  * the next coati_hip_batch_create whose needs they fit (the reference has no counterpart: its work

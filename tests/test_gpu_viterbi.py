@@ -146,6 +146,25 @@ def test_workspace_reuse_across_batches(hip, oracle):
     model.close()
 
 
+def test_model_destroyed_before_its_batch(hip, oracle):
+    """coati_hip.h: a batch keeps its model alive -- destroying the model handle first leaves the
+    batch usable and nothing dangling when the batch goes last."""
+    rng = np.random.default_rng(23)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    enc = util.encode_pairs(util.make_pairs(rng, 6, 5, 40))
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc))
+    model.close()
+    batch.viterbi_launch()
+    scores, ops, off, ln = batch.viterbi_fetch()
+    for p, (a, b) in enumerate(enc):
+        want_ops, want_score = oracle.viterbi(table, consts, 1, a, b)
+        got = ops[int(off[p]):int(off[p]) + int(ln[p])]
+        assert bits(scores[p]) == bits(want_score) and (got == want_ops).all()
+    batch.close()
+
+
 def test_invalid_inputs_rejected(hip, oracle):
     table = util.random_table(np.random.default_rng(1))
     consts = oracle.gap_consts()
