@@ -182,7 +182,7 @@ __device__ __forceinline__ bool wait_rows(const uint32_t* word, uint32_t need) {
 }
 
 template <bool kFast>
-__global__ __launch_bounds__(kFillWaves* kWave, 2) void forward_l1(
+__global__ __launch_bounds__(kFillWaves* kWave, kFast ? 2 : 3) void forward_l1(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
@@ -298,7 +298,8 @@ hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream) {
     e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_fwd_items, 4u), stream);
     if(e != hipSuccess) return e;
     // two workgroups (8 wavefronts) per CU; fewer when there are fewer items than wavefronts
-    const uint32_t blocks = std::min<uint32_t>(512u, std::max<uint32_t>(256u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
+    const uint32_t per_cu = forward_fast_math() ? 2u : 3u;  // (the exact build fits 3 wavefronts per SIMD)
+    const uint32_t blocks = std::min<uint32_t>(256u * per_cu, std::max<uint32_t>(256u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
     if(forward_fast_math())
         hipLaunchKernelGGL(forward_l1<true>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,
                            v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
