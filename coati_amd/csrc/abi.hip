@@ -1123,24 +1123,39 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     HIP_TRY(hipSetDevice(model->device));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = static_cast<uint64_t>(free_b * 0.8);
+    {   // cached workspaces of this model count as free: they are reused or released on demand
+        std::lock_guard<std::mutex> hold(model->arena_lock);
+        for(const auto& a : model->free_arenas) free_b += a.bytes;
+    }
+    uint64_t budget = static_cast<uint64_t>(free_b * 0.8);
+    if(const char* e = std::getenv("COATI_HIP_MEM_BUDGET")) {  // tests: force chunking with a small budget (bytes)
+        const uint64_t forced = std::strtoull(e, nullptr, 10);
+        if(forced > 0) budget = std::min(budget, forced);
+    }
     uint64_t ops_base = 0;  // slot start of the first pair of the current chunk
     uint64_t p0 = 0;
     while(p0 < n_pairs) {
         // grow the chunk until the workspace estimate exceeds the budget
-        uint64_t p1 = p0, need = 0, chunk_ops = 0;
+        uint64_t p1 = p0, need = 0;
         while(p1 < n_pairs) {
             const uint64_t la = a_off[p1 + 1] - a_off[p1], lb = b_off[p1 + 1] - b_off[p1];
             const uint64_t w = (la > 0 && lb > 0) ? n_strips(static_cast<uint32_t>(lb)) * strip_dwords(static_cast<uint32_t>(la)) * 4 : 0;
             const uint64_t add = w + 3 * (la + lb) + 8 * (la + 1) + 128;
             if(p1 > p0 && need + add > budget) break;
             need += add;
-            chunk_ops += la + lb;
             ++p1;
         }
+        // the estimate is not the plan: if the workspace does not fit after all, halve the chunk
         coati_hip_batch_t* b = nullptr;
-        int rc = coati_hip_batch_create(model, p1 - p0, a_cat, a_off + p0, b_cat, b_off + p0, &b);
+        int rc = COATI_HIP_OK;
+        for(;;) {
+            rc = coati_hip_batch_create(model, p1 - p0, a_cat, a_off + p0, b_cat, b_off + p0, &b);
+            if(rc != COATI_HIP_ENOMEM || p1 - p0 <= 1) break;
+            p1 = p0 + (p1 - p0) / 2;
+        }
         if(rc != COATI_HIP_OK) return rc;
+        uint64_t chunk_ops = 0;
+        for(uint64_t p = p0; p < p1; ++p) chunk_ops += (a_off[p + 1] - a_off[p]) + (b_off[p + 1] - b_off[p]);
         rc = coati_hip_viterbi_launch(b);
         if(rc == COATI_HIP_OK)
             rc = coati_hip_viterbi_fetch(b, scores ? scores + p0 : nullptr, ops ? ops + ops_base : nullptr,

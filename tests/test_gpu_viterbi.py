@@ -1,6 +1,8 @@
 """Parity of the HIP Viterbi path (through the C ABI) with the CPU oracle.
 Bit-exact: fp32 score bits, every alignment op, and every per-cell traceback
 decision byte."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -163,6 +165,42 @@ def test_model_destroyed_before_its_batch(hip, oracle):
         got = ops[int(off[p]):int(off[p]) + int(ln[p])]
         assert bits(scores[p]) == bits(want_score) and (got == want_ops).all()
     batch.close()
+
+
+def test_one_shot_call_chunks_to_the_memory_budget():
+    """coati_hip_viterbi_batch cuts its input into as many resident batches as the free HBM needs.
+    COATI_HIP_MEM_BUDGET (bytes) forces that with a tiny budget in a child process: many chunks,
+    same scores / ops / offsets as the unchunked call."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys, zlib, json, numpy as np
+sys.path.insert(0, %r)
+from coati_amd import hip, host
+from tests import util
+rng = np.random.default_rng(31)
+enc = util.encode_pairs(util.make_pairs(rng, 120, 1, 90) + [("", ""), ("ACG", ""), ("", "ACGT")])
+model = hip.Model(host.set_subst("mar-mg"), host.gap_consts(), 1)
+scores, ops, off, ln = model.viterbi(*hip.pack_pairs(enc))
+crc = 0
+for p in range(len(enc)):
+    crc = zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes(), crc)
+print(json.dumps({"ops": crc, "scores": zlib.crc32(scores.tobytes()), "len": int(ln.sum()), "off": zlib.crc32(off.tobytes())}))
+''' % str(root)
+    outs = []
+    for budget in (None, "200000"):  # ~200 kB: a handful of pairs per chunk
+        env = dict(os.environ)
+        env.pop("COATI_HIP_MEM_BUDGET", None)
+        if budget:
+            env["COATI_HIP_MEM_BUDGET"] = budget
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1], outs
 
 
 def test_invalid_inputs_rejected(hip, oracle):
