@@ -154,8 +154,17 @@ void sampleback(const align_pair_work_t& work, const std::string& a, const std::
 }
 
 bool marg_alignment(alignment_t& aln) {
+    const bool timing = std::getenv("COATI_HOST_TIMING") != nullptr;  // stage times on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if(!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::cerr << "marg_alignment: " << what << " " << std::chrono::duration<double, std::milli>(t - t_prev).count() << " ms\n";
+        t_prev = t;
+    };
     aln.data = read_input(aln.data.path);
     set_subst(aln);
+    stage("input + model");
     if(aln.score) {
         std::cout << alignment_score(aln, aln.subst_matrix) << std::endl;
         return true;
@@ -171,9 +180,11 @@ bool marg_alignment(alignment_t& aln) {
         std::cerr << "ERROR: sequences to align exceed available memory." << std::endl;
         return false;  // (upstream returns EXIT_FAILURE from a bool function, i.e. true: align_marginal.cc:72-75)
     }
+    stage("viterbi_mem (HIP runtime start, upload, fill + traceback)");
     traceback_viterbi(work, anc, des, aln, aln.gap.len);
     restore_end_stops(aln.data, aln.gap);
     write_output(aln.data, aln.output);
+    stage("fetch + output");
     return true;
 }
 
