@@ -165,3 +165,24 @@ def test_writers_reject_degenerate_input_cleanly(tmp_path):
     # 128-entry table there, utils.cc:496-528); coati_hip_batch_create rejects codes 15/16
     _, des = host.encode("ACG", "ACé")
     assert des.tolist() == [0, 1, 16, 16]
+
+
+def test_batch_mode_reports_the_first_bad_pair(tmp_path):
+    """`--batch` prepares its pairs on several threads (host/align.cc: parallel_for); the error that
+    comes back must be the one a serial loop would hit first, whatever the threads' timing.
+    (Validation happens before anything touches the GPU, so this runs on CPU.)"""
+    rng = np.random.default_rng(8)
+    good = lambda: ("".join(rng.choice(list("ACG"), 300)), "".join(rng.choice(list("ACGT"), 280)))  # noqa: E731 (no T: no stop codons)
+    recs = []
+    for p in range(2000):
+        a, d = good()
+        if p == 700:
+            a = a[:150] + "NNN" + a[153:]  # ambiguous ancestor: the first error in file order
+        if p in (40 + 700, 1500, 1999):
+            a = a[:30] + "TAA" + a[33:]    # early stop codons further down
+        recs.append(f">a{p}\n{a}\n>d{p}\n{d}\n")
+    fa = tmp_path / "many.fasta"
+    fa.write_text("".join(recs))
+    for _ in range(3):
+        r = run("coati-alignpair", str(fa), "--batch")
+        assert r.returncode == 1 and "Ambiguous nucleotides in ancestor" in r.stderr, r.stderr[-300:]
