@@ -365,6 +365,28 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     b->desc.resize(n_pairs);
     const uint64_t L = static_cast<uint64_t>(model->gap_len);
     static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+    // Forward strip shape (forward_l1): 16 columns per lane, narrowed to 8 and 4 while the batch has
+    // fewer strips than the kernel has wavefront slots (3 per SIMD) -- a wavefront per 1 024 columns
+    // leaves a small batch on a handful of SIMDs (16 pairs of 1 kb: 17.8 ms at W = 16, 6.3 ms at
+    // W = 4).  A Forward cell is ~440 instructions, so the per-step overhead of a narrow strip is
+    // small, unlike in viterbi_l1.  COATI_HIP_FWD_W=<4|8|16> overrides.
+    constexpr uint64_t kFwdSlots = 3 * 1024;
+    uint32_t fwd_wlog2 = 4;
+    if(L == 1 && !force_generic) {
+        auto count_strips = [&](uint32_t w) {
+            uint64_t n = 0;
+            for(uint64_t p = 0; p < n_pairs && n < kFwdSlots; ++p) {
+                const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+                n += (la > 0 && lb > 0 && lb <= 0x7fffff00ull) ? fwd_strips_w(static_cast<uint32_t>(lb), w) : 1;
+            }
+            return n;
+        };
+        while(fwd_wlog2 > 2 && count_strips(1u << fwd_wlog2) < kFwdSlots) --fwd_wlog2;
+        if(const char* e = std::getenv("COATI_HIP_FWD_W")) {
+            const int w = std::atoi(e);
+            if(w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 4 ? 2u : (w == 8 ? 3u : 4u);
+        }
+    }
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
             return cleanup(fail(COATI_HIP_EINVAL, "batch_create: offsets of pair %llu decrease",
@@ -410,10 +432,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.mdi_off = b->mdi_floats;
         // Forward M/D/I arena: gap_len 2, 3 store the live cells only (forward_k.hip)
         const bool fwd_k = (L == 2 || L == 3) && !force_generic;
-        d.f_compact = fwd_k ? static_cast<uint32_t>(L) : 0u;
+        d.f_compact = static_cast<uint16_t>(fwd_k ? L : 0u);
+        d.f_wlog2 = static_cast<uint8_t>(fwd_wlog2);
+        d.reserved_ = 0;
         if(la > 0 && lb > 0)
             b->mdi_floats += fwd_k ? fwd_compact_strips(d.lb, static_cast<uint32_t>(L)) * fwd_compact_strip_floats(d.la, static_cast<uint32_t>(L))
-                                   : n_strips(d.lb) * strip_mdi_floats(d.la);
+                                   : fwd_strips_w(d.lb, 1u << fwd_wlog2) * strip_mdi_floats_w(d.la, 1u << fwd_wlog2);
         b->ops_total += la + lb;
         b->cells += la * lb;
     }
@@ -519,7 +543,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
         // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
-        const uint64_t nf = n_strips(d.lb);
+        const uint64_t nf = fwd_strips_w(d.lb, 1u << d.f_wlog2);
         const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
                                                   nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
                                                   plan_k ? (ns - 1) * ((la / L + 1) + la) : 0,
@@ -546,7 +570,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
         uint32_t nf = 1;
         if(b->desc[p].la > 0 && b->desc[p].lb > 0)
-            nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact) : n_strips(b->desc[p].lb);
+            nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact)
+                                             : fwd_strips_w(b->desc[p].lb, 1u << b->desc[p].f_wlog2);
         for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
     }
     b->n_items = static_cast<uint32_t>(items.size());

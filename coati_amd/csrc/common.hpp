@@ -54,9 +54,12 @@ struct PairDesc {
     // 0: one stored cell per matrix cell (layout below).  L (2 or 3): "compact" layout of viterbi_k:
     // only the live cells (bi - bj) % L == 0 are stored; the plan counts BLOCK columns (lb / L).
     uint32_t v_compact;
-    // Forward M/D/I layout: 0 = every body cell, 1024-column strips (forward_l1 / dp_generic);
-    // L (2 or 3) = live cells only, forward_k's block-column strips (forward_k.hip)
-    uint32_t f_compact;
+    // Forward M/D/I layout: 0 = every body cell, strips of 64 << f_wlog2 columns (forward_l1: 4, 8 or
+    // 16 columns per lane; dp_generic: 16); L (2 or 3) = live cells only, forward_k's block-column
+    // strips (forward_k.hip)
+    uint16_t f_compact;
+    uint8_t f_wlog2;  // log2 of the columns per lane of the Forward strips (2, 3, 4)
+    uint8_t reserved_;
 };
 
 // HBM layout of the decision bits of one strip of one pair.  A strip is 64*W descendant
@@ -294,13 +297,18 @@ __device__ __forceinline__ void viterbi_finish(int lane, const GapConsts& k, uin
 }
 
 // Forward: HBM layout of the fp32 M/D/I of the body cells of one strip of one pair:
-//   float[(((k * 16 + c) * 64 + lane) * 3 + mat], k = wavefront step = body_row + lane,
+//   float[(((k * W + c) * 64 + lane) * 3 + mat], W = 4, 8 or 16 columns per lane, k = wavefront step = body_row + lane,
 //   mat 0/1/2 = M/D/I, c = the lane's column.  Every (k, c) is one coalesced 768-byte row
 //   written by one 12-byte store per lane.  12 bytes per cell.
 constexpr int kMdiStepFloats = 3 * kW * kWave;  // 3072
 __host__ __device__ inline uint64_t strip_mdi_floats(uint32_t la) {
     return static_cast<uint64_t>(la + kWave) * kMdiStepFloats;
 }
+// the same for strips of w columns per lane (forward_l1 narrows its strips when a batch has few pairs)
+__host__ __device__ inline uint64_t strip_mdi_floats_w(uint32_t la, uint32_t w) {
+    return static_cast<uint64_t>(la + kWave) * (3 * w * kWave);
+}
+__host__ __device__ inline uint32_t fwd_strips_w(uint32_t lb, uint32_t w) { return (lb + kWave * w - 1) / (kWave * w); }
 // Compact Forward layout (gap_len L = 2, 3; forward_k.hip): live cells (p*L + r, q*L + r) only.  A
 // lane owns Wf block columns (one shape per L), step k = p + lane:
 //   float[((((k * L + r) * Wf + c) * 64 + lane) * 3 + mat]
@@ -325,8 +333,9 @@ __device__ __forceinline__ uint64_t mdi_index(const PairDesc& pd, uint32_t bi, u
         return pd.mdi_off + strip * fwd_compact_strip_floats(pd.la, L) +
                (((static_cast<uint64_t>(p + t) * L + r) * wf + c) * kWave + t) * 3 + mat;
     }
-    const uint32_t strip = bj / kStrip, t = (bj % kStrip) / kW, c = bj % kW;
-    return pd.mdi_off + strip * strip_mdi_floats(pd.la) + ((static_cast<uint64_t>(bi + t) * kW + c) * kWave + t) * 3 + mat;
+    const uint32_t wl = pd.f_wlog2, w = 1u << wl, colin = bj & (kWave * w - 1);
+    const uint32_t strip = bj >> (6 + wl), t = colin >> wl, c = bj & (w - 1);
+    return pd.mdi_off + strip * strip_mdi_floats_w(pd.la, w) + ((static_cast<uint64_t>(bi + t) * w + c) * kWave + t) * 3 + mat;
 }
 // a live cell of the Forward layout?  (every cell when the layout is not compact)
 __device__ __forceinline__ bool mdi_stored(const PairDesc& pd, uint32_t bi, uint32_t bj) {

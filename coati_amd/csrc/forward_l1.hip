@@ -28,9 +28,10 @@
 namespace coati_hip_detail {
 namespace {
 
+template <int W>
 struct FwdLane {
-    float M[kW], D[kW], I[kW];     // the lane's 16 columns of the row it processed last
-    float oM, oD, oI;              // column 15 of the row before that: the right neighbour's diagonal
+    float M[W], D[W], I[W];        // the lane's W columns of the row it processed last
+    float oM, oD, oI;              // column W-1 of the row before that: the right neighbour's diagonal
 };
 
 struct FwdCtx {
@@ -56,9 +57,9 @@ __device__ __forceinline__ void store_through(float* p, float v) {
 
 // Up to 64 wavefront steps (see viterbi_l1.hip: run_chunk).  ch*: what lane 0 needs at step
 // kbase + l, held by lane l: diagonal cell (M, D, I) and left cell (M, I) of column col0 - 1.
-template <bool kFirst, bool kFast>
-__device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
-                                         const uint32_t (&boff)[kW], uint32_t kbase, uint32_t kk, uint32_t a_chunk,
+template <int W, bool kFirst, bool kFast>
+__device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint32_t& arow, float (&s)[W],
+                                         const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk, uint32_t a_chunk,
                                          float chDM, float chDD, float chDI, float chLM, float chLI,
                                          const char* tab_bytes) {
     const GapConsts& k = cx.k;
@@ -69,10 +70,10 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
             if(kk == static_cast<uint32_t>(lane)) {
                 // the lane starts: the row above is matrix row 0 (align_pair.cc:88-90):
                 // M = D = lowest, I = go + ge*float(j-1)
-                uint32_t bj0 = cx.col0 + lane * kW;
+                uint32_t bj0 = cx.col0 + lane * W;
                 asm volatile("" : "+v"(bj0));
 #pragma unroll
-                for(int c = 0; c < kW; ++c) {
+                for(int c = 0; c < W; ++c) {
                     st.M[c] = kLowest;
                     st.D[c] = kLowest;
                     st.I[c] = k.go + k.ge * static_cast<float>(bj0 + c);
@@ -80,7 +81,7 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
                 if(!cx.last_strip && lane == kWave - 1) {
                     store_through(&cx.bnd_out[0], kLowest);
                     store_through(&cx.bnd_out[1], kLowest);
-                    store_through(&cx.bnd_out[2], st.I[kW - 1]);
+                    store_through(&cx.bnd_out[2], st.I[W - 1]);
                 }
             }
         }
@@ -88,15 +89,15 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
         float dgM = shift_in(st.oM, read_lane(chDM, kk));
         float dgD = shift_in(st.oD, read_lane(chDD, kk));
         float dgI = shift_in(st.oI, read_lane(chDI, kk));
-        float lfM = shift_in(st.M[kW - 1], read_lane(chLM, kk));
-        float lfI = shift_in(st.I[kW - 1], read_lane(chLI, kk));
+        float lfM = shift_in(st.M[W - 1], read_lane(chLM, kk));
+        float lfI = shift_in(st.I[W - 1], read_lane(chLI, kk));
         const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
-        st.oM = st.M[kW - 1];
-        st.oD = st.D[kW - 1];
-        st.oI = st.I[kW - 1];
-        float* dst = cx.mout + static_cast<uint64_t>(kstep) * kMdiStepFloats;
+        st.oM = st.M[W - 1];
+        st.oD = st.D[W - 1];
+        st.oI = st.I[W - 1];
+        float* dst = cx.mout + static_cast<uint64_t>(kstep) * (3 * W * kWave);
 #pragma unroll
-        for(int c = 0; c < kW; ++c) {
+        for(int c = 0; c < W; ++c) {
             const float sc = s[c];
             // gather the next step's score now (consumed a step later)
             s[c] = *reinterpret_cast<const float*>(tab_bytes + arow_next + boff[c]);
@@ -127,14 +128,14 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
         const int r = static_cast<int>(kstep) - lane;  // body row this lane just did
         if(!cx.last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(cx.la)) {
             float* b = cx.bnd_out + 3 * static_cast<uint64_t>(r + 1);
-            store_through(&b[0], st.M[kW - 1]);
-            store_through(&b[1], st.D[kW - 1]);
-            store_through(&b[2], st.I[kW - 1]);
+            store_through(&b[0], st.M[W - 1]);
+            store_through(&b[1], st.D[W - 1]);
+            store_through(&b[2], st.I[W - 1]);
         }
         if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
             float m = st.M[0], d = st.D[0], in = st.I[0];
 #pragma unroll
-            for(int c = 1; c < kW; ++c) {
+            for(int c = 1; c < W; ++c) {
                 m = (c == cx.last_c) ? st.M[c] : m;
                 d = (c == cx.last_c) ? st.D[c] : d;
                 in = (c == cx.last_c) ? st.I[c] : in;
@@ -148,9 +149,9 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane& st, uint32_t
     }
 }
 
-template <bool kFirst, bool kFast>
-__device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_t& arow, float (&s)[kW],
-                                          const uint32_t (&boff)[kW], uint32_t kbase, uint32_t a_chunk, float chDM,
+template <int W, bool kFirst, bool kFast>
+__device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane<W>& st, uint32_t& arow, float (&s)[W],
+                                          const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk, float chDM,
                                           float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
     const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
     if constexpr(!kFirst && kFast) {
@@ -158,13 +159,13 @@ __device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane& st, uint32_
         // instead of being copied (see viterbi_l1.hip: run_chunk)
         uint32_t kk = 0;
         for(; kk + 1 < kend; kk += 2) {
-            fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
-            fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
         }
-        if(kk < kend) fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+        if(kk < kend) fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     } else {
         for(uint32_t kk = 0; kk < kend; ++kk)
-            fwd_step<kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     }
 }
 
@@ -179,6 +180,81 @@ __device__ __forceinline__ bool wait_rows(const uint32_t* word, uint32_t need) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return true;
+}
+
+// One strip (64 * W descendant columns) of one pair by one wavefront.
+template <int W, bool kFast>
+__device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip,
+                                              uint32_t ticket, int lane, const uint8_t* __restrict__ a_cat,
+                                              const uint8_t* __restrict__ b_cat, float* __restrict__ bnd,
+                                              float* __restrict__ mdi, float* __restrict__ final_mdi,
+                                              uint32_t* __restrict__ progress, const uint64_t* exp_tab,
+                                              const char* tab_bytes) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    const uint8_t* __restrict__ a = a_cat + pd.a_off;
+    const uint8_t* __restrict__ b = b_cat + pd.b_off;
+    const uint32_t strips = fwd_strips_w(lb, W);
+    const uint32_t col0 = strip * (kWave * W);
+    const uint32_t ncol = min(static_cast<uint32_t>((kWave * W)), lb - col0);
+    const uint32_t nlanes = (ncol + W - 1) / W;
+    const uint32_t nsteps = la + nlanes - 1;
+    const bool last_strip = strip + 1 == strips;
+    const uint64_t bstride = 3 * (static_cast<uint64_t>(la) + 1);
+    float* __restrict__ bnd_out = bnd + pd.bnd_off + strip * bstride;
+    const float* __restrict__ bnd_in = bnd + pd.bnd_off + (strip - 1) * bstride;  // strip > 0 only
+
+    uint32_t boff[W];
+#pragma unroll
+    for(int c = 0; c < W; ++c) {
+        const uint32_t bj = col0 + lane * W + c;
+        boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+    }
+    const FwdCtx cx{k, la, col0, nsteps, pair, lane,
+                    static_cast<int>(((lb - 1) & ((kWave * W) - 1)) / W), static_cast<int>((lb - 1) & (W - 1)),
+                    last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats_w(la, W) + 3 * lane, bnd_out, final_mdi, exp_tab};
+    FwdLane<W> st;
+#pragma unroll
+    for(int c = 0; c < W; ++c) st.M[c] = st.D[c] = st.I[c] = kLowest;
+    st.oM = st.oD = st.oI = kLowest;
+    uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+    float s[W];
+#pragma unroll
+    for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
+
+    bool ok = true;
+    for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+        const uint32_t crow = kbase + lane;  // the body row lane 0 processes at step kbase + lane
+        uint32_t a_chunk = 0;
+        float chDM = kLowest, chDD = kLowest, chDI = kLowest, chLM = kLowest, chLI = kLowest;
+        if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+        if(strip == 0) {
+            // matrix column 0 (align_pair.cc:82-86): diagonal of body row r is matrix cell (r, 0)
+            if(crow == 0) chDM = 0.0f;
+            else if(crow < la) chDD = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
+        } else {
+            ok = ok && wait_rows(progress + ticket - 1, min(la, kbase + kWave));
+            if(crow < la) {
+                const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
+                const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
+                chDM = dgp[0];
+                chDD = dgp[1];
+                chDI = dgp[2];
+                chLM = lfp[0];
+                chLI = lfp[2];
+            }
+        }
+        asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
+        if(kbase == 0)
+            fwd_chunk<W, true, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+        else
+            fwd_chunk<W, false, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+        if(!last_strip) {
+            const uint32_t done = min(kbase + kWave, nsteps);
+            if(done > kWave - 1) publish(progress + ticket, min(la, done - (kWave - 1)), lane == kWave - 1);
+        }
+    }
+    if(!last_strip) publish(progress + ticket, la, lane == kWave - 1);
+    if(!ok && last_strip && lane == 0) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
 }
 
 template <bool kFast>
@@ -223,70 +299,12 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 2 : 3) void forward_l1(
             }
             continue;
         }
-        const uint8_t* __restrict__ a = a_cat + pd.a_off;
-        const uint8_t* __restrict__ b = b_cat + pd.b_off;
-        const uint32_t strips = n_strips(lb);
-        const uint32_t col0 = strip * kStrip;
-        const uint32_t ncol = min(static_cast<uint32_t>(kStrip), lb - col0);
-        const uint32_t nlanes = (ncol + kW - 1) / kW;
-        const uint32_t nsteps = la + nlanes - 1;
-        const bool last_strip = strip + 1 == strips;
-        const uint64_t bstride = 3 * (static_cast<uint64_t>(la) + 1);
-        float* __restrict__ bnd_out = bnd + pd.bnd_off + strip * bstride;
-        const float* __restrict__ bnd_in = bnd + pd.bnd_off + (strip - 1) * bstride;  // strip > 0 only
-
-        uint32_t boff[kW];
-#pragma unroll
-        for(int c = 0; c < kW; ++c) {
-            const uint32_t bj = col0 + lane * kW + c;
-            boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+        // strips are 64 * W columns, W = 16 unless the batch has too few pairs to fill the GPU (abi.hip)
+        switch(pd.f_wlog2) {
+            case 2: forward_strip<4, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
+            case 3: forward_strip<8, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
+            default: forward_strip<16, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
         }
-        const FwdCtx cx{k, la, col0, nsteps, pair, lane,
-                        static_cast<int>(((lb - 1) & (kStrip - 1)) / kW), static_cast<int>((lb - 1) & (kW - 1)),
-                        last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats(la) + 3 * lane, bnd_out, final_mdi, exp_tab};
-        FwdLane st;
-#pragma unroll
-        for(int c = 0; c < kW; ++c) st.M[c] = st.D[c] = st.I[c] = kLowest;
-        st.oM = st.oD = st.oI = kLowest;
-        uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
-        float s[kW];
-#pragma unroll
-        for(int c = 0; c < kW; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
-
-        bool ok = true;
-        for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
-            const uint32_t crow = kbase + lane;  // the body row lane 0 processes at step kbase + lane
-            uint32_t a_chunk = 0;
-            float chDM = kLowest, chDD = kLowest, chDI = kLowest, chLM = kLowest, chLI = kLowest;
-            if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
-            if(strip == 0) {
-                // matrix column 0 (align_pair.cc:82-86): diagonal of body row r is matrix cell (r, 0)
-                if(crow == 0) chDM = 0.0f;
-                else if(crow < la) chDD = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
-            } else {
-                ok = ok && wait_rows(progress + ticket - 1, min(la, kbase + kWave));
-                if(crow < la) {
-                    const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
-                    const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
-                    chDM = dgp[0];
-                    chDD = dgp[1];
-                    chDI = dgp[2];
-                    chLM = lfp[0];
-                    chLI = lfp[2];
-                }
-            }
-            asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
-            if(kbase == 0)
-                fwd_chunk<true, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
-            else
-                fwd_chunk<false, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
-            if(!last_strip) {
-                const uint32_t done = min(kbase + kWave, nsteps);
-                if(done > kWave - 1) publish(progress + ticket, min(la, done - (kWave - 1)), lane == kWave - 1);
-            }
-        }
-        if(!last_strip) publish(progress + ticket, la, lane == kWave - 1);
-        if(!ok && last_strip && lane == 0) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
     }
 }
 

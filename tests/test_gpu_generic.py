@@ -115,6 +115,21 @@ def test_fast_forward_mode_within_tolerance():
     assert out.returncode == 0, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("w", [8, 16])
+def test_forward_strip_shapes(w):
+    """forward_l1 narrows its strips (16 -> 8 -> 4 columns per lane) while a batch has fewer strips
+    than the GPU has SIMDs, so the small batches of this suite run the 4-column shape.
+    COATI_HIP_FWD_W forces the other two: same bits (matrices, final cells, samples)."""
+    if os.environ.get("COATI_HIP_FWD_W") or os.environ.get("COATI_HIP_FORCE_GENERIC") or os.environ.get("COATI_HIP_FORWARD_FAST"):
+        pytest.skip("already inside a child run")
+    env = dict(os.environ, COATI_HIP_FWD_W=str(w))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", str(ROOT / "tests" / "test_gpu_generic.py"),
+                          str(ROOT / "tests" / "test_gpu_sample.py"),
+                          "-k", "forward_matrices or forward_golden or exact_stream_matches or marg_sample or golden_sample"],
+                         env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
 def rel_close(got, want, tol=1e-5):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     finite = want > -1e30
