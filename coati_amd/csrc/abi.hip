@@ -429,15 +429,11 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.la = static_cast<uint32_t>(la);
         d.lb = static_cast<uint32_t>(lb);
         d.ops_off = b->ops_total;
-        d.mdi_off = b->mdi_floats;
         // Forward M/D/I arena: gap_len 2, 3 store the live cells only (forward_k.hip)
         const bool fwd_k = (L == 2 || L == 3) && !force_generic;
         d.f_compact = static_cast<uint16_t>(fwd_k ? L : 0u);
         d.f_wlog2 = static_cast<uint8_t>(fwd_wlog2);
         d.reserved_ = 0;
-        if(la > 0 && lb > 0)
-            b->mdi_floats += fwd_k ? fwd_compact_strips(d.lb, static_cast<uint32_t>(L)) * fwd_compact_strip_floats(d.la, static_cast<uint32_t>(L))
-                                   : fwd_strips_w(d.lb, 1u << fwd_wlog2) * strip_mdi_floats_w(d.la, 1u << fwd_wlog2);
         b->ops_total += la + lb;
         b->cells += la * lb;
     }
@@ -495,6 +491,22 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             if(homogeneous && n_pairs > kFillSlots * 3 / 2) tail_pairs = kFillSlots / 4;
         }
         for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = 8;
+    }
+    // the same remedy for forward_l1 (3 slots per SIMD as well): a batch of equal pairs that runs
+    // full-width strips ends with its last quarter round in 8-column strips
+    if(L == 1 && !force_generic && fwd_wlog2 == 4 && n_pairs > 3 * 1024 * 3 / 2 && std::getenv("COATI_HIP_FWD_W") == nullptr) {
+        auto cells_of = [&](uint64_t p) { return static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb; };
+        if(cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]))
+            for(uint64_t q = n_pairs - 3 * 1024 / 4; q < n_pairs; ++q) b->desc[order[q]].f_wlog2 = 3;
+    }
+    // Forward M/D/I arena, now that every pair's strip shape is known
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        PairDesc& d = b->desc[p];
+        d.mdi_off = b->mdi_floats;
+        if(d.la > 0 && d.lb > 0)
+            b->mdi_floats += d.f_compact != 0
+                                 ? fwd_compact_strips(d.lb, d.f_compact) * fwd_compact_strip_floats(d.la, d.f_compact)
+                                 : fwd_strips_w(d.lb, 1u << d.f_wlog2) * strip_mdi_floats_w(d.la, 1u << d.f_wlog2);
     }
     // gap_len 2 and 3: viterbi_k works on the live cells only, in block columns (lb / L), strips of
     // 16 block columns per lane and a narrow shape (6 for L = 3, 8 for L = 2) for the last strip
