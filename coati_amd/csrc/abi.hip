@@ -366,11 +366,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     const uint64_t L = static_cast<uint64_t>(model->gap_len);
     static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
     // Forward strip shape (forward_l1): 16 columns per lane, narrowed to 8 and 4 while the batch has
-    // fewer strips than the kernel has wavefront slots (3 per SIMD) -- a wavefront per 1 024 columns
-    // leaves a small batch on a handful of SIMDs (16 pairs of 1 kb: 17.8 ms at W = 16, 6.3 ms at
-    // W = 4).  A Forward cell is ~440 instructions, so the per-step overhead of a narrow strip is
+    // fewer strips than 1.5 rounds of the kernel's wavefront slots (3 per SIMD) -- a wavefront per
+    // 1 024 columns leaves a small batch on a handful of SIMDs (16 pairs of 1 kb: 17.8 ms at W = 16,
+    // 6.3 ms at W = 4), and just over one round of full-width strips wastes most of a second one
+    // (3 000 pairs: 41.7 ms at W = 16, 35.9 ms at W = 8).  A Forward cell is ~440 instructions, so the per-step overhead of a narrow strip is
     // small, unlike in viterbi_l1.  COATI_HIP_FWD_W=<4|8|16> overrides.
-    constexpr uint64_t kFwdSlots = 3 * 1024;
+    constexpr uint64_t kFwdSlots = 3 * 1024 * 3 / 2;
     uint32_t fwd_wlog2 = 4;
     if(L == 1 && !force_generic) {
         auto count_strips = [&](uint32_t w) {
