@@ -831,7 +831,7 @@ int coati_hip_debug_forward_matrices(coati_hip_batch_t* b, uint64_t pair, float*
 namespace {
 // ---- exact-stream sampling in parallel (kernels and rationale: sampleback.hip) ------------------
 // Per chunk and pair: sample j of the chunk is expected to start j * mean draws after the chunk
-// origin; every offset within +-(z * sigma * sqrt(j) + 2) of that is walked as a candidate.  The
+// origin; every offset within +-(z * sigma * sqrt(j) + 2), z = 2, of that is walked as a candidate.  The
 // true chain origin -> sample 0 -> sample 1 ... is then followed through the candidates' draw
 // counts; a sample whose true offset was not a candidate ends the chunk for its pair (it becomes
 // sample 0 of the next chunk, whose offset is always a candidate), so the loop always advances.
@@ -856,7 +856,13 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         const long v = e != nullptr ? std::atol(e) : 0;
         return v >= 1024 && v <= (1 << 22) ? static_cast<uint32_t>(v) : (1u << 17);  // measured best (tools/sample_bench.py)
     }();
-    constexpr double kZ = 5.0;
+    // half-width of a candidate window in standard deviations of the offset; too narrow only ends
+    // a chunk early (COATI_HIP_SPEC_Z overrides, for tuning)
+    static const double kZ = [] {
+        const char* e = std::getenv("COATI_HIP_SPEC_Z");
+        const double v = e != nullptr ? std::atof(e) : 0.0;
+        return v >= 0.25 && v <= 10.0 ? v : 2.0;  // measured (16 x 1 000 samples of 1 kb pairs): z = 5: 38.8 ms, 3: 30.9, 2: 25.9, 1.5: 26.0, 1: 35.9
+    }();
     size_t free_b = 0, total_b = 0;
     hipError_t e = hipMemGetInfo(&free_b, &total_b);
     if(e != hipSuccess) return e;
