@@ -120,17 +120,22 @@ struct coati_hip_model {
     hipStream_t stream = nullptr;
     // Workspaces of destroyed batches, kept for the next batch_create (hipMalloc of a multi-GB
     // workspace was measured at 0.4 ms when the driver still had the pages and 250-550 ms when it
-    // did not).  At most kCachedArenas are kept; coati_hip_model_trim / model_destroy free them.
+    // did not).  At most kCachedArenas are kept (batch workspaces and the sampler's temporaries); coati_hip_model_trim / model_destroy free them.
     struct Arena {
         void* ptr;
         uint64_t bytes;
     };
-    static constexpr size_t kCachedArenas = 2;
+    static constexpr size_t kCachedArenas = 4;
     std::vector<Arena> free_arenas;
     std::mutex arena_lock;
     // the handle itself + one per live batch: coati_hip_model_destroy while batches are alive only
     // marks the model; the last batch_destroy releases it (a batch keeps launching on m->stream)
     std::atomic<int> refs{1};
+    // page-locked host staging for the sampler's per-round exchanges (candidate lists down, draw
+    // counts up): pageable std::vectors made a round's copies cost between 0.1 and several ms
+    // depending on where the process ran; grown on demand, freed with the model
+    void* pinned = nullptr;
+    uint64_t pinned_bytes = 0;
 };
 
 struct coati_hip_batch {
@@ -179,6 +184,102 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_ops,    b->d_ops_start, b->d_ops_len,
                            b->d_mdi,    b->d_final_mdi};
 }
+}  // namespace
+
+
+namespace {
+// An HBM block of at least `need` bytes: one the model cached (not more than ~2x too large) or a
+// fresh hipMalloc; when that fails for lack of memory the cache is emptied and it is tried again.
+hipError_t model_take_arena(coati_hip_model* m, uint64_t need, void** ptr, uint64_t* bytes) {
+    *ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(m->arena_lock);
+        size_t best = m->free_arenas.size();
+        for(size_t i = 0; i < m->free_arenas.size(); ++i) {
+            const uint64_t have = m->free_arenas[i].bytes;
+            if(have >= need && have <= 2 * need + (64ull << 20) &&
+               (best == m->free_arenas.size() || have < m->free_arenas[best].bytes))
+                best = i;
+        }
+        if(best != m->free_arenas.size()) {
+            *ptr = m->free_arenas[best].ptr;
+            *bytes = m->free_arenas[best].bytes;
+            m->free_arenas.erase(m->free_arenas.begin() + static_cast<std::ptrdiff_t>(best));
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(ptr, need);
+    if(e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        std::vector<coati_hip_model::Arena> drop;
+        {
+            std::lock_guard<std::mutex> hold(m->arena_lock);
+            drop.swap(m->free_arenas);
+        }
+        for(const auto& a : drop) (void)hipFree(a.ptr);
+        e = hipMalloc(ptr, need);
+    }
+    if(e != hipSuccess) {
+        *ptr = nullptr;
+        return e;
+    }
+    *bytes = need;
+    return hipSuccess;
+}
+// Back to the cache (the caller made sure nothing on the stream can still touch the block); the
+// smallest cached block goes when there are too many.
+void model_give_arena(coati_hip_model* m, void* ptr, uint64_t bytes) {
+    if(ptr == nullptr) return;
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(m->arena_lock);
+        m->free_arenas.push_back({ptr, bytes});
+        if(m->free_arenas.size() > coati_hip_model::kCachedArenas) {
+            size_t k = 0;
+            for(size_t i = 1; i < m->free_arenas.size(); ++i)
+                if(m->free_arenas[i].bytes < m->free_arenas[k].bytes) k = i;
+            drop = m->free_arenas[k].ptr;
+            m->free_arenas.erase(m->free_arenas.begin() + static_cast<std::ptrdiff_t>(k));
+        }
+    }
+    if(drop != nullptr) (void)hipFree(drop);
+}
+// Carves 256-byte aligned parts out of a block whose size is not known yet: first pass with
+// base == nullptr to add up the need, second pass with the block.
+// fixed-capacity array in the model's page-locked staging block
+template <typename T>
+struct PinnedVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    void push_back(const T& v) { p[n++] = v; }  // (callers keep within cap: see sampleback_speculative)
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    void resize(size_t k) { n = k; }
+    T* data() { return p; }
+    T& operator[](size_t i) { return p[i]; }
+};
+hipError_t model_pinned(coati_hip_model* m, uint64_t bytes, void** out) {
+    if(m->pinned_bytes < bytes) {
+        if(m->pinned != nullptr) (void)hipHostFree(m->pinned);
+        m->pinned = nullptr;
+        m->pinned_bytes = 0;
+        const hipError_t e = hipHostMalloc(&m->pinned, bytes, hipHostMallocDefault);
+        if(e != hipSuccess) return e;
+        m->pinned_bytes = bytes;
+    }
+    *out = m->pinned;
+    return hipSuccess;
+}
+struct Carver {
+    char* base = nullptr;
+    uint64_t used = 0;
+    template <typename T>
+    T* take(uint64_t count) {
+        const uint64_t at = used;
+        used += (std::max<uint64_t>(count * sizeof(T), 16) + 255) / 256 * 256;
+        return base != nullptr ? reinterpret_cast<T*>(base + at) : nullptr;
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -246,6 +347,7 @@ void model_release(coati_hip_model* m) {
     if(m->refs.fetch_sub(1) != 1) return;  // batches (or the handle) still hold it
     (void)hipSetDevice(m->device);
     for(const auto& a : m->free_arenas) (void)hipFree(a.ptr);
+    if(m->pinned != nullptr) (void)hipHostFree(m->pinned);
     if(m->d_table != nullptr) (void)hipFree(m->d_table);
     if(m->stream != nullptr) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -265,21 +367,10 @@ void coati_hip_batch_destroy(coati_hip_batch_t* b) {
         if(p != nullptr) (void)hipFree(p);
     if(b->arena != nullptr) {
         // the workspace goes back to the model once nothing on the stream can still touch it
-        bool keep = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
-        void* drop = b->arena;
-        if(keep) {
-            std::lock_guard<std::mutex> hold(m->arena_lock);
-            m->free_arenas.push_back({b->arena, b->arena_bytes});
-            drop = nullptr;
-            if(m->free_arenas.size() > coati_hip_model::kCachedArenas) {  // evict the smallest
-                size_t k = 0;
-                for(size_t i = 1; i < m->free_arenas.size(); ++i)
-                    if(m->free_arenas[i].bytes < m->free_arenas[k].bytes) k = i;
-                drop = m->free_arenas[k].ptr;
-                m->free_arenas.erase(m->free_arenas.begin() + static_cast<std::ptrdiff_t>(k));
-            }
-        }
-        if(drop != nullptr) (void)hipFree(drop);
+        if(m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess)
+            model_give_arena(m, b->arena, b->arena_bytes);
+        else
+            (void)hipFree(b->arena);
     }
     for(auto& trio : b->ev)
         for(hipEvent_t e : trio)
@@ -604,35 +695,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                    o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
                    o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t));
     {
-        // a workspace a destroyed batch of this model left behind, unless it is far too large
-        std::lock_guard<std::mutex> hold(model->arena_lock);
-        size_t best = model->free_arenas.size();
-        for(size_t i = 0; i < model->free_arenas.size(); ++i) {
-            const uint64_t have = model->free_arenas[i].bytes;
-            if(have >= arena_need && have <= 2 * arena_need + (64ull << 20) &&
-               (best == model->free_arenas.size() || have < model->free_arenas[best].bytes))
-                best = i;
-        }
-        if(best != model->free_arenas.size()) {
-            b->arena = model->free_arenas[best].ptr;
-            b->arena_bytes = model->free_arenas[best].bytes;
-            model->free_arenas.erase(model->free_arenas.begin() + static_cast<std::ptrdiff_t>(best));
-        }
-    }
-    if(b->arena == nullptr) {
-        hipError_t e = hipMalloc(&b->arena, arena_need);
-        if(e == hipErrorOutOfMemory) {  // give the cached workspaces back and try once more
-            (void)hipGetLastError();
-            (void)coati_hip_model_trim(model);
-            e = hipMalloc(&b->arena, arena_need);
-        }
-        if(e != hipSuccess) {
-            b->arena = nullptr;
+        // a workspace a destroyed batch of this model left behind, or a fresh one
+        const hipError_t e = model_take_arena(model, arena_need, &b->arena, &b->arena_bytes);
+        if(e != hipSuccess)
             return cleanup(fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,
                                 "hipMalloc(workspace, %llu bytes) failed: %s", static_cast<unsigned long long>(arena_need),
                                 hipGetErrorString(e)));
-        }
-        b->arena_bytes = arena_need;
     }
     b->device_bytes += arena_need;
     auto at = [&](uint64_t off) { return static_cast<char*>(b->arena) + off; };
@@ -866,8 +934,16 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     size_t free_b = 0, total_b = 0;
     hipError_t e = hipMemGetInfo(&free_b, &total_b);
     if(e != hipSuccess) return e;
-    const uint64_t tmp_budget = std::max<uint64_t>(std::min<uint64_t>(free_b / 4, 2ull << 30), 1ull << 20);
+    {   // (cached blocks of this model count as free)
+        std::lock_guard<std::mutex> hold(m->arena_lock);
+        for(const auto& a : m->free_arenas) free_b += a.bytes;
+    }
+    // work arena for the candidates' ops: 2 GB, or a power of two below a quarter of the free HBM
+    // (a stable size, so that repeated calls find their block in the cache)
+    uint64_t tmp_budget = 2ull << 30;
+    while(tmp_budget > (1ull << 20) && tmp_budget > free_b / 4) tmp_budget >>= 1;
 
+    uint64_t dbg_rounds = 0, dbg_cands = 0;  // reported with COATI_HIP_TIMING=1
     struct PairState {
         u128 st0;
         uint64_t origin = 0;  // draws consumed by the samples resolved so far
@@ -885,16 +961,34 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             mult_pow[2 * bit + 1] = static_cast<uint64_t>(bpow >> 64);
         }
     }
+    // all temporaries in ONE block from the model's workspace cache (a 2 GB hipMalloc per call costs
+    // between 0.4 and several hundred ms, see coati_hip_model::free_arenas)
     uint64_t *d_origin = nullptr, *d_pow = nullptr, *d_cstart = nullptr;
     SpecCandidate* d_cands = nullptr;
     SpecCommit* d_commits = nullptr;
     uint8_t* d_tmp = nullptr;
     uint32_t *d_clen = nullptr, *d_cdraws = nullptr;
     float* d_clw = nullptr;
+    void* block = nullptr;
+    uint64_t block_bytes = 0;
+    auto carve = [&](Carver& cv) {
+        d_origin = cv.take<uint64_t>(2 * n);
+        d_pow = cv.take<uint64_t>(64);
+        d_cstart = cv.take<uint64_t>(kMaxCands);
+        d_cands = cv.take<SpecCandidate>(kMaxCands);
+        d_commits = cv.take<SpecCommit>(std::max<uint64_t>(std::min<uint64_t>(n * kChunkMax, kMaxCands), 1));
+        d_clen = cv.take<uint32_t>(kMaxCands);
+        d_cdraws = cv.take<uint32_t>(kMaxCands);
+        d_clw = cv.take<float>(kMaxCands);
+        d_tmp = cv.take<uint8_t>(tmp_budget);
+    };
     auto release = [&]() {
-        void* ptrs[] = {d_origin, d_pow, d_cstart, d_cands, d_commits, d_tmp, d_clen, d_cdraws, d_clw};
-        for(void* q : ptrs)
-            if(q != nullptr) (void)hipFree(q);
+        if(block == nullptr) return;
+        if(hipStreamSynchronize(m->stream) == hipSuccess)
+            model_give_arena(m, block, block_bytes);
+        else
+            (void)hipFree(block);
+        block = nullptr;
     };
 #define S_TRY(expr)                 \
     do {                            \
@@ -904,25 +998,43 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             return e;               \
         }                           \
     } while(0)
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_origin), 2 * n * sizeof(uint64_t)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_pow), sizeof(mult_pow)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_cstart), kMaxCands * sizeof(uint64_t)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_cands), kMaxCands * sizeof(SpecCandidate)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_commits), std::max<uint64_t>(std::min<uint64_t>(n * kChunkMax, kMaxCands), 1) * sizeof(SpecCommit)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_tmp), tmp_budget));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_clen), kMaxCands * sizeof(uint32_t)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_cdraws), kMaxCands * sizeof(uint32_t)));
-    S_TRY(hipMalloc(reinterpret_cast<void**>(&d_clw), kMaxCands * sizeof(float)));
+    {
+        Carver sizing;
+        carve(sizing);
+        S_TRY(model_take_arena(m, sizing.used, &block, &block_bytes));
+        Carver cv{static_cast<char*>(block), 0};
+        carve(cv);
+    }
     S_TRY(hipMemcpyAsync(d_pow, mult_pow, sizeof(mult_pow), hipMemcpyHostToDevice, m->stream));
 
     struct Window {  // candidates of one (pair, sample-in-chunk)
         uint32_t first_cand, lo, hi;
     };
-    std::vector<SpecCandidate> cands;
     std::vector<std::vector<Window>> windows(n);
-    std::vector<uint64_t> origin_states(2 * n);
-    std::vector<uint32_t> draws;
-    std::vector<SpecCommit> commits;
+    // host sides of the per-round copies, page-locked (a round adds at most one candidate per pair
+    // beyond kMaxCands before the overflow check below)
+    PinnedVec<SpecCandidate> cands;
+    PinnedVec<uint64_t> origin_states;
+    PinnedVec<uint32_t> draws;
+    PinnedVec<SpecCommit> commits;
+    {
+        const uint64_t cap_c = static_cast<uint64_t>(kMaxCands) + n + 16, cap_m = std::min<uint64_t>(n * kChunkMax, cap_c) + 16;
+        Carver sizing;
+        auto carve_host = [&](Carver& cv) {
+            cands.p = cv.take<SpecCandidate>(cap_c);
+            origin_states.p = cv.take<uint64_t>(2 * n);
+            draws.p = cv.take<uint32_t>(cap_c);
+            commits.p = cv.take<SpecCommit>(cap_m);
+        };
+        carve_host(sizing);
+        void* host_block = nullptr;
+        S_TRY(model_pinned(m, sizing.used, &host_block));
+        Carver cv{static_cast<char*>(host_block), 0};
+        carve_host(cv);
+        cands.cap = draws.cap = cap_c;
+        origin_states.cap = origin_states.n = 2 * n;
+        commits.cap = cap_m;
+    }
     const BatchDeviceView view = device_view(b);
     try {
     for(;;) {
@@ -974,6 +1086,8 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             return hipErrorOutOfMemory;
         }
         const uint32_t nc = static_cast<uint32_t>(cands.size());
+        ++dbg_rounds;
+        dbg_cands += nc;
         S_TRY(hipMemcpyAsync(d_origin, origin_states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_cands, cands.data(), nc * sizeof(SpecCandidate), hipMemcpyHostToDevice, m->stream));
         S_TRY(launch_spec_walk(view, d_origin, d_pow, d_cands, nc, d_tmp, d_cstart, d_clen, d_clw, d_cdraws, m->stream));
@@ -1011,6 +1125,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         throw;
     }
 #undef S_TRY
+    if(std::getenv("COATI_HIP_TIMING") != nullptr)
+        std::fprintf(stderr, "sampleback_speculative: %llu rounds, %llu candidate walks for %llu samples\n",
+                     static_cast<unsigned long long>(dbg_rounds), static_cast<unsigned long long>(dbg_cands),
+                     static_cast<unsigned long long>(n * n_samples));
     for(uint64_t p = 0; p < n; ++p) {
         const u128 st = ps[p].st0 * lehmer_pow(ps[p].origin);  // where n serial sampleback calls leave the stream
         states_out[2 * p] = static_cast<uint64_t>(st);
@@ -1083,19 +1201,33 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
     uint8_t* d_ops = nullptr;
     uint32_t* d_len = nullptr;
     float* d_lw = nullptr;
+    void* block = nullptr;
+    uint64_t block_bytes = 0;
+    auto carve = [&](Carver& cv) {
+        d_states = cv.take<uint64_t>(states.size());
+        d_base = cv.take<uint64_t>(n);
+        d_start = cv.take<uint64_t>(n_out);
+        d_len = cv.take<uint32_t>(n_out);
+        d_lw = cv.take<float>(n_out);
+        d_ops = cv.take<uint8_t>(std::max<uint64_t>(total, 16));
+    };
     auto release = [&]() {
-        void* ptrs[] = {d_states, d_base, d_start, d_ops, d_len, d_lw};
-        for(void* q : ptrs)
-            if(q != nullptr) (void)hipFree(q);
+        if(block == nullptr) return;
+        if(hipStreamSynchronize(m->stream) == hipSuccess)
+            model_give_arena(m, block, block_bytes);
+        else
+            (void)hipFree(block);
+        block = nullptr;
     };
     auto attempt = [&]() -> hipError_t {
         hipError_t e;
-        if((e = hipMalloc(reinterpret_cast<void**>(&d_states), states.size() * sizeof(uint64_t))) != hipSuccess) return e;
-        if((e = hipMalloc(reinterpret_cast<void**>(&d_base), n * sizeof(uint64_t))) != hipSuccess) return e;
-        if((e = hipMalloc(reinterpret_cast<void**>(&d_start), n_out * sizeof(uint64_t))) != hipSuccess) return e;
-        if((e = hipMalloc(reinterpret_cast<void**>(&d_ops), std::max<uint64_t>(total, 16))) != hipSuccess) return e;
-        if((e = hipMalloc(reinterpret_cast<void**>(&d_len), n_out * sizeof(uint32_t))) != hipSuccess) return e;
-        if((e = hipMalloc(reinterpret_cast<void**>(&d_lw), n_out * sizeof(float))) != hipSuccess) return e;
+        {
+            Carver sizing;
+            carve(sizing);
+            if((e = model_take_arena(m, sizing.used, &block, &block_bytes)) != hipSuccess) return e;
+            Carver cv{static_cast<char*>(block), 0};
+            carve(cv);
+        }
         // exact stream with several samples per pair: walked in parallel by speculating the stream
         // offsets (identical results); COATI_HIP_SAMPLE_SEQUENTIAL=1 keeps the one-walker-per-pair loop
         static const bool sequential = std::getenv("COATI_HIP_SAMPLE_SEQUENTIAL") != nullptr;
