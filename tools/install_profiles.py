@@ -12,7 +12,8 @@ dst.mkdir(parents=True, exist_ok=True)
 for a, b in (("kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("pmc_summary.csv", "bench_n1_pmc_summary.csv"),
              ("traffic.json", "bench_n1_traffic.json"), ("bench.json", "bench_n1_under_rocprof.json")):
     shutil.copy(src / a, dst / b)
-for extra in ("bench_n1.json", "bench_n1_streams2.json", "sample_bench.json", "long_pair.json", "short_pairs.txt", "steady.txt",
+# (steady.txt and short_pairs.txt are hand-kept records of several tool runs: not overwritten here)
+for extra in ("bench_n1.json", "bench_n1_streams2.json", "sample_bench.json", "sample_bench_fast.json", "long_pair.json",
               "bench_config5_shard.json"):
     f = ROOT / "gpurun_out" / extra
     if f.exists():
