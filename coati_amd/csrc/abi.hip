@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace coati_hip_detail;
@@ -126,6 +127,7 @@ struct coati_hip_model {
         uint64_t bytes;
     };
     static constexpr size_t kCachedArenas = 4;
+    static constexpr uint64_t kMaxCachedBytes = 16ull << 30;  // larger blocks are freed, not cached
     std::vector<Arena> free_arenas;
     std::mutex arena_lock;
     // the handle itself + one per live batch: coati_hip_model_destroy while batches are alive only
@@ -162,7 +164,9 @@ struct coati_hip_batch {
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
     uint32_t* d_flags = nullptr;
     float *d_bnd = nullptr, *d_scores = nullptr;
-    float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward
+    float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward (parts of mdi_block)
+    void* mdi_block = nullptr;
+    uint64_t mdi_block_bytes = 0;
     bool forward_done = false;
     bool compact = false;  // Viterbi plan is the live-cell layout of viterbi_k (gap_len 2, 3)
     bool compact_narrow_only = false;  // ... and every strip has the narrow shape
@@ -230,6 +234,10 @@ hipError_t model_take_arena(coati_hip_model* m, uint64_t need, void** ptr, uint6
 // smallest cached block goes when there are too many.
 void model_give_arena(coati_hip_model* m, void* ptr, uint64_t bytes) {
     if(ptr == nullptr) return;
+    if(bytes > coati_hip_model::kMaxCachedBytes) {  // too large to sit on: other users of the GPU need the memory
+        (void)hipFree(ptr);
+        return;
+    }
     void* drop = nullptr;
     {
         std::lock_guard<std::mutex> hold(m->arena_lock);
@@ -363,14 +371,16 @@ void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(b == nullptr) return;
     coati_hip_model* m = b->model;
     if(m != nullptr) (void)hipSetDevice(m->device);
-    for(void* p : {static_cast<void*>(b->d_mdi), static_cast<void*>(b->d_final_mdi)})
-        if(p != nullptr) (void)hipFree(p);
-    if(b->arena != nullptr) {
-        // the workspace goes back to the model once nothing on the stream can still touch it
-        if(m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess)
-            model_give_arena(m, b->arena, b->arena_bytes);
-        else
-            (void)hipFree(b->arena);
+    if(b->arena != nullptr || b->mdi_block != nullptr) {
+        // the blocks go back to the model once nothing on the stream can still touch them
+        const bool idle = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
+        for(auto blk : {std::pair<void*, uint64_t>{b->arena, b->arena_bytes}, std::pair<void*, uint64_t>{b->mdi_block, b->mdi_block_bytes}}) {
+            if(blk.first == nullptr) continue;
+            if(idle)
+                model_give_arena(m, blk.first, blk.second);
+            else
+                (void)hipFree(blk.first);
+        }
     }
     for(auto& trio : b->ev)
         for(hipEvent_t e : trio)
@@ -838,16 +848,22 @@ int coati_hip_forward_launch(coati_hip_batch_t* b) {
     coati_hip_model* m = b->model;
     HIP_TRY(hipSetDevice(m->device));
     if(b->d_mdi == nullptr) {  // the 12 B/cell arena is only reserved when Forward is actually used
-        const uint64_t bytes = std::max<uint64_t>(b->mdi_floats * sizeof(float), 16);
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_mdi), bytes);
-        if(e != hipSuccess)
-            return fail(COATI_HIP_ENOMEM, "forward_launch: %llu bytes for the Forward matrices: %s",
-                        static_cast<unsigned long long>(bytes), hipGetErrorString(e));
-        b->device_bytes += bytes;
-        const uint64_t fb = std::max<uint64_t>(b->n_pairs * 3 * sizeof(float), 16);
-        e = hipMalloc(reinterpret_cast<void**>(&b->d_final_mdi), fb);
-        if(e != hipSuccess) return fail(COATI_HIP_ENOMEM, "forward_launch: %s", hipGetErrorString(e));
-        b->device_bytes += fb;
+        Carver sizing;
+        auto carve = [&](Carver& cv) {
+            b->d_final_mdi = cv.take<float>(b->n_pairs * 3);
+            b->d_mdi = cv.take<float>(b->mdi_floats);
+        };
+        carve(sizing);
+        const hipError_t e = model_take_arena(m, sizing.used, &b->mdi_block, &b->mdi_block_bytes);
+        if(e != hipSuccess) {
+            b->d_mdi = b->d_final_mdi = nullptr;
+            return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,
+                        "forward_launch: %llu bytes for the Forward matrices: %s", static_cast<unsigned long long>(sizing.used),
+                        hipGetErrorString(e));
+        }
+        Carver cv{static_cast<char*>(b->mdi_block), 0};
+        carve(cv);
+        b->device_bytes += sizing.used;
     }
     if(b->n_pairs > 0) {
         static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;

@@ -95,8 +95,9 @@ int coati_hip_model_create_tables(const float* tables, uint32_t n_tables, float 
  * batches stay usable, the model's memory is released with the last of them); creating new
  * batches from a destroyed handle is not. */
 void coati_hip_model_destroy(coati_hip_model_t* model);
-/* A model keeps the HBM workspaces of its last (at most two) destroyed batches and hands them to
- * the next coati_hip_batch_create whose needs they fit (the reference has no counterpart: its work
+/* A model keeps up to four HBM blocks (of at most 16 GB each) that its destroyed batches and finished
+ * sampling calls no longer need -- batch workspaces, Forward matrices, the sampler's temporaries --
+ * and hands them to the next coati_hip_batch_create / forward_launch / sampleback whose needs they fit (the reference has no counterpart: its work
  * matrices are std::vectors that die with align_pair_work_mem_t, align_pair.hpp:45-62; here a
  * multi-GB hipMalloc costs between 0.4 and 500 ms, which a loop over batches should not pay per
  * batch).  This call frees what is cached; coati_hip_model_destroy does it too. */
