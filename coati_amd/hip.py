@@ -189,14 +189,19 @@ class Model:
         _check(load().coati_hip_debug_rng_f24(self._h, _ptr(st), n, _ptr(out)))
         return out
 
-    def viterbi(self, a_cat, a_off, b_cat, b_off):
-        """One-shot coati_hip_viterbi_batch.  Returns (scores, ops, ops_off, ops_len)."""
+    def viterbi(self, a_cat, a_off, b_cat, b_off, out=None):
+        """One-shot coati_hip_viterbi_batch.  Returns (scores, ops, ops_off, ops_len); `out` may pass
+        the four arrays of an earlier call back in (a loop over batches then writes into memory whose
+        pages exist already -- first-touch page faults are half the cost of downloading the ops)."""
         n = len(a_off) - 1
         total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
-        scores = np.zeros(n, np.float32)
-        ops = np.zeros(max(total, 1), np.uint8)
-        ops_off = np.zeros(n, np.uint64)
-        ops_len = np.zeros(n, np.uint32)
+        if out is not None and len(out[0]) == n and len(out[1]) >= max(total, 1):
+            scores, ops, ops_off, ops_len = out
+        else:
+            scores = np.zeros(n, np.float32)
+            ops = np.zeros(max(total, 1), np.uint8)
+            ops_off = np.zeros(n, np.uint64)
+            ops_len = np.zeros(n, np.uint32)
         _check(load().coati_hip_viterbi_batch(self._h, n, _ptr(a_cat), _ptr(a_off), _ptr(b_cat), _ptr(b_off),
                                               _ptr(scores), _ptr(ops), total, _ptr(ops_off), _ptr(ops_len)))
         return scores, ops, ops_off, ops_len
