@@ -1,25 +1,27 @@
 // forward_l1: the Forward fill (log semiring) for gap_len == 1, in the wavefront shape of
-// viterbi_l1: persistent wavefronts, one strip (1024 descendant columns) of one pair at a
-// time per wavefront, a lane owns 16 columns, one row of skew per lane, DPP hand-off.
+// viterbi_l1: persistent wavefronts, one strip (64 * W descendant columns, W = 16, 8 or 4) of one
+// pair at a time per wavefront, a lane owns W columns, one row of skew per lane, DPP hand-off,
+// strips of a pair pipelined across wavefronts through boundary arrays in HBM.
 //
 // What it replaces in the reference:
 //   forward -> forward_impl<log, align_pair_work_t>   src/lib/align_pair.cc:62-139,149
 //   semiring::log::plus, log_sum_exp, log1p_exp       src/include/coati/semiring.hpp:86-121,
 //                                                     src/include/coati/utils.hpp:134-156
 //
-// Output: fp32 M/D/I of every body cell in HBM (12 B/cell, layout in common.hpp) for
-// sampleback, and the terminal-adjusted last cell per pair.  The reference's eight edge
-// matrices (align_pair.hpp:94-103) are not stored; the sampler recomputes what it needs.
+// Output: fp32 M/D/I of every body cell in HBM (12 B/cell, M, D, I of a cell adjacent; layout in
+// common.hpp) for sampleback, and the terminal-adjusted last cell per pair.  The reference's eight
+// edge matrices (align_pair.hpp:94-103) are not stored; the sampler recomputes what it needs.
 //
 // Every cell evaluates the reference's expressions in the reference's order
-// (align_pair.cc:97-124); only `plus` is computed differently:
-//   plus(a, b) = max(a, b) + log1p(exp(-|a - b|))
-// with the hardware exp2/log2 (v_exp_f32, v_log_f32, ~1 ulp) instead of glibc expf/log1pf.
-// log1p(e) for e in [0, 1] is taken as log(u) + (e - (u - 1)) with u = fl(1 + e): the second
-// term is the exact rounding residue of 1 + e, so the result degrades gracefully to `e` when
-// 1 + e rounds to 1 -- the same value utils.hpp:142-144 returns for y <= -16.  Absolute error
-// of one plus() is below 1e-7; the results are NOT bit-identical to the CPU (neither were
-// expf/log1pf of the device library) and agree within the 1e-5 relative the north star states.
+// (align_pair.cc:97-124).  `plus(a, b) = max(a, b) + log1p(exp(-|a - b|))` comes in two builds of
+// the kernel (template parameter kFast):
+//   kFast = false (default): glibc's expf / log1pf restated for the device (glibc_math.hpp,
+//     log_plus_exact in common.hpp) -- every M/D/I value has the CPU's bits;
+//   kFast = true (COATI_HIP_FORWARD_FAST=1): the hardware exp2/log2 (v_exp_f32, v_log_f32, ~1 ulp).
+//     log1p(e) for e in [0, 1] is taken as log(u) + (e - (u - 1)) with u = fl(1 + e): the second
+//     term is the exact rounding residue of 1 + e, so the result degrades gracefully to `e` when
+//     1 + e rounds to 1 -- the same value utils.hpp:142-144 returns for y <= -16.  Absolute error
+//     of one plus() below 1e-7; results within 1e-5 relative of the CPU's, not bit-identical.
 #include "common.hpp"
 
 #include <algorithm>

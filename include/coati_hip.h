@@ -95,12 +95,13 @@ int coati_hip_model_create_tables(const float* tables, uint32_t n_tables, float 
  * batches stay usable, the model's memory is released with the last of them); creating new
  * batches from a destroyed handle is not. */
 void coati_hip_model_destroy(coati_hip_model_t* model);
-/* A model keeps up to four HBM blocks (of at most 16 GB each) that its destroyed batches and finished
- * sampling calls no longer need -- batch workspaces, Forward matrices, the sampler's temporaries --
- * and hands them to the next coati_hip_batch_create / forward_launch / sampleback whose needs they fit (the reference has no counterpart: its work
- * matrices are std::vectors that die with align_pair_work_mem_t, align_pair.hpp:45-62; here a
- * multi-GB hipMalloc costs between 0.4 and 500 ms, which a loop over batches should not pay per
- * batch).  This call frees what is cached; coati_hip_model_destroy does it too. */
+/* A model keeps up to four HBM blocks (of at most 16 GB each) that its destroyed batches and
+ * finished sampling calls no longer need -- batch workspaces, Forward matrices, the sampler's
+ * temporaries -- and hands them to the next coati_hip_batch_create / forward_launch / sampleback
+ * whose needs they fit.  (The reference has no counterpart: its work matrices are std::vectors that
+ * die with align_pair_work_mem_t, align_pair.hpp:45-62; here a multi-GB hipMalloc costs between
+ * 0.4 and 500 ms, which a loop over batches should not pay per batch.)  This call frees what is
+ * cached; coati_hip_model_destroy does it too. */
 int coati_hip_model_trim(coati_hip_model_t* model);
 
 /* ---- batch -------------------------------------------------------------- *
@@ -168,7 +169,11 @@ int coati_hip_batch_result_ptrs(coati_hip_batch_t* batch, void** scores, void** 
  * every pair of the batch.  Keeps the fp32 M/D/I of all body cells resident in HBM
  * (12 bytes per cell, reserved on the first call) for coati_hip_sampleback; the
  * eight edge matrices of align_pair_work_t are recomputed on demand.  Enqueues and
- * returns. */
+ * returns.
+ * Numerics: log_sum_exp (semiring.hpp:86-121, utils.hpp:134-156) is evaluated with device
+ * restatements of glibc 2.35's expf / log1pf, so every M/D/I value has the bits the reference
+ * computes on an x86-64 glibc host.  With COATI_HIP_FORWARD_FAST=1 in the environment the hardware
+ * exp2/log2 instructions are used instead (4x the throughput, values within 1e-5 relative). */
 int coati_hip_forward_launch(coati_hip_batch_t* batch);
 /* Terminal-adjusted M, D, I of the last cell (align_pair.cc:130-138), 3 floats per
  * pair (synchronises). */
