@@ -71,10 +71,14 @@ struct LaneState {
 // One DP cell = ONE asm block of 25 VALU instructions with a fixed order and a
 // hand register allocation.  Why not leave it to the compiler (all measured or
 // observed):
-//  * on gfx950 v_add/v_sub_f32 and v_add_u32 issue every 2 cycles, v_max_f32 and
-//    v_alignbit_b32 have a 4-cycle initiation interval; a slow op costs nothing
-//    extra only if fast ops sit on both sides of it.  The order below alternates
-//    them (F/S) and keeps every consumer >= 2 instructions behind its producer.
+//  * on gfx950 v_add/v_sub_f32 and v_add_u32 issue every 2 cycles, v_max_f32, v_max3_f32 and
+//    v_alignbit_b32 have a 4-cycle initiation interval, and a 4-cycle op that ALTERNATES with
+//    2-cycle ops costs ~9 cycles per pair instead of 6 (tools/ubench: "mix add,max 1:1").  The
+//    eight slow ops of the cell therefore sit in two runs (max, max3, max3, [alignbit,] alignbit
+//    and alignbit x 3) between two runs of adds/subs; a register-only replay of this order runs at
+//    31.2 ns per 64-lane cell at 3 waves/SIMD against 33.0 for the earlier alternating order
+//    (25.0 against 31.4 at 2 waves/SIMD), the kernel gained 3.3 %.  Every consumer is >= 3
+//    instructions behind its producer.
 //  * hipcc batches the X/Y maxes of a whole row (32 back-to-back v_max), and once
 //    values are opaque adds canonicalising v_max around every fmaxf (IEEE mode);
 //    between adjacent dependent inline-asm statements the hazard recognizer
@@ -84,50 +88,51 @@ struct LaneState {
 // carried in `pend` into the next cell; the LDS address of this column's score
 // for the NEXT wavefront step is computed here, the ds_read is issued by the
 // compiler right after the block (so that it also places the s_waitcnt).
-#define COATI_CELL_HEAD                                                                     \
+#define COATI_CELL_FAST_A                                                                   \
     "v_add_f32 %[t0], %[diag], %[s]\n\t"      /* F  M  = diag + s                        */ \
-    "v_add_f32 %[t1], %[ge], %[zl]\n\t"       /* F  z2 = I + ge                          */
-#define COATI_CELL_PEND                                                                     \
-    "v_alignbit_b32 %[aB], %[aB], %[pend], 31\n\t" /* S  D2 of the previous cell         */
-#define COATI_CELL_BODY                                                                     \
+    "v_add_f32 %[t1], %[ge], %[zl]\n\t"       /* F  z2 = I + ge                          */ \
     "v_add_f32 %[t2], %[gs], %[zl]\n\t"       /* F  i1 = I + gs                          */ \
     "v_add_f32 %[t3], %[go], %[t0]\n\t"       /* F  z1 = M + go                          */ \
     "v_add_f32 %[t0], %[ng], %[t0]\n\t"       /* F  m1 = M + ng                          */ \
-    "v_max_f32 %[zl], %[t3], %[t1]\n\t"       /* S  Z  = max(z1,z2) -> I of next column  */ \
-    "v_add_f32 %[t4], %[ng], %[t0]\n\t"       /* F  x1 = m1 + ng                         */ \
     "v_add_f32 %[t5], %[gs], %[y]\n\t"        /* F  x2 = D + gs                          */ \
+    "v_add_f32 %[t8], %[ge], %[y]\n\t"        /* F  y2 = D + ge                          */ \
+    "v_add_f32 %[t4], %[ng], %[t0]\n\t"       /* F  x1 = m1 + ng                         */ \
     "v_add_f32 %[t6], %[ng], %[t2]\n\t"       /* F  x3 = i1 + ng                         */ \
-    "v_sub_f32 %[t1], %[t1], %[t3]\n\t"       /* F  z2 - z1  (sign: z1 > z2)             */ \
+    "v_add_f32 %[t7], %[go], %[t0]\n\t"       /* F  y1 = m1 + go                         */ \
+    "v_add_f32 %[t9], %[go], %[t2]\n\t"       /* F  y3 = i1 + go                         */ \
+    "v_sub_f32 %[t10], %[t1], %[t3]\n\t"      /* F  z2 - z1  (sign: z1 > z2)             */ \
+    "v_add_u32 %[addr], %[lds], %[boff]\n\t"  /* F  LDS address of next step's score     */ \
+    "v_max_f32 %[zl], %[t3], %[t1]\n\t"       /* S  Z  = max(z1,z2) -> I of next column  */ \
     "v_max3_f32 %[x], %[t4], %[t5], %[t6]\n\t" /* S  X  = max(x1,x2,x3)                  */ \
-    "v_add_f32 %[t3], %[go], %[t0]\n\t"       /* F  y1 = m1 + go                         */ \
-    "v_add_f32 %[t6], %[ge], %[y]\n\t"        /* F  y2 = D + ge                          */ \
-    "v_alignbit_b32 %[aC], %[aC], %[t1], 31\n\t" /* S  IM                                */ \
-    "v_add_f32 %[t2], %[go], %[t2]\n\t"       /* F  y3 = i1 + go                         */ \
+    "v_max3_f32 %[y], %[t7], %[t8], %[t9]\n\t" /* S  Y  = max(y1,y2,y3)                  */
+#define COATI_CELL_PEND                                                                     \
+    "v_alignbit_b32 %[aB], %[aB], %[pend], 31\n\t" /* S  D2 of the previous cell         */
+#define COATI_CELL_TAIL                                                                     \
+    "v_alignbit_b32 %[aC], %[aC], %[t10], 31\n\t" /* S  IM                               */ \
     "v_sub_f32 %[t4], %[t4], %[x]\n\t"        /* F  x1 - X   (sign: x1 is not the max)   */ \
     "v_sub_f32 %[t5], %[t5], %[x]\n\t"        /* F  x2 - X   (sign: x2 is not the max)   */ \
-    "v_max3_f32 %[y], %[t3], %[t6], %[t2]\n\t" /* S  Y  = max(y1,y2,y3)                  */ \
-    "v_add_u32 %[addr], %[lds], %[boff]\n\t"  /* F  LDS address of next step's score     */ \
+    "v_sub_f32 %[t7], %[t7], %[y]\n\t"        /* F  y1 - Y   (sign: y1 is not the max)   */ \
+    "v_sub_f32 %[pend], %[t8], %[y]\n\t"      /* F  y2 - Y, carried into the next cell   */ \
     "v_alignbit_b32 %[aA], %[aA], %[t4], 31\n\t" /* S  M1                                */ \
-    "v_sub_f32 %[t3], %[t3], %[y]\n\t"        /* F  y1 - Y   (sign: y1 is not the max)   */ \
     "v_alignbit_b32 %[aA], %[aA], %[t5], 31\n\t" /* S  M2                                */ \
-    "v_sub_f32 %[pend], %[t6], %[y]\n\t"      /* F  y2 - Y, carried into the next cell   */ \
-    "v_alignbit_b32 %[aB], %[aB], %[t3], 31"  /* S  D1                                   */
+    "v_alignbit_b32 %[aB], %[aB], %[t7], 31"    /* S  D1                                   */
 
 template <int C, int W>
 __device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState<W>& st, float& diag, float& zl, float& pend,
                                         float& s, uint32_t lds_next_row, uint32_t boff) {
-    float x_new, t0, t1, t2, t3, t4, t5, t6;
+    float x_new, t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
     uint32_t addr;
 #define COATI_CELL_OPERANDS                                                                              \
     : [x] "=&v"(x_new), [y] "+v"(st.Y[C]), [zl] "+v"(zl), [pend] "+v"(pend), [aA] "+v"(st.acc[ACC_A]),   \
       [aB] "+v"(st.acc[ACC_B]), [aC] "+v"(st.acc[ACC_C]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
-      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [addr] "=&v"(addr)                  \
+      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8),     \
+      [t9] "=&v"(t9), [t10] "=&v"(t10), [addr] "=&v"(addr)                                                \
     : [diag] "v"(diag), [s] "v"(s), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng),          \
       [gs] "s"(k.gs), [go] "s"(k.go), [ge] "s"(k.ge)
     if constexpr(C > 0) {
-        asm volatile(COATI_CELL_HEAD COATI_CELL_PEND COATI_CELL_BODY COATI_CELL_OPERANDS);
+        asm volatile(COATI_CELL_FAST_A COATI_CELL_PEND COATI_CELL_TAIL COATI_CELL_OPERANDS);
     } else {
-        asm volatile(COATI_CELL_HEAD COATI_CELL_BODY COATI_CELL_OPERANDS);
+        asm volatile(COATI_CELL_FAST_A COATI_CELL_TAIL COATI_CELL_OPERANDS);
     }
 #undef COATI_CELL_OPERANDS
     diag = st.X[C];  // the next column's diagonal input is this column's previous-row X

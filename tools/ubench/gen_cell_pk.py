@@ -99,6 +99,63 @@ def cell_max3(c, parity):
     return L
 
 
+def cell_clustered(c, parity):
+    """The 25 instructions of cell_max3 with the 4-cycle ops (max, max3, alignbit) in two clusters
+    instead of interleaved with the 2-cycle ops (three more temporaries)."""
+    xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
+    xout = f"v{XB+c}" if parity == 0 else f"v{YP+2*c+1}"
+    y = f"v{YP+2*c}"
+    t0, t1, t2, t3, t4, t5, t6, pend, zl = "v10", "v11", "v12", "v13", "v14", "v15", "v17", "v16", f"v{ZL}"
+    t7, t8, t9, t10 = "v18", "v19", "v20", "v21"
+    L = [f"v_add_f32 {t0}, v{DIAG}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}", f"v_add_f32 {t2}, {GS}, {zl}",
+         f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+         f"v_add_f32 {t8}, {GE}, {y}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t6}, {NG}, {t2}",
+         f"v_add_f32 {t7}, {GO}, {t0}", f"v_add_f32 {t9}, {GO}, {t2}", f"v_sub_f32 {t10}, {t1}, {t3}",
+         f"v_mov_b32 v{DIAG}, {xin}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}",
+         # slow cluster A
+         f"v_max_f32 {zl}, {t3}, {t1}", f"v_max3_f32 {xout}, {t4}, {t5}, {t6}", f"v_max3_f32 {y}, {t7}, {t8}, {t9}",
+         f"v_alignbit_b32 v{AB}, v{AB}, {pend}, 31", f"v_alignbit_b32 v{AC}, v{AC}, {t10}, 31",
+         # fast cluster B
+         f"v_sub_f32 {t4}, {t4}, {xout}", f"v_sub_f32 {t5}, {t5}, {xout}", f"v_sub_f32 {t7}, {t7}, {y}",
+         f"v_sub_f32 {pend}, {t8}, {y}", f"v_xor_b32 v{LDS}, v{LDS}, v{ADDR}",
+         # slow cluster B
+         f"v_alignbit_b32 v{AA}, v{AA}, {t4}, 31", f"v_alignbit_b32 v{AA}, v{AA}, {t5}, 31",
+         f"v_alignbit_b32 v{AB}, v{AB}, {t7}, 31"]
+    return L
+
+
+def _clustered_variant(c, parity, variant):
+    xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
+    xout = f"v{XB+c}" if parity == 0 else f"v{YP+2*c+1}"
+    y = f"v{YP+2*c}"
+    t0, t1, t2, t3, t4, t5, t6, pend, zl = "v10", "v11", "v12", "v13", "v14", "v15", "v17", "v16", f"v{ZL}"
+    t7, t8, t9, t10 = "v18", "v19", "v20", "v21"
+    fast_a = [f"v_add_f32 {t0}, v{DIAG}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}", f"v_add_f32 {t2}, {GS}, {zl}",
+              f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+              f"v_add_f32 {t8}, {GE}, {y}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t6}, {NG}, {t2}",
+              f"v_add_f32 {t7}, {GO}, {t0}", f"v_add_f32 {t9}, {GO}, {t2}", f"v_sub_f32 {t10}, {t1}, {t3}",
+              f"v_mov_b32 v{DIAG}, {xin}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}"]
+    maxes = [f"v_max_f32 {zl}, {t3}, {t1}", f"v_max3_f32 {xout}, {t4}, {t5}, {t6}", f"v_max3_f32 {y}, {t7}, {t8}, {t9}"]
+    a_pend, a_c = f"v_alignbit_b32 v{AB}, v{AB}, {pend}, 31", f"v_alignbit_b32 v{AC}, v{AC}, {t10}, 31"
+    subs = [f"v_sub_f32 {t4}, {t4}, {xout}", f"v_sub_f32 {t5}, {t5}, {xout}", f"v_sub_f32 {t7}, {t7}, {y}",
+            f"v_sub_f32 {pend}, {t8}, {y}", f"v_xor_b32 v{LDS}, v{LDS}, v{ADDR}"]
+    a_m1, a_m2, a_d1 = (f"v_alignbit_b32 v{AA}, v{AA}, {t4}, 31", f"v_alignbit_b32 v{AA}, v{AA}, {t5}, 31",
+                        f"v_alignbit_b32 v{AB}, v{AB}, {t7}, 31")
+    if variant == 2:   # as `clustered`, the last run reordered so that aA is not written back to back
+        return fast_a + maxes + [a_pend, a_c] + subs + [a_m1, a_d1, a_m2]
+    if variant == 4:   # three maxes | four subs | all five deposits
+        return fast_a + maxes + subs + [a_pend, a_c, a_m1, a_d1, a_m2]
+    raise ValueError(variant)
+
+
+def cell_clustered2(c, parity):
+    return _clustered_variant(c, parity, 2)
+
+
+def cell_clustered4(c, parity):
+    return _clustered_variant(c, parity, 4)
+
+
 def cell_cmp(c, parity):
     """22 VALU: the five decisions as v_cmp into SGPR pairs (lane masks), stored by the scalar unit."""
     xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
@@ -171,6 +228,9 @@ nb, kb = kernel("cell_base", cell_base)
 npk, kp = kernel("cell_pk", cell_pk)
 ncm, kc = kernel("cell_cmp", cell_cmp)
 nm3, km3 = kernel("cell_max3", cell_max3)
+ncl, kcl = kernel("cell_clustered", cell_clustered)
+ncl2, kcl2 = kernel("cell_clustered2", cell_clustered2)
+ncl4, kcl4 = kernel("cell_clustered4", cell_clustered4)
 src = f'''// GENERATED by gen_cell_pk.py -- do not edit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -179,6 +239,9 @@ src = f'''// GENERATED by gen_cell_pk.py -- do not edit.
 {kp}
 {kc}
 {km3}
+{kcl}
+{kcl2}
+{kcl4}
 template <typename K> int run(const char* name, K kern, int n_instr) {{
     float* d_out; CHECK(hipMalloc(&d_out, sizeof(float) * 256 * 256 * 8));
     char* d_scratch; CHECK(hipMalloc(&d_scratch, 256ull * 4 * 4 * 1280 * 400));
@@ -204,6 +267,9 @@ int main() {{
     if (run("pk", cell_pk, {npk})) return 1;
     if (run("cmp+sst", cell_cmp, {ncm})) return 1;
     if (run("max3", cell_max3, {nm3})) return 1;
+    if (run("clustered", cell_clustered, {ncl})) return 1;
+    if (run("clustered2", cell_clustered2, {ncl2})) return 1;
+    if (run("clustered4", cell_clustered4, {ncl4})) return 1;
     return 0;
 }}
 '''
