@@ -235,14 +235,6 @@ __device__ __forceinline__ void one_step(const StripCtx& cx, LaneState<W>& st, u
             store_through(&cx.bnd_x[r + 1], st.X[W - 1]);
             store_through(&cx.bnd_z[r], st.zlast);
         }
-        if(cx.last_strip && r == static_cast<int>(cx.la) - 1 && lane == cx.last_lane) {
-            // score = max(M,D,I) of the terminal-adjusted last cell
-            // (align_pair.cc:130-138,265) = X of the last body cell.
-            float sc = st.X[0];
-#pragma unroll
-            for(int c = 1; c < W; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
-            cx.scores[cx.pair] = sc;
-        }
     }
 }
 
@@ -355,6 +347,16 @@ __device__ __forceinline__ bool fill_strip(const GapConsts& k, const PairDesc& p
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
         }
+    }
+    // score = max(M,D,I) of the terminal-adjusted last cell (align_pair.cc:130-138,265) = X of the last
+    // body cell.  The lane that owns the last column is the last active lane, and its last step is
+    // the strip's last step (nsteps = la + nlanes - 1): it holds that X now.  (Looked for inside the
+    // step loop, the W-1 selects below were speculated into every step by the compiler.)
+    if(last_strip && lane == cx.last_lane) {
+        float sc = st.X[0];
+#pragma unroll
+        for(int c = 1; c < W; ++c) sc = (c == cx.last_c) ? st.X[c] : sc;
+        scores[pair] = sc;
     }
     // flush the accumulators of an incomplete last dword, left-aligned (layout in common.hpp)
     {
