@@ -307,3 +307,14 @@ def test_per_pair_tables(oracle):
         hip.Batch(model, *hip.pack_pairs(enc), table_index=np.full(len(enc), 5, np.uint32))
     batch.close()
     model.close()
+
+
+def test_extremely_ragged_pairs():
+    """tools/ragged_check.py: a few rows x 50 000 columns, 30 000 rows x 1 column, empty sides ...
+    through Viterbi, Forward and exact-stream sampling, all bit-exact against the oracle."""
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "ragged_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ragged_check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
