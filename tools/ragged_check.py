@@ -14,14 +14,16 @@ from tests import util
 rng = np.random.default_rng(99)
 table = host.set_subst("mar-mg")
 consts = host.gap_consts()
-shapes = [(1, 50000), (1, 1), (10000, 4), (10000, 1), (0, 5000), (1000, 0), (2, 1025), (341, 65), (3, 16385), (5000, 5000)]
-pairs = []
-for n_cod, lb in shapes:
-    anc = util.random_anc(rng, n_cod) if n_cod else ""
-    des = "".join(rng.choice(list("ACGT"), lb)) if lb else ""
-    pairs.append((anc, des))
-enc = util.encode_pairs(pairs)
-for L in (1,):
+SHAPES = {1: [(1, 50000), (1, 1), (10000, 4), (10000, 1), (0, 5000), (1000, 0), (2, 1025), (341, 65), (3, 16385), (5000, 5000)],
+          3: [(1, 49998), (1, 3), (10000, 3), (0, 4998), (1000, 0), (2, 1026), (341, 66), (3, 16386), (2000, 6000)]}
+for L in (1, 3):
+    shapes = SHAPES[L]
+    pairs = []
+    for n_cod, lb in shapes:
+        anc = util.random_anc(rng, n_cod) if n_cod else ""
+        des = "".join(rng.choice(list("ACGT"), lb)) if lb else ""
+        pairs.append((anc, des))
+    enc = util.encode_pairs(pairs)
     model = hip.Model(table, consts, L)
     batch = hip.Batch(model, *hip.pack_pairs(enc))
     batch.viterbi_launch()
@@ -45,6 +47,6 @@ for L in (1,):
                 wo, wl = orc.sampleback_mdi(M, D, I, table, consts, L, a, b, r)
                 assert len(wo) == len(g) and (wo == g).all(), ("sample", p, s, shapes[p])
                 assert np.float32(lw[p, s]).view(np.uint32) == np.float32(wl).view(np.uint32), ("lw", p, s)
-        print("ok", shapes[p], "len_a", len(a), "len_b", len(b), "columns", int(ln[p]))
+        print("ok gap_len", L, shapes[p], "len_a", len(a), "len_b", len(b), "columns", int(ln[p]))
     batch.close(); model.close()
 print("ragged_check ok")
