@@ -19,7 +19,7 @@ rng = np.random.default_rng(seed)
 consts_default = orc.gap_consts()
 exact = util.forward_exact()
 t_end = time.time() + budget
-rounds = pairs_checked = 0
+rounds = pairs_checked = reuse_checked = 0
 while time.time() < t_end:
     L = int(rng.choice([1, 1, 1, 2, 3, 3, 4]))
     n_tables = int(rng.integers(1, 4))
@@ -58,6 +58,26 @@ while time.time() < t_end:
             print("MISMATCH", dict(seed=seed, round=rounds, L=L, pair=p, la=len(a), lb=len(b), g=g, e=e))
             sys.exit(1)
         pairs_checked += 1
-    batch.close(); model.close()
+    batch.close()
+    # the same model again with a reordered subset: the new batch takes over the workspace and the
+    # Forward block the first one left behind (different layout, stale contents) -- same answers
+    if len(enc) > 1:
+        sel = rng.permutation(len(enc))[: max(1, len(enc) * 2 // 3)]
+        enc2 = [enc[i] for i in sel]
+        batch2 = hip.Batch(model, *hip.pack_pairs(enc2), table_index=tix[sel])
+        batch2.viterbi_launch()
+        s2, o2, f2, l2 = batch2.viterbi_fetch()
+        batch2.forward_launch()
+        fin2 = batch2.forward_final()
+        for q, i in enumerate(sel):
+            same = (np.float32(s2[q]).view(np.uint32) == np.float32(scores[i]).view(np.uint32) and int(l2[q]) == int(ln[i]) and
+                    (o2[int(f2[q]):int(f2[q]) + int(l2[q])] == ops[int(off[i]):int(off[i]) + int(ln[i])]).all() and
+                    util.same_bits(fin2[q], final[i]))
+            if not same:
+                print("MISMATCH on the reused workspace", dict(seed=seed, round=rounds, L=L, pair=int(i)))
+                sys.exit(1)
+        batch2.close()
+        reuse_checked += len(sel)
+    model.close()
     rounds += 1
-print(f"fuzz ok: {rounds} batches, {pairs_checked} pairs, seed {seed}")
+print(f"fuzz ok: {rounds} batches, {pairs_checked} pairs, seed {seed}; {reuse_checked} pairs re-run on a reused workspace with identical results")
