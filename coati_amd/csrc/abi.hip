@@ -557,11 +557,11 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // wavefront between 1.15 and 3.4 ms (mean 2.1; `make trace`, tools/trace_fill.py).  The SIMD as a
     // whole is work-conserving, but when the queue runs empty every SIMD still holds up to three
     // items in different states of progress and drains them alone -- a batch of equal pairs ends
-    // raggedly however many rounds it has.  The last quarter round of such a
+    // raggedly however many rounds it has.  The last third of a round (1 024 pairs) of such a
     // batch (the end of the LPT order) therefore gets 8-column-per-lane strips -- twice as many,
     // half as long items that the early finishers pick up.  Measured (tools/ab_fill.py, 1 kb pairs):
     // 9 216 pairs +11 %, 6 644 +6 %, 10 000 +3.7 %, 20 000 and 40 000 +2.3 %, 12 000 and 125 000 +-0.5 %; narrowing more
-    // than ~1 000 pairs, or to 4 columns, loses (W = 8 runs at ~85 %, W = 4 at ~57 % of the W = 16
+    // than ~1 100 pairs (768 and 1 024 are within 1 %, 1 280 loses 3 %), or to 4 columns, loses (W = 8 runs at ~85 %, W = 4 at ~57 % of the W = 16
     // rate per cell).  A mixed bag needs none of it: its short pairs already end the queue.
     // COATI_HIP_TAIL_PAIRS=<n> overrides the count (0: off).
     std::vector<uint8_t> pair_w(n_pairs, 0);
@@ -590,7 +590,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             // and the batch must be clearly longer than one round (3 500 pairs: -1 %, 6 644: +6 %)
             auto cells_of = [&](uint64_t p) { return static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb; };
             const bool homogeneous = cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]);
-            if(homogeneous && n_pairs > kFillSlots * 3 / 2) tail_pairs = kFillSlots / 4;
+            if(homogeneous && n_pairs > kFillSlots * 3 / 2) tail_pairs = kFillSlots / 3;
         }
         for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = 8;
     }
