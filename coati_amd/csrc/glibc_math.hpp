@@ -14,7 +14,7 @@
 //                products are fused) is the one that build has.
 //   log1pf       sysdeps/ieee754/flt-32/s_log1pf.c -- the fdlibm (Sun) algorithm in float; no FMA
 //                variant exists.
-// Parity is pinned, not assumed: tools/libm_check.c compares these restatements (compiled for the
+// Parity is pinned, not assumed: tools/libm_check.cc compares these restatements (compiled for the
 // host) with the container's libm on EVERY float of the ranges the path can produce -- expf on
 // [-104, 0] (1 120 927 745 inputs), log1pf on [0, 1] (1 065 353 217), logf on [2^-126, 4]
 // (1 073 741 825) -- 0 mismatches; tests/test_gpu_math.py compares the DEVICE code with the host libm
