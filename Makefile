@@ -13,15 +13,15 @@ all: lib host oracle
 
 lib: $(BUILD)/libcoati_hip.so
 
-HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/viterbi_l1.hip coati_amd/csrc/dp_generic.hip coati_amd/csrc/forward_l1.hip coati_amd/csrc/viterbi_k.hip coati_amd/csrc/forward_k.hip \
+HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/viterbi_ck.hip coati_amd/csrc/viterbi_l1.hip coati_amd/csrc/dp_generic.hip coati_amd/csrc/forward_l1.hip coati_amd/csrc/viterbi_k.hip coati_amd/csrc/forward_k.hip \
           coati_amd/csrc/sampleback.hip
-$(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip.h
+$(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 
 # debug variant with per-wave clock stamps in the fill kernel (tools/trace_fill.py)
 trace: $(BUILD)/libcoati_hip_trace.so
-$(BUILD)/libcoati_hip_trace.so: $(HIP_SRC) coati_amd/csrc/common.hpp include/coati_hip.h
+$(BUILD)/libcoati_hip_trace.so: $(HIP_SRC) coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -DCOATI_FILL_TRACE -shared -o $@ $(HIP_SRC)
 

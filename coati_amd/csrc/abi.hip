@@ -162,7 +162,9 @@ struct coati_hip_batch {
     uint32_t* d_progress = nullptr;
     uint32_t n_items = 0;
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
-    uint32_t* d_flags = nullptr;
+    uint32_t* d_flags = nullptr;   // decision bits (viterbi_l1/_k, dp_generic) or checkpoints (viterbi_ck)
+    uint32_t* d_wscratch = nullptr;  // viterbi_ck: traceback scratch of the persistent wavefronts
+    bool ck = false;                 // gap_len 1 runs viterbi_ck (checkpoint layout in d_flags)
     float *d_bnd = nullptr, *d_scores = nullptr;
     float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward (parts of mdi_block)
     void* mdi_block = nullptr;
@@ -185,7 +187,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->d_scores,
-                           b->d_ops,    b->d_ops_start, b->d_ops_len,
+                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch,
                            b->d_mdi,    b->d_final_mdi};
 }
 }  // namespace
@@ -545,7 +547,11 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // has fewer strips than the GPU has SIMDs (a few long pairs), narrower strips everywhere put
     // more wavefronts to work on each pair.  dp_generic (gap_len > 1) writes 16-column strips only.
     uint32_t w_main = kW;
-    const bool plan_l1 = L == 1 && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;  // viterbi_l1 will run
+    const bool plan_l1 = L == 1 && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;  // viterbi_ck / viterbi_l1 will run
+    // COATI_HIP_VITERBI_BITS=1: the round-1 kernel (five decision bits per cell written by the fill), kept
+    // as the A/B partner and second implementation of viterbi_ck
+    b->ck = plan_l1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr;
+    const bool ck_shared = model->n_tables == 1;
     // longest-processing-time-first order for the dynamic queue
     std::vector<uint32_t> order(n_pairs);
     for(uint64_t p = 0; p < n_pairs; ++p) order[p] = static_cast<uint32_t>(p);
@@ -576,7 +582,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             for(uint64_t p = 0; p < n_pairs; ++p) items += items_of(p, w);
             return items;
         };
-        constexpr uint64_t kSimds = 1024, kFillSlots = 3 * kSimds;
+        constexpr uint64_t kSimds = 1024;
+        const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
         while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
         if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
             const int w = std::atoi(e);
@@ -652,8 +659,9 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         d.flags_off = b->flag_dwords;
         d.bnd_off = b->bnd_floats;
         if(d.la > 0 && d.lb > 0)
-            b->flag_dwords += plan_k ? ns * compact_strip_dwords(d.la, static_cast<uint32_t>(L))
-                                     : (ns - 1) * strip_dwords(d.la, w_main_p) + strip_dwords(d.la, wl);
+            b->flag_dwords += plan_k  ? ns * compact_strip_dwords(d.la, static_cast<uint32_t>(L))
+                              : b->ck ? (ns - 1) * ck_strip_dwords(d.la, w_main_p) + ck_strip_dwords(d.la, wl)
+                                      : (ns - 1) * strip_dwords(d.la, w_main_p) + strip_dwords(d.la, wl);
         // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
         // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
@@ -703,7 +711,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                    o_start = carve(n_pairs * sizeof(uint64_t)), o_len = carve(n_pairs * sizeof(uint32_t)),
                    o_order = carve(n_pairs * sizeof(uint32_t)), o_queue = carve(sizeof(uint32_t)),
                    o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
-                   o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t));
+                   o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)),
+                   o_wscratch = carve(b->ck ? ck_scratch_waves() * ck_scratch_dwords_per_wave() * sizeof(uint32_t) : 0);
     {
         // a workspace a destroyed batch of this model left behind, or a fresh one
         const hipError_t e = model_take_arena(model, arena_need, &b->arena, &b->arena_bytes);
@@ -728,6 +737,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     b->d_items = reinterpret_cast<WorkItem*>(at(o_items));
     b->d_fwd_items = reinterpret_cast<WorkItem*>(at(o_fwd));
     b->d_progress = reinterpret_cast<uint32_t*>(at(o_progress));
+    b->d_wscratch = reinterpret_cast<uint32_t*>(at(o_wscratch));
     stage("workspace");
     if(n_pairs > 0) {
         B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
@@ -762,7 +772,9 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
     if(n > 0) {
         const BatchDeviceView v = device_view(b);
         static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
-        if(m->gap_len == 1 && !force_generic)
+        if(b->ck)
+            HIP_TRY(launch_viterbi_ck(v, m->n_tables == 1, m->stream));
+        else if(m->gap_len == 1 && !force_generic)
             HIP_TRY(launch_viterbi_l1(v, m->stream));
         else if(b->compact)
             HIP_TRY(launch_viterbi_k(v, b->compact_narrow_only, m->stream));
@@ -1331,7 +1343,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         uint64_t p1 = p0, need = 0;
         while(p1 < n_pairs) {
             const uint64_t la = a_off[p1 + 1] - a_off[p1], lb = b_off[p1 + 1] - b_off[p1];
-            const uint64_t w = (la > 0 && lb > 0) ? n_strips(static_cast<uint32_t>(lb)) * strip_dwords(static_cast<uint32_t>(la)) * 4 : 0;
+            const uint64_t w = (la > 0 && lb > 0) ? n_strips(static_cast<uint32_t>(lb)) * ck_strip_dwords(static_cast<uint32_t>(la), kW) * 4 : 0;
             const uint64_t add = w + 3 * (la + lb) + 8 * (la + 1) + 128;
             if(p1 > p0 && need + add > budget) break;
             need += add;
@@ -1374,9 +1386,21 @@ int coati_hip_debug_viterbi_flags(coati_hip_batch_t* b, uint64_t pair, uint8_t* 
     if(rc != COATI_HIP_OK) return rc;
     uint8_t* d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n));
-    hipLaunchKernelGGL(decode_flags, dim3(static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 4096))),
-                       dim3(256), 0, b->model->stream, b->d_desc, static_cast<uint32_t>(pair), b->d_flags, d_out);
-    hipError_t e = hipStreamSynchronize(b->model->stream);
+    hipError_t e = hipSuccess;
+    if(b->ck) {
+        // no bits in memory: every tile recomputed from the checkpoints by the traceback's own routine
+        constexpr uint32_t kWaves = 64;
+        uint32_t* d_scratch = nullptr;
+        e = hipMalloc(reinterpret_cast<void**>(&d_scratch), kWaves * ck_scratch_dwords_per_wave() * sizeof(uint32_t));
+        if(e == hipSuccess) e = hipMemsetAsync(d_out, 0xff, n, b->model->stream);
+        if(e == hipSuccess) e = launch_ck_all_flags(device_view(b), static_cast<uint32_t>(pair), d_scratch, kWaves, d_out, b->model->stream);
+        if(e == hipSuccess) e = hipStreamSynchronize(b->model->stream);
+        if(d_scratch != nullptr) (void)hipFree(d_scratch);
+    } else {
+        hipLaunchKernelGGL(decode_flags, dim3(static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 4096))),
+                           dim3(256), 0, b->model->stream, b->d_desc, static_cast<uint32_t>(pair), b->d_flags, d_out);
+        e = hipStreamSynchronize(b->model->stream);
+    }
     if(e == hipSuccess) e = hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
     if(e != hipSuccess) return fail(COATI_HIP_EHIP, "debug_viterbi_flags: %s", hipGetErrorString(e));

@@ -79,6 +79,19 @@ __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
     const uint32_t mc = 32u / w;
     return static_cast<uint64_t>((la + kWave - 1 + mc - 1) / mc) * kPairDwords;
 }
+// viterbi_ck.hip (gap_len 1) keeps no per-cell bits: per strip of W columns per lane it stores
+//   colin  float2[k][lane]      what lane `lane` received from its left neighbour at wavefront step k
+//                               (diagonal X, left Z); k < la + 63
+//   rowck  float4[c][q][lane]   the lane state before step c*kCkRows: X[0..W) then Y[0..W) as W/2
+//                               float4 (q), one band c per kCkRows steps
+// from which any (band, lane) tile can be recomputed on its own.  8/W + 8/kCkRows bytes per cell.
+constexpr uint32_t kCkRowsLog2 = 4, kCkRows = 1u << kCkRowsLog2;
+__host__ __device__ constexpr uint32_t ck_rowck_quads(uint32_t w) { return w / 2; }
+__host__ __device__ inline uint32_t ck_bands(uint32_t la) { return (la + kWave + kCkRows - 1) / kCkRows; }
+__host__ __device__ inline uint64_t ck_colin_dwords(uint32_t la) { return static_cast<uint64_t>(la + kWave) * (2 * kWave); }
+__host__ __device__ inline uint64_t ck_strip_dwords(uint32_t la, uint32_t w) {
+    return ck_colin_dwords(la) + static_cast<uint64_t>(ck_bands(la)) * (2 * w * kWave);
+}
 // Compact layout (gap_len L = 2, 3; viterbi_k.hip): live body cell (bi, bj), bi = p*L + r,
 // bj = q*L + r.  A lane owns W <= 16 block columns q; wavefront step k = p + lane.  Per strip and
 // step S = 2L + (L+1)/2 rows of 64 dwords:
@@ -398,10 +411,18 @@ struct BatchDeviceView {
     uint8_t* ops;
     uint64_t* ops_start;
     uint32_t* ops_len;
+    uint32_t* wscratch;  // viterbi_ck: per-wavefront scratch of the traceback (decision bits of one round)
     float* mdi;        // Forward: fp32 M/D/I of every body cell
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
 };
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
+// viterbi_ck.hip: lean fill + checkpoint traceback (`flags` is the checkpoint arena); shared_tab: the
+// model has one substitution table.  The scratch is ck_scratch_waves() x ck_scratch_dwords_per_wave().
+hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream);
+uint32_t ck_scratch_waves();
+uint64_t ck_scratch_dwords_per_wave();
+hipError_t launch_ck_all_flags(const BatchDeviceView& v, uint32_t pair, uint32_t* scratch, uint32_t n_waves, uint8_t* out,
+                               hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
 hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_viterbi_k(const BatchDeviceView& v, bool narrow_only, hipStream_t stream);

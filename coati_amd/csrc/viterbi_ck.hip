@@ -1,0 +1,813 @@
+// viterbi_ck: the Viterbi kernel for gap_len == 1 (the default and by far the common case).
+// Persistent wavefronts, one strip of one sequence pair at a time per wavefront: a LEAN fill that
+// keeps no per-cell traceback information, then the traceback by the same wavefront, which
+// re-derives the decisions of the cells the path visits from checkpoints the fill left in HBM.
+//
+// What it replaces in the reference (all CPU, one pair per process):
+//   forward_impl<tropical, align_pair_work_mem_t>   src/lib/align_pair.cc:62-139
+//   traceback<tropical> / max_mdi / max_mi          src/lib/align_pair.cc:210-303
+//
+// Why (DESIGN.md §3.1 has the derivation and the measurements).  The reference's traceback
+// re-derives each decision from the stored scores of the cell it arrives at
+// (align_pair.cc:275-296): five comparisons per cell.  Evaluating them for EVERY cell in the fill
+// (viterbi_l1.hip) costs 10 of its 25 VALU instructions per cell -- for cells of which ~0.2 % are
+// ever visited.  Here the fill cell is the 15 instructions of the recurrence alone, and per
+// wavefront step the fill stores
+//   * what every lane RECEIVED from its left neighbour (diagonal X and left Z: 8 B per lane),
+//   * every kR steps the lane state (X, Y of its W columns),
+// which makes every (kR steps) x (one lane = W columns) tile of the matrix recomputable on its own.
+// The traceback then works in rounds: the 64 lanes recompute, each on its own, the 64 tiles of a
+// band around the predicted continuation of the path -- with the 25-instruction cell of
+// viterbi_cell.hpp, i.e. the same adds in the same order, so every bit equals what a full fill would
+// have stored -- and the wave-cooperative walker follows the path through those tiles until it
+// leaves the band.  A 1 kb pair takes 3-4 rounds of 256 cells per lane: ~8 % of the fill's work.
+//
+// fp32 only, adds/max in the reference's evaluation order; -ffp-contract=off -fno-slp-vectorize.
+#include "viterbi_cell.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace coati_hip_detail {
+namespace {
+
+// Register state of one lane of the lean fill: its W columns of the row it processed last.
+template <int W>
+struct CkLane {
+    float X[W];  // max((M+ng)+ng, D+gs, (I+gs)+ng): feeds M of the next diagonal cell
+    float Y[W];  // max((M+ng)+go, D+ge, (I+gs)+go): the D value of the cell below
+    float xlast_old;  // X[W-1] of the row before: the right neighbour's diagonal input
+    float zlast;      // max(M+go, I+ge) of column W-1: the right neighbour's I value
+};
+
+// The recurrence of one cell (align_pair.cc:97-124 with look_back = 1; the algebra is in
+// viterbi_cell.hpp / DESIGN.md §2): 11 v_add_f32, the LDS address of this column's score for the
+// next wavefront step, and the three maxima.
+#define COATI_CELL_LEAN                                                                       \
+    "v_add_f32 %[t0], %[diag], %[s]\n\t"       /* M  = diag + s                            */ \
+    "v_add_f32 %[t1], %[ge], %[zl]\n\t"        /* z2 = I + ge                              */ \
+    "v_add_f32 %[t2], %[gs], %[zl]\n\t"        /* i1 = I + gs                              */ \
+    "v_add_f32 %[t3], %[go], %[t0]\n\t"        /* z1 = M + go                              */ \
+    "v_add_f32 %[t0], %[ng], %[t0]\n\t"        /* m1 = M + ng                              */ \
+    "v_add_u32 %[s], %[lds], %[boff]\n\t"      /* LDS address of next step's score         */ \
+    "v_add_f32 %[t4], %[ng], %[t2]\n\t"        /* x3 = i1 + ng                             */ \
+    "v_max_f32 %[zl], %[t3], %[t1]\n\t"        /* Z  = max(z1,z2) -> I of the next column  */ \
+    "v_add_f32 %[t1], %[gs], %[y]\n\t"         /* x2 = D + gs                              */ \
+    "v_add_f32 %[t3], %[ng], %[t0]\n\t"        /* x1 = m1 + ng                             */ \
+    "v_add_f32 %[t2], %[go], %[t2]\n\t"        /* y3 = i1 + go                             */ \
+    "v_max3_f32 %[x], %[t3], %[t1], %[t4]\n\t" /* X  = max(x1,x2,x3)                       */ \
+    "v_add_f32 %[t1], %[ge], %[y]\n\t"         /* y2 = D + ge                              */ \
+    "v_add_f32 %[t0], %[go], %[t0]\n\t"        /* y1 = m1 + go                             */ \
+    "v_max3_f32 %[y], %[t0], %[t1], %[t2]"      /* Y  = max(y1,y2,y3)                       */
+
+// (Five temporaries: the register-only replay of the cell, tools/ubench/gen_cell_pk.py, runs at the
+// same rate whatever the order of the 15 instructions, so the order is the one with the shortest
+// live ranges.  `s` is consumed by the first instruction and then carries the LDS address.)
+template <int C, int W>
+__device__ __forceinline__ void cell_lean(const GapConsts& k, CkLane<W>& st, float& diag, float& zl, float& s,
+                                          uint32_t lds_next_row, uint32_t boff) {
+    float x_new, t0, t1, t2, t3, t4;
+    asm volatile(COATI_CELL_LEAN
+                 : [x] "=&v"(x_new), [y] "+v"(st.Y[C]), [zl] "+v"(zl), [s] "+v"(s), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                   [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
+                 : [diag] "v"(diag), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng), [gs] "s"(k.gs),
+                   [go] "s"(k.go), [ge] "s"(k.ge));
+    diag = st.X[C];  // the next column's diagonal input is this column's previous-row X
+    st.X[C] = x_new;
+    // next step's score (s holds its LDS byte address now).  volatile: the read is issued HERE, a step
+    // ahead of its use -- left to itself the compiler sinks all W of them to the top of the next step
+    s = *reinterpret_cast<const volatile __attribute__((address_space(3))) float*>(__builtin_bit_cast(uint32_t, s));
+}
+
+template <int W, int... C>
+__device__ __forceinline__ void row_lean(const GapConsts& k, CkLane<W>& st, float diag, float zl, float (&s)[W],
+                                         uint32_t lds_next_row, const uint32_t (&boff)[W],
+                                         std::integer_sequence<int, C...>) {
+    st.xlast_old = st.X[W - 1];
+    (cell_lean<C, W>(k, st, diag, zl, s[C], lds_next_row, boff[C]), ...);
+    st.zlast = zl;
+}
+
+// HBM accesses of the hot loop are raw buffer stores: the base sits in four SGPRs, the lane part of
+// the address is ONE constant VGPR and the step part an SGPR offset -- no 64-bit VGPR pointers to
+// keep (and spill) in a loop that needs every VGPR for the cells.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+
+// Read-only per-strip context of one wavefront.
+struct CkCtx {
+    GapConsts k;
+    uint32_t la, col0, nsteps, lds_tab;
+    int lane;
+    bool last_strip;
+    float *bnd_x, *bnd_z;  // (wave-uniform)
+};
+// HBM windows of one 64-step chunk (rebased per chunk so that offsets stay far below 2^32)
+struct CkChunkMem {
+    rsrc_t colin;  // float2[kk][lane] of this chunk's steps
+    rsrc_t rowck;  // float4[band in chunk][q][lane]
+};
+
+// lane state -> row checkpoint of the band that starts at chunk step kb (state BEFORE that step)
+template <int W>
+__device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, const CkLane<W>& st, uint32_t kb) {
+    const uint32_t soff = (kb / kCkRows) * (ck_rowck_quads(W) * kWave * 16u);
+    uint32_t voff = static_cast<uint32_t>(lane);
+    asm volatile("" : "+v"(voff));  // (derived here, once per kCkRows steps: not another VGPR held across the hot loop)
+    voff *= 16u;
+#pragma unroll
+    for(int q = 0; q < W / 4; ++q) {
+        const u32x4 x = {fbits(st.X[4 * q]), fbits(st.X[4 * q + 1]), fbits(st.X[4 * q + 2]), fbits(st.X[4 * q + 3])};
+        const u32x4 y = {fbits(st.Y[4 * q]), fbits(st.Y[4 * q + 1]), fbits(st.Y[4 * q + 2]), fbits(st.Y[4 * q + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * (kWave * 16u), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * (kWave * 16u), 0);
+    }
+}
+
+// One wavefront step.  In chunk 0 lane l does its first row at step l: until then it computes on
+// whatever it holds (never looked at), and at step l it takes the state of the margin row.  ONE
+// instantiation serves every chunk: a separate start-up copy of the loop (as viterbi_l1.hip has)
+// cost ~50 VGPRs here and with them the fourth wavefront per SIMD.
+template <int W>
+__device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
+                                        float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
+                                        uint32_t a_chunk, float bx, float bz) {
+    const GapConsts& k = cx.k;
+    const int lane = cx.lane;
+    const uint32_t kstep = kbase + kk;
+    if(kbase == 0 && kk == static_cast<uint32_t>(lane)) {
+        // This lane starts now: state of the margin row (matrix row 0, align_pair.cc:88-90):
+        // M = D = lowest, I = go + ge*float(j-1).
+        uint32_t bj0 = cx.col0 + lane * W;
+        asm volatile("" : "+v"(bj0));  // compute in place (hoisted out of the loop these 2W values get spilled)
+#pragma unroll
+        for(int c = 0; c < W; ++c) {
+            const float im = k.go + k.ge * static_cast<float>(bj0 + c);
+            const float i1 = im + k.gs;
+            st.X[c] = i1 + k.ng;
+            st.Y[c] = i1 + k.go;
+        }
+    }
+    // ---- hand-off from the left neighbour (full exec)
+    const float diag = shift_in(st.xlast_old, read_lane(bx, kk));
+    const float zl = shift_in(st.zlast, read_lane(bz, kk));
+    const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
+    // ---- checkpoint: what this lane received (one coalesced 512-byte row per wavefront step)
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, static_cast<uint32_t>(lane) * 8u,
+                                          kk * (kWave * 8u), 0);
+    // ---- the W cells (and the LDS gather for the next step)
+    row_lean<W>(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
+    arow = arow_next;
+    // lane 63 just did body row kstep - 63: its last column is the next strip's boundary
+    if(!cx.last_strip && lane == kWave - 1 && kstep >= static_cast<uint32_t>(kWave - 1) && kstep - (kWave - 1) < cx.la) {
+        const uint32_t r = kstep - (kWave - 1);  // (wave-uniform: the addresses stay in SGPRs)
+        store_through(&cx.bnd_x[r + 1], st.X[W - 1]);
+        store_through(&cx.bnd_z[r], st.zlast);
+    }
+}
+
+// Up to 64 wavefront steps in sub-blocks of kCkRows, each preceded by its row checkpoint.
+template <int W>
+__device__ __forceinline__ void ck_chunk(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
+                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk,
+                                         float bx, float bz) {
+    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    for(uint32_t kb = 0; kb < kend; kb += kCkRows) {
+        store_rowck<W>(mem, cx.lane, st, kb);
+        const uint32_t ke = min(kb + kCkRows, kend);
+        // two steps per iteration: the new X of a column must not overwrite the old one before the
+        // next column has taken it as its diagonal input; with two copies of the body the register
+        // allocator ping-pongs X between two register sets instead of copying W values per step
+        uint32_t kk = kb;
+        for(; kk + 1 < ke; kk += 2) {
+            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
+            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz);
+        }
+        if(kk < ke) ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
+    }
+}
+
+// Checkpoint arena of strip `strip` of a pair (dwords from the arena start)
+__device__ __forceinline__ uint64_t ck_strip_base(const PairDesc& pd, uint32_t strip) {
+    return pd.flags_off + strip * ck_strip_dwords(pd.la, pd.v_wmain);
+}
+
+// One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
+// the left neighbour's boundary column did not arrive within the spin bound.
+template <int W>
+__device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip,
+                                              uint32_t ticket, int lane, uint32_t lds_tab, const char* tab_bytes,
+                                              const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                              uint32_t* __restrict__ ck, float* __restrict__ bnd,
+                                              float* __restrict__ scores, uint32_t* __restrict__ progress) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    const uint32_t col0 = strip * (kWave * pd.v_wmain);  // every strip before this one has the main width
+    const uint32_t ncol = min(static_cast<uint32_t>(kWave * W), lb - col0);
+    const uint32_t nlanes = (ncol + W - 1) / W;
+    const uint32_t nsteps = la + nlanes - 1;
+    const bool last_strip = strip + 1 == pd.v_strips;
+    uint32_t* __restrict__ ck_strip = ck + ck_strip_base(pd, strip);
+    // strip-boundary columns, one array per strip boundary: [0, la] = X of the strip's last
+    // column (index r = X of body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
+    const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
+    float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
+    float* __restrict__ bnd_z = bnd_x + (la + 1);
+    const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
+    const float* __restrict__ in_z = in_x + (la + 1);
+    bool handoff_ok = true;
+
+    uint32_t boff[W];  // byte offsets of this lane's W table columns
+#pragma unroll
+    for(int c = 0; c < W; ++c) {
+        const uint32_t bj = col0 + lane * W + c;
+        boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+    }
+    const CkCtx cx{k, la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z};
+    const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
+    // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
+    // ge*float(j-1)); a lane takes it again at its first step (ck_step)
+    CkLane<W> st;
+    {
+        const uint32_t bj0 = col0 + lane * W;
+#pragma unroll
+        for(int c = 0; c < W; ++c) {
+            const float im = k.go + k.ge * static_cast<float>(bj0 + c);
+            const float i1 = im + k.gs;
+            st.X[c] = i1 + k.ng;
+            st.Y[c] = i1 + k.go;
+        }
+        if(!last_strip && lane == kWave - 1) store_through(&bnd_x[0], st.X[W - 1]);
+    }
+    st.xlast_old = 0.0f;
+    st.zlast = 0.0f;
+    // table-row byte offset of the row this lane processes at the CURRENT step, and the W
+    // substitution scores gathered for it one step earlier (every lane's first row is body row 0)
+    uint32_t arow = static_cast<uint32_t>(a[0]) * (kTabStride * 4u);
+    float s[W];
+#pragma unroll
+    for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
+
+    for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+        // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l (boundary
+        // column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
+        const uint32_t crow = kbase + lane;
+        uint32_t a_chunk = 0;
+        float bx = kLowest, bz = kLowest;
+        if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+        if(crow < la && strip == 0) {
+            // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
+            if(crow == 0) {
+                bx = (0.0f + k.ng) + k.ng;
+            } else {
+                const float dm = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
+                bx = dm + k.gs;
+            }
+        }
+        if(strip > 0) {
+            // rows kbase .. kbase+63 of the left neighbour's last column must be published
+            handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
+            if(crow < la) {
+                bx = in_x[crow];
+                bz = in_z[crow];
+            }
+        }
+        // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
+        asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
+        const CkChunkMem mem{make_rsrc(ck_strip + static_cast<uint64_t>(kbase) * (2 * kWave)),
+                             make_rsrc(rowck_strip + static_cast<uint64_t>(kbase / kCkRows) * (2 * W * kWave))};
+        ck_chunk<W>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz);
+        if(!last_strip) {
+            const uint32_t done = min(kbase + kWave, nsteps);
+            if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
+        }
+    }
+    // score = max(M,D,I) of the terminal-adjusted last cell (align_pair.cc:130-138,265) = X of the
+    // last body cell, held by the lane that owns the last column after the strip's last step
+    if(last_strip && lane == static_cast<int>((lb - 1 - col0) / W)) {
+        const int last_c = static_cast<int>((lb - 1 - col0) % W);
+        float sc = st.X[0];
+#pragma unroll
+        for(int c = 1; c < W; ++c) sc = (c == last_c) ? st.X[c] : sc;
+        scores[pair] = sc;
+    }
+    if(!last_strip) {
+        // The pair's traceback runs on the wavefront of the LAST strip: release this strip's
+        // (plainly stored) checkpoints before saying "complete".
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        publish_progress(progress + ticket, la, lane == kWave - 1);
+    }
+    return handoff_ok;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traceback: tile recompute + walker
+// ---------------------------------------------------------------------------------------------
+// One strip of a pair as the traceback sees it (wave-uniform).
+struct CkStrip {
+    uint32_t strip, w, lg, col0, nlanes;
+    const float2* colin;
+    const float4* rowck;
+};
+__device__ __forceinline__ CkStrip ck_strip_of(const PairDesc& pd, const uint32_t* __restrict__ ck, uint32_t bj) {
+    const uint32_t full = kWave * pd.v_wmain;
+    uint32_t strip = bj / full, w = pd.v_wmain;
+    if(strip + 1 >= pd.v_strips) {
+        strip = pd.v_strips - 1;
+        w = pd.v_wlast;
+    }
+    const uint32_t col0 = strip * full;
+    const uint32_t ncol = min(kWave * w, pd.lb - col0);
+    const uint32_t* base = ck + ck_strip_base(pd, strip);
+    return {strip, w, 31u - static_cast<uint32_t>(__clz(static_cast<int>(w))), col0, (ncol + w - 1) / w,
+            reinterpret_cast<const float2*>(base), reinterpret_cast<const float4*>(base + ck_colin_dwords(pd.la))};
+}
+
+// The 64 tiles of one round: a band around the predicted continuation of the path from the cell
+// whose decision is pending, body coordinates (bi, bj).  A tile is (band c of kCkRows wavefront
+// steps, lane t) of the strip; lane t of band c holds body rows c*kCkRows - t + [0, kCkRows) of
+// columns col0 + t*W + [0, W).  Going back along the path a match moves up and left, a deletion
+// up, an insertion left, so the prediction depends on the kind of run the walk is in:
+//   mode D (after a match):     tile columns t0, t0-1, ... t0-20, three bands each around the
+//                               diagonal through (bi, bj)
+//   mode V (after a deletion):  bands c0, c0-1, ... c0-31 of tile columns t0 and t0-1
+//   mode H (after an insertion): tile columns t0 ... t0-31, the band of row bi and the one above
+// A wrong prediction costs a round, never correctness: a cell outside the set reads "unknown",
+// the walk stops there and the next round is built around it.
+struct TileSet {
+    int mode;  // COATI_HIP_OP_MATCH / _DEL / _INS
+    uint32_t strip, w, lg, col0, t0;
+    int32_t bi, bj, c0;
+};
+__device__ __forceinline__ int32_t tileset_cmid(const TileSet& ts, uint32_t dt) {
+    const int32_t t = static_cast<int32_t>(ts.t0 - dt);
+    const int32_t jr = min(ts.bj, static_cast<int32_t>(ts.col0 + ts.w * (t + 1)) - 1);  // right edge of the tile column
+    const int32_t ir = ts.bi - (ts.bj - jr);                                            // the diagonal's row there
+    return (ir + t - static_cast<int32_t>(ts.w / 2)) >> kCkRowsLog2;                    // band of the middle of its span
+}
+// slot -> tile (t, c); false if the slot is unused
+__device__ __forceinline__ bool tileset_tile(const TileSet& ts, uint32_t slot, int32_t& t, int32_t& c) {
+    if(ts.mode == COATI_HIP_OP_MATCH) {
+        const uint32_t dt = slot / 3u;
+        if(dt > 20u || dt > ts.t0) return false;
+        t = static_cast<int32_t>(ts.t0 - dt);
+        c = tileset_cmid(ts, dt) + static_cast<int32_t>(slot % 3u) - 1;
+    } else if(ts.mode == COATI_HIP_OP_DEL) {
+        const uint32_t o = slot & 1u;
+        if(o > ts.t0) return false;
+        t = static_cast<int32_t>(ts.t0 - o);
+        c = ts.c0 - static_cast<int32_t>(slot >> 1);
+    } else {
+        const uint32_t dt = slot >> 1;
+        if(dt > ts.t0) return false;
+        t = static_cast<int32_t>(ts.t0 - dt);
+        c = ((ts.bi + t) >> kCkRowsLog2) - static_cast<int32_t>(slot & 1u);
+    }
+    return c >= 0;
+}
+// tile (t, c) -> slot, or -1
+__device__ __forceinline__ int tileset_slot(const TileSet& ts, uint32_t t, int32_t c) {
+    if(t > ts.t0) return -1;
+    const uint32_t dt = ts.t0 - t;
+    if(ts.mode == COATI_HIP_OP_MATCH) {
+        if(dt > 20u) return -1;
+        const int32_t o = c - tileset_cmid(ts, dt);
+        return (o >= -1 && o <= 1) ? static_cast<int>(3u * dt) + o + 1 : -1;
+    }
+    if(ts.mode == COATI_HIP_OP_DEL) {
+        const int32_t u = ts.c0 - c;
+        return (dt <= 1u && u >= 0 && u < 32) ? 2 * u + static_cast<int>(dt) : -1;
+    }
+    if(dt > 31u) return -1;
+    const int32_t o = ((ts.bi + static_cast<int32_t>(t)) >> kCkRowsLog2) - c;
+    return (o >= 0 && o <= 1) ? static_cast<int>(2u * dt) + o : -1;
+}
+
+// Per-wavefront scratch for the decision bits of one round: [which 0..2][step in band][slot], one
+// dword each (A = (M1,M2) pairs, B = (D1,D2) pairs, C = IM; viterbi_cell.hpp).  After the W cells of
+// a step the accumulators hold column cc's pair at bits 2(W-1-cc)+1, 2(W-1-cc) and its IM bit at
+// bit W-1-cc (older steps sit above and are ignored).
+constexpr uint32_t kCkScratchDwords = 3u * kCkRows * kWave;
+
+// Recompute one tile per lane: lane state from the row checkpoint (or the margin row if the lane
+// started inside the band), then kCkRows wavefront steps of W cells with the received values of
+// the fill as left inputs, depositing the five decision bits of every cell.
+template <int W>
+__device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc& pd, const CkStrip& sp, bool valid,
+                                             int32_t t, int32_t c, uint32_t lds_tab, const char* tab_bytes,
+                                             const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                             uint32_t* __restrict__ bits /* wave scratch + lane */) {
+    const int32_t la = static_cast<int32_t>(pd.la);
+    const int32_t k0 = c * static_cast<int32_t>(kCkRows);
+    // rows this tile covers: k0 - t + [0, kCkRows)
+    valid = valid && t >= 0 && t < static_cast<int32_t>(sp.nlanes) && k0 - t + static_cast<int32_t>(kCkRows) > 0 && k0 - t < la;
+    if(!valid) {
+        t = 0;
+        c = 0;
+    }
+    uint32_t boff[W];
+#pragma unroll
+    for(int cc = 0; cc < W; ++cc) {
+        const uint32_t bj = sp.col0 + static_cast<uint32_t>(t) * W + cc;
+        boff[cc] = (valid && bj < pd.lb) ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+    }
+    LaneState<W> st;
+    if(valid && t < k0) {
+        const float4* rk = sp.rowck + (static_cast<uint64_t>(c) * ck_rowck_quads(W)) * kWave + t;
+#pragma unroll
+        for(int q = 0; q < W / 4; ++q) {
+            const float4 x = rk[q * kWave], y = rk[(W / 4 + q) * kWave];
+            st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
+            st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
+        }
+    } else {
+        // the lane starts inside this band: margin-row state (align_pair.cc:88-90), as in ck_step
+        const uint32_t bj0 = sp.col0 + static_cast<uint32_t>(t) * W;
+#pragma unroll
+        for(int cc = 0; cc < W; ++cc) {
+            const float im = k.go + k.ge * static_cast<float>(bj0 + cc);
+            const float i1 = im + k.gs;
+            st.X[cc] = i1 + k.ng;
+            st.Y[cc] = i1 + k.go;
+        }
+    }
+#pragma unroll
+    for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
+    st.xlast_old = 0.0f;
+    st.zlast = 0.0f;
+    // scores of the first row this lane will do, then (inside a step) those of the next one
+    auto row_code = [&](int32_t r) { return static_cast<uint32_t>(a[min(max(r, 0), la - 1)]) * (kTabStride * 4u); };
+    uint32_t arow = row_code(k0 - t);
+    float s[W];
+#pragma unroll
+    for(int cc = 0; cc < W; ++cc) s[cc] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[cc]);
+    const float2* cin = sp.colin + t;
+    for(int32_t ks = 0; ks < static_cast<int32_t>(kCkRows); ++ks) {
+        const int32_t kstep = k0 + ks, r = kstep - t;
+        if(valid && r >= 0 && r < la) {
+            const float2 in = cin[static_cast<uint64_t>(kstep) * kWave];
+            const uint32_t arow_next = row_code(r + 1);
+            row_l1<W>(k, st, in.x, in.y, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
+            bits[(0 * kCkRows + ks) * kWave] = st.acc[ACC_A];
+            bits[(1 * kCkRows + ks) * kWave] = st.acc[ACC_B];
+            bits[(2 * kCkRows + ks) * kWave] = st.acc[ACC_C];
+        }
+    }
+}
+
+constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
+
+// COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
+// pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
+__device__ unsigned long long g_ck_stats[4];
+
+// State the walk is in after a move of kind `moved` arrives at body cell (bi, bj): from the
+// round's recomputed bits, or kWalkUnknown.
+__device__ __forceinline__ int ck_state_after(const PairDesc& pd, const TileSet& ts, const uint32_t* __restrict__ wbits,
+                                              uint32_t bi, uint32_t bj, int moved) {
+    const uint32_t full = kWave * pd.v_wmain;
+    uint32_t strip = bj / full;
+    if(strip + 1 >= pd.v_strips) strip = pd.v_strips - 1;
+    if(strip != ts.strip) return kWalkUnknown;
+    const uint32_t colin = bj - ts.col0, t = colin >> ts.lg, cc = colin & (ts.w - 1u);
+    const uint32_t kstep = bi + t;
+    const int slot = tileset_slot(ts, t, static_cast<int32_t>(kstep >> kCkRowsLog2));
+    if(slot < 0) return kWalkUnknown;
+    const uint32_t ks = kstep & (kCkRows - 1u);
+    const uint32_t which = moved == COATI_HIP_OP_INS ? 2u : (moved == COATI_HIP_OP_DEL ? 1u : 0u);
+    const uint32_t word = wbits[(which * kCkRows + ks) * kWave + static_cast<uint32_t>(slot)];
+    if(which == 2u) return ((word >> (ts.w - 1u - cc)) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+    const uint32_t two = (word >> (2u * (ts.w - 1u - cc))) & 3u;
+    if(!(two & 2u)) return COATI_HIP_OP_MATCH;  // the M argument is the maximum (ties: M first)
+    return (two & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL;
+}
+// the same for MATRIX cell (i, j), gap_len 1: margins by formula, (0,0) ends the walk
+__device__ __forceinline__ int ck_arrival_state(const GapConsts& k, const PairDesc& pd, const TileSet& ts,
+                                                const uint32_t* __restrict__ wbits, uint32_t i, uint32_t j, int moved) {
+    if(i < 1 && j < 1) return kWalkEnd;  // loop condition of align_pair.cc:268
+    if(i >= 1 && j >= 1) return ck_state_after(pd, ts, wbits, i - 1, j - 1, moved);
+    float m, d, in;
+    margin_mdi(k, 1u, i, j, m, d, in);
+    return decide_after(k, moved, m, d, in);
+}
+
+struct CkWalkArgs {
+    GapConsts k;
+    uint32_t lds_tab;
+    const char* tab_bytes;
+    const uint8_t *a, *b;
+    const uint32_t* ck;
+    uint32_t* wbits;  // this wavefront's scratch
+    bool stats;
+};
+
+// traceback<tropical> (align_pair.cc:249-303) of one pair by one WAVEFRONT, in rounds (above).
+// Within a round the walk is the wave-cooperative one of common.hpp: lane l looks up the state
+// after l+1 further moves of the current kind, a ballot finds where the run ends.  Ops are
+// written right-to-left into the pair's slot so they end up in alignment order.
+__device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, const PairDesc& pd, uint32_t pair,
+                                             uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
+                                             uint32_t* __restrict__ ops_len) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    uint32_t i = la, j = lb;  // matrix coordinates of the cell whose decision is pending
+    int moved = COATI_HIP_OP_MATCH;  // max_mdi of the terminal-adjusted last cell == its "after match" decision
+    uint64_t pos = pd.ops_off + la + lb;
+    TileSet ts{COATI_HIP_OP_MATCH, 0xffffffffu, 16u, 4u, 0u, 0u, 0, 0, 0};
+    bool ok = true;
+    while(i >= 1 || j >= 1) {
+        if(i >= 1 && j >= 1) {
+            // ---- a round: the tile set around body cell (i-1, j-1), recomputed one tile per lane
+            const CkStrip sp = ck_strip_of(pd, wa.ck, j - 1);
+            ts.mode = moved;
+            ts.strip = sp.strip, ts.w = sp.w, ts.lg = sp.lg, ts.col0 = sp.col0;
+            ts.bi = static_cast<int32_t>(i - 1), ts.bj = static_cast<int32_t>(j - 1);
+            ts.t0 = (j - 1 - sp.col0) >> sp.lg;
+            ts.c0 = static_cast<int32_t>((i - 1 + ts.t0) >> kCkRowsLog2);
+            int32_t t = 0, c = 0;
+            const bool valid = tileset_tile(ts, static_cast<uint32_t>(lane), t, c);
+            if(wa.stats) {
+                const unsigned long long nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
+                if(lane == 0) {
+                    atomicAdd(&g_ck_stats[0], 1ull);
+                    atomicAdd(&g_ck_stats[1], nv);
+                }
+            }
+            // the previous round's lookups are done (their results were consumed by ballots);
+            // this round's bits are written and then read by the same wavefront through L2
+            if(sp.w == 16)
+                ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane);
+            else if(sp.w == 8)
+                ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane);
+            else
+                ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane);
+            // the wavefront reads back what it stored itself: once the stores are acknowledged its
+            // loads see them (same L1, write-through)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        int st = __builtin_amdgcn_readfirstlane(ck_arrival_state(wa.k, pd, ts, wa.wbits, i, j, moved));
+        if(st == kWalkUnknown) {  // cannot happen: every round's set holds the tile of its pending cell.  Never spin.
+            ok = false;
+            break;
+        }
+        while(st != kWalkEnd && st != kWalkUnknown) {
+            const uint32_t di = st == COATI_HIP_OP_INS ? 0u : 1u;
+            const uint32_t dj = st == COATI_HIP_OP_DEL ? 0u : 1u;
+            if(di > i || dj > j) {  // cannot happen for decision bits of a finite path; never walk off the matrix
+                st = kWalkEnd;
+                i = j = 0;
+                break;
+            }
+            // lane l: where the walk is after l+1 more moves of kind st, and in which state
+            const uint32_t step = static_cast<uint32_t>(lane) + 1u;
+            const bool valid = di * step <= i && dj * step <= j;
+            int next = kWalkEnd;
+            if(valid) next = ck_arrival_state(wa.k, pd, ts, wa.wbits, i - di * step, j - dj * step, st);
+            if(wa.stats && lane == 0) atomicAdd(&g_ck_stats[2], 1ull);
+            const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
+            const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
+            const uint32_t moves = run == kWave ? kWave : run + 1u;
+            for(uint32_t q = lane; q < moves; q += kWave) ops[pos - 1 - q] = static_cast<uint8_t>(st);
+            pos -= moves;
+            i -= di * moves;
+            j -= dj * moves;
+            if(run < kWave) {
+                const int nst = __builtin_amdgcn_readlane(next, static_cast<int>(run));
+                if(nst == kWalkUnknown) moved = st;  // arrived at (i, j) by a move of kind st: next round
+                st = nst;
+            }
+        }
+        if(st == kWalkEnd) break;
+    }
+    if(lane == 0) {
+        ops_start[pair] = pos;
+        ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
+    }
+    return ok;
+}
+
+// Viterbi fill + traceback for gap_len == 1.  PERSISTENT: the grid is sized to fill every CU with
+// the same number of workgroups (host: ck_launch_shape) and each wavefront pulls work items from
+// an atomic queue until it is empty; `items` lists the pairs longest first.
+// kSharedTab: the model has ONE substitution table -- one copy per workgroup in LDS (12.4 KB), which
+// lets four workgroups (16 wavefronts, 4 per SIMD) share a CU.  Otherwise (per-leaf tables of
+// `coati msa`) every wavefront keeps the table of its current pair.
+template <bool kSharedTab>
+__global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
+    const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+    const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
+    uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
+    uint32_t* __restrict__ ck, float* __restrict__ bnd, float* __restrict__ scores, uint8_t* __restrict__ ops,
+    uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t* __restrict__ wscratch, uint32_t dbg) {
+    __shared__ float tab_all[kSharedTab ? 1 : kFillWaves][kTabRows * kTabStride];
+    const int lane_id = threadIdx.x & (kWave - 1);
+    float* tab = tab_all[kSharedTab ? 0 : threadIdx.x / kWave];
+    uint32_t tab_held = 0xffffffffu;
+    if constexpr(kSharedTab) {
+        for(int idx = threadIdx.x; idx < kTabFloats; idx += kFillWaves * kWave) {
+            const int r = idx / kTabCols, c = idx - r * kTabCols;
+            tab[r * kTabStride + c] = table[idx];
+        }
+        __syncthreads();
+        tab_held = 0u;
+    }
+    const char* tab_bytes = reinterpret_cast<const char*>(tab);
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
+    uint32_t* wbits = wscratch + static_cast<uint64_t>(blockIdx.x * kFillWaves + threadIdx.x / kWave) * kCkScratchDwords;
+    for(;;) {
+        // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
+        // loop-invariant condition and may peel/unswitch this loop per lane, after which the
+        // wave-level operations inside (readfirstlane, DPP, ballots) no longer see the whole wave.
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);  // every lane takes part; lane 0 draws
+        ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        if(ticket >= n_items) break;
+        const WorkItem item = items[ticket];
+        const uint32_t pair = item.pair, strip = item.strip;
+        const PairDesc pd = pairs[pair];
+        bool handoff_ok = true;
+        if constexpr(!kSharedTab) {
+            if(pd.table != tab_held) {  // (wave-uniform)
+                const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+                for(int idx = lane; idx < kTabFloats; idx += kWave) {
+                    const int r = idx / kTabCols, c = idx - r * kTabCols;
+                    tab[r * kTabStride + c] = src[idx];
+                }
+                tab_held = pd.table;
+            }
+        }
+        const uint8_t* __restrict__ a = a_cat + pd.a_off;
+        const uint8_t* __restrict__ b = b_cat + pd.b_off;
+        if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
+            const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
+            if(w == 16)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
+            else if(w == 8)
+                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
+            else
+                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
+        }
+        if(strip + 1 < pd.v_strips || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
+        // ---- traceback of this pair by the wavefront of its last strip.  What the wave wrote
+        // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
+        // strips): they released before publishing "complete", which this wave polled; acquire.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if(pd.la == 0 || pd.lb == 0) {
+            float m, d, in, score;
+            margin_mdi(k, 1u, pd.la, pd.lb, m, d, in);
+            (void)terminal_state(k, m, d, in, score);
+            if(lane == 0) scores[pair] = score;
+        }
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ck, wbits, (dbg & 2u) != 0u};
+        if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[3], 1ull);
+        const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len);
+        // NaN = "this pair failed": a producer strip never arrived (spin bound), or the walk lost its way
+        if((!handoff_ok || !walk_ok) && lane == 0) scores[pair] = __builtin_nanf("");
+    }  // next ticket
+}
+
+// Debug: the decision byte of every body cell of one pair (coati_hip_debug_viterbi_flags), by
+// recomputing EVERY tile from the checkpoints with the traceback's own routine.  One wavefront per
+// workgroup, 64 tiles per wavefront and pass.
+__global__ __launch_bounds__(kWave) void ck_all_flags(const float* __restrict__ table, GapConsts k,
+                                                      const PairDesc* __restrict__ pairs, uint32_t pair,
+                                                      const uint8_t* __restrict__ a_cat,
+                                                      const uint8_t* __restrict__ b_cat,
+                                                      const uint32_t* __restrict__ ck, uint32_t* __restrict__ scratch,
+                                                      uint8_t* __restrict__ out) {
+    __shared__ float tab[kTabRows * kTabStride];
+    const PairDesc pd = pairs[pair];
+    const int lane = threadIdx.x;
+    const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+    for(int idx = lane; idx < kTabFloats; idx += kWave) {
+        const int r = idx / kTabCols, c = idx - r * kTabCols;
+        tab[r * kTabStride + c] = src[idx];
+    }
+    __syncthreads();
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));
+    const uint8_t* a = a_cat + pd.a_off;
+    const uint8_t* b = b_cat + pd.b_off;
+    uint32_t* wbits = scratch + static_cast<uint64_t>(blockIdx.x) * kCkScratchDwords;
+    const uint32_t bands = ck_bands(pd.la);
+    for(uint32_t strip = 0; strip < pd.v_strips; ++strip) {
+        const uint32_t col0 = strip * kWave * pd.v_wmain;
+        const CkStrip sp = ck_strip_of(pd, ck, col0);
+        const uint32_t n_tiles = bands * kWave;
+        for(uint32_t base = blockIdx.x * kWave; base < n_tiles; base += gridDim.x * kWave) {
+            const uint32_t tile = base + lane;
+            const int32_t c = static_cast<int32_t>(tile / kWave), t = static_cast<int32_t>(tile % kWave);
+            const bool valid = tile < n_tiles;
+            if(sp.w == 16)
+                ck_recompute<16>(k, pd, sp, valid, t, c, lds_tab, reinterpret_cast<const char*>(tab), a, b, wbits + lane);
+            else if(sp.w == 8)
+                ck_recompute<8>(k, pd, sp, valid, t, c, lds_tab, reinterpret_cast<const char*>(tab), a, b, wbits + lane);
+            else
+                ck_recompute<4>(k, pd, sp, valid, t, c, lds_tab, reinterpret_cast<const char*>(tab), a, b, wbits + lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if(valid && t < static_cast<int32_t>(sp.nlanes)) {
+                for(uint32_t ks = 0; ks < kCkRows; ++ks) {
+                    const int32_t r = c * static_cast<int32_t>(kCkRows) + static_cast<int32_t>(ks) - t;
+                    if(r < 0 || r >= static_cast<int32_t>(pd.la)) continue;
+                    const uint32_t wa = wbits[(0 * kCkRows + ks) * kWave + lane], wb = wbits[(1 * kCkRows + ks) * kWave + lane],
+                                   wc = wbits[(2 * kCkRows + ks) * kWave + lane];
+                    for(uint32_t cc = 0; cc < sp.w; ++cc) {
+                        const uint32_t bj = sp.col0 + static_cast<uint32_t>(t) * sp.w + cc;
+                        if(bj >= pd.lb) break;
+                        const uint32_t mm = (wa >> (2u * (sp.w - 1u - cc))) & 3u, dd = (wb >> (2u * (sp.w - 1u - cc))) & 3u,
+                                       im = (wc >> (sp.w - 1u - cc)) & 1u;
+                        const uint32_t fm = !(mm & 2u) ? 0u : ((mm & 1u) ? 2u : 1u), fd = !(dd & 2u) ? 0u : ((dd & 1u) ? 2u : 1u);
+                        out[static_cast<uint64_t>(r) * pd.lb + bj] = static_cast<uint8_t>(fm | (fd << 2) | ((im ^ 1u) << 4));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the next pass overwrites the scratch
+        }
+    }
+}
+
+// Launch shape of the persistent kernel: `blocks_per_cu` workgroups on each of the 256 CUs (one
+// wave per SIMD each), enforced by padding the launch with unused dynamic LDS so that exactly that
+// many fit.  All waves start together and draw tickets at once, so a grid with more waves than
+// items would scatter the items unevenly over the SIMDs: use no more waves than items.
+struct CkShape {
+    uint32_t grid;
+    size_t dynamic_lds;
+};
+CkShape ck_launch_shape(uint32_t n_items, bool shared_tab) {
+    constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
+    const int max_blocks = shared_tab ? 4 : 3;  // <= 128 VGPRs -> 4 waves per SIMD; per-wave tables: 3 x 49.8 KB of LDS
+    static const int forced = [] {
+        const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
+        return e != nullptr ? std::atoi(e) : 0;
+    }();
+    int best = static_cast<int>(std::min<uint64_t>(max_blocks, (static_cast<uint64_t>(n_items) + kSimds - 1) / kSimds));
+    best = std::max(best, 1);
+    if(forced >= 1 && forced <= max_blocks) best = forced;
+    // LDS footprint per block that admits exactly `best` blocks on a CU's 160 KB: more than
+    // 160/(best+1) KB, and `best` of them fit with room for the allocation granule
+    const size_t stat = (shared_tab ? 1 : kFillWaves) * kTabRows * kTabStride * sizeof(float);
+    constexpr size_t kPerBlock[5] = {0, 96 * 1024, 72 * 1024, 52 * 1024, 38 * 1024};
+    const size_t stat_r = (stat + 255) / 256 * 256;
+    const size_t dyn = kPerBlock[best] > stat_r ? kPerBlock[best] - stat_r : 0;
+    return {kCUs * static_cast<uint32_t>(best), dyn};
+}
+
+}  // namespace
+
+uint32_t ck_scratch_waves() { return 256u * 4u * kFillWaves; }
+uint64_t ck_scratch_dwords_per_wave() { return kCkScratchDwords; }
+
+hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
+    if(e != hipSuccess) return e;
+    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);  // polled words: zero every launch
+    if(e != hipSuccess) return e;
+    const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
+    // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
+    static const uint32_t dbg = [] {
+        const char* e = std::getenv("COATI_HIP_CK_DEBUG");
+        return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+    }();
+    const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck<true>) : reinterpret_cast<const void*>(viterbi_ck<false>);
+    if(shape.dynamic_lds > 0) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));
+        if(e != hipSuccess) return e;
+    }
+    if(shared_tab)
+        hipLaunchKernelGGL(viterbi_ck<true>, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, stream, v.table,
+                           v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, dbg);
+    else
+        hipLaunchKernelGGL(viterbi_ck<false>, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, stream, v.table,
+                           v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, dbg);
+    if(dbg & 2u) {
+        unsigned long long st[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+        e = hipStreamSynchronize(stream);
+        if(e == hipSuccess) e = hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ck_stats), sizeof st);
+        if(e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ck_stats), zero, sizeof zero);
+        if(e != hipSuccess) return e;
+        std::fprintf(stderr, "viterbi_ck: %llu pairs, %.2f rounds/pair, %.1f valid tiles/round, %.1f walker iterations/pair\n", st[3],
+                     st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ck_all_flags(const BatchDeviceView& v, uint32_t pair, uint32_t* scratch, uint32_t n_waves, uint8_t* out,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(ck_all_flags, dim3(n_waves), dim3(kWave), 0, stream, v.table, v.k, v.pairs, pair, v.a_cat, v.b_cat,
+                       v.flags, scratch, out);
+    return hipGetLastError();
+}
+
+}  // namespace coati_hip_detail

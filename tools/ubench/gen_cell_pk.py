@@ -187,6 +187,102 @@ def cell_cmp(c, parity):
     return L
 
 
+def _lean_regs(c, parity):
+    xin = f"v{YP+2*c+1}" if parity == 0 else f"v{XB+c}"
+    xout = f"v{XB+c}" if parity == 0 else f"v{YP+2*c+1}"
+    return xin, xout, f"v{YP+2*c}"
+
+
+def cell_lean(c, parity):
+    """15 VALU: the fill without decision bits (checkpoint design), slow ops clustered at the end.
+    The diagonal input is read from the ping-pong register directly (no v_mov)."""
+    xin, xout, y = _lean_regs(c, parity)
+    diag = f"v{DIAG}" if c == 0 else _lean_regs(c - 1, parity)[0]
+    t0, t1, t2, t3, t4, t5, t6, zl = "v10", "v11", "v12", "v13", "v14", "v15", "v17", f"v{ZL}"
+    t7, t8, t9 = "v18", "v19", "v20"
+    return [f"v_add_f32 {t0}, {diag}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}", f"v_add_f32 {t2}, {GS}, {zl}",
+            f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+            f"v_add_f32 {t8}, {GE}, {y}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t6}, {NG}, {t2}",
+            f"v_add_f32 {t7}, {GO}, {t0}", f"v_add_f32 {t9}, {GO}, {t2}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}",
+            f"v_max_f32 {zl}, {t3}, {t1}", f"v_max3_f32 {xout}, {t4}, {t5}, {t6}", f"v_max3_f32 {y}, {t7}, {t8}, {t9}"]
+
+
+def cell_lean31(c, parity):
+    """The same 15 instructions with one slow op after every 3+ fast ones."""
+    xin, xout, y = _lean_regs(c, parity)
+    diag = f"v{DIAG}" if c == 0 else _lean_regs(c - 1, parity)[0]
+    t0, t1, t2, t3, t4, t5, t6, zl = "v10", "v11", "v12", "v13", "v14", "v15", "v17", f"v{ZL}"
+    t7, t8, t9 = "v18", "v19", "v20"
+    return [f"v_add_f32 {t0}, {diag}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}", f"v_add_f32 {t2}, {GS}, {zl}",
+            f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+            f"v_max_f32 {zl}, {t3}, {t1}",
+            f"v_add_f32 {t8}, {GE}, {y}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t6}, {NG}, {t2}",
+            f"v_add_f32 {t7}, {GO}, {t0}",
+            f"v_max3_f32 {xout}, {t4}, {t5}, {t6}",
+            f"v_add_f32 {t9}, {GO}, {t2}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}",
+            f"v_max3_f32 {y}, {t7}, {t8}, {t9}"]
+
+
+def cell_lean2(c, parity):
+    """Two columns interleaved is not possible (zl chains); instead: slow ops of the PREVIOUS cell are
+    delayed into this cell's adds (software pipelining by one cell), 3:1."""
+    xin, xout, y = _lean_regs(c, parity)
+    diag = f"v{DIAG}" if c == 0 else _lean_regs(c - 1, parity)[0]
+    # two temp sets alternate by column so that the delayed max3 of cell c-1 can still read its inputs
+    sets = ([10, 11, 12, 13, 14, 15, 17, 18, 19, 20], [22, 23, 24, 25, 26, 27, 35, 36, 37, 38])
+    t0, t1, t2, t3, t4, t5, t6, t7, t8, t9 = (f"v{r}" for r in sets[c & 1])
+    p4, p5, p6, p7, p8, p9 = (f"v{r}" for r in sets[(c + 1) & 1][4:])
+    zl = f"v{ZL}"
+    pxout, py = (_lean_regs(c - 1, parity)[1], _lean_regs(c - 1, parity)[2]) if c > 0 else (_lean_regs(15, 1 - parity)[1], _lean_regs(15, 1 - parity)[2])
+    return [f"v_add_f32 {t0}, {diag}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}", f"v_add_f32 {t2}, {GS}, {zl}",
+            f"v_max3_f32 {pxout}, {p4}, {p5}, {p6}",
+            f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+            f"v_max3_f32 {py}, {p7}, {p8}, {p9}",
+            f"v_add_f32 {t8}, {GE}, {y}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t6}, {NG}, {t2}",
+            f"v_max_f32 {zl}, {t3}, {t1}",
+            f"v_add_f32 {t7}, {GO}, {t0}", f"v_add_f32 {t9}, {GO}, {t2}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}"]
+
+
+def _step_overhead():
+    """What a wavefront step adds to its 16 cells in the checkpoint design: the hand-off of X/Z/row code
+    (readlane + mov + DPP shift each), one 8-byte store per lane of the received (diag, zl), half a
+    16-byte row-checkpoint store (8 of them per 16 steps), the scalar bookkeeping."""
+    L = []
+    for src, dst in ((9, 29), (8, 8), (39, 39)):
+        L += [f"v_readlane_b32 s20, v{src}, 5", "v_mov_b32 v21, s20", f"v_mov_b32_dpp v21, v{src} wave_shr:1 row_mask:0xf bank_mask:0xf",
+              f"v_mov_b32 v{dst}, v21"]
+    L += ["global_store_dwordx2 v3, v[8:9], s[16:17]", "s_add_u32 s16, s16, 1024", "s_addc_u32 s17, s17, 0"]
+    return L
+
+
+def cell_lean_st(c, parity):
+    L = cell_lean(c, parity)
+    if c == 15:
+        L += _step_overhead()
+        L.append(f"global_store_dwordx4 v4, v[{40 + 8 * parity}:{43 + 8 * parity}], s[16:17] offset:512")
+    return L
+
+
+def cell_lean31_st(c, parity):
+    L = cell_lean31(c, parity)
+    if c == 15:
+        L += _step_overhead()
+        L.append(f"global_store_dwordx4 v4, v[{40 + 8 * parity}:{43 + 8 * parity}], s[16:17] offset:512")
+    return L
+
+
+def cell_clustered_st(c, parity):
+    """The current 25-instruction cell with the current per-step overhead (2.5 row stores)."""
+    L = cell_clustered(c, parity)
+    if c == 15:
+        L += _step_overhead()[:-3]
+        L += ["global_store_dword v2, v32, s[16:17]", "global_store_dword v2, v33, s[16:17] offset:256"]
+        if parity:
+            L.append("global_store_dword v2, v34, s[16:17] offset:512")
+        L += ["s_add_u32 s16, s16, 768", "s_addc_u32 s17, s17, 0"]
+    return L
+
+
 def kernel(name, cell):
     body = []
     for parity in (0, 1):
@@ -206,6 +302,7 @@ __global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, 
         "s_mov_b32 s16, %[splo]\\n\\t s_mov_b32 s17, %[sphi]\\n\\t"
         "s_mov_b32 s4, %[ng]\\n\\t s_mov_b32 s5, %[gs]\\n\\t s_mov_b32 s6, %[go]\\n\\t s_mov_b32 s7, %[ge]\\n\\t"
         "v_mov_b32 v2, s5\\n\\t v_mov_b32 v3, s7\\n\\t v_mov_b32 v4, s6\\n\\t v_mov_b32 v5, s4\\n\\t v_mov_b32 v6, s4\\n\\t v_mov_b32 v7, s6\\n\\t"
+        "v_mbcnt_lo_u32_b32 v2, -1, 0\\n\\t v_mbcnt_hi_u32_b32 v2, -1, v2\\n\\t v_lshlrev_b32 v3, 3, v2\\n\\t v_lshlrev_b32 v4, 4, v2\\n\\t v_lshlrev_b32 v2, 2, v2\\n\\t"
         "v_mov_b32 v8, %[seed]\\n\\t v_mov_b32 v9, 0\\n\\t v_mov_b32 v11, 0\\n\\t v_mov_b32 v16, 0\\n\\t v_mov_b32 v29, %[seed]\\n\\t v_mov_b32 v31, 0\\n\\t"
         "v_mov_b32 v32, 0\\n\\t v_mov_b32 v33, 0\\n\\t v_mov_b32 v34, 0\\n\\t"
         {init}
@@ -224,24 +321,28 @@ __global__ __launch_bounds__(256) void {name}(float* out, float seed, float ng, 
 '''
 
 
-nb, kb = kernel("cell_base", cell_base)
-npk, kp = kernel("cell_pk", cell_pk)
-ncm, kc = kernel("cell_cmp", cell_cmp)
-nm3, km3 = kernel("cell_max3", cell_max3)
-ncl, kcl = kernel("cell_clustered", cell_clustered)
-ncl2, kcl2 = kernel("cell_clustered2", cell_clustered2)
-ncl4, kcl4 = kernel("cell_clustered4", cell_clustered4)
-src = f'''// GENERATED by gen_cell_pk.py -- do not edit.
+import sys
+
+ALL = {"base": cell_base, "pk": cell_pk, "cmp+sst": cell_cmp, "max3": cell_max3, "clustered": cell_clustered,
+       "clustered2": cell_clustered2, "clustered4": cell_clustered4, "clustered_st": cell_clustered_st,
+       "lean": cell_lean, "lean31": cell_lean31, "lean2": cell_lean2, "lean_st": cell_lean_st,
+       "lean31_st": cell_lean31_st}
+# default: the round-2 question (how fast can the fill go without decision bits); `all` adds the round-1 codings
+# (pk needs v2..v7 as constants: run it alone, `gen_cell_pk.py pk`, the store variants overwrite them)
+names = sys.argv[1:] or ["clustered", "clustered_st", "lean", "lean31", "lean2", "lean_st", "lean31_st"]
+if names == ["all"]:
+    names = [n for n in ALL if n != "pk"]
+kernels, runs = [], []
+for n in names:
+    fn = "cell_" + n.replace("+", "_")
+    cnt, src_k = kernel(fn, ALL[n])
+    kernels.append(src_k)
+    runs.append(f'    if (run("{n}", {fn}, {cnt})) return 1;')
+src = f'''// GENERATED by gen_cell_pk.py -- do not edit, do not commit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CHECK(x) do {{ hipError_t e = (x); if (e != hipSuccess) {{ printf("%s: %s\\n", #x, hipGetErrorString(e)); return 1; }} }} while (0)
-{kb}
-{kp}
-{kc}
-{km3}
-{kcl}
-{kcl2}
-{kcl4}
+{"".join(kernels)}
 template <typename K> int run(const char* name, K kern, int n_instr) {{
     float* d_out; CHECK(hipMalloc(&d_out, sizeof(float) * 256 * 256 * 8));
     char* d_scratch; CHECK(hipMalloc(&d_scratch, 256ull * 4 * 4 * 1280 * 400));
@@ -256,22 +357,16 @@ template <typename K> int run(const char* name, K kern, int n_instr) {{
             float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
         }}
         const double cells = 32.0 * iters * wps;  // per SIMD
-        printf("%-10s %2d instr/cell  waves/SIMD %d: %.3f ms -> %.2f ns per cell per SIMD, %.2f ns/instr\\n", name, n_instr, wps, best,
-               best * 1e6 / cells, best * 1e6 / cells / n_instr);
+        printf("%-12s %2d VALU/cell  waves/SIMD %d: %.3f ms -> %.2f ns per 64-lane cell per SIMD = %.0f GCUPS on 1024 SIMDs\\n", name, n_instr, wps, best,
+               best * 1e6 / cells, 65536.0 / (best * 1e6 / cells));
     }}
     CHECK(hipFree(d_out)); CHECK(hipFree(d_scratch));
     return 0;
 }}
 int main() {{
-    if (run("base", cell_base, {nb})) return 1;
-    if (run("pk", cell_pk, {npk})) return 1;
-    if (run("cmp+sst", cell_cmp, {ncm})) return 1;
-    if (run("max3", cell_max3, {nm3})) return 1;
-    if (run("clustered", cell_clustered, {ncl})) return 1;
-    if (run("clustered2", cell_clustered2, {ncl2})) return 1;
-    if (run("clustered4", cell_clustered4, {ncl4})) return 1;
+{chr(10).join(runs)}
     return 0;
 }}
 '''
 Path(__file__).with_name("cell_pk.hip").write_text(src)
-print("base", nb, "pk", npk)
+print("generated", names)
