@@ -27,11 +27,24 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
 
 namespace coati_hip_detail {
+#ifdef COATI_FILL_TRACE
+// Debug build only (make trace): per-wave wall-clock stamps (s_memrealtime, 100 MHz) of the
+// persistent loop, read back by tools/trace_fill.py through coati_hip_debug_trace.
+__device__ unsigned long long g_ck_trace[4096 * 16];
+#define COATI_CK_STAMP(slot)                                                                     \
+    do {                                                                                         \
+        if(lane_id == 0 && trace_n + (slot) < 15)                                                \
+            g_ck_trace[trace_wave * 16 + trace_n + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+    } while(0)
+#else
+#define COATI_CK_STAMP(slot) do { } while(0)
+#endif
 namespace {
 
 // Register state of one lane of the lean fill: its W columns of the row it processed last.
@@ -469,6 +482,10 @@ constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
 // pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
 __device__ unsigned long long g_ck_stats[4];
 
+// COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
+// pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
+__device__ unsigned long long g_ck_stats[4];
+
 // State the walk is in after a move of kind `moved` arrives at body cell (bi, bj): from the
 // round's recomputed bits, or kWalkUnknown.
 __device__ __forceinline__ int ck_state_after(const PairDesc& pd, const TileSet& ts, const uint32_t* __restrict__ wbits,
@@ -571,6 +588,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             int next = kWalkEnd;
             if(valid) next = ck_arrival_state(wa.k, pd, ts, wa.wbits, i - di * step, j - dj * step, st);
             if(wa.stats && lane == 0) atomicAdd(&g_ck_stats[2], 1ull);
+            if(wa.stats && lane == 0) atomicAdd(&g_ck_stats[2], 1ull);
             const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
             const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
             const uint32_t moves = run == kWave ? kWave : run + 1u;
@@ -621,6 +639,17 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
     uint32_t* wbits = wscratch + static_cast<uint64_t>(blockIdx.x * kFillWaves + threadIdx.x / kWave) * kCkScratchDwords;
+#ifdef COATI_FILL_TRACE
+    const uint32_t trace_wave = (blockIdx.x * kFillWaves + threadIdx.x / kWave) & 4095u;
+    uint32_t trace_n = 1;
+    if(lane_id == 0) {
+        g_ck_trace[trace_wave * 16] = __builtin_amdgcn_s_memrealtime();
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        g_ck_trace[trace_wave * 16 + 15] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
+    }
+#endif
     for(;;) {
         // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
         // loop-invariant condition and may peel/unswitch this loop per lane, after which the
@@ -672,6 +701,10 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
         const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len);
         // NaN = "this pair failed": a producer strip never arrived (spin bound), or the walk lost its way
         if((!handoff_ok || !walk_ok) && lane == 0) scores[pair] = __builtin_nanf("");
+        COATI_CK_STAMP(1);  // traceback done
+#ifdef COATI_FILL_TRACE
+        trace_n += 2;
+#endif
     }  // next ticket
 }
 
@@ -764,6 +797,17 @@ CkShape ck_launch_shape(uint32_t n_items, bool shared_tab) {
 
 }  // namespace
 
+#ifdef COATI_FILL_TRACE
+extern "C" int coati_hip_debug_trace(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ck_trace), sizeof(g_ck_trace));
+    if(e != hipSuccess) return static_cast<int>(e);
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_ck_trace));
+    if(e != hipSuccess) return static_cast<int>(e);
+    return static_cast<int>(hipMemset(p, 0, sizeof(g_ck_trace)));  // next launch starts clean
+}
+#endif
+
 uint32_t ck_scratch_waves() { return 256u * 4u * kFillWaves; }
 uint64_t ck_scratch_dwords_per_wave() { return kCkScratchDwords; }
 
@@ -773,6 +817,12 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);  // polled words: zero every launch
     if(e != hipSuccess) return e;
     const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
+    // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback; bit 1 = traceback
+    // statistics on stderr
+    static const uint32_t dbg = [] {
+        const char* e = std::getenv("COATI_HIP_CK_DEBUG");
+        return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+    }();
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
     static const uint32_t dbg = [] {
         const char* e = std::getenv("COATI_HIP_CK_DEBUG");

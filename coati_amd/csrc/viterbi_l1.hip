@@ -367,7 +367,7 @@ FillShape fill_launch_shape(uint32_t n_items) {
 }  // namespace
 
 #ifdef COATI_FILL_TRACE
-extern "C" int coati_hip_debug_trace(unsigned long long* out) {
+extern "C" int coati_hip_debug_trace_l1(unsigned long long* out) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_trace), sizeof(g_fill_trace));
     if(e != hipSuccess) return static_cast<int>(e);
     void* p = nullptr;
