@@ -27,7 +27,6 @@
 
 #include <algorithm>
 #include <cstdio>
-#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -478,9 +477,6 @@ __device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc&
 
 constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
 
-// COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
-// pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
-__device__ unsigned long long g_ck_stats[4];
 
 // COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
 // pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
@@ -588,7 +584,6 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             int next = kWalkEnd;
             if(valid) next = ck_arrival_state(wa.k, pd, ts, wa.wbits, i - di * step, j - dj * step, st);
             if(wa.stats && lane == 0) atomicAdd(&g_ck_stats[2], 1ull);
-            if(wa.stats && lane == 0) atomicAdd(&g_ck_stats[2], 1ull);
             const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
             const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
             const uint32_t moves = run == kWave ? kWave : run + 1u;
@@ -684,6 +679,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
         }
+        COATI_CK_STAMP(0);  // fill of this item done
         if(strip + 1 < pd.v_strips || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
         // ---- traceback of this pair by the wavefront of its last strip.  What the wave wrote
         // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
@@ -817,12 +813,6 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);  // polled words: zero every launch
     if(e != hipSuccess) return e;
     const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
-    // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback; bit 1 = traceback
-    // statistics on stderr
-    static const uint32_t dbg = [] {
-        const char* e = std::getenv("COATI_HIP_CK_DEBUG");
-        return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
-    }();
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
     static const uint32_t dbg = [] {
         const char* e = std::getenv("COATI_HIP_CK_DEBUG");
