@@ -9,7 +9,7 @@ BUILD     = coati_amd/_build
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -Wall -Wextra -Wno-unused-parameter -Iinclude
 
-all: lib host oracle
+all: lib dist host oracle
 
 lib: $(BUILD)/libcoati_hip.so
 
@@ -18,6 +18,11 @@ HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/viterbi_ck.hip coati_amd/csrc/vi
 $(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+# multi-GPU layer: RCCL linked directly (include/coati_hip_dist.h)
+dist: $(BUILD)/libcoati_hip_dist.so
+$(BUILD)/libcoati_hip_dist.so: coati_amd/csrc/dist.hip include/coati_hip_dist.h include/coati_hip.h $(BUILD)/libcoati_hip.so
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ coati_amd/csrc/dist.hip -L$(BUILD) -lcoati_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 # debug variant with per-wave clock stamps in the fill kernel (tools/trace_fill.py)
 trace: $(BUILD)/libcoati_hip_trace.so
@@ -63,4 +68,4 @@ clean:
 	rm -rf $(BUILD)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host oracle ref clean asan trace
+.PHONY: all lib dist host oracle ref clean asan trace

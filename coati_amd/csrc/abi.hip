@@ -138,6 +138,18 @@ struct coati_hip_model {
     // depending on where the process ran; grown on demand, freed with the model
     void* pinned = nullptr;
     uint64_t pinned_bytes = 0;
+    // coati_hip_viterbi_batch pipelines its chunks through these slots: each has its own stream, its
+    // own page-locked staging block and its own HBM workspace, all kept between calls
+    struct Slot {
+        hipStream_t stream = nullptr;
+        void* pinned = nullptr;
+        uint64_t pinned_bytes = 0;
+        void* arena = nullptr;
+        uint64_t arena_bytes = 0;
+    };
+    static constexpr int kSlots = 3;
+    Slot slots[kSlots];
+    std::mutex pipeline_lock;  // one pipelined call at a time per model
 };
 
 struct coati_hip_batch {
@@ -153,6 +165,8 @@ struct coati_hip_batch {
     // device: one workspace allocation, everything below except d_mdi / d_final_mdi points into it
     void* arena = nullptr;
     uint64_t arena_bytes = 0;
+    bool arena_owned = true;        // false: the workspace belongs to a pipeline slot of the model
+    hipStream_t stream = nullptr;   // where this batch's Viterbi work runs (the model's stream, or a slot's)
     PairDesc* d_desc = nullptr;
     uint32_t* d_order = nullptr;   // pair indices, most cells first
     uint32_t* d_queue = nullptr;   // ticket counter of the persistent fill kernel
@@ -357,6 +371,11 @@ void model_release(coati_hip_model* m) {
     if(m->refs.fetch_sub(1) != 1) return;  // batches (or the handle) still hold it
     (void)hipSetDevice(m->device);
     for(const auto& a : m->free_arenas) (void)hipFree(a.ptr);
+    for(auto& sl : m->slots) {
+        if(sl.arena != nullptr) (void)hipFree(sl.arena);
+        if(sl.pinned != nullptr) (void)hipHostFree(sl.pinned);
+        if(sl.stream != nullptr) (void)hipStreamDestroy(sl.stream);
+    }
     if(m->pinned != nullptr) (void)hipHostFree(m->pinned);
     if(m->d_table != nullptr) (void)hipFree(m->d_table);
     if(m->stream != nullptr) (void)hipStreamDestroy(m->stream);
@@ -373,10 +392,11 @@ void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(b == nullptr) return;
     coati_hip_model* m = b->model;
     if(m != nullptr) (void)hipSetDevice(m->device);
-    if(b->arena != nullptr || b->mdi_block != nullptr) {
+    if((b->arena != nullptr && b->arena_owned) || b->mdi_block != nullptr) {
         // the blocks go back to the model once nothing on the stream can still touch them
-        const bool idle = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
-        for(auto blk : {std::pair<void*, uint64_t>{b->arena, b->arena_bytes}, std::pair<void*, uint64_t>{b->mdi_block, b->mdi_block_bytes}}) {
+        bool idle = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
+        if(idle && b->stream != nullptr && b->stream != m->stream) idle = hipStreamSynchronize(b->stream) == hipSuccess;
+        for(auto blk : {std::pair<void*, uint64_t>{b->arena_owned ? b->arena : nullptr, b->arena_bytes}, std::pair<void*, uint64_t>{b->mdi_block, b->mdi_block_bytes}}) {
             if(blk.first == nullptr) continue;
             if(idle)
                 model_give_arena(m, blk.first, blk.second);
@@ -400,6 +420,15 @@ int coati_hip_model_trim(coati_hip_model_t* m) {
         drop.swap(m->free_arenas);
     }
     for(const auto& a : drop) (void)hipFree(a.ptr);
+    {
+        std::lock_guard<std::mutex> hold(m->pipeline_lock);
+        for(auto& sl : m->slots) {
+            if(sl.stream != nullptr) (void)hipStreamSynchronize(sl.stream);
+            if(sl.arena != nullptr) (void)hipFree(sl.arena);
+            sl.arena = nullptr;
+            sl.arena_bytes = 0;
+        }
+    }
     return COATI_HIP_OK;
 }
 
@@ -410,15 +439,28 @@ int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uin
 }
 
 namespace {
+// How batch_create_impl places a batch: by default on the model's stream with its own workspace and
+// blocking uploads; a pipeline slot passes its stream, its workspace and its page-locked staging block,
+// and every upload becomes an asynchronous copy on that stream.
+struct BatchOpts {
+    hipStream_t stream = nullptr;
+    void* arena = nullptr;
+    uint64_t arena_bytes = 0;
+    char* staging = nullptr;  // page-locked; descriptors (and sequences that are not page-locked themselves) pass through it
+    uint64_t staging_bytes = 0;
+    bool seqs_pinned = false;  // a_cat / b_cat are page-locked: copied straight from the caller's memory
+    uint64_t* arena_need_out = nullptr;  // receives the workspace size of the plan (also when `arena` is too small)
+};
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
-                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, coati_hip_batch_t** out);
+                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
+                      coati_hip_batch_t** out);
 }
 
 int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                                   const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                                   const uint32_t* table_index, coati_hip_batch_t** out) {
     try {  // no C++ exception may cross the C ABI (host-side vectors can throw bad_alloc)
-        return batch_create_impl(model, n_pairs, a_cat, a_off, b_cat, b_off, table_index, out);
+        return batch_create_impl(model, n_pairs, a_cat, a_off, b_cat, b_off, table_index, nullptr, out);
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
     } catch(const std::exception& ex) {
@@ -434,7 +476,8 @@ inline uint8_t max_byte(const uint8_t* p, uint64_t n) {
 }
 
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
-                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, coati_hip_batch_t** out) {
+                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
+                      coati_hip_batch_t** out) {
     if(out == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: out is NULL");
     *out = nullptr;
     if(model == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: model is NULL");
@@ -449,6 +492,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     b->model = model;
     model->refs.fetch_add(1);  // released by coati_hip_batch_destroy
     b->n_pairs = n_pairs;
+    b->stream = opts != nullptr && opts->stream != nullptr ? opts->stream : model->stream;
     struct Owner {  // destroys the half-built batch on every exit but the successful one
         coati_hip_batch* b;
         ~Owner() {
@@ -715,7 +759,15 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                    o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
                    o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)),
                    o_wscratch = carve(b->ck ? ck_scratch_waves() * ck_scratch_dwords_per_wave() * sizeof(uint32_t) : 0);
-    {
+    if(opts != nullptr && opts->arena_need_out != nullptr) *opts->arena_need_out = arena_need;
+    if(opts != nullptr && opts->arena != nullptr) {
+        if(opts->arena_bytes < arena_need)
+            return cleanup(fail(COATI_HIP_ENOMEM, "batch_create: the slot's workspace (%llu bytes) is smaller than the chunk needs (%llu)",
+                                static_cast<unsigned long long>(opts->arena_bytes), static_cast<unsigned long long>(arena_need)));
+        b->arena = opts->arena;
+        b->arena_bytes = opts->arena_bytes;
+        b->arena_owned = false;
+    } else {
         // a workspace a destroyed batch of this model left behind, or a fresh one
         const hipError_t e = model_take_arena(model, arena_need, &b->arena, &b->arena_bytes);
         if(e != hipSuccess)
@@ -741,19 +793,31 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     b->d_progress = reinterpret_cast<uint32_t*>(at(o_progress));
     b->d_wscratch = reinterpret_cast<uint32_t*>(at(o_wscratch));
     stage("workspace");
+    // uploads: blocking copies by default; for a pipeline slot asynchronous copies on its stream, out of
+    // page-locked memory (the slot's staging block, or the caller's arrays when those are page-locked)
+    uint64_t staged = 0;
+    auto upload = [&](void* dst, const void* src, uint64_t bytes, bool src_pinned) -> hipError_t {
+        if(bytes == 0) return hipSuccess;
+        if(opts == nullptr || opts->staging == nullptr) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+        if(!src_pinned) {
+            if(staged + bytes > opts->staging_bytes) return hipErrorOutOfMemory;
+            std::memcpy(opts->staging + staged, src, bytes);
+            src = opts->staging + staged;
+            staged += (bytes + 255) / 256 * 256;
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream);
+    };
     if(n_pairs > 0) {
-        B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+        B_TRY(upload(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), false));
+        B_TRY(upload(b->d_order, order.data(), n_pairs * sizeof(uint32_t), false));
+        B_TRY(upload(b->d_items, items.data(), items.size() * sizeof(WorkItem), false));
+        B_TRY(upload(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), false));
     }
     stage("descriptors + work items upload");
-    if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
-    if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));
+    const bool seqs_pinned = opts != nullptr && opts->seqs_pinned;
+    if(a_total > 0) B_TRY(upload(b->d_a, a_cat + a_off[0], a_total, seqs_pinned));
+    if(b_total > 0) B_TRY(upload(b->d_b, b_cat + b_off[0], b_total, seqs_pinned));
     stage("sequences upload");
-    for(auto& trio : b->ev)
-        for(auto& e : trio) B_TRY(hipEventCreate(&e));
-    stage("events");
 #undef B_TRY
     owner.b = nullptr;
     *out = b;
@@ -761,6 +825,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
 }
 }  // namespace
 
+uint64_t coati_hip_batch_pairs(const coati_hip_batch_t* b) { return b ? b->n_pairs : 0; }
 uint64_t coati_hip_batch_device_bytes(const coati_hip_batch_t* b) { return b ? b->device_bytes : 0; }
 uint64_t coati_hip_batch_cells(const coati_hip_batch_t* b) { return b ? b->cells : 0; }
 
@@ -770,21 +835,23 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
     HIP_TRY(hipSetDevice(m->device));
     const uint32_t n = static_cast<uint32_t>(b->n_pairs);
     hipEvent_t* ev = b->ev[b->n_launches % coati_hip_batch::kTimingRing];
-    HIP_TRY(hipEventRecord(ev[0], m->stream));
+    for(int q = 0; q < 3; ++q)
+        if(ev[q] == nullptr) HIP_TRY(hipEventCreate(&ev[q]));  // (created on first use: 192 events per batch cost 0.3 ms)
+    HIP_TRY(hipEventRecord(ev[0], b->stream));
     if(n > 0) {
         const BatchDeviceView v = device_view(b);
         static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
         if(b->ck)
-            HIP_TRY(launch_viterbi_ck(v, m->n_tables == 1, m->stream));
+            HIP_TRY(launch_viterbi_ck(v, m->n_tables == 1, b->stream));
         else if(m->gap_len == 1 && !force_generic)
-            HIP_TRY(launch_viterbi_l1(v, m->stream));
+            HIP_TRY(launch_viterbi_l1(v, b->stream));
         else if(b->compact)
-            HIP_TRY(launch_viterbi_k(v, b->compact_narrow_only, m->stream));
+            HIP_TRY(launch_viterbi_k(v, b->compact_narrow_only, b->stream));
         else
-            HIP_TRY(launch_dp_generic(v, /*forward=*/false, m->stream));
+            HIP_TRY(launch_dp_generic(v, /*forward=*/false, b->stream));
     }
-    HIP_TRY(hipEventRecord(ev[1], m->stream));
-    HIP_TRY(hipEventRecord(ev[2], m->stream));  // (the traceback is fused into the fill kernel)
+    HIP_TRY(hipEventRecord(ev[1], b->stream));
+    HIP_TRY(hipEventRecord(ev[2], b->stream));  // (the traceback is fused into the fill kernel)
     b->n_launches += 1;
     b->launched = true;
     return COATI_HIP_OK;
@@ -794,6 +861,7 @@ int coati_hip_batch_sync(coati_hip_batch_t* b) {
     if(b == nullptr) return fail(COATI_HIP_EINVAL, "batch_sync: batch is NULL");
     HIP_TRY(hipSetDevice(b->model->device));
     HIP_TRY(hipStreamSynchronize(b->model->stream));
+    if(b->stream != b->model->stream) HIP_TRY(hipStreamSynchronize(b->stream));
     return COATI_HIP_OK;
 }
 
@@ -1320,12 +1388,60 @@ int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2
     return COATI_HIP_OK;
 }
 
+namespace {
+// Is `p` page-locked host memory HIP knows about (hipHostMalloc / hipHostRegister / coati_hip_host_alloc)?
+bool is_pinned_host(const void* p) {
+    if(p == nullptr) return false;
+    hipPointerAttribute_t attr;
+    if(hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// HBM workspace + page-locked staging a chunk of pairs [p0, p1) needs (upper bounds; the plan of
+// batch_create_impl is authoritative and fails cleanly if a chunk does not fit after all)
+struct ChunkNeed {
+    uint64_t arena = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
+};
+void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
+    uint64_t w = 0;
+    if(la > 0 && lb > 0) {
+        if(gap_len == 1) {  // the plan may narrow the strips (4, 8 or 16 columns per lane): take the largest
+            for(uint32_t cw = 4; cw <= 16; cw *= 2)
+                w = std::max<uint64_t>(w, (lb + kWave * cw - 1) / (kWave * cw) * ck_strip_dwords(static_cast<uint32_t>(la), cw) * 4);
+        } else
+            w = static_cast<uint64_t>(n_strips(static_cast<uint32_t>(lb))) * strip_dwords(static_cast<uint32_t>(la)) * 4;
+    }
+    const uint64_t strips = std::max<uint64_t>(1, (lb + 255) / 256);  // (narrowest plan: 4 columns per lane)
+    nd.arena += w + 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 1024;
+    nd.seq_bytes += la + lb;
+    nd.meta_bytes += sizeof(PairDesc) + 4 + strips * 16 + 16;  // descriptor, order entry, work items (both lists)
+    nd.ops += la + lb;
+    nd.cells += la * lb;
+}
+
+struct PipeChunk {
+    uint64_t p0 = 0, p1 = 0, ops_base = 0, ops_bytes = 0;
+};
+}  // namespace
+
+/* One-shot Viterbi over any number of pairs, PIPELINED: the input is cut into chunks; chunk k's
+ * upload and kernel run on one of three slots (stream + HBM workspace + page-locked staging, kept by
+ * the model between calls) while chunk k-1's results travel back and the host plans chunk k+1; the
+ * kernels of consecutive chunks overlap at their ragged ends.  The first chunks are small so that the
+ * GPU starts early.  Arrays the caller allocated with coati_hip_host_alloc (or page-locked otherwise)
+ * are copied from / into directly; pageable ones pass through the slot's staging block. */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                             const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                             float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off,
                             uint32_t* ops_len) {
     if(model == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_batch: model is NULL");
     if(a_off == nullptr || b_off == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets are NULL");
+    if(n_pairs == 0) return COATI_HIP_OK;
+    try {
+    std::lock_guard<std::mutex> one_call(model->pipeline_lock);
     HIP_TRY(hipSetDevice(model->device));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1333,48 +1449,245 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         std::lock_guard<std::mutex> hold(model->arena_lock);
         for(const auto& a : model->free_arenas) free_b += a.bytes;
     }
-    uint64_t budget = static_cast<uint64_t>(free_b * 0.8);
+    for(const auto& sl : model->slots) free_b += sl.arena_bytes;
+    constexpr int kSlots = coati_hip_model::kSlots;
+    // per-slot workspace budget: a third of 80 % of the free HBM, at most 16 GB (~14 000 pairs of 1 kb:
+    // larger chunks gain nothing, the kernel is at its steady rate from ~10 000 pairs)
+    uint64_t budget = std::min<uint64_t>(static_cast<uint64_t>(free_b * 0.8) / kSlots, 16ull << 30);
     if(const char* e = std::getenv("COATI_HIP_MEM_BUDGET")) {  // tests: force chunking with a small budget (bytes)
         const uint64_t forced = std::strtoull(e, nullptr, 10);
         if(forced > 0) budget = std::min(budget, forced);
     }
-    uint64_t ops_base = 0;  // slot start of the first pair of the current chunk
-    uint64_t p0 = 0;
-    while(p0 < n_pairs) {
-        // grow the chunk until the workspace estimate exceeds the budget
-        uint64_t p1 = p0, need = 0;
-        while(p1 < n_pairs) {
-            const uint64_t la = a_off[p1 + 1] - a_off[p1], lb = b_off[p1 + 1] - b_off[p1];
-            const uint64_t w = (la > 0 && lb > 0) ? n_strips(static_cast<uint32_t>(lb)) * ck_strip_dwords(static_cast<uint32_t>(la), kW) * 4 : 0;
-            const uint64_t add = w + 3 * (la + lb) + 8 * (la + 1) + 128;
-            if(p1 > p0 && need + add > budget) break;
-            need += add;
-            ++p1;
+    // ---- chunk schedule.  Full chunks hold ~1.2e10 cells (12 000 pairs of 1 kb) or what the budget
+    // allows; the first two are 1/16 and 1/4 of that, so the GPU has work after ~0.5 ms of planning.
+    const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
+    constexpr uint64_t kFullCells = 12000ull * 1002 * 1002;
+    std::vector<PipeChunk> chunks;
+    ChunkNeed max_need;
+    {
+        uint64_t p0 = 0, ops_base = 0;
+        while(p0 < n_pairs) {
+            const uint64_t target = chunks.size() == 0 ? kFullCells / 16 : (chunks.size() == 1 ? kFullCells / 4 : kFullCells);
+            ChunkNeed nd;
+            // per-batch fixed parts of the workspace: the traceback scratch of the persistent wavefronts
+            // (viterbi_ck), queue words, alignment slack of the ~15 carved arrays
+            nd.arena = static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + (64u << 10);
+            uint64_t p1 = p0;
+            while(p1 < n_pairs) {
+                if(a_off[p1 + 1] < a_off[p1] || b_off[p1 + 1] < b_off[p1])
+                    return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p1));
+                const uint64_t la = a_off[p1 + 1] - a_off[p1], lb = b_off[p1 + 1] - b_off[p1];
+                ChunkNeed with = nd;
+                chunk_need_add(with, la, lb, gap_len);
+                if(p1 > p0 && (with.arena > budget || with.cells > target)) break;
+                nd = with;
+                ++p1;
+            }
+            chunks.push_back(PipeChunk{p0, p1, ops_base, nd.ops});
+            max_need.arena = std::max(max_need.arena, nd.arena);
+            max_need.seq_bytes = std::max(max_need.seq_bytes, nd.seq_bytes);
+            max_need.meta_bytes = std::max(max_need.meta_bytes, nd.meta_bytes);
+            ops_base += nd.ops;
+            p0 = p1;
         }
-        // the estimate is not the plan: if the workspace does not fit after all, halve the chunk
-        coati_hip_batch_t* b = nullptr;
-        int rc = COATI_HIP_OK;
-        for(;;) {
-            rc = coati_hip_batch_create(model, p1 - p0, a_cat, a_off + p0, b_cat, b_off + p0, &b);
-            if(rc != COATI_HIP_ENOMEM || p1 - p0 <= 1) break;
-            p1 = p0 + (p1 - p0) / 2;
-        }
-        if(rc != COATI_HIP_OK) return rc;
-        uint64_t chunk_ops = 0;
-        for(uint64_t p = p0; p < p1; ++p) chunk_ops += (a_off[p + 1] - a_off[p]) + (b_off[p + 1] - b_off[p]);
-        rc = coati_hip_viterbi_launch(b);
-        if(rc == COATI_HIP_OK)
-            rc = coati_hip_viterbi_fetch(b, scores ? scores + p0 : nullptr, ops ? ops + ops_base : nullptr,
-                                         ops ? ops_capacity - ops_base : 0, ops_off ? ops_off + p0 : nullptr,
-                                         ops_len ? ops_len + p0 : nullptr);
-        coati_hip_batch_destroy(b);
-        if(rc != COATI_HIP_OK) return rc;
-        if(ops_off != nullptr)
-            for(uint64_t p = p0; p < p1; ++p) ops_off[p] += ops_base;
-        ops_base += chunk_ops;
-        p0 = p1;
+        if(ops != nullptr && ops_capacity < ops_base)
+            return fail(COATI_HIP_EINVAL, "viterbi_batch: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
+                        static_cast<unsigned long long>(ops_base));
     }
+    const bool in_pinned = is_pinned_host(a_cat) && is_pinned_host(b_cat);
+    const bool out_pinned = (ops == nullptr || is_pinned_host(ops)) && (scores == nullptr || is_pinned_host(scores)) &&
+                            (ops_off == nullptr || is_pinned_host(ops_off)) && (ops_len == nullptr || is_pinned_host(ops_len));
+    // ---- slots: stream, staging, workspace (grown on demand, kept by the model)
+    const int n_slots = static_cast<int>(std::min<uint64_t>(kSlots, chunks.size()));
+    uint64_t max_pairs = 0;
+    for(const PipeChunk& c : chunks) max_pairs = std::max(max_pairs, c.p1 - c.p0);
+    // staging block of a slot: [descriptors + (pageable) sequences going up | (pageable) results coming back]
+    auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) {
+        return out_pinned ? uint64_t{0} : 4 * 256 + n * (sizeof(float) + sizeof(uint64_t) + sizeof(uint32_t)) + ops_bytes;
+    };
+    const uint64_t staging_need = max_need.meta_bytes + 8 * 256 + (in_pinned ? 0 : max_need.seq_bytes + 512) +
+                                  out_bytes_of(max_pairs, max_need.seq_bytes) + 512;
+    for(int q = 0; q < n_slots; ++q) {
+        coati_hip_model::Slot& sl = model->slots[q];
+        if(sl.stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        if(sl.pinned_bytes < staging_need) {
+            if(sl.pinned != nullptr) (void)hipHostFree(sl.pinned);
+            sl.pinned = nullptr;
+            sl.pinned_bytes = 0;
+            HIP_TRY(hipHostMalloc(&sl.pinned, staging_need, hipHostMallocDefault));
+            sl.pinned_bytes = staging_need;
+        }
+        if(sl.arena_bytes < max_need.arena) {
+            HIP_TRY(hipStreamSynchronize(sl.stream));
+            if(sl.arena != nullptr) (void)hipFree(sl.arena);
+            sl.arena = nullptr;
+            sl.arena_bytes = 0;
+            hipError_t e = hipMalloc(&sl.arena, max_need.arena);
+            if(e == hipErrorOutOfMemory) {  // give the model's cached blocks back and try again
+                (void)hipGetLastError();
+                std::vector<coati_hip_model::Arena> drop;
+                {
+                    std::lock_guard<std::mutex> hold(model->arena_lock);
+                    drop.swap(model->free_arenas);
+                }
+                for(const auto& a : drop) (void)hipFree(a.ptr);
+                e = hipMalloc(&sl.arena, max_need.arena);
+            }
+            if(e != hipSuccess)
+                return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "viterbi_batch: hipMalloc(%llu bytes of workspace): %s",
+                            static_cast<unsigned long long>(max_need.arena), hipGetErrorString(e));
+            sl.arena_bytes = max_need.arena;
+        }
+    }
+    // ---- the pipeline
+    struct InFlight {
+        coati_hip_batch_t* batch = nullptr;
+        const PipeChunk* chunk = nullptr;
+        hipEvent_t done = nullptr;
+        char* out_stage = nullptr;  // results in the slot's staging block (pageable destinations)
+    };
+    InFlight fl[kSlots];
+    int rc = COATI_HIP_OK;
+    // wait for a slot's chunk, hand its results to the caller, free the slot
+    auto finish = [&](InFlight& f) -> int {
+        if(f.batch == nullptr) return COATI_HIP_OK;
+        int r = COATI_HIP_OK;
+        const hipError_t e = hipEventSynchronize(f.done);
+        if(e != hipSuccess) r = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+        const PipeChunk& c = *f.chunk;
+        const uint64_t n = c.p1 - c.p0;
+        if(r == COATI_HIP_OK && f.out_stage != nullptr) {
+            char* at = f.out_stage;
+            if(scores != nullptr) std::memcpy(scores + c.p0, at, n * sizeof(float));
+            at += (n * sizeof(float) + 255) / 256 * 256;
+            if(ops_off != nullptr) std::memcpy(ops_off + c.p0, at, n * sizeof(uint64_t));
+            at += (n * sizeof(uint64_t) + 255) / 256 * 256;
+            if(ops_len != nullptr) std::memcpy(ops_len + c.p0, at, n * sizeof(uint32_t));
+            at += (n * sizeof(uint32_t) + 255) / 256 * 256;
+            if(ops != nullptr && c.ops_bytes > 0) std::memcpy(ops + c.ops_base, at, c.ops_bytes);
+        }
+        if(r == COATI_HIP_OK && ops_off != nullptr)
+            for(uint64_t p = c.p0; p < c.p1; ++p) ops_off[p] += c.ops_base;
+        coati_hip_batch_destroy(f.batch);
+        f.batch = nullptr;
+        return r;
+    };
+    for(size_t ci = 0; ci < chunks.size() && rc == COATI_HIP_OK; ++ci) {
+        const PipeChunk& c = chunks[ci];
+        const int q = static_cast<int>(ci % static_cast<size_t>(n_slots));
+        coati_hip_model::Slot& sl = model->slots[q];
+        InFlight& f = fl[q];
+        rc = finish(f);
+        if(rc != COATI_HIP_OK) break;
+        const uint64_t n = c.p1 - c.p0;
+        const uint64_t out_off = (sl.pinned_bytes - out_bytes_of(n, c.ops_bytes)) / 256 * 256;  // results land behind the uploads
+        BatchOpts bo;
+        bo.stream = sl.stream;
+        bo.arena = sl.arena;
+        bo.arena_bytes = sl.arena_bytes;
+        bo.staging = static_cast<char*>(sl.pinned);
+        bo.staging_bytes = out_off;
+        bo.seqs_pinned = in_pinned;
+        uint64_t plan_need = 0;
+        bo.arena_need_out = &plan_need;
+        rc = batch_create_impl(model, n, a_cat, a_off + c.p0, b_cat, b_off + c.p0, nullptr, &bo, &f.batch);
+        if(rc == COATI_HIP_ENOMEM && plan_need > sl.arena_bytes) {
+            // the estimate behind the slot's workspace was short of this chunk's plan: grow the slot, once
+            HIP_TRY(hipStreamSynchronize(sl.stream));
+            (void)hipFree(sl.arena);
+            sl.arena = nullptr;
+            sl.arena_bytes = 0;
+            const uint64_t grown = plan_need + plan_need / 16;
+            const hipError_t ge = hipMalloc(&sl.arena, grown);
+            if(ge != hipSuccess) {
+                rc = fail(ge == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "viterbi_batch: hipMalloc(%llu bytes of workspace): %s",
+                          static_cast<unsigned long long>(grown), hipGetErrorString(ge));
+                break;
+            }
+            sl.arena_bytes = grown;
+            bo.arena = sl.arena;
+            bo.arena_bytes = sl.arena_bytes;
+            rc = batch_create_impl(model, n, a_cat, a_off + c.p0, b_cat, b_off + c.p0, nullptr, &bo, &f.batch);
+        }
+        if(rc != COATI_HIP_OK) break;
+        f.chunk = &c;
+        rc = coati_hip_viterbi_launch(f.batch);
+        if(rc != COATI_HIP_OK) break;
+        // results: asynchronous copies on the slot's stream, straight into page-locked destinations or
+        // into the tail of the slot's staging block
+        hipError_t e = hipSuccess;
+        coati_hip_batch* b = f.batch;
+        if(out_pinned) {
+            f.out_stage = nullptr;
+            if(scores != nullptr) e = hipMemcpyAsync(scores + c.p0, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
+            if(e == hipSuccess && ops_off != nullptr) e = hipMemcpyAsync(ops_off + c.p0, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream);
+            if(e == hipSuccess && ops_len != nullptr) e = hipMemcpyAsync(ops_len + c.p0, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream);
+            if(e == hipSuccess && ops != nullptr && c.ops_bytes > 0) e = hipMemcpyAsync(ops + c.ops_base, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, sl.stream);
+        } else {
+            f.out_stage = static_cast<char*>(sl.pinned) + out_off;
+            char* at = f.out_stage;
+            if(scores != nullptr) e = hipMemcpyAsync(at, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
+            at += (n * sizeof(float) + 255) / 256 * 256;
+            if(e == hipSuccess && ops_off != nullptr) e = hipMemcpyAsync(at, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream);
+            at += (n * sizeof(uint64_t) + 255) / 256 * 256;
+            if(e == hipSuccess && ops_len != nullptr) e = hipMemcpyAsync(at, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream);
+            at += (n * sizeof(uint32_t) + 255) / 256 * 256;
+            if(e == hipSuccess && ops != nullptr && c.ops_bytes > 0) e = hipMemcpyAsync(at, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, sl.stream);
+        }
+        if(e == hipSuccess && f.done == nullptr) e = hipEventCreateWithFlags(&f.done, hipEventDisableTiming);
+        if(e == hipSuccess) e = hipEventRecord(f.done, sl.stream);
+        if(e != hipSuccess) rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+    }
+    for(InFlight& f : fl) {
+        const int r = finish(f);
+        if(rc == COATI_HIP_OK) rc = r;
+        if(f.done != nullptr) (void)hipEventDestroy(f.done);
+    }
+    return rc;
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "viterbi_batch: host allocation failed");
+    } catch(const std::exception& ex) {
+        return fail(COATI_HIP_EHIP, "viterbi_batch: %s", ex.what());
+    }
+}
+
+int coati_hip_shard_bounds(uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, int world, uint64_t* bounds) {
+    if(world < 1 || bounds == nullptr || (n_pairs > 0 && (a_off == nullptr || b_off == nullptr)))
+        return fail(COATI_HIP_EINVAL, "shard_bounds: bad argument");
+    // weights as long double sums are overkill: cells fit 2^62 for any input the ABI accepts per pair,
+    // but a sum over 2^32 pairs may not -- accumulate in unsigned __int128
+    using u128 = unsigned __int128;
+    u128 total = 0;
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p]) return fail(COATI_HIP_EINVAL, "shard_bounds: offsets of pair %llu decrease", static_cast<unsigned long long>(p));
+        total += static_cast<u128>(a_off[p + 1] - a_off[p]) * (b_off[p + 1] - b_off[p]);
+    }
+    bounds[0] = 0;
+    u128 run = 0;
+    uint64_t p = 0;
+    for(int r = 1; r < world; ++r) {
+        // first index at which the cells of pairs [0, index) reach r/world of the total
+        while(p < n_pairs && run * static_cast<u128>(world) < total * static_cast<u128>(r)) {
+            run += static_cast<u128>(a_off[p + 1] - a_off[p]) * (b_off[p + 1] - b_off[p]);
+            ++p;
+        }
+        bounds[r] = p;
+    }
+    bounds[world] = n_pairs;
     return COATI_HIP_OK;
+}
+
+/* Page-locked host memory for the arrays of coati_hip_viterbi_batch (inputs and outputs): copies to
+ * and from such memory are asynchronous DMA transfers that overlap the kernels; pageable memory goes
+ * through a staging copy. */
+int coati_hip_host_alloc(uint64_t bytes, void** out) {
+    if(out == nullptr) return fail(COATI_HIP_EINVAL, "host_alloc: out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+    return COATI_HIP_OK;
+}
+void coati_hip_host_free(void* p) {
+    if(p != nullptr) (void)hipHostFree(p);
 }
 
 int coati_hip_debug_viterbi_flags(coati_hip_batch_t* b, uint64_t pair, uint8_t* out, uint64_t capacity) {

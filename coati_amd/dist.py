@@ -1,0 +1,121 @@
+"""ctypes binding of libcoati_hip_dist.so (include/coati_hip_dist.h): the native multi-GPU layer --
+one process per GPU, RCCL linked directly.  Plumbing for tests and tools; the product is the library
+(and `coati-alignpair --batch --devices ...`, which drives it from C++)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import hip
+
+LIB_PATH = Path(__file__).resolve().parent / "_build" / "libcoati_hip_dist.so"
+ID_BYTES = 128
+
+EXPORTS = (
+    "coati_hip_dist_last_error",
+    "coati_hip_dist_unique_id",
+    "coati_hip_dist_init",
+    "coati_hip_dist_destroy",
+    "coati_hip_dist_rank",
+    "coati_hip_dist_world",
+    "coati_hip_dist_broadcast_model",
+    "coati_hip_dist_gather",
+    "coati_hip_dist_viterbi",
+)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    hip.load()  # libcoati_hip.so first (the dist library links it)
+    path = Path(os.environ.get("COATI_HIP_DIST_LIB", LIB_PATH))
+    if not path.exists():
+        raise ImportError(f"{path} not found: build it with `make dist`")
+    lib = C.CDLL(str(path))
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.coati_hip_dist_last_error.restype = C.c_char_p
+    lib.coati_hip_dist_unique_id.argtypes = [vp]
+    lib.coati_hip_dist_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.coati_hip_dist_destroy.argtypes = [vp]
+    lib.coati_hip_dist_destroy.restype = None
+    lib.coati_hip_dist_rank.argtypes = [vp]
+    lib.coati_hip_dist_world.argtypes = [vp]
+    lib.coati_hip_dist_broadcast_model.argtypes = [vp, i32, vp, C.c_uint32, vp, vp, vp]
+    lib.coati_hip_dist_gather.argtypes = [vp, i32, vp, vp, vp, vp, u64, vp, vp]
+    lib.coati_hip_dist_viterbi.argtypes = [vp, i32, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise hip.CoatiHipError(rc, load().coati_hip_dist_last_error().decode(errors="replace"))
+
+
+def unique_id() -> bytes:
+    buf = C.create_string_buffer(ID_BYTES)
+    _check(load().coati_hip_dist_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    def __init__(self, uid: bytes, world: int, rank: int, device: int = 0):
+        self._h = C.c_void_p()
+        self.world, self.rank = world, rank
+        _check(load().coati_hip_dist_init(C.c_char_p(uid), world, rank, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().coati_hip_dist_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def broadcast_model(self, tables=None, consts=None, gap_len=None, root: int = 0, capacity: int = 64):
+        """Root passes (tables [n,183,15], consts[4], gap_len); every rank gets them back bit-identical."""
+        if self.rank == root:
+            t = np.ascontiguousarray(tables, np.float32).reshape(-1, hip.TABLE_ROWS, hip.TABLE_COLS).copy()
+            n = C.c_uint32(t.shape[0])
+            k = np.ascontiguousarray(consts, np.float32).copy()
+            g = C.c_int(int(gap_len))
+        else:
+            t = np.zeros((capacity, hip.TABLE_ROWS, hip.TABLE_COLS), np.float32)
+            n, k, g = C.c_uint32(0), np.zeros(4, np.float32), C.c_int(0)
+        _check(load().coati_hip_dist_broadcast_model(self._h, root, hip._ptr(t), t.shape[0], C.byref(n), hip._ptr(k), C.byref(g)))
+        return t[:n.value].copy(), k, g.value
+
+    def gather(self, batch, root: int = 0):
+        """Collective gather of one launched hip.Batch (or None); on root returns
+        (counts[world,2], scores, ops, ops_off, ops_len), elsewhere (counts, None, None, None, None)."""
+        counts = np.zeros(2 * self.world, np.uint64)
+        h = batch._h if batch is not None else None
+        if self.rank != root:
+            _check(load().coati_hip_dist_gather(self._h, root, h, hip._ptr(counts), None, None, 0, None, None))
+            return counts.reshape(-1, 2), None, None, None, None
+        # capacity is not known before the counts are: every rank's share is at most what this rank holds x world
+        # (tests use equal shards); a caller with ragged shards passes through Comm.viterbi instead
+        cap_p = max(int(batch.n if batch is not None else 0), 1) * self.world * 2
+        cap_o = max(int(batch.ops_total if batch is not None else 0), 1) * self.world * 2
+        scores, ops = np.zeros(cap_p, np.float32), np.zeros(cap_o, np.uint8)
+        off, ln = np.zeros(cap_p, np.uint64), np.zeros(cap_p, np.uint32)
+        _check(load().coati_hip_dist_gather(self._h, root, h, hip._ptr(counts), hip._ptr(scores), hip._ptr(ops), cap_o,
+                                            hip._ptr(off), hip._ptr(ln)))
+        c = counts.reshape(-1, 2)
+        n, nb = int(c[:, 0].sum()), int(c[:, 1].sum())
+        return c, scores[:n], ops[:nb], off[:n], ln[:n]
+
+    def viterbi(self, model, a_cat, a_off, b_cat, b_off, root: int = 0):
+        """coati_hip_dist_viterbi: the whole sharded job; results on root (None elsewhere)."""
+        a_cat, b_cat = np.ascontiguousarray(a_cat, np.uint8), np.ascontiguousarray(b_cat, np.uint8)
+        a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+        n = len(a_off) - 1
+        total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
+        scores, ops = np.zeros(n, np.float32), np.zeros(max(total, 1), np.uint8)
+        off, ln = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        _check(load().coati_hip_dist_viterbi(self._h, root, model._h, n, hip._ptr(a_cat), hip._ptr(a_off), hip._ptr(b_cat),
+                                             hip._ptr(b_off), hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln)))
+        return (scores, ops, off, ln) if self.rank == root else None

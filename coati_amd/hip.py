@@ -29,6 +29,7 @@ EXPORTS = (
     "coati_hip_batch_create",
     "coati_hip_batch_create_tables",
     "coati_hip_batch_destroy",
+    "coati_hip_batch_pairs",
     "coati_hip_batch_device_bytes",
     "coati_hip_batch_cells",
     "coati_hip_viterbi_launch",
@@ -45,6 +46,9 @@ EXPORTS = (
     "coati_hip_debug_rng_f24",
     "coati_hip_debug_libm",
     "coati_hip_viterbi_batch",
+    "coati_hip_shard_bounds",
+    "coati_hip_host_alloc",
+    "coati_hip_host_free",
     "coati_hip_debug_viterbi_flags",
 )
 
@@ -107,6 +111,12 @@ def load() -> C.CDLL:
         lib.coati_hip_debug_libm.argtypes = [vp, i32, vp, u64, vp]
     lib.coati_hip_viterbi_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_debug_viterbi_flags.argtypes = [vp, u64, vp, u64]
+    if hasattr(lib, "coati_hip_shard_bounds"):
+        lib.coati_hip_shard_bounds.argtypes = [u64, vp, vp, i32, vp]
+    if hasattr(lib, "coati_hip_host_alloc"):
+        lib.coati_hip_host_alloc.argtypes = [u64, C.POINTER(vp)]
+        lib.coati_hip_host_free.argtypes = [vp]
+        lib.coati_hip_host_free.restype = None
     _lib = lib
     return lib
 
@@ -118,6 +128,48 @@ def _check(rc: int) -> None:
 
 def _ptr(arr):
     return None if arr is None else arr.ctypes.data_as(C.c_void_p)
+
+
+def shard_bounds(a_off, b_off, world: int) -> np.ndarray:
+    """coati_hip_shard_bounds: world+1 pair indices of contiguous shards of equal DP-cell count."""
+    a_off = np.ascontiguousarray(a_off, np.uint64)
+    b_off = np.ascontiguousarray(b_off, np.uint64)
+    out = np.zeros(world + 1, np.uint64)
+    _check(load().coati_hip_shard_bounds(len(a_off) - 1, _ptr(a_off), _ptr(b_off), world, _ptr(out)))
+    return out
+
+
+class _PinnedBlock:
+    """Owner of one coati_hip_host_alloc block; freed when the last array viewing it goes."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        _check(load().coati_hip_host_alloc(max(int(nbytes), 1), C.byref(self.ptr)))
+        self.nbytes = max(int(nbytes), 1)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().coati_hip_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """numpy array in page-locked host memory (coati_hip_host_alloc): coati_hip_viterbi_batch copies
+    from / into such arrays by DMA, overlapped with its kernels."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    block = _PinnedBlock(n * dtype.itemsize)
+    buf = (C.c_char * block.nbytes).from_address(block.ptr.value)
+    buf._coati_owner = block  # the array keeps `buf` alive (its .base), `buf` keeps the block: freed with the last view
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def pinned_copy(arr) -> np.ndarray:
+    out = pinned_empty(np.shape(arr), np.asarray(arr).dtype)
+    out[...] = arr
+    return out
 
 
 def device_count() -> int:
@@ -189,7 +241,7 @@ class Model:
         _check(load().coati_hip_debug_rng_f24(self._h, _ptr(st), n, _ptr(out)))
         return out
 
-    def viterbi(self, a_cat, a_off, b_cat, b_off, out=None):
+    def viterbi(self, a_cat, a_off, b_cat, b_off, out=None, pinned=False):
         """One-shot coati_hip_viterbi_batch.  Returns (scores, ops, ops_off, ops_len); `out` may pass
         the four arrays of an earlier call back in (a loop over batches then writes into memory whose
         pages exist already -- first-touch page faults are half the cost of downloading the ops)."""
@@ -197,6 +249,9 @@ class Model:
         total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
         if out is not None and len(out[0]) == n and len(out[1]) >= max(total, 1):
             scores, ops, ops_off, ops_len = out
+        elif pinned:
+            scores, ops = pinned_empty(n, np.float32), pinned_empty(max(total, 1), np.uint8)
+            ops_off, ops_len = pinned_empty(n, np.uint64), pinned_empty(n, np.uint32)
         else:
             scores = np.zeros(n, np.float32)
             ops = np.zeros(max(total, 1), np.uint8)

@@ -118,6 +118,8 @@ int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, co
                                   const uint32_t* table_index, coati_hip_batch_t** out);
 void coati_hip_batch_destroy(coati_hip_batch_t* batch);
 
+/* Number of pairs of a batch. */
+uint64_t coati_hip_batch_pairs(const coati_hip_batch_t* batch);
 /* Bytes of HBM a batch holds (inputs + workspace + results). */
 uint64_t coati_hip_batch_device_bytes(const coati_hip_batch_t* batch);
 /* Sum over pairs of len_a*len_b ("cell updates"). */
@@ -209,12 +211,31 @@ int coati_hip_debug_libm(coati_hip_model_t* model, int op, const float* in, uint
 /* Parity/debug: the first n f24() draws (random.hpp:213-216) of a stream, computed on the device. */
 int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2], uint32_t n, float* out);
 
-/* One-shot convenience: create batch(es), launch, fetch, destroy.  Splits the
- * input into chunks that fit the device's free memory. */
+/* One-shot viterbi_mem + traceback_viterbi over any number of pairs -- the batched counterpart of the
+ * reference's per-pair loop (src/lib/align_marginal.cc:69-80 called once per process, utils.cc:809-812).
+ * The input is cut into chunks that fit the device's memory and PIPELINED: three slots (stream + HBM
+ * workspace + page-locked staging, kept by the model between calls) carry chunk k's upload and kernel
+ * while chunk k-1's results travel back and the host plans chunk k+1; consecutive kernels overlap at
+ * their ragged ends.  Arrays from coati_hip_host_alloc are copied from / into directly (DMA); pageable
+ * ones pass through the slot's staging block. */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                             const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                             float* scores, uint8_t* ops, uint64_t ops_capacity,
                             uint64_t* ops_off, uint32_t* ops_len);
+
+/* Contiguous shards of (nearly) equal DP-cell count for `world` devices: pairs
+ * [bounds[r], bounds[r+1]) go to rank r; bounds has world+1 entries, bounds[0] = 0, bounds[world] =
+ * n_pairs.  The cut before rank r is the first pair index at which the running cell count reaches
+ * r/world of the total, so no shard exceeds the ideal share by more than one pair.  (The reference has
+ * no counterpart: one pair per process, src/lib/utils.cc:809-812.)  Pure host arithmetic: usable
+ * without a device, by every rank on the same input. */
+int coati_hip_shard_bounds(uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, int world,
+                           uint64_t* bounds);
+
+/* Page-locked host memory (hipHostMalloc behind a C signature) for the arrays handed to
+ * coati_hip_viterbi_batch; free with coati_hip_host_free.  Optional: any host memory works. */
+int coati_hip_host_alloc(uint64_t bytes, void** out);
+void coati_hip_host_free(void* p);
 
 /* Parity/debug export: the per-cell traceback decision byte of pair `pair`
  * (bits 0-1 state after a match move arrives at the cell, bits 2-3 after a

@@ -1,0 +1,72 @@
+/* coati_hip_dist.h -- C ABI of libcoati_hip_dist.so: the multi-GPU layer over libcoati_hip.so.
+ *
+ * What it replaces: nothing in the reference is multi-device -- `coati alignpair` aligns ONE pair per
+ * process (src/lib/utils.cc:809-812, src/lib/align_marginal.cc:44-88), and a user with a million pairs
+ * runs a million processes.  Pairs are independent, so the batched engine shards them: ONE PROCESS PER
+ * GPU, contiguous shards of equal DP-cell count (coati_hip_shard_bounds, in libcoati_hip.so), no
+ * collective on the data path.  The exchanges that are real:
+ *   * the model (marginal substitution table(s) + gap constants, 11 KB per table) is computed on rank 0
+ *     and broadcast, so that every rank scores with bit-identical tables: ncclBroadcast;
+ *   * the results return to rank 0, which writes the output: an ncclAllGather of every rank's counts,
+ *     then one group of ncclSend / ncclRecv straight out of the ranks' HBM result arrays over xGMI.
+ * RCCL is linked directly (librccl.so); torch is not involved.
+ *
+ * Conventions as in coati_hip.h: 0 on success, otherwise an error code with the text in
+ * coati_hip_dist_last_error() (thread-local).  Every function taking a communicator is COLLECTIVE:
+ * all ranks of the communicator must call it, in the same order.
+ */
+#ifndef COATI_HIP_DIST_H
+#define COATI_HIP_DIST_H
+
+#include "coati_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COATI_HIP_DIST_ID_BYTES 128
+
+typedef struct coati_hip_comm coati_hip_comm_t;
+
+const char* coati_hip_dist_last_error(void);
+
+/* Rank 0 creates the rendezvous id (ncclGetUniqueId) and hands its 128 bytes to the other ranks out of
+ * band (a file, a pipe, an environment variable, a torch store ...). */
+int coati_hip_dist_unique_id(void* id128);
+/* Joins the communicator: `world` processes, this one is `rank` and drives HIP device `device`
+ * (ncclCommInitRank; creates the stream the collectives run on). */
+int coati_hip_dist_init(const void* id128, int world, int rank, int device, coati_hip_comm_t** out);
+void coati_hip_dist_destroy(coati_hip_comm_t* comm);
+int coati_hip_dist_rank(const coati_hip_comm_t* comm);
+int coati_hip_dist_world(const coati_hip_comm_t* comm);
+
+/* Broadcast of the model from `root`.  On root: tables (n_tables * 183*15 floats), *n_tables, consts
+ * (no_gap, gap_stop, gap_open, gap_extend), *gap_len are inputs; on the other ranks they are outputs
+ * (`tables` must hold table_capacity_tables tables; fails if the root's model has more). */
+int coati_hip_dist_broadcast_model(coati_hip_comm_t* comm, int root, float* tables, uint32_t table_capacity_tables,
+                                   uint32_t* n_tables, float consts[4], int* gap_len);
+
+/* Gather of ONE launched resident batch per rank (NULL = this rank contributes nothing) to `root`.
+ * Waits for the batch's Viterbi launch, then: ncclAllGather of (pairs, op bytes) of every rank into
+ * counts[2 * world] (valid on every rank), grouped ncclSend / ncclRecv of scores, ops, op offsets and op
+ * lengths from the batches' HBM result arrays into root's HBM, and on root the download into
+ *   scores[], ops_off[], ops_len[]  -- rank r's entries start at index sum_{q<r} counts[2q]
+ *   ops[]                           -- rank r's op bytes start at sum_{q<r} counts[2q+1]; ops_off[] is
+ *                                      rebased to index into this concatenation.
+ * Outputs are ignored on the other ranks (may be NULL). */
+int coati_hip_dist_gather(coati_hip_comm_t* comm, int root, coati_hip_batch_t* batch, uint64_t* counts, float* scores,
+                          uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len);
+
+/* The whole sharded job: viterbi_mem + traceback_viterbi of n_pairs pairs over all ranks.  EVERY rank
+ * passes the same input (each process reads the same file; nothing but results crosses the links);
+ * rank r computes the pairs [bounds[r], bounds[r+1]) of coati_hip_shard_bounds in chunks that fit its
+ * HBM, the kernel of chunk k+1 running while chunk k is gathered.  Outputs as coati_hip_viterbi_batch,
+ * valid on `root` only. */
+int coati_hip_dist_viterbi(coati_hip_comm_t* comm, int root, coati_hip_model_t* model, uint64_t n_pairs,
+                           const uint8_t* a_cat, const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                           float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COATI_HIP_DIST_H */

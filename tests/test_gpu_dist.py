@@ -1,0 +1,48 @@
+"""The native multi-GPU layer (libcoati_hip_dist.so, RCCL linked directly) with a ONE-rank communicator
+on the 1-GPU box: rendezvous id, ncclCommInitRank, model broadcast, counts all-gather, the gather's
+download path and the sharded driver -- everything but a second peer.  Runs in a child process so that
+the RCCL it loads is the one the library links (the pytest process may hold torch's)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import sys, json, zlib, numpy as np
+sys.path.insert(0, %r)
+from coati_amd import hip, host, dist
+table, consts = host.set_subst("mar-ecm"), host.gap_consts()
+comm = dist.Comm(dist.unique_id(), 1, 0, 0)
+t, k, g = comm.broadcast_model(table, consts, 1)
+assert t.shape == (1, 183, 15) and (t[0].view(np.uint32) == np.asarray(table, np.float32).view(np.uint32)).all()
+assert (k.view(np.uint32) == np.asarray(consts, np.float32).view(np.uint32)).all() and g == 1
+model = hip.Model(t[0], k, g)
+a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 300)
+batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+batch.viterbi_launch()
+want = batch.viterbi_fetch()
+counts, sc, ops, off, ln = comm.gather(batch)
+assert counts.tolist() == [[300, int(a_off[-1] + b_off[-1])]]
+ok = (sc.view(np.uint32) == want[0].view(np.uint32)).all() and (ops == want[1]).all() and (off == want[2]).all() and (ln == want[3]).all()
+batch.close()
+got = comm.viterbi(model, a_cat, a_off, b_cat, b_off)
+ok = ok and (got[0].view(np.uint32) == want[0].view(np.uint32)).all() and (got[1][:len(want[1])] == want[1]).all()
+ok = ok and (got[2] == want[2]).all() and (got[3] == want[3]).all()
+empty = comm.gather(None)
+ok = ok and empty[0].tolist() == [[0, 0]]
+comm.close(); model.close()
+print(json.dumps({"ok": bool(ok)}))
+'''
+
+
+def test_one_rank_rccl_path():
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-c", CHILD % str(root)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    # (RCCL prints a version banner on stdout when the communicator is created)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"ok"')]
+    assert lines and json.loads(lines[-1]) == {"ok": True}, r.stdout[-2000:]

@@ -318,3 +318,46 @@ def test_extremely_ragged_pairs():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tools" / "ragged_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ragged_check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_pipelined_one_shot_pinned_and_pageable(hip, oracle):
+    """coati_hip_viterbi_batch pipelines chunks over three slots (own stream, workspace, page-locked
+    staging).  Page-locked caller arrays (coati_hip_host_alloc) are copied by DMA directly, pageable
+    ones go through the staging block: both must give what one resident batch gives, also when the
+    schedule has many more chunks than slots (slot reuse) and when a model is reused for a second call."""
+    from coati_amd import host
+
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 2600)  # 3 chunks by the ramp-up schedule
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    want = batch.viterbi_fetch()
+    batch.close()
+
+    # (a pair's ops occupy the tail of its la+lb slot: only [off, off+len) is defined)
+    valid = np.zeros(len(want[1]), bool)
+    for p in range(len(want[0])):
+        valid[int(want[2][p]):int(want[2][p]) + int(want[3][p])] = True
+
+    def same(got):
+        sc, ops, off, ln = got
+        assert (bits(sc) == bits(want[0])).all() and (ln == want[3]).all() and (off == want[2]).all()
+        assert (ops[:len(want[1])][valid] == want[1][valid]).all()
+
+    same(model.viterbi(a_cat, a_off, b_cat, b_off))  # pageable in, pageable out
+    pa, pb = hip.pinned_copy(a_cat), hip.pinned_copy(b_cat)
+    same(model.viterbi(pa, a_off, pb, b_off, pinned=True))  # page-locked in and out
+    same(model.viterbi(pa, a_off, pb, b_off))  # page-locked in, pageable out
+    same(model.viterbi(a_cat, a_off, b_cat, b_off, pinned=True))
+    model.close()
+    # many chunks (tiny budget): slots are reused again and again
+    import os
+    os.environ["COATI_HIP_MEM_BUDGET"] = str(40 << 20)
+    try:
+        model = hip.Model(table, consts, 1)
+        same(model.viterbi(pa, a_off, pb, b_off, pinned=True))
+        same(model.viterbi(a_cat, a_off, b_cat, b_off))
+        model.close()
+    finally:
+        del os.environ["COATI_HIP_MEM_BUDGET"]
