@@ -41,14 +41,14 @@ host: $(BUILD)/libcoati_host.so $(BUILD)/coati-alignpair $(BUILD)/coati-sample $
 # the host layer calls the DP through the C ABI of libcoati_hip.so only
 $(BUILD)/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so
 	@mkdir -p $(BUILD)
-	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm -ldl
 
 $(BUILD)/coati: coati_amd/host/coati_main.cc
 	@mkdir -p $(BUILD)
 	$(CXX) $(HOSTFLAGS) -o $@ $<
 
 $(BUILD)/coati-%: coati_amd/host/coati_%.cc $(BUILD)/libcoati_host.so
-	$(CXX) $(HOSTFLAGS) -o $@ $< -L$(BUILD) -lcoati_host -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm
+	$(CXX) $(HOSTFLAGS) -o $@ $< -L$(BUILD) -lcoati_host -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm -ldl
 
 # sanitizer build of the host layer (CPU only; GPU ASan is not available on the pool):
 # run the CPU tests / tools/fuzz_host_io.py against it with COATI_HOST_LIB + LD_PRELOAD (see the tool)
@@ -56,7 +56,7 @@ asan: $(BUILD)/asan/libcoati_host.so
 $(BUILD)/asan/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so
 	@mkdir -p $(BUILD)/asan
 	$(CXX) -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer -pthread \
-	    -Iinclude -Icoati_amd/host -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN/..' -lm
+	    -Iinclude -Icoati_amd/host -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN/..' -lm -ldl
 
 oracle:
 	$(MAKE) -C oracle

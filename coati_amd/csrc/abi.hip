@@ -178,6 +178,7 @@ struct coati_hip_batch {
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
     uint32_t* d_flags = nullptr;   // decision bits (viterbi_l1/_k, dp_generic) or checkpoints (viterbi_ck)
     uint32_t* d_wscratch = nullptr;  // viterbi_ck: traceback scratch of the persistent wavefronts
+    uint64_t ck_slot_dwords = 0;     // viterbi_ck: per-wavefront checkpoint slots at the start of d_flags (0: none)
     bool ck = false;                 // gap_len 1 runs viterbi_ck (checkpoint layout in d_flags)
     float *d_bnd = nullptr, *d_scores = nullptr;
     float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward (parts of mdi_block)
@@ -201,7 +202,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->d_scores,
-                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch,
+                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords,
                            b->d_mdi,    b->d_final_mdi};
 }
 }  // namespace
@@ -374,7 +375,7 @@ void model_release(coati_hip_model* m) {
     for(auto& sl : m->slots) {
         if(sl.arena != nullptr) (void)hipFree(sl.arena);
         if(sl.pinned != nullptr) (void)hipHostFree(sl.pinned);
-        if(sl.stream != nullptr) (void)hipStreamDestroy(sl.stream);
+        if(sl.stream != nullptr && sl.stream != m->stream) (void)hipStreamDestroy(sl.stream);
     }
     if(m->pinned != nullptr) (void)hipHostFree(m->pinned);
     if(m->d_table != nullptr) (void)hipFree(m->d_table);
@@ -450,6 +451,8 @@ struct BatchOpts {
     uint64_t staging_bytes = 0;
     bool seqs_pinned = false;  // a_cat / b_cat are page-locked: copied straight from the caller's memory
     uint64_t* arena_need_out = nullptr;  // receives the workspace size of the plan (also when `arena` is too small)
+    bool ck_per_pair = false;  // viterbi_ck: keep every pair's checkpoints (coati_hip_debug_viterbi_flags reads them afterwards)
+    uint32_t force_w_main = 0;  // (debug re-run of one pair: the strip shape it had in its batch)
 };
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                       const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
@@ -633,6 +636,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             const int w = std::atoi(e);
             if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
         }
+        if(opts != nullptr && opts->force_w_main != 0) w_main = opts->force_w_main;
         uint64_t tail_pairs = 0;
         if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {
             tail_pairs = std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10));
@@ -721,6 +725,42 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         b->bnd_floats += (need + 31) / 32 * 32;
     }
     b->compact_narrow_only = plan_k && all_narrow;
+    // viterbi_ck: checkpoints of single-strip pairs in per-wavefront slots instead of per pair, when that is
+    // the smaller arena (a 1 kb pair needs 1.09 MB: 10 000 pairs 10.9 GB per pair, 4.5 GB in 4 096 slots; a
+    // batch of a few pairs keeps per-pair storage).  Pairs above kSlotCap keep their own storage either way.
+    if(b->ck && !(opts != nullptr && opts->ck_per_pair) && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
+        constexpr uint64_t kSlotCap = 1ull << 20;  // dwords (4 MB)
+        uint64_t slot = 0, per_pair_total = 0;
+        auto need_of = [&](const PairDesc& d) { return d.la > 0 && d.lb > 0 ? ck_strip_dwords(d.la, d.v_wlast) : 0; };
+        for(uint64_t p = 0; p < n_pairs; ++p) {
+            const PairDesc& d = b->desc[p];
+            if(d.v_strips != 1) continue;
+            const uint64_t nd = need_of(d);
+            if(nd == 0 || nd > kSlotCap) continue;
+            slot = std::max(slot, nd);
+            per_pair_total += nd;
+        }
+        const uint64_t slots_total = slot * ck_scratch_waves();
+        if(slot > 0 && slots_total < per_pair_total) {
+            // re-lay the arena: [wave slots | pairs that keep their own storage]
+            uint64_t at = slots_total;
+            for(uint64_t p = 0; p < n_pairs; ++p) {
+                PairDesc& d = b->desc[p];
+                if(!(d.la > 0 && d.lb > 0)) {
+                    d.flags_off = at;
+                    continue;
+                }
+                if(d.v_strips == 1 && need_of(d) <= kSlotCap) {
+                    d.flags_off = kCkWaveSlot;
+                } else {
+                    d.flags_off = at;
+                    at += (d.v_strips - 1) * ck_strip_dwords(d.la, d.v_wmain) + ck_strip_dwords(d.la, d.v_wlast);
+                }
+            }
+            b->flag_dwords = at;
+            b->ck_slot_dwords = slot;
+        }
+    }
 
     stage("plan");
     if(hipSetDevice(model->device) != hipSuccess)
@@ -1403,7 +1443,9 @@ bool is_pinned_host(const void* p) {
 // HBM workspace + page-locked staging a chunk of pairs [p0, p1) needs (upper bounds; the plan of
 // batch_create_impl is authoritative and fails cleanly if a chunk does not fit after all)
 struct ChunkNeed {
-    uint64_t arena = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
+    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
+    // checkpoints: per pair, or in per-wavefront slots when that is smaller (batch_create_impl decides the same way)
+    uint64_t arena() const { return fixed + std::min<uint64_t>(ck_sum, ck_max * ck_scratch_waves() + ck_sum / 64); }
 };
 void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
     uint64_t w = 0;
@@ -1415,7 +1457,9 @@ void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
             w = static_cast<uint64_t>(n_strips(static_cast<uint32_t>(lb))) * strip_dwords(static_cast<uint32_t>(la)) * 4;
     }
     const uint64_t strips = std::max<uint64_t>(1, (lb + 255) / 256);  // (narrowest plan: 4 columns per lane)
-    nd.arena += w + 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 1024;
+    nd.ck_sum += w;
+    if(gap_len == 1 && lb <= static_cast<uint64_t>(kWave) * kW && w <= (4ull << 20)) nd.ck_max = std::max(nd.ck_max, w);  // slot-eligible
+    nd.fixed += 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 1024;
     nd.seq_bytes += la + lb;
     nd.meta_bytes += sizeof(PairDesc) + 4 + strips * 16 + 16;  // descriptor, order entry, work items (both lists)
     nd.ops += la + lb;
@@ -1458,33 +1502,59 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         const uint64_t forced = std::strtoull(e, nullptr, 10);
         if(forced > 0) budget = std::min(budget, forced);
     }
-    // ---- chunk schedule.  Full chunks hold ~1.2e10 cells (12 000 pairs of 1 kb) or what the budget
-    // allows; the first two are 1/16 and 1/4 of that, so the GPU has work after ~0.5 ms of planning.
+    // ---- chunk schedule.  Full chunks hold ~1.6e10 cells (16 000 pairs of 1 kb) or what the budget
+    // allows; the first one is a sixth of that (planning it takes ~0.4 ms, then the GPU has work while the next is planned).
     const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
-    constexpr uint64_t kFullCells = 12000ull * 1002 * 1002;
+    constexpr uint64_t kFullCells = 16000ull * 1002 * 1002;
     std::vector<PipeChunk> chunks;
     ChunkNeed max_need;
+    uint64_t max_arena = 0;
     {
+        // cells of every pair once (prefix sums): the schedule is made on them
+        std::vector<long double> cum(n_pairs + 1, 0);
+        for(uint64_t p = 0; p < n_pairs; ++p) {
+            if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
+                return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p));
+            cum[p + 1] = cum[p] + static_cast<long double>(a_off[p + 1] - a_off[p]) * (b_off[p + 1] - b_off[p]);
+        }
+        // targets: a sixth and a third of a full chunk to get the GPU going while the next chunks are planned
+        // and uploaded, then equal chunks of at most kFullCells, the last of them cut 2:1 (the smaller part
+        // fills the ragged end of the larger and its download, the only exposed one, is short)
+        std::vector<uint64_t> targets;
+        {
+            const long double total = cum[n_pairs];
+            long double left = total;
+            for(const uint64_t ramp : {kFullCells / 6, kFullCells / 3}) {
+                if(left <= 0) break;
+                targets.push_back(ramp);
+                left -= static_cast<long double>(ramp);
+            }
+            if(left > 0) {
+                const uint64_t parts = static_cast<uint64_t>(left / kFullCells) + 1;
+                const uint64_t each = static_cast<uint64_t>(left / parts) + 2 * 1002 * 1002;
+                for(uint64_t q = 0; q + 1 < parts; ++q) targets.push_back(each);
+                targets.push_back(each * 2 / 3);
+                targets.push_back(each);  // (what is left)
+            }
+        }
         uint64_t p0 = 0, ops_base = 0;
         while(p0 < n_pairs) {
-            const uint64_t target = chunks.size() == 0 ? kFullCells / 16 : (chunks.size() == 1 ? kFullCells / 4 : kFullCells);
+            const uint64_t target = chunks.size() < targets.size() ? targets[chunks.size()] : kFullCells;
             ChunkNeed nd;
             // per-batch fixed parts of the workspace: the traceback scratch of the persistent wavefronts
             // (viterbi_ck), queue words, alignment slack of the ~15 carved arrays
-            nd.arena = static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + (64u << 10);
+            nd.fixed = static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + (64u << 10);
             uint64_t p1 = p0;
             while(p1 < n_pairs) {
-                if(a_off[p1 + 1] < a_off[p1] || b_off[p1 + 1] < b_off[p1])
-                    return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p1));
                 const uint64_t la = a_off[p1 + 1] - a_off[p1], lb = b_off[p1 + 1] - b_off[p1];
                 ChunkNeed with = nd;
                 chunk_need_add(with, la, lb, gap_len);
-                if(p1 > p0 && (with.arena > budget || with.cells > target)) break;
+                if(p1 > p0 && (with.arena() > budget || with.cells > target)) break;
                 nd = with;
                 ++p1;
             }
             chunks.push_back(PipeChunk{p0, p1, ops_base, nd.ops});
-            max_need.arena = std::max(max_need.arena, nd.arena);
+            max_arena = std::max(max_arena, nd.arena());
             max_need.seq_bytes = std::max(max_need.seq_bytes, nd.seq_bytes);
             max_need.meta_bytes = std::max(max_need.meta_bytes, nd.meta_bytes);
             ops_base += nd.ops;
@@ -1509,7 +1579,14 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
                                   out_bytes_of(max_pairs, max_need.seq_bytes) + 512;
     for(int q = 0; q < n_slots; ++q) {
         coati_hip_model::Slot& sl = model->slots[q];
-        if(sl.stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        // (slot 0 runs on the model's own stream: HIP multiplexes its streams onto a handful of hardware queues --
+        // four by default -- and two slots that share one queue run strictly one after the other)
+        if(sl.stream == nullptr) {
+            if(q == 0)
+                sl.stream = model->stream;
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        }
         if(sl.pinned_bytes < staging_need) {
             if(sl.pinned != nullptr) (void)hipHostFree(sl.pinned);
             sl.pinned = nullptr;
@@ -1517,12 +1594,12 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
             HIP_TRY(hipHostMalloc(&sl.pinned, staging_need, hipHostMallocDefault));
             sl.pinned_bytes = staging_need;
         }
-        if(sl.arena_bytes < max_need.arena) {
+        if(sl.arena_bytes < max_arena) {
             HIP_TRY(hipStreamSynchronize(sl.stream));
             if(sl.arena != nullptr) (void)hipFree(sl.arena);
             sl.arena = nullptr;
             sl.arena_bytes = 0;
-            hipError_t e = hipMalloc(&sl.arena, max_need.arena);
+            hipError_t e = hipMalloc(&sl.arena, max_arena);
             if(e == hipErrorOutOfMemory) {  // give the model's cached blocks back and try again
                 (void)hipGetLastError();
                 std::vector<coati_hip_model::Arena> drop;
@@ -1531,29 +1608,99 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
                     drop.swap(model->free_arenas);
                 }
                 for(const auto& a : drop) (void)hipFree(a.ptr);
-                e = hipMalloc(&sl.arena, max_need.arena);
+                e = hipMalloc(&sl.arena, max_arena);
             }
             if(e != hipSuccess)
                 return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "viterbi_batch: hipMalloc(%llu bytes of workspace): %s",
-                            static_cast<unsigned long long>(max_need.arena), hipGetErrorString(e));
-            sl.arena_bytes = max_need.arena;
+                            static_cast<unsigned long long>(max_arena), hipGetErrorString(e));
+            sl.arena_bytes = max_arena;
         }
     }
     // ---- the pipeline
     struct InFlight {
         coati_hip_batch_t* batch = nullptr;
         const PipeChunk* chunk = nullptr;
-        hipEvent_t done = nullptr;
+        hipEvent_t kernel_done = nullptr, copied = nullptr;
+        bool d2h_submitted = false;
         char* out_stage = nullptr;  // results in the slot's staging block (pageable destinations)
+        uint64_t out_off = 0;
+        int slot = 0;
     };
     InFlight fl[kSlots];
     int rc = COATI_HIP_OK;
+    const bool pipe_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;  // timeline of the call on stderr
+    static const bool no_d2h = std::getenv("COATI_HIP_PIPE_NO_D2H") != nullptr;   // (timing experiment: results stay on the device)
+    const auto t_call = std::chrono::steady_clock::now();
+    auto t_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    hipEvent_t ev_base = nullptr;
+    if(pipe_timing) {
+        HIP_TRY(hipEventCreate(&ev_base));
+        HIP_TRY(hipEventRecord(ev_base, model->slots[0].stream));
+    }
+    // The download of a chunk's results is only SUBMITTED once its kernel has finished: a copy that waits
+    // for a kernel sits at the head of the copy engine's queue and holds up the uploads of the following
+    // chunks behind it (measured: their kernels then started only after the waiting chunk's kernel had ended).
+    auto submit_d2h = [&](InFlight& f) -> hipError_t {
+        f.d2h_submitted = true;
+        coati_hip_model::Slot& sl = model->slots[f.slot];
+        const PipeChunk& c = *f.chunk;
+        const uint64_t n = c.p1 - c.p0;
+        coati_hip_batch* b = f.batch;
+        hipError_t e = hipSuccess;
+        if(no_d2h) {
+            f.out_stage = nullptr;
+        } else if(out_pinned) {
+            f.out_stage = nullptr;
+            if(scores != nullptr) e = hipMemcpyAsync(scores + c.p0, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
+            if(e == hipSuccess && ops_off != nullptr) e = hipMemcpyAsync(ops_off + c.p0, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream);
+            if(e == hipSuccess && ops_len != nullptr) e = hipMemcpyAsync(ops_len + c.p0, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream);
+            if(e == hipSuccess && ops != nullptr && c.ops_bytes > 0) e = hipMemcpyAsync(ops + c.ops_base, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, sl.stream);
+        } else {
+            f.out_stage = static_cast<char*>(sl.pinned) + f.out_off;
+            char* at = f.out_stage;
+            if(scores != nullptr) e = hipMemcpyAsync(at, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
+            at += (n * sizeof(float) + 255) / 256 * 256;
+            if(e == hipSuccess && ops_off != nullptr) e = hipMemcpyAsync(at, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream);
+            at += (n * sizeof(uint64_t) + 255) / 256 * 256;
+            if(e == hipSuccess && ops_len != nullptr) e = hipMemcpyAsync(at, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream);
+            at += (n * sizeof(uint32_t) + 255) / 256 * 256;
+            if(e == hipSuccess && ops != nullptr && c.ops_bytes > 0) e = hipMemcpyAsync(at, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, sl.stream);
+        }
+        if(e == hipSuccess && f.copied == nullptr) e = hipEventCreateWithFlags(&f.copied, hipEventDisableTiming);
+        if(e == hipSuccess) e = hipEventRecord(f.copied, sl.stream);
+        return e;
+    };
+    // submit the download of every chunk whose kernel has finished by now (never blocks)
+    auto drain_ready = [&]() -> int {
+        for(InFlight& f : fl) {
+            if(f.batch == nullptr || f.d2h_submitted) continue;
+            const hipError_t q = hipEventQuery(f.kernel_done);
+            if(q == hipErrorNotReady) continue;
+            hipError_t e = q;
+            if(e == hipSuccess) e = submit_d2h(f);
+            if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+        }
+        return COATI_HIP_OK;
+    };
     // wait for a slot's chunk, hand its results to the caller, free the slot
     auto finish = [&](InFlight& f) -> int {
         if(f.batch == nullptr) return COATI_HIP_OK;
         int r = COATI_HIP_OK;
-        const hipError_t e = hipEventSynchronize(f.done);
+        hipError_t e = hipSuccess;
+        if(!f.d2h_submitted) {
+            e = hipEventSynchronize(f.kernel_done);
+            if(e == hipSuccess) e = submit_d2h(f);
+        }
+        if(e == hipSuccess) e = hipEventSynchronize(f.copied);
         if(e != hipSuccess) r = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+        if(pipe_timing && r == COATI_HIP_OK) {
+            hipEvent_t* ev = f.batch->ev[(f.batch->n_launches - 1) % coati_hip_batch::kTimingRing];
+            float k0 = 0, k1 = 0;
+            (void)hipEventElapsedTime(&k0, ev_base, ev[0]);
+            (void)hipEventElapsedTime(&k1, ev_base, ev[1]);
+            std::fprintf(stderr, "viterbi_batch: chunk of %llu pairs: kernel on the GPU %.2f .. %.2f ms, results on the host at %.2f ms\n",
+                         static_cast<unsigned long long>(f.chunk->p1 - f.chunk->p0), k0, k1, t_ms());
+        }
         const PipeChunk& c = *f.chunk;
         const uint64_t n = c.p1 - c.p0;
         if(r == COATI_HIP_OK && f.out_stage != nullptr) {
@@ -1566,7 +1713,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
             at += (n * sizeof(uint32_t) + 255) / 256 * 256;
             if(ops != nullptr && c.ops_bytes > 0) std::memcpy(ops + c.ops_base, at, c.ops_bytes);
         }
-        if(r == COATI_HIP_OK && ops_off != nullptr)
+        if(r == COATI_HIP_OK && ops_off != nullptr && !no_d2h)
             for(uint64_t p = c.p0; p < c.p1; ++p) ops_off[p] += c.ops_base;
         coati_hip_batch_destroy(f.batch);
         f.batch = nullptr;
@@ -1574,10 +1721,12 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     };
     for(size_t ci = 0; ci < chunks.size() && rc == COATI_HIP_OK; ++ci) {
         const PipeChunk& c = chunks[ci];
+        const double t_begin = t_ms();
         const int q = static_cast<int>(ci % static_cast<size_t>(n_slots));
         coati_hip_model::Slot& sl = model->slots[q];
         InFlight& f = fl[q];
-        rc = finish(f);
+        rc = drain_ready();
+        if(rc == COATI_HIP_OK) rc = finish(f);
         if(rc != COATI_HIP_OK) break;
         const uint64_t n = c.p1 - c.p0;
         const uint64_t out_off = (sl.pinned_bytes - out_bytes_of(n, c.ops_bytes)) / 256 * 256;  // results land behind the uploads
@@ -1611,38 +1760,39 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         }
         if(rc != COATI_HIP_OK) break;
         f.chunk = &c;
+        f.slot = q;
+        f.out_off = out_off;
+        f.d2h_submitted = false;
         rc = coati_hip_viterbi_launch(f.batch);
         if(rc != COATI_HIP_OK) break;
-        // results: asynchronous copies on the slot's stream, straight into page-locked destinations or
-        // into the tail of the slot's staging block
         hipError_t e = hipSuccess;
-        coati_hip_batch* b = f.batch;
-        if(out_pinned) {
-            f.out_stage = nullptr;
-            if(scores != nullptr) e = hipMemcpyAsync(scores + c.p0, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
-            if(e == hipSuccess && ops_off != nullptr) e = hipMemcpyAsync(ops_off + c.p0, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream);
-            if(e == hipSuccess && ops_len != nullptr) e = hipMemcpyAsync(ops_len + c.p0, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream);
-            if(e == hipSuccess && ops != nullptr && c.ops_bytes > 0) e = hipMemcpyAsync(ops + c.ops_base, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, sl.stream);
-        } else {
-            f.out_stage = static_cast<char*>(sl.pinned) + out_off;
-            char* at = f.out_stage;
-            if(scores != nullptr) e = hipMemcpyAsync(at, b->d_scores, n * sizeof(float), hipMemcpyDeviceToHost, sl.stream);
-            at += (n * sizeof(float) + 255) / 256 * 256;
-            if(e == hipSuccess && ops_off != nullptr) e = hipMemcpyAsync(at, b->d_ops_start, n * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream);
-            at += (n * sizeof(uint64_t) + 255) / 256 * 256;
-            if(e == hipSuccess && ops_len != nullptr) e = hipMemcpyAsync(at, b->d_ops_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.stream);
-            at += (n * sizeof(uint32_t) + 255) / 256 * 256;
-            if(e == hipSuccess && ops != nullptr && c.ops_bytes > 0) e = hipMemcpyAsync(at, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, sl.stream);
-        }
-        if(e == hipSuccess && f.done == nullptr) e = hipEventCreateWithFlags(&f.done, hipEventDisableTiming);
-        if(e == hipSuccess) e = hipEventRecord(f.done, sl.stream);
+        if(f.kernel_done == nullptr) e = hipEventCreateWithFlags(&f.kernel_done, hipEventDisableTiming);
+        if(e == hipSuccess) e = hipEventRecord(f.kernel_done, sl.stream);
         if(e != hipSuccess) rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+        if(rc == COATI_HIP_OK) rc = drain_ready();
+        if(pipe_timing)
+            std::fprintf(stderr, "viterbi_batch: chunk %zu (%llu pairs, slot %d) host work %.2f .. %.2f ms\n", ci,
+                         static_cast<unsigned long long>(n), q, t_begin, t_ms());
     }
-    for(InFlight& f : fl) {
+    if(pipe_timing) std::fprintf(stderr, "viterbi_batch: all chunks enqueued at %.2f ms\n", t_ms());
+    // the rest in the order the kernels finish
+    for(size_t k = 0; k < chunks.size() && k < static_cast<size_t>(n_slots); ++k) {
+        const size_t ci = chunks.size() - std::min<size_t>(chunks.size(), static_cast<size_t>(n_slots)) + k;
+        InFlight& f = fl[ci % static_cast<size_t>(n_slots)];
         const int r = finish(f);
         if(rc == COATI_HIP_OK) rc = r;
-        if(f.done != nullptr) (void)hipEventDestroy(f.done);
     }
+    for(InFlight& f : fl) {
+        if(f.batch != nullptr) {  // (only after an error above)
+            (void)hipStreamSynchronize(model->slots[f.slot].stream);
+            coati_hip_batch_destroy(f.batch);
+            f.batch = nullptr;
+        }
+        if(f.kernel_done != nullptr) (void)hipEventDestroy(f.kernel_done);
+        if(f.copied != nullptr) (void)hipEventDestroy(f.copied);
+    }
+    if(pipe_timing) std::fprintf(stderr, "viterbi_batch: done at %.2f ms\n", t_ms());
+    if(ev_base != nullptr) (void)hipEventDestroy(ev_base);
     return rc;
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "viterbi_batch: host allocation failed");
@@ -1702,7 +1852,30 @@ int coati_hip_debug_viterbi_flags(coati_hip_batch_t* b, uint64_t pair, uint8_t* 
     uint8_t* d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n));
     hipError_t e = hipSuccess;
-    if(b->ck) {
+    if(b->ck && b->desc[pair].flags_off == kCkWaveSlot) {
+        // the pair's checkpoints lived in a wavefront's slot and are gone: run the pair again, alone, in a
+        // batch that keeps them, and decode that
+        const PairDesc& d = b->desc[pair];
+        std::vector<uint8_t> ha(std::max<uint32_t>(d.la, 1)), hb(std::max<uint32_t>(d.lb, 1));
+        e = hipMemcpy(ha.data(), b->d_a + d.a_off, d.la, hipMemcpyDeviceToHost);
+        if(e == hipSuccess) e = hipMemcpy(hb.data(), b->d_b + d.b_off, d.lb, hipMemcpyDeviceToHost);
+        if(e != hipSuccess) {
+            (void)hipFree(d_out);
+            return fail(COATI_HIP_EHIP, "debug_viterbi_flags: %s", hipGetErrorString(e));
+        }
+        const uint64_t ao[2] = {0, d.la}, bo[2] = {0, d.lb};
+        const uint32_t ti = d.table;
+        BatchOpts keep;
+        keep.ck_per_pair = true;
+        keep.force_w_main = d.v_wmain;
+        coati_hip_batch_t* one = nullptr;
+        int rc1 = batch_create_impl(b->model, 1, ha.data(), ao, hb.data(), bo, &ti, &keep, &one);
+        if(rc1 == COATI_HIP_OK) rc1 = coati_hip_viterbi_launch(one);
+        if(rc1 == COATI_HIP_OK) rc1 = coati_hip_debug_viterbi_flags(one, 0, out, capacity);
+        if(one != nullptr) coati_hip_batch_destroy(one);
+        (void)hipFree(d_out);
+        return rc1;
+    } else if(b->ck) {
         // no bits in memory: every tile recomputed from the checkpoints by the traceback's own routine
         constexpr uint32_t kWaves = 64;
         uint32_t* d_scratch = nullptr;

@@ -86,6 +86,12 @@ __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
 //                               float4 (q), one band c per kCkRows steps
 // from which any (band, lane) tile can be recomputed on its own.  8/W + 8/kCkRows bytes per cell.
 constexpr uint32_t kCkRowsLog2 = 4, kCkRows = 1u << kCkRowsLog2;
+// A single-strip pair needs its checkpoints only until its own wavefront has walked it, so a large
+// batch does not reserve them per pair: PairDesc::flags_off == kCkWaveSlot means "the slot of the
+// wavefront that processes the pair" (BatchDeviceView::ck_slot_dwords dwords per resident wavefront at
+// the start of the arena).  Pairs of several strips (other wavefronts read their checkpoints) and the
+// pairs of small batches keep per-pair storage.
+constexpr uint64_t kCkWaveSlot = ~0ull;
 __host__ __device__ constexpr uint32_t ck_rowck_quads(uint32_t w) { return w / 2; }
 __host__ __device__ inline uint32_t ck_bands(uint32_t la) { return (la + kWave + kCkRows - 1) / kCkRows; }
 __host__ __device__ inline uint64_t ck_colin_dwords(uint32_t la) { return static_cast<uint64_t>(la + kWave) * (2 * kWave); }
@@ -412,6 +418,7 @@ struct BatchDeviceView {
     uint64_t* ops_start;
     uint32_t* ops_len;
     uint32_t* wscratch;  // viterbi_ck: per-wavefront scratch of the traceback (decision bits of one round)
+    uint64_t ck_slot_dwords;  // viterbi_ck: size of one per-wavefront checkpoint slot (0: every pair has its own storage)
     float* mdi;        // Forward: fp32 M/D/I of every body cell
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
 };

@@ -207,9 +207,10 @@ __device__ __forceinline__ void ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
     }
 }
 
-// Checkpoint arena of strip `strip` of a pair (dwords from the arena start)
+// Checkpoints of strip `strip` of a pair (dwords from the start of the PAIR's checkpoint area, which is
+// PairDesc::flags_off in the arena or the slot of the wavefront that processes the pair)
 __device__ __forceinline__ uint64_t ck_strip_base(const PairDesc& pd, uint32_t strip) {
-    return pd.flags_off + strip * ck_strip_dwords(pd.la, pd.v_wmain);
+    return strip * ck_strip_dwords(pd.la, pd.v_wmain);
 }
 
 // One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
@@ -475,6 +476,11 @@ __device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc&
     }
 }
 
+// Wavefronts per workgroup.  Two, not four: a workgroup's slot on its CU is only free for the next launch's
+// workgroups when ALL its wavefronts have left, and the SIMDs' issue arbitration makes a workgroup's
+// wavefronts finish far apart -- with four per workgroup the ragged end of a launch overlaps the start of
+// the next one (pipelined chunks, consecutive batches on two streams) noticeably worse.
+constexpr int kCkWaves = 2;
 constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
 
 
@@ -613,18 +619,19 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
 // lets four workgroups (16 wavefronts, 4 per SIMD) share a CU.  Otherwise (per-leaf tables of
 // `coati msa`) every wavefront keeps the table of its current pair.
 template <bool kSharedTab>
-__global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
+__global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ ck, float* __restrict__ bnd, float* __restrict__ scores, uint8_t* __restrict__ ops,
-    uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t* __restrict__ wscratch, uint32_t dbg) {
-    __shared__ float tab_all[kSharedTab ? 1 : kFillWaves][kTabRows * kTabStride];
+    uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t* __restrict__ wscratch,
+    uint64_t ck_slot_dwords, uint32_t dbg) {
+    __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[kSharedTab ? 0 : threadIdx.x / kWave];
     uint32_t tab_held = 0xffffffffu;
     if constexpr(kSharedTab) {
-        for(int idx = threadIdx.x; idx < kTabFloats; idx += kFillWaves * kWave) {
+        for(int idx = threadIdx.x; idx < kTabFloats; idx += kCkWaves * kWave) {
             const int r = idx / kTabCols, c = idx - r * kTabCols;
             tab[r * kTabStride + c] = table[idx];
         }
@@ -633,9 +640,12 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
     }
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
-    uint32_t* wbits = wscratch + static_cast<uint64_t>(blockIdx.x * kFillWaves + threadIdx.x / kWave) * kCkScratchDwords;
+    // (readfirstlane: the compiler must know this is wave-uniform, or every buffer descriptor derived from it
+    // lands in VGPRs and each store becomes a readfirstlane loop)
+    const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * kCkWaves + threadIdx.x / kWave)));
+    uint32_t* wbits = wscratch + static_cast<uint64_t>(wave_id) * kCkScratchDwords;
 #ifdef COATI_FILL_TRACE
-    const uint32_t trace_wave = (blockIdx.x * kFillWaves + threadIdx.x / kWave) & 4095u;
+    const uint32_t trace_wave = (blockIdx.x * kCkWaves + threadIdx.x / kWave) & 4095u;
     uint32_t trace_n = 1;
     if(lane_id == 0) {
         g_ck_trace[trace_wave * 16] = __builtin_amdgcn_s_memrealtime();
@@ -657,6 +667,8 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
         const WorkItem item = items[ticket];
         const uint32_t pair = item.pair, strip = item.strip;
         const PairDesc pd = pairs[pair];
+        // the pair's checkpoint area: its own, or (single-strip pair of a large batch) this wavefront's slot
+        uint32_t* __restrict__ ckp = ck + (pd.flags_off == kCkWaveSlot ? static_cast<uint64_t>(wave_id) * ck_slot_dwords : pd.flags_off);
         bool handoff_ok = true;
         if constexpr(!kSharedTab) {
             if(pd.table != tab_held) {  // (wave-uniform)
@@ -673,11 +685,11 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
             if(w == 16)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
             else if(w == 8)
-                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
+                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
             else
-                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ck, bnd, scores, progress);
+                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
         }
         COATI_CK_STAMP(0);  // fill of this item done
         if(strip + 1 < pd.v_strips || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 4) void viterbi_ck(
             (void)terminal_state(k, m, d, in, score);
             if(lane == 0) scores[pair] = score;
         }
-        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ck, wbits, (dbg & 2u) != 0u};
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u};
         if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[3], 1ull);
         const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len);
         // NaN = "this pair failed": a producer strip never arrived (spin bound), or the walk lost its way
@@ -729,7 +741,7 @@ __global__ __launch_bounds__(kWave) void ck_all_flags(const float* __restrict__ 
     const uint32_t bands = ck_bands(pd.la);
     for(uint32_t strip = 0; strip < pd.v_strips; ++strip) {
         const uint32_t col0 = strip * kWave * pd.v_wmain;
-        const CkStrip sp = ck_strip_of(pd, ck, col0);
+        const CkStrip sp = ck_strip_of(pd, ck + pd.flags_off, col0);
         const uint32_t n_tiles = bands * kWave;
         for(uint32_t base = blockIdx.x * kWave; base < n_tiles; base += gridDim.x * kWave) {
             const uint32_t tile = base + lane;
@@ -774,7 +786,7 @@ struct CkShape {
 };
 CkShape ck_launch_shape(uint32_t n_items, bool shared_tab) {
     constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
-    const int max_blocks = shared_tab ? 4 : 3;  // <= 128 VGPRs -> 4 waves per SIMD; per-wave tables: 3 x 49.8 KB of LDS
+    const int max_blocks = shared_tab ? 4 : 3;  // wavefronts per SIMD: <= 128 VGPRs -> 4; per-wavefront tables (12.4 KB each): 12 per CU
     static const int forced = [] {
         const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
         return e != nullptr ? std::atoi(e) : 0;
@@ -784,11 +796,13 @@ CkShape ck_launch_shape(uint32_t n_items, bool shared_tab) {
     if(forced >= 1 && forced <= max_blocks) best = forced;
     // LDS footprint per block that admits exactly `best` blocks on a CU's 160 KB: more than
     // 160/(best+1) KB, and `best` of them fit with room for the allocation granule
-    const size_t stat = (shared_tab ? 1 : kFillWaves) * kTabRows * kTabStride * sizeof(float);
-    constexpr size_t kPerBlock[5] = {0, 96 * 1024, 72 * 1024, 52 * 1024, 38 * 1024};
+    const size_t stat = (shared_tab ? 1 : kCkWaves) * kTabRows * kTabStride * sizeof(float);
+    static_assert(kCkWaves == 2, "LDS table below is for two wavefronts per workgroup");
+    // `best` wavefronts per SIMD = 2 * best workgroups per CU: per-workgroup LDS in (160/(2 best + 1), 160/(2 best)] KB
+    constexpr size_t kPerBlock[5] = {0, 72 * 1024, 38 * 1024, 25 * 1024, 19 * 1024};
     const size_t stat_r = (stat + 255) / 256 * 256;
     const size_t dyn = kPerBlock[best] > stat_r ? kPerBlock[best] - stat_r : 0;
-    return {kCUs * static_cast<uint32_t>(best), dyn};
+    return {kCUs * static_cast<uint32_t>(best) * (4 / kCkWaves), dyn};
 }
 
 }  // namespace
@@ -804,7 +818,7 @@ extern "C" int coati_hip_debug_trace(unsigned long long* out) {
 }
 #endif
 
-uint32_t ck_scratch_waves() { return 256u * 4u * kFillWaves; }
+uint32_t ck_scratch_waves() { return 256u * 4u * 4u; }  // 4 wavefronts on each of the 1 024 SIMDs
 uint64_t ck_scratch_dwords_per_wave() { return kCkScratchDwords; }
 
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
@@ -824,13 +838,13 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
         if(e != hipSuccess) return e;
     }
     if(shared_tab)
-        hipLaunchKernelGGL(viterbi_ck<true>, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, stream, v.table,
+        hipLaunchKernelGGL(viterbi_ck<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, dbg);
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, dbg);
     else
-        hipLaunchKernelGGL(viterbi_ck<false>, dim3(shape.grid), dim3(kFillWaves * kWave), shape.dynamic_lds, stream, v.table,
+        hipLaunchKernelGGL(viterbi_ck<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, dbg);
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, dbg);
     if(dbg & 2u) {
         unsigned long long st[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
         e = hipStreamSynchronize(stream);

@@ -109,6 +109,15 @@ def synth_encoded(first: int, n: int, seed_base: int = 0xC0A71, n_codons: int = 
     return a_cat, a_off, b_cat, b_off
 
 
+def synth_lengths(first: int, n: int, seed_base: int = 0xC0A71, n_codons: int = 334):
+    """(len_a[n], len_b[n]) of the synthetic pairs [first, first+n) without materialising them."""
+    a_off = np.zeros(n + 1, np.uint64)
+    b_off = np.zeros(n + 1, np.uint64)
+    _check(load().coati_host_synth_encoded(C.c_ulonglong(first), C.c_ulonglong(n), C.c_ulonglong(seed_base),
+                                           C.c_uint(n_codons), None, _p(a_off), None, _p(b_off)))
+    return np.diff(a_off), np.diff(b_off)
+
+
 def synth_raw(index: int, seed_base: int = 0xC0A71, n_codons: int = 334):
     cap = n_codons * 3 * 3 + 64
     a = C.create_string_buffer(cap)

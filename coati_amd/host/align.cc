@@ -4,7 +4,9 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <exception>
 #include <fstream>
 #include <iostream>
@@ -28,6 +30,21 @@ namespace {
 void hip_check(int rc) {
     if(rc != COATI_HIP_OK) throw_hip(rc);
 }
+// COATI_HOST_TIMING=1: wall time of the stages of a driver on stderr
+struct host_timer {
+    const char* what;
+    bool on;
+    std::chrono::steady_clock::time_point t0, prev;
+    explicit host_timer(const char* w) : what(w), on(std::getenv("COATI_HOST_TIMING") != nullptr) { t0 = prev = std::chrono::steady_clock::now(); }
+    void stage(const char* name) {
+        if(!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::cerr << what << ": " << name << " " << std::chrono::duration<double, std::milli>(t - prev).count() << " ms (total "
+                  << std::chrono::duration<double, std::milli>(t - t0).count() << ")\n";
+        prev = t;
+    }
+};
+
 coati_hip_model* make_model(const alignment_t& aln) {
     if(aln.gap.len < 1) throw std::invalid_argument("Gap unit length must be positive.");
     if(aln.subst_matrix.size() != kTableRows * kTableCols) throw std::invalid_argument("Substitution matrix not set.");
@@ -282,42 +299,45 @@ std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, 
     return out;
 }
 
-bool marg_alignment_batch(alignment_t& aln) {
+namespace {
+// The encoded pairs of a --batch input and what is needed to print them again.
+struct batch_input_t {
+    std::size_t n{0};
+    std::vector<data_t> pairs;
+    std::vector<std::string> ancs, dess;
+    std::vector<uint64_t> a_off, b_off;
+    std::vector<unsigned char> a_cat, b_cat;
+};
+batch_input_t read_batch_input(alignment_t& aln) {
     data_t all = read_input(aln.data.path);
     if(all.size() == 0 || all.size() % 2 != 0) throw std::invalid_argument("Batch input needs an even number of sequences.");
-    set_subst(aln);
-    const std::size_t n = all.size() / 2;
-    std::vector<data_t> pairs(n);
-    std::vector<std::string> ancs(n), dess(n);
+    batch_input_t in;
+    const std::size_t n = in.n = all.size() / 2;
+    in.pairs.resize(n), in.ancs.resize(n), in.dess.resize(n);
     parallel_for(n, 256, [&](std::size_t p) {
-        pairs[p].names = {all.names[2 * p], all.names[2 * p + 1]};
-        pairs[p].seqs = {all.seqs[2 * p], all.seqs[2 * p + 1]};
-        process_marginal(pairs[p], aln.gap, std::string(), aln.rev);
-        ancs[p] = pairs[p].seqs[0];
-        dess[p] = pairs[p].seqs[1];
+        in.pairs[p].names = {all.names[2 * p], all.names[2 * p + 1]};
+        in.pairs[p].seqs = {all.seqs[2 * p], all.seqs[2 * p + 1]};
+        process_marginal(in.pairs[p], aln.gap, std::string(), aln.rev);
+        in.ancs[p] = in.pairs[p].seqs[0];
+        in.dess[p] = in.pairs[p].seqs[1];
     });
-    std::vector<uint64_t> a_off(n + 1, 0), b_off(n + 1, 0);
+    in.a_off.assign(n + 1, 0), in.b_off.assign(n + 1, 0);
     for(std::size_t p = 0; p < n; ++p) {
-        a_off[p + 1] = a_off[p] + ancs[p].size();
-        b_off[p + 1] = b_off[p] + dess[p].size();
+        in.a_off[p + 1] = in.a_off[p] + in.ancs[p].size();
+        in.b_off[p + 1] = in.b_off[p] + in.dess[p].size();
     }
-    std::vector<unsigned char> a_cat(a_off[n]), b_cat(b_off[n]);
+    in.a_cat.resize(in.a_off[n]), in.b_cat.resize(in.b_off[n]);
     parallel_for(n, 256, [&](std::size_t p) {
-        encode_ancestor(ancs[p], a_cat.data() + a_off[p]);
-        unsigned char* des = b_cat.data() + b_off[p];
-        encode_descendant(dess[p], des);
-        for(std::size_t i = 0; i < dess[p].size(); ++i)
+        encode_ancestor(in.ancs[p], in.a_cat.data() + in.a_off[p]);
+        unsigned char* des = in.b_cat.data() + in.b_off[p];
+        encode_descendant(in.dess[p], des);
+        for(std::size_t i = 0; i < in.dess[p].size(); ++i)
             if(des[i] >= kTableCols) throw std::invalid_argument("Invalid character in descendant sequence.");
     });
-    coati_hip_model* model = make_model(aln);
-    std::vector<float> scores(n);
-    std::vector<uint8_t> ops(a_cat.size() + b_cat.size() + 1);
-    std::vector<uint64_t> off(n);
-    std::vector<uint32_t> len(n);
-    const int rc = coati_hip_viterbi_batch(model, n, a_cat.data(), a_off.data(), b_cat.data(), b_off.data(), scores.data(),
-                                           ops.data(), a_cat.size() + b_cat.size(), off.data(), len.data());
-    coati_hip_model_destroy(model);
-    hip_check(rc);
+    return in;
+}
+void write_batch_output(alignment_t& aln, batch_input_t& in, const std::vector<float>& scores, const std::vector<uint8_t>& ops,
+                        const std::vector<uint64_t>& off, const std::vector<uint32_t>& len) {
     std::ofstream file;
     std::ostream* out = &std::cout;
     if(!(aln.output.empty() || aln.output == "-")) {
@@ -325,12 +345,145 @@ bool marg_alignment_batch(alignment_t& aln) {
         if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
         out = &file;
     }
-    for(std::size_t p = 0; p < n; ++p) {
-        pairs[p].seqs.assign(2, std::string());
-        ops_to_alignment(ops.data() + off[p], len[p], ancs[p], dess[p], pairs[p].seqs[0], pairs[p].seqs[1]);
-        pairs[p].score = scores[p];
-        restore_end_stops(pairs[p], aln.gap);
-        write_json(pairs[p], *out, p, n);
+    // gapped strings for all pairs in parallel, then the (ordered) JSON stream
+    parallel_for(in.n, 64, [&](std::size_t p) {
+        in.pairs[p].seqs.assign(2, std::string());
+        ops_to_alignment(ops.data() + off[p], len[p], in.ancs[p], in.dess[p], in.pairs[p].seqs[0], in.pairs[p].seqs[1]);
+        in.pairs[p].score = scores[p];
+        restore_end_stops(in.pairs[p], aln.gap);
+    });
+    for(std::size_t p = 0; p < in.n; ++p) write_json(in.pairs[p], *out, p, in.n);
+}
+}  // namespace
+
+bool marg_alignment_batch(alignment_t& aln) {
+    host_timer tm("alignpair --batch");
+    batch_input_t in = read_batch_input(aln);
+    tm.stage("read + encode");
+    set_subst(aln);
+    coati_hip_model* model = make_model(aln);
+    tm.stage("model");
+    const std::size_t n = in.n;
+    std::vector<float> scores(n);
+    std::vector<uint8_t> ops(in.a_cat.size() + in.b_cat.size() + 1);
+    std::vector<uint64_t> off(n);
+    std::vector<uint32_t> len(n);
+    const int rc = coati_hip_viterbi_batch(model, n, in.a_cat.data(), in.a_off.data(), in.b_cat.data(), in.b_off.data(),
+                                           scores.data(), ops.data(), in.a_cat.size() + in.b_cat.size(), off.data(), len.data());
+    coati_hip_model_destroy(model);
+    hip_check(rc);
+    tm.stage("device (upload, kernels, download)");
+    write_batch_output(aln, in, scores, ops, off, len);
+    tm.stage("gapped strings + output");
+    return true;
+}
+
+namespace {
+// libcoati_hip_dist.so (the RCCL layer) is loaded on demand, so that the single-GPU tools run on a box
+// without librccl.
+struct dist_api_t {
+    void* handle{nullptr};
+    const char* (*last_error)(){nullptr};
+    int (*unique_id)(void*){nullptr};
+    int (*init)(const void*, int, int, int, void**){nullptr};
+    void (*destroy)(void*){nullptr};
+    int (*broadcast_model)(void*, int, float*, uint32_t, uint32_t*, float*, int*){nullptr};
+    int (*viterbi)(void*, int, coati_hip_model*, uint64_t, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, float*,
+                   uint8_t*, uint64_t, uint64_t*, uint32_t*){nullptr};
+};
+dist_api_t load_dist_api() {
+    dist_api_t api;
+    // next to libcoati_host.so (same directory as this library)
+    std::string dir;
+    Dl_info info;
+    if(dladdr(reinterpret_cast<void*>(&load_dist_api), &info) != 0 && info.dli_fname != nullptr) {
+        dir = info.dli_fname;
+        const std::size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+    }
+    for(const std::string& path : {dir + "libcoati_hip_dist.so", std::string("libcoati_hip_dist.so")}) {
+        api.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if(api.handle != nullptr) break;
+    }
+    if(api.handle == nullptr) throw std::runtime_error(std::string("--devices needs libcoati_hip_dist.so (make dist): ") + dlerror());
+    auto sym = [&](const char* name) {
+        void* p = dlsym(api.handle, name);
+        if(p == nullptr) throw std::runtime_error(std::string("libcoati_hip_dist.so lacks ") + name);
+        return p;
+    };
+    api.last_error = reinterpret_cast<decltype(api.last_error)>(sym("coati_hip_dist_last_error"));
+    api.unique_id = reinterpret_cast<decltype(api.unique_id)>(sym("coati_hip_dist_unique_id"));
+    api.init = reinterpret_cast<decltype(api.init)>(sym("coati_hip_dist_init"));
+    api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("coati_hip_dist_destroy"));
+    api.broadcast_model = reinterpret_cast<decltype(api.broadcast_model)>(sym("coati_hip_dist_broadcast_model"));
+    api.viterbi = reinterpret_cast<decltype(api.viterbi)>(sym("coati_hip_dist_viterbi"));
+    return api;
+}
+}  // namespace
+
+bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std::string& id_file) {
+    if(world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("--devices: bad rank / world");
+    host_timer tm(rank == 0 ? "alignpair --batch --devices (rank 0)" : "alignpair --batch --devices");
+    const dist_api_t api = load_dist_api();
+    auto dist_check = [&](int rc) {
+        if(rc != 0) throw std::runtime_error(api.last_error());
+    };
+    batch_input_t in = read_batch_input(aln);  // every rank reads the same input: only results cross the links
+    tm.stage("read + encode");
+    // ---- rendezvous: rank 0 leaves the id in a file (written under another name, then renamed)
+    unsigned char id[128];
+    if(rank == 0) {
+        dist_check(api.unique_id(id));
+        const std::string tmp = id_file + ".tmp";
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(reinterpret_cast<const char*>(id), sizeof id);
+        f.close();
+        if(!f || std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("--devices: cannot write " + id_file);
+    } else {
+        bool got = false;
+        for(int tries = 0; tries < 6000 && !got; ++tries) {  // up to a minute
+            std::ifstream f(id_file, std::ios::binary);
+            if(f && f.read(reinterpret_cast<char*>(id), sizeof id) && f.gcount() == static_cast<std::streamsize>(sizeof id)) got = true;
+            if(!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if(!got) throw std::runtime_error("--devices: rank 0 never published the rendezvous id (" + id_file + ")");
+    }
+    void* comm = nullptr;
+    dist_check(api.init(id, world, rank, aln.device, &comm));
+    struct comm_guard {
+        const dist_api_t& api;
+        void* c;
+        ~comm_guard() { api.destroy(c); }
+    } guard{api, comm};
+    tm.stage("communicator");
+    // ---- the model: computed on rank 0 only, broadcast, so every rank scores with the same bits
+    std::vector<float> table(kTableRows * kTableCols, 0.f);
+    uint32_t n_tables = 1;
+    float consts[4] = {0, 0, 0, 0};
+    int gap_len = static_cast<int>(aln.gap.len);
+    if(rank == 0) {
+        set_subst(aln);
+        std::copy(aln.subst_matrix.data(), aln.subst_matrix.data() + table.size(), table.begin());
+        const auto k = gap_log_consts(aln.gap);
+        std::copy(k.begin(), k.end(), consts);
+    }
+    dist_check(api.broadcast_model(comm, 0, table.data(), 1, &n_tables, consts, &gap_len));
+    coati_hip_model* model = nullptr;
+    hip_check(coati_hip_model_create(table.data(), consts[0], consts[1], consts[2], consts[3], gap_len, aln.device, &model));
+    tm.stage("model broadcast");
+    const std::size_t n = in.n;
+    std::vector<float> scores(rank == 0 ? n : 0);
+    std::vector<uint8_t> ops(rank == 0 ? in.a_cat.size() + in.b_cat.size() + 1 : 1);
+    std::vector<uint64_t> off(rank == 0 ? n : 0);
+    std::vector<uint32_t> len(rank == 0 ? n : 0);
+    const int rc = api.viterbi(comm, 0, model, n, in.a_cat.data(), in.a_off.data(), in.b_cat.data(), in.b_off.data(), scores.data(),
+                               ops.data(), in.a_cat.size() + in.b_cat.size(), off.data(), len.data());
+    coati_hip_model_destroy(model);
+    dist_check(rc);
+    tm.stage("sharded Viterbi + gather");
+    if(rank == 0) {
+        write_batch_output(aln, in, scores, ops, off, len);
+        tm.stage("gapped strings + output");
     }
     return true;
 }

@@ -89,6 +89,12 @@ void marg_sample(alignment_t& aln, std::size_t sample_size, random_t& rand);
 // Batch extension: the input holds 2n sequences, consecutive ones form a pair
 // (reference first unless rev); writes a JSON array of n alignments.
 bool marg_alignment_batch(alignment_t& aln);
+// The same over several GPUs, ONE PROCESS PER GPU (this process is rank `rank` of `world` and drives
+// aln.device): every rank reads the input, rank 0 computes the model and broadcasts it (ncclBroadcast),
+// each rank aligns its shard of coati_hip_shard_bounds, the results are gathered to rank 0 over RCCL
+// and rank 0 writes the output (include/coati_hip_dist.h; libcoati_hip_dist.so is loaded on demand).
+// id_file: where rank 0 leaves the rendezvous id for the others.
+bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std::string& id_file);
 
 // The pairwise step of `coati msa` (align_leafs, src/lib/align_msa.cc:285-318) for all leaves at
 // once: every leaf is aligned to `ref_seq` with the substitution table of ITS branch length

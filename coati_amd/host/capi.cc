@@ -1,3 +1,7 @@
+#include <vector>
+#include <algorithm>
+#include <mutex>
+#include <thread>
 // C entry points of libcoati_host.so used by the Python tests and bench.py to
 // reach the C++ host layer (model construction, sequence preparation, the
 // synthetic workload).  Errors: non-zero return + coati_host_last_error().
@@ -239,18 +243,48 @@ int coati_host_synth_encoded(unsigned long long first, unsigned long long n, uns
         coati_amd::synth_params_t prm;
         prm.seed_base = seed_base;
         prm.n_codons = n_codons;
-        std::string anc, des;
+        // pair p is a function of its index: lengths first (parallel), prefix sums, then the codes in place
+        const unsigned n_threads = static_cast<unsigned>(std::min<unsigned long long>(
+            std::max<unsigned long long>(1, n / 512), std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
+        auto run = [&](auto&& body) {
+            std::vector<std::thread> pool;
+            std::exception_ptr failure;
+            std::mutex lock;
+            for(unsigned t = 0; t < n_threads; ++t)
+                pool.emplace_back([&, t] {
+                    try {
+                        body(n * t / n_threads, n * (t + 1) / n_threads);
+                    } catch(...) {
+                        std::lock_guard<std::mutex> hold(lock);
+                        if(!failure) failure = std::current_exception();
+                    }
+                });
+            for(auto& th : pool) th.join();
+            if(failure) std::rethrow_exception(failure);
+        };
         a_off[0] = b_off[0] = 0;
+        run([&](unsigned long long lo, unsigned long long hi) {
+            std::string anc, des;
+            for(unsigned long long p = lo; p < hi; ++p) {
+                coati_amd::synth_pair(first + p, prm, anc, des);
+                a_off[p + 1] = anc.size();
+                b_off[p + 1] = des.size();
+            }
+        });
         for(unsigned long long p = 0; p < n; ++p) {
-            coati_amd::synth_pair(first + p, prm, anc, des);
-            a_off[p + 1] = a_off[p] + anc.size();
-            b_off[p + 1] = b_off[p] + des.size();
-            if(a_cat != nullptr) {
+            a_off[p + 1] += a_off[p];
+            b_off[p + 1] += b_off[p];
+        }
+        if(a_cat == nullptr) return;
+        run([&](unsigned long long lo, unsigned long long hi) {
+            std::string anc, des;
+            for(unsigned long long p = lo; p < hi; ++p) {
+                coati_amd::synth_pair(first + p, prm, anc, des);
                 const auto enc = coati_amd::marginal_seq_encoding(anc, des);
                 std::memcpy(a_cat + a_off[p], enc[0].data(), enc[0].size());
                 std::memcpy(b_cat + b_off[p], enc[1].data(), enc[1].size());
             }
-        }
+        });
     });
 }
 

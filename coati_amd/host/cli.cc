@@ -1,5 +1,6 @@
 #include "cli.hpp"
 
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -76,7 +77,9 @@ std::string usage(verb_t verb) {
              "  -r,--ref TEXT               Name of reference sequence (default: 1st seq)\n"
              "  -v,--rev-ref                Use 2nd seq as reference (default: 1st seq)\n"
              "  -s,--score                  Score input alignment and exit\n"
-             "  --batch                     Input holds 2n sequences: align consecutive pairs (JSON array out)\n";
+             "  --batch                     Input holds 2n sequences: align consecutive pairs (JSON array out)\n"
+             "  --devices LIST              With --batch: one process per listed HIP device (e.g. 0,1,2,3), pairs sharded\n"
+             "                              by DP cells, model broadcast and results gathered over RCCL\n";
     else
         u += "  -n,--sample-size UINT       Sample size\n"
              "  --independent-streams       Every sample from its own jumped-ahead RNG stream (all walks in parallel;\n"
@@ -153,6 +156,24 @@ args_t parse_arguments(verb_t verb, int argc, const char* const* argv) {
             aln.score = true;
         } else if(verb == verb_t::alignpair && a == "--batch") {
             args.batch = true;
+        } else if(verb == verb_t::alignpair && a == "--devices") {
+            const std::string v = need(i, a);
+            std::size_t at = 0;
+            while(at <= v.size()) {
+                const std::size_t comma = std::min(v.find(',', at), v.size());
+                const std::string tok = v.substr(at, comma - at);
+                char* end = nullptr;
+                const long d = std::strtol(tok.c_str(), &end, 10);
+                if(tok.empty() || *end != '\0' || d < 0) throw std::invalid_argument(a + ": Value " + v + " could not be converted");
+                args.devices.push_back(static_cast<int>(d));
+                at = comma + 1;
+            }
+        } else if(verb == verb_t::alignpair && a == "--dist-rank") {
+            args.dist_rank = std::atoi(need(i, a).c_str());
+        } else if(verb == verb_t::alignpair && a == "--dist-world") {
+            args.dist_world = std::atoi(need(i, a).c_str());
+        } else if(verb == verb_t::alignpair && a == "--dist-id") {
+            args.dist_id = need(i, a);
         } else if(verb == verb_t::sample && a == "--independent-streams") {
             args.aln.independent_streams = true;
         } else if(verb == verb_t::sample && (a == "-n" || a == "--sample-size")) {
@@ -192,6 +213,7 @@ args_t parse_arguments(verb_t verb, int argc, const char* const* argv) {
         else
             throw std::invalid_argument("tree: File does not exist: " + aln.tree);  // CLI::ExistingFile
     }
+    if(!args.devices.empty() && !args.batch) throw std::invalid_argument("--devices requires --batch");
     if(have_model && !aln.rate.empty()) throw std::invalid_argument("--sub excludes --model");
     if(have_ref && aln.rev) throw std::invalid_argument("--rev-ref excludes --ref");
     return args;

@@ -17,6 +17,9 @@ struct args_t {
     std::size_t sample_size{1};
     std::vector<std::string> seeds{{""}};  // structs.hpp:120: the default is one empty seed string
     bool batch{false};                    // extension: consecutive sequence pairs
+    std::vector<int> devices;             // extension: --devices 0,1,... = one process per listed GPU (--batch only)
+    int dist_rank{-1}, dist_world{0};     // (internal: what the --devices launcher passes to its children)
+    std::string dist_id;                  // (internal: rendezvous file)
     bool help{false};
 };
 

@@ -1,9 +1,82 @@
 // coati-alignpair: the `coati alignpair` verb (src/coati-alignpair.cc:30-50) for the
 // marginal models, with the DP on an MI355X.
+#include <csignal>
+#include <cstdio>
 #include <cstdlib>
+#include <fcntl.h>
 #include <iostream>
+#include <spawn.h>
+#include <stdexcept>
+#include <string>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <vector>
 
 #include "cli.hpp"
+
+extern char** environ;
+
+namespace {
+// --devices d0,d1,...: ONE PROCESS PER GPU.  This process only launches and waits -- it never touches
+// HIP -- so every rank is a fresh process that initialises exactly one device (children are started
+// with posix_spawn of this very binary plus the internal --dist-* flags; no exec from a process that has
+// used the GPU).  Exit status: the first non-zero status of a rank, or 128 + signal.
+int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
+    const int world = static_cast<int>(devices.size());
+    char id_path[] = "/tmp/coati-dist-XXXXXX";
+    const int fd = mkstemp(id_path);
+    if(fd < 0) throw std::runtime_error("--devices: cannot create a rendezvous file in /tmp");
+    close(fd);
+    std::remove(id_path);  // rank 0 creates it (by rename) once the id exists
+    char self[4096];
+    const ssize_t len = readlink("/proc/self/exe", self, sizeof self - 1);
+    if(len <= 0) throw std::runtime_error("--devices: cannot resolve /proc/self/exe");
+    self[len] = '\0';
+    std::vector<pid_t> pids;
+    for(int r = 0; r < world; ++r) {
+        std::vector<std::string> av;
+        av.emplace_back(self);
+        for(int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            if(a == "--devices" || a == "--device") {  // replaced below
+                ++i;
+                continue;
+            }
+            av.push_back(a);
+        }
+        av.insert(av.end(), {"--device", std::to_string(devices[static_cast<std::size_t>(r)]), "--dist-rank", std::to_string(r),
+                             "--dist-world", std::to_string(world), "--dist-id", id_path});
+        std::vector<char*> cav;
+        for(std::string& x : av) cav.push_back(x.data());
+        cav.push_back(nullptr);
+        pid_t pid = 0;
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        if(r != 0) posix_spawn_file_actions_addopen(&fa, STDOUT_FILENO, "/dev/null", O_WRONLY, 0);  // only rank 0 writes the result
+        const int rc = posix_spawn(&pid, self, &fa, nullptr, cav.data(), environ);
+        posix_spawn_file_actions_destroy(&fa);
+        if(rc != 0) {
+            for(pid_t p : pids) kill(p, SIGTERM);
+            throw std::runtime_error("--devices: posix_spawn failed");
+        }
+        pids.push_back(pid);
+    }
+    int status_all = 0;
+    for(std::size_t left = pids.size(); left > 0; --left) {
+        int st = 0;
+        const pid_t done = waitpid(-1, &st, 0);
+        if(done < 0) break;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if(code != 0 && status_all == 0) {
+            status_all = code;
+            for(pid_t p : pids)  // a rank failed: the others would wait for it in a collective
+                if(p != done) kill(p, SIGTERM);
+        }
+    }
+    std::remove(id_path);
+    return status_all;
+}
+}  // namespace
 
 int main(int argc, char* argv[]) {
     using namespace coati_amd;
@@ -23,6 +96,10 @@ int main(int argc, char* argv[]) {
             // the triplet/FST models (tri-mg, tri-ecm, dna) are a different algorithm and not served here
             throw std::invalid_argument("Mutation model unknown.");
         }
+        if(args.dist_rank >= 0)  // a child of the --devices launcher below: rank dist_rank on --device
+            return marg_alignment_batch_dist(args.aln, args.dist_rank, args.dist_world, args.dist_id) ? EXIT_SUCCESS : EXIT_FAILURE;
+        if(args.devices.size() > 1) return launch_ranks(args.devices, argc, argv);
+        if(args.devices.size() == 1) args.aln.device = args.devices[0];
         const bool ok = args.batch ? marg_alignment_batch(args.aln) : marg_alignment(args.aln);
         return ok ? EXIT_SUCCESS : EXIT_FAILURE;
     } catch(const std::exception& e) {

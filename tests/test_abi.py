@@ -9,8 +9,8 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def declared_symbols():
-    text = (ROOT / "include" / "coati_hip.h").read_text()
+def declared_symbols(header="coati_hip.h"):
+    text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(coati_hip_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,6 +24,18 @@ def test_header_symbols_exported():
     for name in syms:
         assert hasattr(lib, name), f"{name} declared in coati_hip.h but not exported"
     assert set(hip.EXPORTS) == set(syms)
+
+
+def test_dist_header_symbols_exported():
+    """include/coati_hip_dist.h <-> libcoati_hip_dist.so (links librccl directly; loading it needs no GPU)."""
+    from coati_amd import dist
+
+    lib = dist.load()
+    syms = declared_symbols("coati_hip_dist.h")
+    assert len(syms) >= 8
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in coati_hip_dist.h but not exported"
+    assert set(dist.EXPORTS) == set(syms)
 
 
 def test_version_and_error_string():

@@ -24,6 +24,34 @@ def test_shard_bounds_balance_cells():
     assert cd.shard_bounds([5.0], 4)[-1] == 1
 
 
+def test_native_shard_bounds_matches_and_balances():
+    """coati_hip_shard_bounds (the C ABI partitioner bench.py, coati_hip_dist_viterbi and
+    `coati-alignpair --devices` use): contiguous, monotone, cell-balanced to within one pair, and
+    identical to the numpy statement of the same rule."""
+    from coati_amd import hip
+
+    rng = np.random.default_rng(5)
+    la = rng.integers(0, 400, 3000) * 3
+    lb = rng.integers(0, 1500, 3000)
+    a_off = np.concatenate([[0], np.cumsum(la)]).astype(np.uint64)
+    b_off = np.concatenate([[0], np.cumsum(lb)]).astype(np.uint64)
+    w = (la * lb).astype(np.float64)
+    for world in (1, 2, 3, 8, 64):
+        b = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
+        assert b[0] == 0 and b[-1] == len(w) and (np.diff(b) >= 0).all()
+        shares = np.array([w[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert shares.max() - w.sum() / world <= w.max() + 1
+        assert b.tolist() == cd.shard_bounds(w, world)
+    assert hip.shard_bounds(np.zeros(1, np.uint64), np.zeros(1, np.uint64), 4).tolist() == [0, 0, 0, 0, 0]
+    # one heavy pair among light ones: it sits alone in its shard, nothing is lost or duplicated
+    la2, lb2 = np.full(100, 3), np.full(100, 3)
+    la2[40], lb2[40] = 30000, 30000
+    a2 = np.concatenate([[0], np.cumsum(la2)]).astype(np.uint64)
+    b2 = np.concatenate([[0], np.cumsum(lb2)]).astype(np.uint64)
+    bb = hip.shard_bounds(a2, b2, 4)
+    assert bb[0] == 0 and bb[-1] == 100 and (np.diff(bb.astype(np.int64)) >= 0).all()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,6 +88,18 @@ def _worker(rank, world, port, q):
                 sc, ops, off, ln = pg.unpack(r)
                 ok = ok and sc.tolist() == [float(x + r) for x in range(m)] and ops.tolist() == [x % 3 for x in range(7 * m)]
                 ok = ok and off.tolist() == [x * (r + 5) for x in range(m)] and ln.tolist() == [x + 9 * r for x in range(m)]
+        # the real partitioner: every rank plans the same shards of one workload from the lengths alone and
+        # "computes" its own (here: a checksum per pair); gathered in rank order the input order is restored
+        from coati_amd import hip
+        lr = np.random.default_rng(7)
+        la, lb = lr.integers(1, 300, 500) * 3, lr.integers(1, 900, 500)
+        a_off = np.concatenate([[0], np.cumsum(la)]).astype(np.uint64)
+        b_off = np.concatenate([[0], np.cumsum(lb)]).astype(np.uint64)
+        bounds = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
+        mine = torch.from_numpy((la * 7 + lb)[bounds[rank]:bounds[rank + 1]].astype(np.int64))
+        parts = cd.gather_ragged(mine, dst=0)
+        if rank == 0:
+            ok = ok and torch.cat(parts).tolist() == (la * 7 + lb).tolist()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

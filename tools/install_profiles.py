@@ -6,7 +6,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = ROOT / "gpurun_out" / "prof_n1", ROOT / "profiles" / rnd
 dst.mkdir(parents=True, exist_ok=True)
 for a, b in (("kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("pmc_summary.csv", "bench_n1_pmc_summary.csv"),
@@ -18,9 +18,13 @@ for extra in ("bench_n1.json", "bench_n1_streams2.json", "sample_bench.json", "s
     f = ROOT / "gpurun_out" / extra
     if f.exists():
         shutil.copy(f, dst / extra)
-t = json.loads((dst / "bench_n1_traffic.json").read_text())["viterbi_l1"]
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402  (kernel_sources_sha16: ties the figure to the kernel build it was measured on)
+
+t = json.loads((dst / "bench_n1_traffic.json").read_text())["viterbi_ck"]
 (ROOT / "profiles" / "traffic_latest.json").write_text(json.dumps({
-    "viterbi_l1_bytes_per_launch_10000_pairs": t["bytes_per_launch"],
+    "viterbi_ck_bytes_per_launch_10000_pairs": t["bytes_per_launch"],
+    "kernel_sources_sha16": bench.kernel_sources_sha16(),
     "how": "tools/profile.sh: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes of `bench.py --steps 3 "
            "--warmup 1`; bytes = (WRITE_SIZE + 2*FETCH_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a coalesced "
            "stream, MI355X_MICROARCH.md section HBM)",
