@@ -106,3 +106,35 @@ def test_full_baseline_workload_checksums():
     for p in range(want["pairs"]):
         crc = zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes(), crc)
     assert "%08x" % crc == want["ops_crc32"]
+
+
+def test_config4_mar_ecm_workload_checksums():
+    """BASELINE configs[4]'s workload (synthetic 1 kb pairs, mar-ecm) on one GPU: 2 000 pairs through the
+    resident batch AND through the pipelined one-shot call; CRC32 of every op of every pair, of the fp32
+    score bits and the column total equal those of the unmodified reference engine
+    (tools/make_golden_synth.py -> tests/golden/synth_ecm2k_checksums.json).  Also pins host::ecm_p /
+    set_subst("mar-ecm"): the table checksum must be the one the fixture was generated with."""
+    import zlib
+
+    from coati_amd import hip, host
+
+    want = json.loads((GOLD / "synth_ecm2k_checksums.json").read_text())
+    table = host.set_subst("mar-ecm")
+    assert "%08x" % zlib.crc32(np.ascontiguousarray(table).tobytes()) == want["table_crc32"], "host ECM model drifted"
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, want["pairs"])
+    model = hip.Model(table, host.gap_consts(), 1)
+
+    def check(scores, ops, off, ln):
+        assert "%08x" % zlib.crc32(np.ascontiguousarray(scores).tobytes()) == want["scores_crc32"]
+        assert int(ln.sum()) == want["columns"]
+        crc = 0
+        for p in range(want["pairs"]):
+            crc = zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes(), crc)
+        assert "%08x" % crc == want["ops_crc32"]
+
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    check(*batch.viterbi_fetch())
+    batch.close()
+    check(*model.viterbi(a_cat, a_off, b_cat, b_off))
+    model.close()

@@ -77,6 +77,22 @@ def test_exact_stream_matches_oracle(oracle, L):
     assert identical >= 0.98 * total, (identical, total)
 
 
+def test_config3_16_pairs_x_1000_samples_match_oracle(oracle):
+    """BASELINE configs[3] at its stated size: `coati sample -n 1000` on 16 synthetic 1 kb pairs, mar-mg94.
+    The speculative exact-stream sampler against the ORACLE's sampleback (oracle sampleback_mdi, pinned to
+    the compiled reference in tests/test_oracle_vs_ref.py), draw for draw: every one of the 16 000 samples
+    has the oracle's ops and log-weight bits, and the generator ends in the oracle's state."""
+    from coati_amd import hip, host
+
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    pairs = [host.synth_raw(i) for i in range(16)]
+    identical, total = run_exact(hip, host, oracle, table, consts, 1, pairs, ["42"], 1000)
+    assert total == 16 * 1000
+    if util.forward_exact():
+        assert identical == total, (identical, total)
+    assert identical >= 0.97 * total, (identical, total)
+
+
 def test_reference_doctest_marg_sample():
     """marg_sample known answers (align_marginal.cc:653-672), seed "42", default model."""
     from coati_amd import hip, host
