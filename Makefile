@@ -53,10 +53,14 @@ $(BUILD)/coati-%: coati_amd/host/coati_%.cc $(BUILD)/libcoati_host.so
 # sanitizer build of the host layer (CPU only; GPU ASan is not available on the pool):
 # run the CPU tests / tools/fuzz_host_io.py against it with COATI_HOST_LIB + LD_PRELOAD (see the tool)
 asan: $(BUILD)/asan/libcoati_host.so
-$(BUILD)/asan/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/libcoati_hip.so
+# ... against a STUB libcoati_hip.so (every entry answers COATI_HIP_ENODEVICE): the sanitizer build maps no HIP runtime
+$(BUILD)/asan/libcoati_hip.so: coati_amd/host/hip_stub.cc include/coati_hip.h
+	@mkdir -p $(BUILD)/asan
+	$(CXX) -std=c++17 -O1 -g -fPIC -Iinclude -shared -o $@ $<
+$(BUILD)/asan/libcoati_host.so: $(HOST_SRC) $(HOST_HDR) $(BUILD)/asan/libcoati_hip.so
 	@mkdir -p $(BUILD)/asan
 	$(CXX) -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -fsanitize=address,undefined -fno-omit-frame-pointer -pthread \
-	    -Iinclude -Icoati_amd/host -shared -o $@ $(HOST_SRC) -L$(BUILD) -lcoati_hip -Wl,-rpath,'$$ORIGIN/..' -lm -ldl
+	    -Iinclude -Icoati_amd/host -shared -o $@ $(HOST_SRC) -L$(BUILD)/asan -lcoati_hip -Wl,-rpath,'$$ORIGIN' -lm -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -336,6 +336,15 @@ int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float n
     if(gap_len < 1) return fail(COATI_HIP_EINVAL, "model_create: gap_len must be >= 1 (got %d)", gap_len);
     if(gap_len > 8)
         return fail(COATI_HIP_EINVAL, "model_create: gap_len %d not supported by the GPU path (1..8)", gap_len);
+    // log-probabilities: NaN or +inf in the table is never meaningful and turns scores into NaN (-inf, the log
+    // of a zero probability in a --sub matrix, is let through as in the reference; the samplers bound their walks)
+    for(uint64_t i = 0; i < static_cast<uint64_t>(n_tables) * kTabFloats; ++i)
+        if(std::isnan(table[i]) || (std::isinf(table[i]) && table[i] > 0))
+            return fail(COATI_HIP_EINVAL, "model_create: table %llu has a non-finite entry at row %llu column %llu",
+                        static_cast<unsigned long long>(i / kTabFloats), static_cast<unsigned long long>(i % kTabFloats / kTabCols),
+                        static_cast<unsigned long long>(i % kTabCols));
+    for(const float c : {no_gap, gap_stop, gap_open, gap_extend})
+        if(std::isnan(c) || (std::isinf(c) && c > 0)) return fail(COATI_HIP_EINVAL, "model_create: a gap constant is NaN or +inf");
     int n = 0;
     if(hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(COATI_HIP_ENODEVICE, "model_create: no HIP device available");
@@ -630,13 +639,31 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             return items;
         };
         constexpr uint64_t kSimds = 1024;
-        const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
         while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
         if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
             const int w = std::atoi(e);
             if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
         }
         if(opts != nullptr && opts->force_w_main != 0) w_main = opts->force_w_main;
+        // Which gap_len-1 kernel.  viterbi_ck (lean fill + checkpoint traceback) wins where the fill
+        // dominates; viterbi_l1 (decision bits written by the fill) keeps two regimes, both measured
+        // (profiles/r02/kernel_choice.txt): batches of SHORT pairs, where a traceback round recomputes a
+        // large share of the little matrix (150 nt pairs: 588 vs 440 GCUPS; from 300 nt on the two are level,
+        // at 750 nt viterbi_ck leads by 16 %), and a few LONG pairs cut into narrow strips, where every
+        // wavefront is alone on its SIMD and the 4x larger checkpoint stream of 4-column strips costs more
+        // than the shorter cell saves (160 kb pair: 86 vs 104 ms).  COATI_HIP_VITERBI_CK=1 / _BITS=1 force one.
+        if(b->ck && std::getenv("COATI_HIP_VITERBI_CK") == nullptr && !(opts != nullptr && opts->force_w_main != 0)) {
+            long double cells = 0;
+            uint64_t live = 0;
+            for(uint64_t p = 0; p < n_pairs; ++p)
+                if(b->desc[p].la > 0 && b->desc[p].lb > 0) {
+                    cells += static_cast<long double>(b->desc[p].la) * b->desc[p].lb;
+                    ++live;
+                }
+            constexpr long double kShortPair = 250.0L * 250.0L;
+            if(w_main < kW || (live > 0 && cells / live < kShortPair)) b->ck = false;
+        }
+        const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
         uint64_t tail_pairs = 0;
         if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {
             tail_pairs = std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10));

@@ -142,8 +142,15 @@ __device__ uint64_t sample_walk(const Walker& w, Rng128& rng, uint8_t* __restric
         // where this step goes, and M/D/I there (a walk that would leave the matrix -- impossible
         // with non-zero probability -- reads nothing)
         const uint32_t pi = is_m ? i - 1 : (is_d ? i - L : i), pj = is_m ? j - 1 : (is_d ? j : j - L);
+        // A walk can only leave the matrix (or overrun its slot of la + lb ops) if every weight of a draw
+        // was zero or NaN -- a table with -inf / NaN entries; model_create rejects those, this is the belt to
+        // those braces: end the walk, mark the sample with a NaN log-weight, never write outside the slot.
+        if(pi > i || pj > j || pos < slot + (is_m ? 1u : L)) {
+            score = __builtin_nanf("");
+            break;
+        }
         Triple t{kLowest, kLowest, kLowest};
-        if(pi <= i && pj <= j) w.pred(pi, pj, t.m, t.d, t.in);
+        w.pred(pi, pj, t.m, t.d, t.in);
         const float top = is_m ? cur.m : (is_d ? cur.d : cur.in);
         // the emitted columns: one match, or L gap columns
         const uint32_t n_emit = is_m ? 1u : L;

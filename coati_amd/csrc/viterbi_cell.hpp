@@ -131,6 +131,8 @@ __device__ __forceinline__ void publish_progress(uint32_t* word, uint32_t rows, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if(leader) __hip_atomic_store(word, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// what a strip publishes instead of its row count when its own left neighbour timed out
+constexpr uint32_t kHandoffPoison = 0xffffffffu;
 // false if the producer did not get there within the spin bound (never hang the GPU)
 __device__ __forceinline__ bool wait_progress(const uint32_t* word, uint32_t need) {
     for(uint32_t spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spins) {

@@ -287,6 +287,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         if(strip > 0) {
             // rows kbase .. kbase+63 of the left neighbour's last column must be published
             handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
+            if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
             if(crow < la) {
                 bx = in_x[crow];
                 bz = in_z[crow];
@@ -316,7 +317,9 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         // (plainly stored) checkpoints before saying "complete".
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        publish_progress(progress + ticket, la, lane == kWave - 1);
+        // (a strip whose own input never arrived publishes the poison value: every later strip of the pair,
+        // down to the one that writes the result, then knows)
+        publish_progress(progress + ticket, handoff_ok ? la : kHandoffPoison, lane == kWave - 1);
     }
     return handoff_ok;
 }

@@ -125,12 +125,24 @@ class PackedGather:
         for v, n in zip(self.views, self.sizes):
             self.packed[pos:pos + n].copy_(v)
             pos += self._pad(n)
+        # The copies above read the library's result arrays on torch's current stream; the library relaunches
+        # the batch on ITS stream, which knows nothing of them.  wait_copies() (host wait on this event) is
+        # what a caller does before relaunching the batch whose arrays were packed here.
+        if self.packed.is_cuda:
+            self.copied = torch.cuda.Event()
+            self.copied.record()
         work = dist.gather(self.packed, self.bucket, dst=self.dst, async_op=True)
         if async_op:
             self.work = work
             return work
         work.wait()  # (device-side dependency on NCCL; does not block the host there)
         return None
+
+    def wait_copies(self):
+        """Block the host until the result arrays this gather packed have been read (then the batch may be relaunched)."""
+        ev = getattr(self, "copied", None)
+        if ev is not None:
+            ev.synchronize()
 
     def finish(self):
         if self.work is not None:

@@ -45,6 +45,13 @@ struct host_timer {
     }
 };
 
+// The kernels mark a pair they could not finish (a strip hand-off that timed out) with a NaN score
+// instead of hanging the GPU: that is an error of the run, not a result to print as `null`.
+void check_scores(const std::vector<float>& scores) {
+    for(std::size_t p = 0; p < scores.size(); ++p)
+        if(std::isnan(scores[p])) throw std::runtime_error("The device did not finish pair " + std::to_string(p) + " (strip hand-off timed out).");
+}
+
 coati_hip_model* make_model(const alignment_t& aln) {
     if(aln.gap.len < 1) throw std::invalid_argument("Gap unit length must be positive.");
     if(aln.subst_matrix.size() != kTableRows * kTableCols) throw std::invalid_argument("Substitution matrix not set.");
@@ -137,6 +144,7 @@ void viterbi_mem(align_pair_work_mem_t& work, const seq_view_t& a, const seq_vie
     uint64_t off = 0;
     uint32_t len = 0;
     hip_check(coati_hip_viterbi_fetch(work.batch, &work.score, work.ops.data(), a.size() + b.size(), &off, &len));
+    check_scores({work.score});
     work.ops.erase(work.ops.begin(), work.ops.begin() + static_cast<std::ptrdiff_t>(off));
     work.ops.resize(len);
 }
@@ -286,6 +294,7 @@ std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, 
     if(rc == COATI_HIP_OK) rc = coati_hip_viterbi_launch(batch);
     if(rc == COATI_HIP_OK)
         rc = coati_hip_viterbi_fetch(batch, scores.data(), ops.data(), a_cat.size() + b_cat.size(), off.data(), len.data());
+    if(rc == COATI_HIP_OK) check_scores(scores);
     if(batch != nullptr) coati_hip_batch_destroy(batch);
     coati_hip_model_destroy(model);
     hip_check(rc);
@@ -372,6 +381,7 @@ bool marg_alignment_batch(alignment_t& aln) {
                                            scores.data(), ops.data(), in.a_cat.size() + in.b_cat.size(), off.data(), len.data());
     coati_hip_model_destroy(model);
     hip_check(rc);
+    check_scores(scores);
     tm.stage("device (upload, kernels, download)");
     write_batch_output(aln, in, scores, ops, off, len);
     tm.stage("gapped strings + output");

@@ -60,8 +60,9 @@ def test_reference_doctest_alignments_default_model():
         assert [sa, sb] == case["out"], case
 
 
+@pytest.mark.parametrize("kernel", ["auto", "ck"])
 @pytest.mark.parametrize("key", ["10k", "20k", "40k", "80k", "160k"])
-def test_long_sample_pairs(key):
+def test_long_sample_pairs(key, kernel, monkeypatch):
     """BASELINE configs[2]: the reference's long sample pairs (sanitised)
     up to 160 002 x 160 002 nt.  Their strips run on different wavefronts, pipelined through HBM
     boundary columns.  Expected score bits / columns / CRC32(ops) come from the compiled reference
@@ -70,6 +71,13 @@ def test_long_sample_pairs(key):
 
     from coati_amd import hip, host
 
+    # (a lone long pair is the planner's case for viterbi_l1; "ck" forces the checkpoint kernel through the
+    # same narrow pipelined strips)
+    monkeypatch.delenv("COATI_HIP_VITERBI_BITS", raising=False)
+    if kernel == "ck":
+        monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")
+    else:
+        monkeypatch.delenv("COATI_HIP_VITERBI_CK", raising=False)
     a, b, case, doc = util.load_long_pair(key)
     table = np.load(GOLD / doc["table"])
     consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])

@@ -23,6 +23,22 @@ def hip():
     return h
 
 
+@pytest.fixture(params=["auto", "ck", "bits"], autouse=True)
+def kernel_choice(request, monkeypatch):
+    """gap_len 1 has two kernels and a planner that picks by batch shape (abi.hip: viterbi_ck -- lean
+    fill + checkpoint traceback -- except for batches of short pairs and narrow-strip long pairs, which
+    keep viterbi_l1).  Every test of this file runs three times: planner's choice, viterbi_ck forced
+    (so its 4- and 8-column shapes, multi-strip hand-off and tile recompute see the small and the
+    ragged cases too), viterbi_l1 forced."""
+    monkeypatch.delenv("COATI_HIP_VITERBI_CK", raising=False)
+    monkeypatch.delenv("COATI_HIP_VITERBI_BITS", raising=False)
+    if request.param == "ck":
+        monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")
+    elif request.param == "bits":
+        monkeypatch.setenv("COATI_HIP_VITERBI_BITS", "1")
+    return request.param
+
+
 def run_and_compare(hip, oracle, table, consts, pairs, check_flags=True):
     enc = util.encode_pairs(pairs)
     a_cat, a_off, b_cat, b_off = hip.pack_pairs(enc)

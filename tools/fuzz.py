@@ -22,6 +22,15 @@ t_end = time.time() + budget
 rounds = pairs_checked = reuse_checked = 0
 while time.time() < t_end:
     L = int(rng.choice([1, 1, 1, 2, 3, 3, 4]))
+    # gap_len 1: the planner's kernel choice, or one of the two kernels forced (read per batch_create)
+    import os
+    os.environ.pop("COATI_HIP_VITERBI_CK", None)
+    os.environ.pop("COATI_HIP_VITERBI_BITS", None)
+    forced = rng.choice(["auto", "ck", "ck", "bits"])
+    if forced == "ck":
+        os.environ["COATI_HIP_VITERBI_CK"] = "1"
+    elif forced == "bits":
+        os.environ["COATI_HIP_VITERBI_BITS"] = "1"
     n_tables = int(rng.integers(1, 4))
     tables = np.stack([util.tie_table() if rng.random() < 0.3 else util.random_table(rng) for _ in range(n_tables)])
     g = float(rng.choice([0.001, 0.01, 0.05]))
