@@ -425,7 +425,7 @@ def main():
         extras = {} if args.no_extras or world > 1 else measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off,
                                                                          cells, args)
         out = {
-            "metric": "GCUPS (DP cell updates/s), marginal Viterbi fill+traceback, mar-mg94 1kb x 1kb pairs",
+            "metric": f"GCUPS (DP cell updates/s), marginal Viterbi fill+traceback, {'mar-ecm' if args.model == 'mar-ecm' else 'mar-mg94'} 1kb x 1kb pairs",
             "value": total_cells * args.steps / elapsed / 1e9,
             "unit": "GCUPS",
             "n_gpus": world,

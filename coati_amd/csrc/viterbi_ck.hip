@@ -466,11 +466,23 @@ __device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc&
 #pragma unroll
     for(int cc = 0; cc < W; ++cc) s[cc] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[cc]);
     const float2* cin = sp.colin + t;
+    // the left inputs and the row code of a step are loaded one step ahead (a round is otherwise 16 dependent
+    // load -> compute steps: what the traceback of the last items of a launch waits for)
+    auto inputs_of = [&](int32_t ks, float2& in, uint32_t& code) {
+        const int32_t kstep = k0 + ks, r = kstep - t;
+        const bool act = valid && ks < static_cast<int32_t>(kCkRows) && r >= 0 && r < la;
+        in = act ? cin[static_cast<uint64_t>(kstep) * kWave] : make_float2(0.0f, 0.0f);
+        code = row_code(r + 1);
+    };
+    float2 in_next;
+    uint32_t code_next;
+    inputs_of(0, in_next, code_next);
     for(int32_t ks = 0; ks < static_cast<int32_t>(kCkRows); ++ks) {
         const int32_t kstep = k0 + ks, r = kstep - t;
+        const float2 in = in_next;
+        const uint32_t arow_next = code_next;
+        inputs_of(ks + 1, in_next, code_next);
         if(valid && r >= 0 && r < la) {
-            const float2 in = cin[static_cast<uint64_t>(kstep) * kWave];
-            const uint32_t arow_next = row_code(r + 1);
             row_l1<W>(k, st, in.x, in.y, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
             bits[(0 * kCkRows + ks) * kWave] = st.acc[ACC_A];
             bits[(1 * kCkRows + ks) * kWave] = st.acc[ACC_B];
