@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <sched.h>
 #include <new>
 #include <string>
 #include <utility>
@@ -149,6 +150,20 @@ struct coati_hip_model {
     };
     static constexpr int kSlots = 3;
     Slot slots[kSlots];
+    // viterbi_ck_stream (one persistent launch per coati_hip_viterbi_batch call): its control block in HBM and
+    // the page-locked words the host and the kernel talk through
+    void* d_stream_ctl = nullptr;
+    void* h_stream = nullptr;  // CkStreamHost
+    struct StreamSlot {        // a chunk in flight: its workspace and its page-locked staging block
+        void* arena = nullptr;
+        size_t arena_bytes = 0;
+        void* pinned = nullptr;
+        size_t pinned_bytes = 0;
+    };
+    StreamSlot sslots[kCkStreamSlots];
+    void* d_stream_waves = nullptr;  // per-wavefront checkpoint slots + traceback scratch, shared by all chunks of a call
+    size_t stream_waves_bytes = 0;
+    hipEvent_t stream_events[kCkStreamSlots + 1] = {};  // [slot]: its download is done; [last]: an upload is done
     std::mutex pipeline_lock;  // one pipelined call at a time per model
 };
 
@@ -387,6 +402,15 @@ void model_release(coati_hip_model* m) {
         if(sl.stream != nullptr && sl.stream != m->stream) (void)hipStreamDestroy(sl.stream);
     }
     if(m->pinned != nullptr) (void)hipHostFree(m->pinned);
+    if(m->d_stream_ctl != nullptr) (void)hipFree(m->d_stream_ctl);
+    if(m->h_stream != nullptr) (void)hipHostFree(m->h_stream);
+    if(m->d_stream_waves != nullptr) (void)hipFree(m->d_stream_waves);
+    for(hipEvent_t e : m->stream_events)
+        if(e != nullptr) (void)hipEventDestroy(e);
+    for(auto& ss : m->sslots) {
+        if(ss.arena != nullptr) (void)hipFree(ss.arena);
+        if(ss.pinned != nullptr) (void)hipHostFree(ss.pinned);
+    }
     if(m->d_table != nullptr) (void)hipFree(m->d_table);
     if(m->stream != nullptr) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -438,6 +462,14 @@ int coati_hip_model_trim(coati_hip_model_t* m) {
             sl.arena = nullptr;
             sl.arena_bytes = 0;
         }
+        for(auto& ss : m->sslots) {  // (no streamed call is running: pipeline_lock)
+            if(ss.arena != nullptr) (void)hipFree(ss.arena);
+            ss.arena = nullptr;
+            ss.arena_bytes = 0;
+        }
+        if(m->d_stream_waves != nullptr) (void)hipFree(m->d_stream_waves);
+        m->d_stream_waves = nullptr;
+        m->stream_waves_bytes = 0;
     }
     return COATI_HIP_OK;
 }
@@ -452,6 +484,14 @@ namespace {
 // How batch_create_impl places a batch: by default on the model's stream with its own workspace and
 // blocking uploads; a pipeline slot passes its stream, its workspace and its page-locked staging block,
 // and every upload becomes an asynchronous copy on that stream.
+// hipMemcpyAsync moves this many bytes or fewer with a copy KERNEL, more with the copy engine (the runtime's
+// GPU_FORCE_BLIT_COPY_SIZE, 16 KB by default)
+constexpr uint64_t kMinDmaBytes = 16 * 1024;
+
+// the streamed form of coati_hip_viterbi_batch takes pairs of at most this many cells (the checkpoints of a pair
+// that does not use a wavefront slot must fit a stream slot's workspace: 1.1 bytes per cell and the narrow last strip)
+constexpr uint64_t kStreamPairCells = 64ull << 20;
+
 struct BatchOpts {
     hipStream_t stream = nullptr;
     void* arena = nullptr;
@@ -462,6 +502,10 @@ struct BatchOpts {
     uint64_t* arena_need_out = nullptr;  // receives the workspace size of the plan (also when `arena` is too small)
     bool ck_per_pair = false;  // viterbi_ck: keep every pair's checkpoints (coati_hip_debug_viterbi_flags reads them afterwards)
     uint32_t force_w_main = 0;  // (debug re-run of one pair: the strip shape it had in its batch)
+    bool force_ck = false;      // viterbi_ck whatever the planner's rule says (the chunks of a streamed call)
+    // chunks of a streamed call: the per-wavefront checkpoint slots (this many dwords each) and the traceback
+    // scratch live outside the chunk's workspace, shared by all chunks (viterbi_batch_stream)
+    uint64_t wave_slot_dwords = 0;
 };
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                       const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
@@ -505,6 +549,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     model->refs.fetch_add(1);  // released by coati_hip_batch_destroy
     b->n_pairs = n_pairs;
     b->stream = opts != nullptr && opts->stream != nullptr ? opts->stream : model->stream;
+    // a chunk of a streamed Viterbi call never runs Forward: no Forward work items, no Forward boundary arrays
+    const bool viterbi_only = opts != nullptr && opts->wave_slot_dwords != 0;
     struct Owner {  // destroys the half-built batch on every exit but the successful one
         coati_hip_batch* b;
         ~Owner() {
@@ -652,7 +698,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // at 750 nt viterbi_ck leads by 16 %), and a few LONG pairs cut into narrow strips, where every
         // wavefront is alone on its SIMD and the 4x larger checkpoint stream of 4-column strips costs more
         // than the shorter cell saves (160 kb pair: 86 vs 104 ms).  COATI_HIP_VITERBI_CK=1 / _BITS=1 force one.
-        if(b->ck && std::getenv("COATI_HIP_VITERBI_CK") == nullptr && !(opts != nullptr && opts->force_w_main != 0)) {
+        if(b->ck && std::getenv("COATI_HIP_VITERBI_CK") == nullptr && !(opts != nullptr && (opts->force_w_main != 0 || opts->force_ck))) {
             long double cells = 0;
             uint64_t live = 0;
             for(uint64_t p = 0; p < n_pairs; ++p)
@@ -742,7 +788,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
         // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
-        const uint64_t nf = fwd_strips_w(d.lb, 1u << d.f_wlog2);
+        const uint64_t nf = viterbi_only ? 1 : fwd_strips_w(d.lb, 1u << d.f_wlog2);
         const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
                                                   nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
                                                   plan_k ? (ns - 1) * ((la / L + 1) + la) : 0,
@@ -755,7 +801,23 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // viterbi_ck: checkpoints of single-strip pairs in per-wavefront slots instead of per pair, when that is
     // the smaller arena (a 1 kb pair needs 1.09 MB: 10 000 pairs 10.9 GB per pair, 4.5 GB in 4 096 slots; a
     // batch of a few pairs keeps per-pair storage).  Pairs above kSlotCap keep their own storage either way.
-    if(b->ck && !(opts != nullptr && opts->ck_per_pair) && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
+    if(b->ck && opts != nullptr && opts->wave_slot_dwords != 0) {
+        // streamed chunk: every single-strip pair that fits the call's shared slots uses them; the workspace keeps the rest
+        uint64_t at = 0;
+        for(uint64_t p = 0; p < n_pairs; ++p) {
+            PairDesc& d = b->desc[p];
+            if(!(d.la > 0 && d.lb > 0)) {
+                d.flags_off = at;
+            } else if(d.v_strips == 1 && ck_strip_dwords(d.la, d.v_wlast) <= opts->wave_slot_dwords) {
+                d.flags_off = kCkWaveSlot;
+            } else {
+                d.flags_off = at;
+                at += (d.v_strips - 1) * ck_strip_dwords(d.la, d.v_wmain) + ck_strip_dwords(d.la, d.v_wlast);
+            }
+        }
+        b->flag_dwords = at;
+        b->ck_slot_dwords = opts->wave_slot_dwords;
+    } else if(b->ck && !(opts != nullptr && opts->ck_per_pair) && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
         constexpr uint64_t kSlotCap = 1ull << 20;  // dwords (4 MB)
         uint64_t slot = 0, per_pair_total = 0;
         auto need_of = [&](const PairDesc& d) { return d.la > 0 && d.lb > 0 ? ck_strip_dwords(d.la, d.v_wlast) : 0; };
@@ -803,6 +865,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     std::vector<WorkItem> items, fwd_items;
     for(const uint32_t p : order) {
         for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
+        if(viterbi_only) continue;
         uint32_t nf = 1;
         if(b->desc[p].la > 0 && b->desc[p].lb > 0)
             nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact)
@@ -818,14 +881,18 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         arena_need += (std::max<uint64_t>(bytes, 16) + 255) / 256 * 256;
         return at;
     };
-    const uint64_t o_desc = carve(n_pairs * sizeof(PairDesc)), o_a = carve(a_total), o_b = carve(b_total),
-                   o_ops = carve(b->ops_total), o_flags = carve(b->flag_dwords * sizeof(uint32_t)),
-                   o_bnd = carve(b->bnd_floats * sizeof(float)), o_scores = carve(n_pairs * sizeof(float)),
-                   o_start = carve(n_pairs * sizeof(uint64_t)), o_len = carve(n_pairs * sizeof(uint32_t)),
-                   o_order = carve(n_pairs * sizeof(uint32_t)), o_queue = carve(sizeof(uint32_t)),
+    // [what goes up: descriptors, order, queue word, work items, progress words, sequences | what comes back: scores,
+    // ops offsets and lengths, ops | scratch]: each group contiguous, so that a pipeline slot moves it with ONE copy
+    const uint64_t o_desc = carve(n_pairs * sizeof(PairDesc)), o_order = carve(n_pairs * sizeof(uint32_t)), o_queue = carve(sizeof(uint32_t)),
                    o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
                    o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)),
-                   o_wscratch = carve(b->ck ? ck_scratch_waves() * ck_scratch_dwords_per_wave() * sizeof(uint32_t) : 0);
+                   o_a = carve(a_total), o_b = carve(b_total), o_up_end = arena_need,
+                   o_scores = carve(n_pairs * sizeof(float)), o_start = carve(n_pairs * sizeof(uint64_t)),
+                   o_len = carve(n_pairs * sizeof(uint32_t)), o_ops = carve(b->ops_total),
+                   o_flags = carve(b->flag_dwords * sizeof(uint32_t)), o_bnd = carve(b->bnd_floats * sizeof(float)),
+                   o_wscratch = carve(b->ck && !(opts != nullptr && opts->wave_slot_dwords != 0)
+                                          ? ck_scratch_waves() * ck_scratch_dwords_per_wave() * sizeof(uint32_t) : 0);
+    arena_need = std::max<uint64_t>(arena_need, 2 * kMinDmaBytes);
     if(opts != nullptr && opts->arena_need_out != nullptr) *opts->arena_need_out = arena_need;
     if(opts != nullptr && opts->arena != nullptr) {
         if(opts->arena_bytes < arena_need)
@@ -862,28 +929,48 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     stage("workspace");
     // uploads: blocking copies by default; for a pipeline slot asynchronous copies on its stream, out of
     // page-locked memory (the slot's staging block, or the caller's arrays when those are page-locked)
-    uint64_t staged = 0;
-    auto upload = [&](void* dst, const void* src, uint64_t bytes, bool src_pinned) -> hipError_t {
-        if(bytes == 0) return hipSuccess;
-        if(opts == nullptr || opts->staging == nullptr) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
-        if(!src_pinned) {
-            if(staged + bytes > opts->staging_bytes) return hipErrorOutOfMemory;
-            std::memcpy(opts->staging + staged, src, bytes);
-            src = opts->staging + staged;
-            staged += (bytes + 255) / 256 * 256;
-        }
-        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream);
-    };
-    if(n_pairs > 0) {
-        B_TRY(upload(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), false));
-        B_TRY(upload(b->d_order, order.data(), n_pairs * sizeof(uint32_t), false));
-        B_TRY(upload(b->d_items, items.data(), items.size() * sizeof(WorkItem), false));
-        B_TRY(upload(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), false));
-    }
-    stage("descriptors + work items upload");
     const bool seqs_pinned = opts != nullptr && opts->seqs_pinned;
-    if(a_total > 0) B_TRY(upload(b->d_a, a_cat + a_off[0], a_total, seqs_pinned));
-    if(b_total > 0) B_TRY(upload(b->d_b, b_cat + b_off[0], b_total, seqs_pinned));
+    if(opts == nullptr || opts->staging == nullptr) {
+        if(n_pairs > 0) {
+            B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
+            B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if(!items.empty()) B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+            if(!fwd_items.empty()) B_TRY(hipMemcpy(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+        }
+        stage("descriptors + work items upload");
+        if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
+        if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));
+    } else {
+        // a pipeline slot: the group is laid out in the slot's page-locked block exactly as in the workspace and goes
+        // up as one asynchronous copy (queue and progress words as zeros); page-locked caller sequences go directly.
+        // Copies of kMinDmaBytes or less are done by a kernel, not by the copy engine -- which must not happen while
+        // viterbi_ck_stream owns the chip -- so short groups are padded (what follows in the workspace is scratch).
+        const bool stage_a = !seqs_pinned || a_total <= kMinDmaBytes, stage_b = !seqs_pinned || b_total <= kMinDmaBytes;
+        const uint64_t group = stage_a ? (stage_b ? o_up_end : o_b) : o_a;
+        const uint64_t sent = std::max<uint64_t>(group, kMinDmaBytes + 256);
+        const uint64_t b_alone = stage_b && !stage_a ? std::min<uint64_t>(std::max<uint64_t>(b_total, kMinDmaBytes + 256), arena_need - o_b) : 0;
+        if(std::max(sent, o_a + b_alone) > opts->staging_bytes) B_TRY(hipErrorOutOfMemory);
+        char* st = opts->staging;
+        std::memset(st + o_queue, 0, o_items - o_queue);
+        std::memset(st + o_progress, 0, o_a - o_progress);
+        if(n_pairs > 0) {
+            std::memcpy(st + o_desc, b->desc.data(), n_pairs * sizeof(PairDesc));
+            std::memcpy(st + o_order, order.data(), n_pairs * sizeof(uint32_t));
+            if(!items.empty()) std::memcpy(st + o_items, items.data(), items.size() * sizeof(WorkItem));
+            if(!fwd_items.empty()) std::memcpy(st + o_fwd, fwd_items.data(), fwd_items.size() * sizeof(WorkItem));
+        }
+        if(stage_a && a_total > 0) std::memcpy(st + o_a, a_cat + a_off[0], a_total);
+        if(stage_a && stage_b && b_total > 0) std::memcpy(st + o_b, b_cat + b_off[0], b_total);
+        B_TRY(hipMemcpyAsync(at(0), st, sent, hipMemcpyHostToDevice, b->stream));
+        stage("descriptors + work items upload");
+        if(!stage_a) B_TRY(hipMemcpyAsync(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice, b->stream));
+        if(!stage_b) {
+            B_TRY(hipMemcpyAsync(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice, b->stream));
+        } else if(!stage_a && b_total > 0) {  // (short b beside long page-locked a: staged behind the group, after it has gone)
+            std::memcpy(st + o_a, b_cat + b_off[0], b_total);
+            B_TRY(hipMemcpyAsync(b->d_b, st + o_a, b_alone, hipMemcpyHostToDevice, b->stream));
+        }
+    }
     stage("sequences upload");
 #undef B_TRY
     owner.b = nullptr;
@@ -1470,9 +1557,13 @@ bool is_pinned_host(const void* p) {
 // HBM workspace + page-locked staging a chunk of pairs [p0, p1) needs (upper bounds; the plan of
 // batch_create_impl is authoritative and fails cleanly if a chunk does not fit after all)
 struct ChunkNeed {
-    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
+    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, ck_own16 = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
     // checkpoints: per pair, or in per-wavefront slots when that is smaller (batch_create_impl decides the same way)
     uint64_t arena() const { return fixed + std::min<uint64_t>(ck_sum, ck_max * ck_scratch_waves() + ck_sum / 64); }
+    // chunk of a streamed call: wavefront slots and traceback scratch are the call's, not the chunk's
+    uint64_t arena_streamed() const {
+        return fixed - static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + ck_own16;
+    }
 };
 void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
     uint64_t w = 0;
@@ -1485,10 +1576,19 @@ void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
     }
     const uint64_t strips = std::max<uint64_t>(1, (lb + 255) / 256);  // (narrowest plan: 4 columns per lane)
     nd.ck_sum += w;
-    if(gap_len == 1 && lb <= static_cast<uint64_t>(kWave) * kW && w <= (4ull << 20)) nd.ck_max = std::max(nd.ck_max, w);  // slot-eligible
+    if(gap_len == 1 && lb <= static_cast<uint64_t>(kWave) * kW && w <= (4ull << 20))
+        nd.ck_max = std::max(nd.ck_max, w);  // slot-eligible
+    if(gap_len == 1 && la > 0 && lb > 0) {
+        // chunk of a streamed call (16 columns per lane always; batch_create_impl with wave_slot_dwords): pairs of
+        // several strips, or too long for a wavefront slot, keep their checkpoints in the chunk's workspace
+        uint32_t ns = 1, wl = kW;
+        viterbi_strip_plan(static_cast<uint32_t>(lb), kW, ns, wl);
+        const uint64_t last = ck_strip_dwords(static_cast<uint32_t>(la), wl);
+        if(ns > 1 || last > (1ull << 20)) nd.ck_own16 += ((ns - 1) * ck_strip_dwords(static_cast<uint32_t>(la), kW) + last) * 4;
+    }
     nd.fixed += 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 1024;
     nd.seq_bytes += la + lb;
-    nd.meta_bytes += sizeof(PairDesc) + 4 + strips * 16 + 16;  // descriptor, order entry, work items (both lists)
+    nd.meta_bytes += sizeof(PairDesc) + 4 + strips * 24 + 16;  // descriptor, order entry, work items (both lists), progress word
     nd.ops += la + lb;
     nd.cells += la * lb;
 }
@@ -1496,6 +1596,299 @@ void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
 struct PipeChunk {
     uint64_t p0 = 0, p1 = 0, ops_base = 0, ops_bytes = 0;
 };
+}  // namespace
+
+namespace {
+// The streamed form of coati_hip_viterbi_batch: viterbi_ck_stream runs for the whole call on the model's stream;
+// the host plans chunk after chunk into kCkStreamSlots small workspaces, uploads on ONE in-order stream, tells the
+// kernel how many work items exist through page-locked memory, and downloads a chunk (on a third stream) when the
+// kernel has flagged it complete.  Only copy-ENGINE copies may be issued while the kernel owns every wavefront
+// slot of the chip: no hipMemset, no copy of kMinDmaBytes or less (both are kernels), no hipMalloc / hipFree
+// (they may wait for the device).  Everything is allocated before the launch; COATI_HIP_ESTATE = nothing usable
+// happened (an allocation failed before the launch, or the kernel gave up waiting): the caller runs the chunk
+// pipeline instead.
+int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off, const uint8_t* b_cat,
+                         const uint64_t* b_off, float* scores, uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len, bool in_pinned,
+                         bool out_pinned, long double total_cells, uint64_t longest_single, std::chrono::steady_clock::time_point t_call) {
+    constexpr int kSlots = kCkStreamSlots;
+    for(int q = 1; q <= 2; ++q)
+        if(model->slots[q].stream == nullptr && hipStreamCreateWithFlags(&model->slots[q].stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            return COATI_HIP_ESTATE;
+        }
+    hipStream_t kernel_stream = model->stream, up_stream = model->slots[1].stream, down_stream = model->slots[2].stream;
+    const uint64_t host_bytes = ck_stream_host_bytes();
+    auto soft = [](hipError_t e) {  // an allocation that fails here is not an error of the call
+        if(e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    };
+    if(model->d_stream_ctl == nullptr && !soft(hipMalloc(&model->d_stream_ctl, ck_stream_ctl_bytes()))) return COATI_HIP_ESTATE;
+    if(model->h_stream == nullptr && !soft(hipHostMalloc(&model->h_stream, host_bytes, hipHostMallocCoherent | hipHostMallocMapped)))
+        return COATI_HIP_ESTATE;
+    // the wavefronts' checkpoint slots (as large as the longest single-strip pair of the call needs, at most 4 MB:
+    // longer ones keep their checkpoints in their chunk's workspace) and traceback scratch
+    uint64_t slot_dwords = 256;
+    for(uint32_t cw = 4; cw <= 16; cw *= 2) slot_dwords = std::max<uint64_t>(slot_dwords, ck_strip_dwords(static_cast<uint32_t>(longest_single), cw));
+    const uint64_t wave_slot_bytes = (std::min<uint64_t>(slot_dwords, 1ull << 20) * 4 + 255) / 256 * 256;
+    const uint64_t scratch_bytes = ck_scratch_dwords_per_wave() * sizeof(uint32_t);
+    const uint64_t waves_bytes = static_cast<uint64_t>(ck_scratch_waves()) * (wave_slot_bytes + scratch_bytes);
+    if(model->stream_waves_bytes < waves_bytes) {
+        if(model->d_stream_waves != nullptr) (void)hipFree(model->d_stream_waves);
+        model->d_stream_waves = nullptr;
+        model->stream_waves_bytes = 0;
+        if(!soft(hipMalloc(&model->d_stream_waves, waves_bytes))) return COATI_HIP_ESTATE;
+        model->stream_waves_bytes = waves_bytes;
+    }
+    // slots: fixed sizes (nothing can grow while the kernel runs; the chunks are cut to fit).  Workspace: room for
+    // the largest pair this form accepts (kStreamPairCells) with its own checkpoints; staging block
+    // [what goes up | short result arrays, and the ops when the caller's array is pageable]
+    constexpr uint64_t kSlotArena = 192ull << 20, kSlotStaging = 48ull << 20;
+    auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) {
+        return 4 * 256 + 2 * kMinDmaBytes + n * (sizeof(float) + sizeof(uint64_t) + sizeof(uint32_t)) + (out_pinned ? uint64_t{0} : ops_bytes);
+    };
+    auto staging_of = [&](const ChunkNeed& nd, uint64_t n) {
+        return nd.meta_bytes + 8 * 256 + 2 * kMinDmaBytes + (in_pinned ? std::min<uint64_t>(nd.seq_bytes, 2 * kMinDmaBytes) : nd.seq_bytes) + 512 +
+               out_bytes_of(n, nd.ops) + 512;
+    };
+    for(auto& ss : model->sslots) {
+        if(ss.arena_bytes < kSlotArena) {
+            if(ss.arena != nullptr) (void)hipFree(ss.arena);
+            ss.arena = nullptr;
+            ss.arena_bytes = 0;
+            if(!soft(hipMalloc(&ss.arena, kSlotArena))) return COATI_HIP_ESTATE;
+            ss.arena_bytes = kSlotArena;
+        }
+        if(ss.pinned_bytes < kSlotStaging) {
+            if(ss.pinned != nullptr) (void)hipHostFree(ss.pinned);
+            ss.pinned = nullptr;
+            ss.pinned_bytes = 0;
+            if(!soft(hipHostMalloc(&ss.pinned, kSlotStaging, hipHostMallocDefault))) return COATI_HIP_ESTATE;
+            ss.pinned_bytes = kSlotStaging;
+        }
+    }
+    void* hs = model->h_stream;
+    std::memset(hs, 0, host_bytes);
+    void* hs_dev = nullptr;
+    if(!soft(hipHostGetDevicePointer(&hs_dev, hs, 0))) return COATI_HIP_ESTATE;
+    if(model->stream_events[0] == nullptr) {
+        bool events_ok = true;
+        for(hipEvent_t& e : model->stream_events) events_ok = events_ok && soft(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if(!events_ok) {
+            for(hipEvent_t& e : model->stream_events) {
+                if(e != nullptr) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+            return COATI_HIP_ESTATE;
+        }
+    }
+    hipEvent_t up_done = model->stream_events[kSlots];
+    hipEvent_t* copied = model->stream_events;
+    // the control block starts zeroed (before the launch a fill kernel may run)
+    uint32_t* wave_ck = static_cast<uint32_t*>(model->d_stream_waves);
+    uint32_t* wave_scratch = reinterpret_cast<uint32_t*>(static_cast<char*>(model->d_stream_waves) + static_cast<uint64_t>(ck_scratch_waves()) * wave_slot_bytes);
+    hipError_t e0 = hipMemsetAsync(model->d_stream_ctl, 0, ck_stream_ctl_bytes(), kernel_stream);
+    if(e0 == hipSuccess)
+        e0 = launch_viterbi_ck_stream(model->d_table, model->k, model->n_tables == 1, model->d_stream_ctl, hs_dev, wave_ck, wave_slot_bytes / 4,
+                                      wave_scratch, kernel_stream);
+    if(e0 != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e0));
+    struct Closer {  // whatever happens below, the kernel is told to finish
+        void* host;
+        ~Closer() { ck_stream_host_close(host); }
+    } closer{hs};
+
+    struct InFlight {
+        coati_hip_batch_t* batch = nullptr;
+        PipeChunk chunk;
+        uint32_t chunk_no = 0;
+        bool d2h_submitted = false;
+        char* out_stage = nullptr;
+        uint64_t out_off = 0;
+        bool ops_staged = false;
+    };
+    InFlight fl[kSlots];
+    int rc = COATI_HIP_OK;
+    const bool pipe_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;
+    auto t_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: schedule made, kernel launched at %.2f ms\n", t_ms());
+    constexpr int kGaveUp = -1000;  // (private to this function)
+    auto kernel_gone = [&]() { return hipStreamQuery(kernel_stream) == hipSuccess; };  // (it only ends after `closed`: early = gave up)
+
+    // results: [scores | ops offsets | ops lengths | ops] are one contiguous group of the workspace.  Pageable
+    // destination: one copy of the group into the slot's page-locked block.  Page-locked destination: the three
+    // short arrays still go through the block (one copy, padded past kMinDmaBytes: shorter ones would be done by
+    // a copy kernel, which cannot start under viterbi_ck_stream), the ops go straight to the caller's array.
+    auto submit_d2h = [&](InFlight& f, int slot) -> hipError_t {
+        f.d2h_submitted = true;
+        coati_hip_model::StreamSlot& sl = model->sslots[slot];
+        const PipeChunk& c = f.chunk;
+        coati_hip_batch* b = f.batch;
+        f.out_stage = static_cast<char*>(sl.pinned) + f.out_off;
+        const uint64_t group = static_cast<uint64_t>(reinterpret_cast<char*>(b->d_ops) - reinterpret_cast<char*>(b->d_scores));  // (the three short arrays, each padded to 256 bytes)
+        const bool ops_direct = out_pinned && ops != nullptr && c.ops_bytes > kMinDmaBytes;
+        f.ops_staged = ops != nullptr && c.ops_bytes > 0 && !ops_direct;
+        const uint64_t bytes = std::max<uint64_t>(group + (f.ops_staged ? c.ops_bytes : 0), kMinDmaBytes + 256);
+        hipError_t e = hipMemcpyAsync(f.out_stage, b->d_scores, bytes, hipMemcpyDeviceToHost, down_stream);
+        if(e == hipSuccess && ops_direct) e = hipMemcpyAsync(ops + c.ops_base, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, down_stream);
+        if(e == hipSuccess) e = hipEventRecord(copied[slot], down_stream);
+        return e;
+    };
+    // non-blocking: submit the download of every chunk the kernel has flagged, retire every chunk whose download is done
+    auto progress = [&]() -> int {
+        for(int q = 0; q < kSlots; ++q) {
+            InFlight& f = fl[q];
+            if(f.batch == nullptr) continue;
+            if(!f.d2h_submitted) {
+                if(*ck_stream_host_done_flag(hs, q) != f.chunk_no + 1u) continue;
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                const hipError_t e = submit_d2h(f, q);
+                if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+            }
+            const hipError_t qd = hipEventQuery(copied[q]);
+            if(qd == hipErrorNotReady) continue;
+            if(qd != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(qd));
+            const PipeChunk& c = f.chunk;
+            const uint64_t n = c.p1 - c.p0;
+            {
+                char* at = f.out_stage;
+                if(scores != nullptr) std::memcpy(scores + c.p0, at, n * sizeof(float));
+                at += (n * sizeof(float) + 255) / 256 * 256;
+                if(ops_off != nullptr) std::memcpy(ops_off + c.p0, at, n * sizeof(uint64_t));
+                at += (n * sizeof(uint64_t) + 255) / 256 * 256;
+                if(ops_len != nullptr) std::memcpy(ops_len + c.p0, at, n * sizeof(uint32_t));
+                at += (n * sizeof(uint32_t) + 255) / 256 * 256;
+                if(f.ops_staged) std::memcpy(ops + c.ops_base, at, c.ops_bytes);
+            }
+            if(ops_off != nullptr)
+                for(uint64_t p = c.p0; p < c.p1; ++p) ops_off[p] += c.ops_base;
+            if(pipe_timing)
+                std::fprintf(stderr, "viterbi_batch[stream]: chunk %u (%llu pairs) complete %.2f ms after the kernel started, on the host at %.2f ms\n",
+                             f.chunk_no, static_cast<unsigned long long>(n), ck_stream_host_done_ms(hs, q), t_ms());
+            coati_hip_batch_destroy(f.batch);
+            f.batch = nullptr;
+        }
+        return COATI_HIP_OK;
+    };
+    // blocking: until slot q is free (or the kernel is gone without finishing it)
+    auto wait_free = [&](int q) -> int {
+        for(uint64_t spins = 0; fl[q].batch != nullptr; ++spins) {
+            const int r = progress();
+            if(r != COATI_HIP_OK) return r;
+            if(fl[q].batch == nullptr) break;
+            if((spins & 1023u) == 1023u && !fl[q].d2h_submitted && kernel_gone() && *ck_stream_host_done_flag(hs, q) != fl[q].chunk_no + 1u)
+                return kGaveUp;  // (the kernel ended before this chunk was complete: it had given up waiting for the host)
+            if(spins > 64) sched_yield();
+        }
+        return COATI_HIP_OK;
+    };
+
+    // chunks are cut as the call goes (the kernel is already waiting): 3 units of 10^9 cells (3 000 pairs of 1 kb),
+    // the first ones and the last ones smaller (the GPU starts after ~0.1 ms of planning; the very last download is
+    // the only one nothing hides); never more than fits a slot.  The persistent kernel takes chunks of any size at
+    // full rate, but a chunk occupies its slot for as long as its SLOWEST pair takes -- measured: 5 to 6 ms for a
+    // 1 kb pair on a fully shared SIMD, three times the mean, the four wavefronts of a SIMD do not advance evenly --
+    // so the slots together must hold well over 6 ms of work (12 300 pairs of 1 kb) or the GPU runs dry
+    long double kUnit = 1000.0L * 1002 * 1002;
+    if(const char* e = std::getenv("COATI_HIP_STREAM_UNIT")) {  // tests: many small chunks out of a small input (cells)
+        const long double forced = std::strtold(e, nullptr);
+        if(forced >= 1.0L) kUnit = forced;
+    }
+    const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
+    uint32_t published = 0;
+    uint64_t p0 = 0, ops_base = 0;
+    long double cells_done = 0;
+    for(size_t ci = 0; p0 < n_pairs && rc == COATI_HIP_OK; ++ci) {
+        const int q = static_cast<int>(ci % kSlots);
+        coati_hip_model::StreamSlot& sl = model->sslots[q];
+        InFlight& f = fl[q];
+        const double t_begin = t_ms();
+        rc = wait_free(q);
+        if(rc != COATI_HIP_OK) break;
+        const long double target = ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
+        ChunkNeed nd;
+        nd.fixed = static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + (64u << 10);
+        uint64_t p1 = p0;
+        while(p1 < n_pairs) {
+            ChunkNeed with = nd;
+            chunk_need_add(with, a_off[p1 + 1] - a_off[p1], b_off[p1 + 1] - b_off[p1], gap_len);
+            if(p1 > p0 && (static_cast<long double>(with.cells) > target || with.arena_streamed() + with.arena_streamed() / 8 + (1u << 20) > sl.arena_bytes ||
+                           staging_of(with, p1 + 1 - p0) > sl.pinned_bytes))
+                break;
+            nd = with;
+            ++p1;
+        }
+        const PipeChunk c{p0, p1, ops_base, nd.ops};
+        p0 = p1;
+        ops_base += nd.ops;
+        cells_done += static_cast<long double>(nd.cells);
+        const uint64_t n = c.p1 - c.p0;
+        const uint64_t out_off = (sl.pinned_bytes - out_bytes_of(n, c.ops_bytes)) / 256 * 256;
+        BatchOpts bo;
+        bo.stream = up_stream;
+        bo.arena = sl.arena;
+        bo.arena_bytes = sl.arena_bytes;
+        bo.staging = static_cast<char*>(sl.pinned);
+        bo.staging_bytes = out_off;
+        bo.seqs_pinned = in_pinned;
+        bo.force_ck = true;
+        bo.force_w_main = kW;  // (a small chunk is not a small batch: no narrowed strips)
+        bo.wave_slot_dwords = wave_slot_bytes / 4;
+        rc = batch_create_impl(model, n, a_cat, a_off + c.p0, b_cat, b_off + c.p0, nullptr, &bo, &f.batch);
+        if(rc != COATI_HIP_OK) {  // (ENOMEM: the slot's workspace cannot grow while the kernel runs)
+            if(pipe_timing)
+                std::fprintf(stderr, "viterbi_batch[stream]: chunk %zu of %llu pairs: estimate %llu bytes (fixed %llu, own checkpoints %llu)\n", ci,
+                             static_cast<unsigned long long>(n), static_cast<unsigned long long>(nd.arena_streamed()),
+                             static_cast<unsigned long long>(nd.fixed), static_cast<unsigned long long>(nd.ck_own16));
+            break;
+        }
+        coati_hip_batch* b = f.batch;
+        if(!b->ck) {
+            rc = fail(COATI_HIP_ESTATE, "viterbi_batch: a streamed chunk was not planned for viterbi_ck");
+            break;
+        }
+        f.chunk = c;
+        f.chunk_no = static_cast<uint32_t>(ci);
+        f.d2h_submitted = false;
+        f.out_off = out_off;
+        // the chunk's data (with its zeroed progress words) is on its way; once it is in HBM the kernel may know
+        hipError_t e = hipEventRecord(up_done, up_stream);
+        ck_stream_fill_chunk(hs, hs_dev, q, b->arena, device_view(b), static_cast<uint32_t>(n), published, static_cast<uint32_t>(ci));
+        if(e == hipSuccess) e = hipEventSynchronize(up_done);
+        if(e != hipSuccess) {
+            rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+            break;
+        }
+        published += b->n_items;
+        ck_stream_host_announce(hs, static_cast<uint32_t>(ci) + 1u, published);
+        if(pipe_timing)
+            std::fprintf(stderr, "viterbi_batch[stream]: chunk %zu (%llu pairs, %u items, slot %d) planned + uploaded %.2f .. %.2f ms\n", ci,
+                         static_cast<unsigned long long>(n), b->n_items, q, t_begin, t_ms());
+        rc = progress();
+    }
+    ck_stream_host_close(hs);
+    for(int q = 0; q < kSlots && rc == COATI_HIP_OK; ++q) rc = wait_free(q);
+    // the kernel ends by itself once it has seen `closed`; then its verdict
+    const hipError_t es = hipStreamSynchronize(kernel_stream);
+    uint32_t dev_error = 0;
+    if(es == hipSuccess) (void)hipMemcpy(&dev_error, static_cast<char*>(model->d_stream_ctl) + ck_stream_error_offset(), sizeof dev_error, hipMemcpyDeviceToHost);
+    for(InFlight& f : fl) {
+        if(f.batch != nullptr) {  // (only after an error)
+            (void)hipStreamSynchronize(up_stream);
+            (void)hipStreamSynchronize(down_stream);
+            coati_hip_batch_destroy(f.batch);
+            f.batch = nullptr;
+        }
+    }
+    if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: done at %.2f ms\n", t_ms());
+    if(rc == COATI_HIP_OK && es != hipSuccess) rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(es));
+    if(es == hipSuccess && (rc == kGaveUp || (rc == COATI_HIP_OK && dev_error != 0))) {
+        // the kernel's waits are bounded (a host thread that was stopped for seconds must not hang the GPU): it gave
+        // up, some chunks are incomplete.  Everything is quiet now; the chunk pipeline does the call again.
+        if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: the kernel gave up waiting (code %u); falling back\n", dev_error);
+        return COATI_HIP_ESTATE;
+    }
+    if(rc == kGaveUp) rc = fail(COATI_HIP_EHIP, "viterbi_batch: the streaming kernel ended early");
+    return rc;
+}
 }  // namespace
 
 /* One-shot Viterbi over any number of pairs, PIPELINED: the input is cut into chunks; chunk k's
@@ -1512,8 +1905,47 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     if(a_off == nullptr || b_off == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets are NULL");
     if(n_pairs == 0) return COATI_HIP_OK;
     try {
+    const auto t_entry = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> one_call(model->pipeline_lock);
     HIP_TRY(hipSetDevice(model->device));
+    const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
+    // ---- the input once: valid offsets, cells, what decides the form of the call
+    long double total_cells = 0;
+    uint64_t widest = 0, max_pair_cells = 0, longest_single = 0;
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
+            return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p));
+        const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+        if(la > 0xffffffffull || lb > 0xffffffffull)
+            return fail(COATI_HIP_EINVAL, "viterbi_batch: pair %llu is longer than 2^32", static_cast<unsigned long long>(p));
+        const uint64_t cells = la * lb;
+        total_cells += static_cast<long double>(cells);
+        widest = std::max(widest, lb);
+        max_pair_cells = std::max(max_pair_cells, cells);
+        if(lb > 0 && lb <= static_cast<uint64_t>(kStrip)) longest_single = std::max(longest_single, la);
+    }
+    const uint64_t ops_total = (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]);
+    if(ops != nullptr && ops_capacity < ops_total)
+        return fail(COATI_HIP_EINVAL, "viterbi_batch: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
+                    static_cast<unsigned long long>(ops_total));
+    const bool in_pinned = is_pinned_host(a_cat) && is_pinned_host(b_cat);
+    const bool out_pinned = (ops == nullptr || is_pinned_host(ops)) && (scores == nullptr || is_pinned_host(scores)) &&
+                            (ops_off == nullptr || is_pinned_host(ops_off)) && (ops_len == nullptr || is_pinned_host(ops_len));
+    // ---- which form: ONE persistent kernel fed chunk by chunk (viterbi_batch_stream) for many pairs of viterbi_ck's
+    // kind (the planner's rule: not short pairs, not lone long ones; and no pair whose own checkpoints would not fit
+    // a stream slot's workspace); else a launch per chunk (below).  COATI_HIP_PIPE=chunks|stream forces one.
+    {
+        const char* pipe_env = std::getenv("COATI_HIP_PIPE");
+        bool streamed = gap_len == 1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr &&
+                        !(pipe_env != nullptr && std::strcmp(pipe_env, "chunks") == 0) && widest <= 8 * kStrip && max_pair_cells <= kStreamPairCells;
+        if(streamed && !(pipe_env != nullptr && std::strcmp(pipe_env, "stream") == 0))
+            streamed = n_pairs >= 4096 && total_cells / n_pairs >= 250.0L * 250.0L;
+        if(streamed) {
+            const int rc_stream = viterbi_batch_stream(model, n_pairs, a_cat, a_off, b_cat, b_off, scores, ops, ops_off, ops_len, in_pinned,
+                                                       out_pinned, total_cells, longest_single, t_entry);
+            if(rc_stream != COATI_HIP_ESTATE) return rc_stream;  // (ESTATE: nothing was started; the chunk pipeline takes the call)
+        }
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     {   // cached workspaces of this model count as free: they are reused or released on demand
@@ -1531,25 +1963,17 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     }
     // ---- chunk schedule.  Full chunks hold ~1.6e10 cells (16 000 pairs of 1 kb) or what the budget
     // allows; the first one is a sixth of that (planning it takes ~0.4 ms, then the GPU has work while the next is planned).
-    const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
     constexpr uint64_t kFullCells = 16000ull * 1002 * 1002;
     std::vector<PipeChunk> chunks;
     ChunkNeed max_need;
     uint64_t max_arena = 0;
     {
-        // cells of every pair once (prefix sums): the schedule is made on them
-        std::vector<long double> cum(n_pairs + 1, 0);
-        for(uint64_t p = 0; p < n_pairs; ++p) {
-            if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
-                return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p));
-            cum[p + 1] = cum[p] + static_cast<long double>(a_off[p + 1] - a_off[p]) * (b_off[p + 1] - b_off[p]);
-        }
         // targets: a sixth and a third of a full chunk to get the GPU going while the next chunks are planned
         // and uploaded, then equal chunks of at most kFullCells, the last of them cut 2:1 (the smaller part
         // fills the ragged end of the larger and its download, the only exposed one, is short)
         std::vector<uint64_t> targets;
         {
-            const long double total = cum[n_pairs];
+            const long double total = total_cells;
             long double left = total;
             for(const uint64_t ramp : {kFullCells / 6, kFullCells / 3}) {
                 if(left <= 0) break;
@@ -1587,22 +2011,18 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
             ops_base += nd.ops;
             p0 = p1;
         }
-        if(ops != nullptr && ops_capacity < ops_base)
-            return fail(COATI_HIP_EINVAL, "viterbi_batch: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
-                        static_cast<unsigned long long>(ops_base));
     }
-    const bool in_pinned = is_pinned_host(a_cat) && is_pinned_host(b_cat);
-    const bool out_pinned = (ops == nullptr || is_pinned_host(ops)) && (scores == nullptr || is_pinned_host(scores)) &&
-                            (ops_off == nullptr || is_pinned_host(ops_off)) && (ops_len == nullptr || is_pinned_host(ops_len));
     // ---- slots: stream, staging, workspace (grown on demand, kept by the model)
     const int n_slots = static_cast<int>(std::min<uint64_t>(kSlots, chunks.size()));
     uint64_t max_pairs = 0;
     for(const PipeChunk& c : chunks) max_pairs = std::max(max_pairs, c.p1 - c.p0);
     // staging block of a slot: [descriptors + (pageable) sequences going up | (pageable) results coming back]
     auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) {
-        return out_pinned ? uint64_t{0} : 4 * 256 + n * (sizeof(float) + sizeof(uint64_t) + sizeof(uint32_t)) + ops_bytes;
+        return 4 * 256 + 2 * kMinDmaBytes + n * (sizeof(float) + sizeof(uint64_t) + sizeof(uint32_t)) + (out_pinned ? uint64_t{0} : ops_bytes);
     };
-    const uint64_t staging_need = max_need.meta_bytes + 8 * 256 + (in_pinned ? 0 : max_need.seq_bytes + 512) +
+    // (sequences: a chunk with short ones stages them even when the caller's arrays are page-locked)
+    const uint64_t staging_need = max_need.meta_bytes + 8 * 256 + 2 * kMinDmaBytes +
+                                  (in_pinned ? std::min<uint64_t>(max_need.seq_bytes, 2 * kMinDmaBytes) + 512 : max_need.seq_bytes + 512) +
                                   out_bytes_of(max_pairs, max_need.seq_bytes) + 512;
     for(int q = 0; q < n_slots; ++q) {
         coati_hip_model::Slot& sl = model->slots[q];

@@ -428,6 +428,22 @@ hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream);
 uint32_t ck_scratch_waves();
 uint64_t ck_scratch_dwords_per_wave();
+// viterbi_ck_stream (viterbi_ck.hip): one persistent launch fed chunk by chunk; the control block lives in HBM
+constexpr int kCkStreamSlots = 12;
+uint64_t ck_stream_ctl_bytes();
+uint64_t ck_stream_error_offset();
+// the page-locked, device-visible block host and kernel talk through (host = its host address, host_dev = its
+// device address): chunk table entries, {chunks, items} announced, closed; completion word per slot
+uint64_t ck_stream_host_bytes();
+void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* arena, const BatchDeviceView& v, uint32_t n_pairs,
+                          uint32_t first_ticket, uint32_t chunk_no);
+void ck_stream_host_announce(void* host, uint32_t chunks, uint32_t items);
+void ck_stream_host_close(void* host);
+double ck_stream_host_done_ms(void* host, int slot);  // (ms after the kernel started: when the slot's chunk was complete)
+volatile uint32_t* ck_stream_host_done_flag(void* host, int slot);
+// wave_ck: ck_scratch_waves() checkpoint slots of wave_slot_dwords each; wave_scratch: as many traceback scratch areas
+hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared_tab, void* ctl, const void* host_words, uint32_t* wave_ck,
+                                    uint64_t wave_slot_dwords, uint32_t* wave_scratch, hipStream_t stream);
 hipError_t launch_ck_all_flags(const BatchDeviceView& v, uint32_t pair, uint32_t* scratch, uint32_t n_waves, uint8_t* out,
                                hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);

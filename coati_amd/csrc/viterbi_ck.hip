@@ -27,7 +27,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -547,6 +549,16 @@ struct CkWalkArgs {
 // Within a round the walk is the wave-cooperative one of common.hpp: lane l looks up the state
 // after l+1 further moves of the current kind, a ballot finds where the run ends.  Ops are
 // written right-to-left into the pair's slot so they end up in alignment order.
+// kThrough: the results are stored write-through at system scope (viterbi_ck_stream: the host's copy engine
+// reads them while the kernel is still running, so they may not sit in an XCD's L2).
+template <bool kThrough, typename V>
+__device__ __forceinline__ void put_result(V* p, V v) {
+    if constexpr(kThrough)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+        *p = v;
+}
+template <bool kThrough = false>
 __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, const PairDesc& pd, uint32_t pair,
                                              uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
                                              uint32_t* __restrict__ ops_len) {
@@ -608,7 +620,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
             const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
             const uint32_t moves = run == kWave ? kWave : run + 1u;
-            for(uint32_t q = lane; q < moves; q += kWave) ops[pos - 1 - q] = static_cast<uint8_t>(st);
+            for(uint32_t q = lane; q < moves; q += kWave) put_result<kThrough>(&ops[pos - 1 - q], static_cast<uint8_t>(st));
             pos -= moves;
             i -= di * moves;
             j -= dj * moves;
@@ -621,8 +633,8 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
         if(st == kWalkEnd) break;
     }
     if(lane == 0) {
-        ops_start[pair] = pos;
-        ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
+        put_result<kThrough>(&ops_start[pair], pos);
+        put_result<kThrough>(&ops_len[pair], static_cast<uint32_t>(pd.ops_off + la + lb - pos));
     }
     return ok;
 }
@@ -729,6 +741,261 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         trace_n += 2;
 #endif
     }  // next ticket
+}
+
+// ---------------------------------------------------------------------------------------------
+// viterbi_ck_stream: ONE persistent launch for a whole coati_hip_viterbi_batch call.  The host keeps
+// planning and uploading chunks of pairs while the kernel runs and tells it through `published` (the
+// number of work items that are ready; written into HBM by the same in-order upload stream that carried
+// the chunk, so the data is there when the number is); the kernel tells the host through a flag in
+// page-locked host memory when a chunk's last pair is done, and the host downloads that chunk's results
+// while the kernel works on the next.  No ragged end between chunks, no under-filled ramp-up kernels.
+// Visibility: a wavefront that takes a ticket invalidates its vector and scalar caches at system scope
+// before it reads anything of the chunk (the slot's addresses held another chunk's data before);
+// results are stored write-through at system scope and completed (vmcnt) before the pair is counted.
+// Every wait is bounded: a host that stops publishing makes the kernel give up, not hang.
+struct CkStreamChunk {
+    // every array of a chunk is a 256-byte aligned part of ONE arena (abi.hip): base + 32-bit offsets in units
+    // of 256 bytes keep the entry small enough to live in SGPRs while a wavefront works on an item
+    uint64_t arena;
+    uint32_t off_pairs, off_items, off_a, off_b, off_ck, off_bnd, off_scores, off_ops, off_start, off_len, off_progress, pad0_;
+    uint32_t* host_flag;   // page-locked host memory: set to chunk_no + 1 when the chunk is complete
+    uint32_t n_pairs, n_items, first_ticket, chunk_no;
+    uint32_t done, pad_[3];  // pairs finished (device atomics)
+};
+static_assert(sizeof(CkStreamChunk) % 16 == 0, "chunk table entries are copied as a block");
+struct CkStreamCtl {
+    uint32_t queue, published, closed, error;
+    CkStreamChunk chunk[kCkStreamSlots];
+};
+
+template <typename T>
+__device__ __forceinline__ T sys_load(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <typename T>
+__device__ __forceinline__ T dev_load(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The page-locked, device-visible block the host and the kernel talk through.  Host -> kernel: the chunk
+// table entries, then ONE 64-bit word {chunks announced, items published} (one store: the pilot never sees
+// one half without the other), and "no more chunks".  Kernel -> host: a word per slot, chunk_no + 1 when the
+// chunk in it is complete.  Nothing of this goes through hipMemcpy: copies this small are done by a copy
+// KERNEL, which could not start while viterbi_ck_stream owns every wavefront slot of the chip.
+struct CkStreamHost {
+    uint64_t announced;  // (chunks << 32) | items
+    uint32_t closed, pad_[13];
+    uint32_t done_flag[16];
+    uint64_t t_start, t_done[16];  // device clock (100 MHz) when the pilot started / when a slot's chunk was complete
+    CkStreamChunk chunk[kCkStreamSlots];
+};
+static_assert(kCkStreamSlots <= 16 && sizeof(CkStreamChunk) <= 4 * kWave, "the pilot mirrors an entry a word per lane");
+static_assert(offsetof(CkStreamHost, t_done) == offsetof(CkStreamHost, done_flag) + 16 * sizeof(uint32_t) + sizeof(uint64_t),
+              "the worker that completes a chunk finds t_done[slot] from its done_flag[slot]");
+
+template <bool kSharedTab>
+__global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const float* __restrict__ table, GapConsts k,
+                                                                          CkStreamCtl* ctl, const CkStreamHost* host,
+                                                                          uint32_t* __restrict__ wave_ck, uint64_t wave_slot_dwords,
+                                                                          uint32_t* __restrict__ wave_scratch) {
+    __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
+    const int lane_id = threadIdx.x & (kWave - 1);
+
+    float* tab = tab_all[kSharedTab ? 0 : threadIdx.x / kWave];
+    uint32_t tab_held = 0xffffffffu;
+    if constexpr(kSharedTab) {
+        for(int idx = threadIdx.x; idx < kTabFloats; idx += kCkWaves * kWave) {
+            const int r = idx / kTabCols, c = idx - r * kTabCols;
+            tab[r * kTabStride + c] = table[idx];
+        }
+        __syncthreads();
+        tab_held = 0u;
+    }
+    if(blockIdx.x == 0 && threadIdx.x / kWave == 0) {
+        // PILOT wavefront: the only one that reads the host's block (over PCIe); it mirrors new chunk table
+        // entries and the item count into HBM, where the 4 095 workers poll.  (Four thousand wavefronts polling
+        // host memory would compete with the uploads for the link.)
+        uint32_t last = 0, mirrored = 0;
+        if(lane_id == 0) __hip_atomic_store(const_cast<uint64_t*>(&host->t_start), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for(uint32_t idle = 0;; ++idle) {
+            const uint64_t word = sys_load(&host->announced);
+            const uint32_t closed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sys_load(&host->closed))));
+            uint32_t items = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(word))));
+            uint32_t chunks = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(word >> 32))));
+            if(closed != 0u) {  // (final once closed is set)
+                const uint64_t fin = sys_load(&host->announced);
+                items = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(fin))));
+                chunks = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(fin >> 32))));
+            }
+            for(; mirrored != chunks; ++mirrored) {  // entries first ...
+                const uint32_t q = mirrored % kCkStreamSlots;
+                if(lane_id < static_cast<int>(sizeof(CkStreamChunk) / 4)) {
+                    const uint32_t v = sys_load(reinterpret_cast<const uint32_t*>(&host->chunk[q]) + lane_id);
+                    __hip_atomic_store(reinterpret_cast<uint32_t*>(&ctl->chunk[q]) + lane_id, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if(items != last) {  // ... then the count that makes their tickets valid
+                if(lane_id == 0) __hip_atomic_store(&ctl->published, items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = items;
+                idle = 0;
+            }
+            if(closed != 0u) break;
+            if(idle > (1u << 23)) {  // ~20 s without a word from the host: give up, never hang
+                if(lane_id == 0) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(lane_id == 0) __hip_atomic_store(&ctl->closed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;  // (its workgroup partner works on items as usual)
+    }
+    const char* tab_bytes = reinterpret_cast<const char*>(tab);
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));
+    const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * kCkWaves + threadIdx.x / kWave)));
+    for(;;) {
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        uint32_t ticket = atomicAdd(&ctl->queue, lane == 0 ? 1u : 0u);
+        ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        // ---- wait until the item is published, or the call is closed (bounded)
+        bool mine = false;
+        const uint64_t t_wait = __builtin_amdgcn_s_memrealtime();  // (100 MHz)
+        for(uint32_t spins = 0;; ++spins) {
+            const uint32_t pub = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(dev_load(&ctl->published))));
+            if(static_cast<int32_t>(pub - ticket) > 0) {
+                mine = true;
+                break;
+            }
+            const uint32_t closed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(dev_load(&ctl->closed))));
+            if(closed != 0u) {  // (the pilot stores the final `published` before it sets `closed`)
+                const uint32_t last = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(dev_load(&ctl->published))));
+                mine = static_cast<int32_t>(last - ticket) > 0;
+                break;
+            }
+            if(__builtin_amdgcn_s_memrealtime() - t_wait > 3000000000ull) {  // 30 s (the pilot gives up first and closes): never hang
+                if(lane == 0) __hip_atomic_store(&ctl->error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            // thousands of idle wavefronts poll ONE word: back off to a poll every ~10 us, or the memory channel that
+            // holds it becomes the bottleneck of the wavefronts that do have work
+            __builtin_amdgcn_s_sleep(127);
+            if(spins > 2) {
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        if(!mine) break;
+        // the chunk's arrays were written by the copy engine after this wavefront may have cached the slot's
+        // previous contents: drop them (vector L1/L2 at system scope, scalar cache)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        __builtin_amdgcn_s_dcache_inv();
+        // ---- which chunk: the slots hold disjoint ticket ranges
+        int slot = -1;
+#pragma unroll
+        for(int q = 0; q < kCkStreamSlots; ++q) {
+            const uint32_t first = dev_load(&ctl->chunk[q].first_ticket), n = dev_load(&ctl->chunk[q].n_items);
+            if(ticket - first < n) slot = q;
+        }
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if(slot < 0) {  // cannot happen: a published ticket lies in a resident chunk
+            if(lane == 0) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        CkStreamChunk* chp = &ctl->chunk[slot];
+        // the entry, wave-uniform (SGPRs): base + offsets
+        auto u32 = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+        auto u64 = [&](uint64_t v) { return static_cast<uint64_t>(u32(static_cast<uint32_t>(v))) | (static_cast<uint64_t>(u32(static_cast<uint32_t>(v >> 32))) << 32); };
+        char* const arena = reinterpret_cast<char*>(u64(chp->arena));
+        auto part = [&](uint32_t off256) { return arena + (static_cast<uint64_t>(u32(off256)) << 8); };
+        const uint32_t first_ticket = u32(chp->first_ticket), n_pairs_chunk = u32(chp->n_pairs), chunk_no = u32(chp->chunk_no);
+        uint32_t* const host_flag = reinterpret_cast<uint32_t*>(u64(reinterpret_cast<uint64_t>(chp->host_flag)));
+        const PairDesc* __restrict__ ch_pairs = reinterpret_cast<const PairDesc*>(part(chp->off_pairs));
+        const WorkItem* __restrict__ ch_items = reinterpret_cast<const WorkItem*>(part(chp->off_items));
+        const uint8_t* __restrict__ ch_a = reinterpret_cast<const uint8_t*>(part(chp->off_a));
+        const uint8_t* __restrict__ ch_b = reinterpret_cast<const uint8_t*>(part(chp->off_b));
+        uint32_t* __restrict__ ch_ck = reinterpret_cast<uint32_t*>(part(chp->off_ck));
+        float* __restrict__ ch_bnd = reinterpret_cast<float*>(part(chp->off_bnd));
+        float* __restrict__ ch_scores = reinterpret_cast<float*>(part(chp->off_scores));
+        uint8_t* __restrict__ ch_ops = reinterpret_cast<uint8_t*>(part(chp->off_ops));
+        uint64_t* __restrict__ ch_start = reinterpret_cast<uint64_t*>(part(chp->off_start));
+        uint32_t* __restrict__ ch_len = reinterpret_cast<uint32_t*>(part(chp->off_len));
+        uint32_t* __restrict__ ch_progress = reinterpret_cast<uint32_t*>(part(chp->off_progress));
+        const uint32_t local = ticket - first_ticket;
+        const WorkItem item = ch_items[local];
+        const uint32_t pair = u32(item.pair), strip = u32(item.strip);
+        // (loaded through a pointer the compiler cannot trace to a kernel argument, i.e. with vector loads: made
+        // wave-uniform word by word, or every address derived from it -- buffer descriptors included -- counts as
+        // divergent)
+        PairDesc pd;
+        {
+            const PairDesc raw = ch_pairs[pair];
+            static_assert(sizeof(PairDesc) % 4 == 0, "PairDesc is copied word by word");
+            uint32_t words[sizeof(PairDesc) / 4];
+            __builtin_memcpy(words, &raw, sizeof raw);
+#pragma unroll
+            for(size_t q = 0; q < sizeof(PairDesc) / 4; ++q) words[q] = u32(words[q]);
+            __builtin_memcpy(&pd, words, sizeof pd);
+        }
+        // single-strip pairs: the wavefront's own checkpoint slot, shared by all chunks (it holds one item at a time);
+        // others: the pair's area in its chunk's workspace
+        uint32_t* __restrict__ ckp = pd.flags_off == kCkWaveSlot ? wave_ck + static_cast<uint64_t>(wave_id) * wave_slot_dwords : ch_ck + pd.flags_off;
+        uint32_t* wbits = wave_scratch + static_cast<uint64_t>(wave_id) * kCkScratchDwords;
+        bool handoff_ok = true;
+        if constexpr(!kSharedTab) {
+            if(pd.table != tab_held) {
+                const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+                for(int idx = lane; idx < kTabFloats; idx += kWave) {
+                    const int r = idx / kTabCols, c = idx - r * kTabCols;
+                    tab[r * kTabStride + c] = src[idx];
+                }
+                tab_held = pd.table;
+            }
+        }
+        const uint8_t* __restrict__ a = ch_a + pd.a_off;
+        const uint8_t* __restrict__ b = ch_b + pd.b_off;
+        if(pd.la > 0 && pd.lb > 0) {
+            const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
+            if(w == 16)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+            else if(w == 8)
+                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+            else
+                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+        }
+        if(strip + 1 < pd.v_strips) continue;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float score = 0.0f;
+        if(pd.la == 0 || pd.lb == 0) {
+            float m, d, in;
+            margin_mdi(k, 1u, pd.la, pd.lb, m, d, in);
+            (void)terminal_state(k, m, d, in, score);
+        }
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, false};
+        const bool walk_ok = ck_walk_pair<true>(lane, wa, pd, pair, ch_ops, ch_start, ch_len);
+        if(lane == 0) {
+            // the score (stored plainly by the lane that owned the last column; acknowledged above) goes out
+            // write-through like the rest of the pair's results
+            if(pd.la > 0 && pd.lb > 0) score = ch_scores[pair];
+            if(!handoff_ok || !walk_ok) score = __builtin_nanf("");
+            __hip_atomic_store(&ch_scores[pair], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // the pair's results are in memory -> count it; the last pair of a chunk tells the host
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(lane == 0) {
+            const uint32_t done = __hip_atomic_fetch_add(&chp->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if(done == n_pairs_chunk) {
+                // (done_flag[slot] and t_done[slot] are 128 + 8 * slot bytes apart: CkStreamHost)
+                uint64_t* t_done = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(host_flag - slot) + sizeof(uint32_t) * 16 + sizeof(uint64_t)) + slot;
+                __hip_atomic_store(t_done, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(host_flag, chunk_no + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // Debug: the decision byte of every body cell of one pair (coati_hip_debug_viterbi_flags), by
@@ -869,6 +1136,53 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
         std::fprintf(stderr, "viterbi_ck: %llu pairs, %.2f rounds/pair, %.1f valid tiles/round, %.1f walker iterations/pair\n", st[3],
                      st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0);
     }
+    return hipGetLastError();
+}
+
+uint64_t ck_stream_ctl_bytes() { return sizeof(CkStreamCtl); }
+uint64_t ck_stream_error_offset() { return offsetof(CkStreamCtl, error); }
+uint64_t ck_stream_host_bytes() { return sizeof(CkStreamHost); }
+void* ck_stream_host_entry(void* host, int slot) { return &static_cast<CkStreamHost*>(host)->chunk[slot]; }
+volatile uint32_t* ck_stream_host_done_flag(void* host, int slot) { return &static_cast<CkStreamHost*>(host)->done_flag[slot]; }
+void ck_stream_host_announce(void* host, uint32_t chunks, uint32_t items) {
+    __atomic_store_n(&static_cast<CkStreamHost*>(host)->announced, (static_cast<uint64_t>(chunks) << 32) | items, __ATOMIC_RELEASE);
+}
+double ck_stream_host_done_ms(void* host, int slot) {
+    const CkStreamHost* h = static_cast<const CkStreamHost*>(host);
+    return static_cast<double>(static_cast<int64_t>(h->t_done[slot] - h->t_start)) * 1e-5;
+}
+void ck_stream_host_close(void* host) { __atomic_store_n(&static_cast<CkStreamHost*>(host)->closed, 1u, __ATOMIC_SEQ_CST); }
+
+void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* arena, const BatchDeviceView& v, uint32_t n_pairs,
+                          uint32_t first_ticket, uint32_t chunk_no) {
+    void* host_entry = ck_stream_host_entry(host, slot);
+    uint32_t* host_flag_dev = &static_cast<CkStreamHost*>(host_dev)->done_flag[slot];
+    CkStreamChunk c{};
+    const char* base = static_cast<const char*>(arena);
+    auto off = [&](const void* p) { return static_cast<uint32_t>((static_cast<const char*>(p) - base) >> 8); };
+    c.arena = reinterpret_cast<uint64_t>(arena);
+    c.off_pairs = off(v.pairs), c.off_items = off(v.items), c.off_a = off(v.a_cat), c.off_b = off(v.b_cat), c.off_ck = off(v.flags);
+    c.off_bnd = off(v.bnd), c.off_scores = off(v.scores), c.off_ops = off(v.ops), c.off_start = off(v.ops_start), c.off_len = off(v.ops_len);
+    c.off_progress = off(v.progress);
+    c.host_flag = host_flag_dev;
+    c.n_pairs = n_pairs, c.n_items = v.n_items, c.first_ticket = first_ticket, c.chunk_no = chunk_no, c.done = 0;
+    std::memcpy(host_entry, &c, sizeof c);
+}
+
+hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared_tab, void* ctl, const void* host_words, uint32_t* wave_ck,
+                                    uint64_t wave_slot_dwords, uint32_t* wave_scratch, hipStream_t stream) {
+    const CkShape shape = ck_launch_shape(0xffffffffu, shared_tab);  // the whole chip: the kernel does not know how much is coming
+    const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck_stream<true>) : reinterpret_cast<const void*>(viterbi_ck_stream<false>);
+    if(shape.dynamic_lds > 0) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));
+        if(e != hipSuccess) return e;
+    }
+    if(shared_tab)
+        hipLaunchKernelGGL(viterbi_ck_stream<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
+                           static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch);
+    else
+        hipLaunchKernelGGL(viterbi_ck_stream<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
+                           static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch);
     return hipGetLastError();
 }
 

@@ -377,3 +377,60 @@ def test_pipelined_one_shot_pinned_and_pageable(hip, oracle):
         model.close()
     finally:
         del os.environ["COATI_HIP_MEM_BUDGET"]
+
+
+def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeypatch):
+    """The streamed form of coati_hip_viterbi_batch (one persistent viterbi_ck_stream launch fed chunk by chunk;
+    chosen by itself from 4 096 pairs of >= 250 x 250 cells, forced here): bit-exact against one resident
+    batch of the same pairs -- page-locked and pageable arrays; many more chunks than the 12 stream slots
+    (every slot reused, small unit forced); pairs of two and three strips (own checkpoints, cross-wavefront
+    hand-off inside the persistent kernel), empty and one-letter sides in the same call; a model with
+    several tables; a second call on the same model.  A few pairs are checked against the oracle too."""
+    from coati_amd import host
+
+    if kernel_choice == "bits":
+        pytest.skip("viterbi_l1 forced: the streamed form is viterbi_ck only")
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    rng = np.random.default_rng(77)
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 1500)
+    enc = [(a_cat[int(a_off[p]):int(a_off[p + 1])], b_cat[int(b_off[p]):int(b_off[p + 1])]) for p in range(1500)]
+    extra = util.encode_pairs(util.make_pairs(rng, 40, 0, 60, L=1, amb=0.05))  # short and empty sides
+    for la, lb in [(900, 2300), (1200, 1025), (300, 3100), (2502, 700), (3, 1500), (1500, 1)]:
+        extra.append((rng.integers(0, 183, la).astype(np.uint8), rng.integers(0, 4, lb).astype(np.uint8)))
+    order = rng.permutation(len(enc) + len(extra))
+    enc = [(enc + extra)[i] for i in order]
+    a_cat, a_off, b_cat, b_off = hip.pack_pairs(enc)
+
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    want = batch.viterbi_fetch()
+    batch.close()
+    valid = np.zeros(len(want[1]), bool)
+    for p in range(len(enc)):
+        valid[int(want[2][p]):int(want[2][p]) + int(want[3][p])] = True
+    for p in list(rng.choice(len(enc), 6, replace=False)):
+        a, b = enc[p]
+        w_ops, w_sc = oracle.viterbi(table, consts, 1, a, b, lowmem=len(a) * len(b) > 4_000_000)
+        got = want[1][int(want[2][p]):int(want[2][p]) + int(want[3][p])]
+        assert bits(want[0][p]) == bits(w_sc) and len(got) == len(w_ops) and (got == w_ops).all(), p
+
+    def same(got):
+        sc, ops, off, ln = got
+        assert (bits(sc) == bits(want[0])).all() and (ln == want[3]).all() and (off == want[2]).all()
+        assert (ops[:len(want[1])][valid] == want[1][valid]).all()
+
+    monkeypatch.setenv("COATI_HIP_PIPE", "stream")
+    pa, pb = hip.pinned_copy(a_cat), hip.pinned_copy(b_cat)
+    same(model.viterbi(pa, a_off, pb, b_off, pinned=True))  # default unit: 3 chunks
+    same(model.viterbi(a_cat, a_off, b_cat, b_off))
+    monkeypatch.setenv("COATI_HIP_STREAM_UNIT", "30000000")  # ~30 pairs of 1 kb: ~50 chunks, every slot reused
+    same(model.viterbi(pa, a_off, pb, b_off, pinned=True))
+    same(model.viterbi(a_cat, a_off, b_cat, b_off))
+    same(model.viterbi(pa, a_off, pb, b_off))
+    model.close()
+    # several tables in the model (each wavefront keeps its own copy of the table in LDS): table 0 is used
+    tables = np.stack([table, util.random_table(rng)])
+    model = hip.Model(tables, consts, 1)
+    same(model.viterbi(a_cat, a_off, b_cat, b_off))
+    model.close()

@@ -207,6 +207,23 @@ def cell_lean(c, parity):
             f"v_max_f32 {zl}, {t3}, {t1}", f"v_max3_f32 {xout}, {t4}, {t5}, {t6}", f"v_max3_f32 {y}, {t7}, {t8}, {t9}"]
 
 
+def cell_lean_bc(c, parity):
+    """cell_lean with the sources of each v_max3 / v_max in ONE VGPR bank (register number mod 4): does a
+    bank clash cost issue cycles on this chip?  (The compiler allocates the kernel's temporaries; ~1.4 of the
+    multi-source instructions per cell clash there.)"""
+    xin, xout, y = _lean_regs(c, parity)
+    diag = f"v{DIAG}" if c == 0 else _lean_regs(c - 1, parity)[0]
+    t0, t2, zl = "v10", "v12", f"v{ZL}"
+    t3, t1 = "v13", "v25"             # bank 1, 1
+    t4, t5, t6 = "v14", "v22", "v26"  # bank 2, 2, 2
+    t7, t8, t9 = "v19", "v23", "v27"  # bank 3, 3, 3
+    return [f"v_add_f32 {t0}, {diag}, v{S+c}", f"v_add_f32 {t1}, {GE}, {zl}", f"v_add_f32 {t2}, {GS}, {zl}",
+            f"v_add_f32 {t3}, {GO}, {t0}", f"v_add_f32 {t0}, {NG}, {t0}", f"v_add_f32 {t5}, {GS}, {y}",
+            f"v_add_f32 {t8}, {GE}, {y}", f"v_add_f32 {t4}, {NG}, {t0}", f"v_add_f32 {t6}, {NG}, {t2}",
+            f"v_add_f32 {t7}, {GO}, {t0}", f"v_add_f32 {t9}, {GO}, {t2}", f"v_add_u32 v{ADDR}, v{LDS}, v{BOFF+c}",
+            f"v_max_f32 {zl}, {t3}, {t1}", f"v_max3_f32 {xout}, {t4}, {t5}, {t6}", f"v_max3_f32 {y}, {t7}, {t8}, {t9}"]
+
+
 def cell_lean31(c, parity):
     """The same 15 instructions with one slow op after every 3+ fast ones."""
     xin, xout, y = _lean_regs(c, parity)
@@ -325,7 +342,7 @@ import sys
 
 ALL = {"base": cell_base, "pk": cell_pk, "cmp+sst": cell_cmp, "max3": cell_max3, "clustered": cell_clustered,
        "clustered2": cell_clustered2, "clustered4": cell_clustered4, "clustered_st": cell_clustered_st,
-       "lean": cell_lean, "lean31": cell_lean31, "lean2": cell_lean2, "lean_st": cell_lean_st,
+       "lean": cell_lean, "lean_bc": cell_lean_bc, "lean31": cell_lean31, "lean2": cell_lean2, "lean_st": cell_lean_st,
        "lean31_st": cell_lean31_st}
 # default: the round-2 question (how fast can the fill go without decision bits); `all` adds the round-1 codings
 # (pk needs v2..v7 as constants: run it alone, `gen_cell_pk.py pk`, the store variants overwrite them)
