@@ -19,7 +19,7 @@ rng = np.random.default_rng(seed)
 consts_default = orc.gap_consts()
 exact = util.forward_exact()
 t_end = time.time() + budget
-rounds = pairs_checked = reuse_checked = 0
+rounds = pairs_checked = reuse_checked = oneshot_checked = 0
 while time.time() < t_end:
     L = int(rng.choice([1, 1, 1, 2, 3, 3, 4]))
     # gap_len 1: the planner's kernel choice, or one of the two kernels forced (read per batch_create)
@@ -87,6 +87,27 @@ while time.time() < t_end:
                 sys.exit(1)
         batch2.close()
         reuse_checked += len(sel)
+    # the one-shot call on the same pairs (table 0): chunk pipeline, or the streamed form (one persistent
+    # viterbi_ck_stream launch) with a small random unit so that a few dozen pairs make many chunks
+    if L == 1 and rng.random() < 0.5:
+        os.environ.pop("COATI_HIP_STREAM_UNIT", None)
+        form = str(rng.choice(["stream", "stream", "chunks"]))
+        os.environ["COATI_HIP_PIPE"] = form
+        if form == "stream":
+            os.environ["COATI_HIP_STREAM_UNIT"] = str(int(rng.choice([2e4, 3e5, 4e6, 1e9])))
+        a_cat, a_off, b_cat, b_off = hip.pack_pairs(enc)
+        pinned = bool(rng.random() < 0.5)
+        if pinned:
+            a_cat, b_cat = hip.pinned_copy(a_cat), hip.pinned_copy(b_cat)
+        s3, o3, f3, l3 = model.viterbi(a_cat, a_off, b_cat, b_off, pinned=pinned)
+        os.environ.pop("COATI_HIP_PIPE", None)
+        for p, (a, b) in enumerate(enc):
+            w_ops, w_sc = orc.viterbi(tables[0], consts, L, a, b, lowmem=len(a) * len(b) > 4_000_000)
+            got = o3[int(f3[p]):int(f3[p]) + int(l3[p])]
+            if not (len(got) == len(w_ops) and (got == w_ops).all() and np.float32(s3[p]).view(np.uint32) == np.float32(w_sc).view(np.uint32)):
+                print("MISMATCH in the one-shot call", dict(seed=seed, round=rounds, form=form, unit=os.environ.get("COATI_HIP_STREAM_UNIT"), pinned=pinned, pair=p, la=len(a), lb=len(b)))
+                sys.exit(1)
+        oneshot_checked += len(enc)
     model.close()
     rounds += 1
-print(f"fuzz ok: {rounds} batches, {pairs_checked} pairs, seed {seed}; {reuse_checked} pairs re-run on a reused workspace with identical results")
+print(f"fuzz ok: {rounds} batches, {pairs_checked} pairs, seed {seed}; {reuse_checked} pairs re-run on a reused workspace with identical results; {oneshot_checked} pairs through the one-shot call (chunked / streamed)")
