@@ -213,11 +213,14 @@ int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2
 
 /* One-shot viterbi_mem + traceback_viterbi over any number of pairs -- the batched counterpart of the
  * reference's per-pair loop (src/lib/align_marginal.cc:69-80 called once per process, utils.cc:809-812).
- * The input is cut into chunks that fit the device's memory and PIPELINED: three slots (stream + HBM
- * workspace + page-locked staging, kept by the model between calls) carry chunk k's upload and kernel
- * while chunk k-1's results travel back and the host plans chunk k+1; consecutive kernels overlap at
- * their ragged ends.  Arrays from coati_hip_host_alloc are copied from / into directly (DMA); pageable
- * ones pass through the slot's staging block. */
+ * Pairs arrive in host memory and alignments leave to host memory; uploads, compute and downloads overlap.
+ * Large gap_len 1 inputs (from 4 096 pairs of >= 250 x 250 cells, no pair wider than 8 192 columns or larger
+ * than 64 M cells) run as ONE persistent kernel that the host feeds chunk by chunk over 12 slots (HBM
+ * workspace + page-locked staging, kept by the model between calls); while such a call runs it owns the
+ * device, other work on the GPU waits until it returns.  Everything else is cut into chunks that fit the
+ * device's memory and pipelined with one launch per chunk over three slots.  Either way results are
+ * identical to a resident batch's.  Arrays from coati_hip_host_alloc are copied from / into directly (DMA);
+ * pageable ones pass through a slot's staging block.  One call at a time per model (serialised inside). */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                             const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                             float* scores, uint8_t* ops, uint64_t ops_capacity,
