@@ -18,6 +18,11 @@ if (fwd / "pmc_summary.csv").exists():
     shutil.copy(fwd / "kernel_stats.csv", dst / "forward_kernel_stats.csv")
     shutil.copy(fwd / "pmc_summary.csv", dst / "forward_pmc_summary.csv")
     shutil.copy(fwd / "fwd.json", dst / "forward_fwd_time.txt")
+# the streamed one-shot call: kernel statistics + the probe's wall times
+strm = ROOT / "gpurun_out" / "prof_stream"
+if (strm / "kernel_stats.csv").exists():
+    shutil.copy(strm / "kernel_stats.csv", dst / "stream_kernel_stats.csv")
+    shutil.copy(strm / "stream_probe.txt", dst / "stream_probe_under_rocprof.txt")
 # (steady.txt and short_pairs.txt are hand-kept records of several tool runs: not overwritten here)
 for extra in ("bench_n1.json",
               ):

@@ -16,6 +16,13 @@ for C in WRITE_SIZE FETCH_SIZE; do
         python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_pmc_$C.json" 2> "$OUT/bench_pmc_$C.stderr"
 done
 python3 "$ROOT/tools/summarize_profile.py" "$OUT"
+# the streamed one-shot call (one persistent viterbi_ck_stream launch per call): kernel statistics of
+# tools/stream_probe.py (40 000 pairs, page-locked and pageable arrays, both pipeline forms)
+STR="$ROOT/gpurun_out/prof_stream"
+mkdir -p "$STR"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$STR/stats" -o stream -- \
+    python3 "$ROOT/tools/stream_probe.py" 40000 4 > "$STR/stream_probe.txt" 2> "$STR/stream_probe.stderr"
+cp "$(find "$STR/stats" -name '*kernel_stats.csv' | head -1)" "$STR/kernel_stats.csv" 2>/dev/null
 # the exact Forward fill (configs[3]): kernel statistics and the counters that say what its ~440 VALU slots per
 # cell and its spills cost (separate passes, same command)
 FWD="$ROOT/gpurun_out/prof_fwd"

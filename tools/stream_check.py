@@ -1,7 +1,7 @@
 """GPU check of the streamed one-shot call against one resident batch (bit-exact), both pipeline forms.
 usage: python tools/stream_check.py [n_pairs]"""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from coati_amd import hip, host
 

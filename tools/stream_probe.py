@@ -1,7 +1,7 @@
 """Timing of the one-shot streamed call (page-locked arrays, outputs reused) in both pipeline forms.
 usage: python tools/stream_probe.py [n_pairs] [reps]   (COATI_HIP_PIPE_TIMING=1 for the per-chunk log of the last call)"""
 import sys, time, os
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from coati_amd import hip, host
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
