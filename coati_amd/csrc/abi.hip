@@ -194,6 +194,7 @@ struct coati_hip_batch {
     uint32_t* d_flags = nullptr;   // decision bits (viterbi_l1/_k, dp_generic) or checkpoints (viterbi_ck)
     uint32_t* d_wscratch = nullptr;  // viterbi_ck: traceback scratch of the persistent wavefronts
     uint64_t ck_slot_dwords = 0;     // viterbi_ck: per-wavefront checkpoint slots at the start of d_flags (0: none)
+    uint32_t ck_split_items = 0;     // viterbi_ck: pairs cut into row parts (the last ones of the LPT order); 0: none
     bool ck = false;                 // gap_len 1 runs viterbi_ck (checkpoint layout in d_flags)
     float *d_bnd = nullptr, *d_scores = nullptr;
     float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward (parts of mdi_block)
@@ -217,7 +218,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->d_scores,
-                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords,
+                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
                            b->d_mdi,    b->d_final_mdi};
 }
 }  // namespace
@@ -639,7 +640,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         const bool fwd_k = (L == 2 || L == 3) && !force_generic;
         d.f_compact = static_cast<uint16_t>(fwd_k ? L : 0u);
         d.f_wlog2 = static_cast<uint8_t>(fwd_wlog2);
-        d.reserved_ = 0;
+        d.v_parts = 0;
         b->ops_total += la + lb;
         b->cells += la * lb;
     }
@@ -830,16 +831,57 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             per_pair_total += nd;
         }
         const uint64_t slots_total = slot * ck_scratch_waves();
-        if(slot > 0 && slots_total < per_pair_total) {
+        const bool use_slots = slot > 0 && slots_total < per_pair_total;
+        // The ragged end: when the ticket queue runs dry every wavefront holds an item, and the launch lasts as long as
+        // the SIMD with the most left (10 000 pairs of 1 kb: 0.5 ms of 5.5).  The last pairs of the LPT order are
+        // therefore cut into ROW parts, each its own item at the end of the queue: a part leaves the lane state at a
+        // 64-step boundary and whichever wavefront takes the next part continues there (viterbi_ck.hip).  Measured
+        // (tools/split_ab.py, 10 000 pairs): 2 048 pairs in 3 parts 5.50 -> 4.95 ms; 2 parts 5.05; 4 parts 5.05;
+        // 8 parts or 4 096 pairs lose again (hand-overs, waits for the predecessor).  6 000 pairs: 1 024 x 3 +4 %;
+        // 40 000: +0.8 %.  Their checkpoints must outlive the wavefront that wrote them: own storage.
+        // COATI_HIP_CK_SPLIT="pairs,parts" forces a plan (0 = off).
+        uint64_t split_pairs = 0, parts = 3;
+        if(use_slots && n_pairs > ck_scratch_waves()) {
+            split_pairs = std::min<uint64_t>(ck_scratch_waves() / 2, (n_pairs - ck_scratch_waves()) / 2);
+            if(split_pairs < 256) split_pairs = 0;
+        }
+        if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {
+            char* rest = nullptr;
+            split_pairs = std::strtoull(e, &rest, 10);
+            if(rest != nullptr && *rest == ',') parts = std::strtoull(rest + 1, nullptr, 10);
+            if(parts < 2 || parts > 8) split_pairs = 0;
+        }
+        split_pairs = std::min<uint64_t>(split_pairs, n_pairs);
+        std::vector<uint32_t> cut;  // in LPT order
+        for(uint64_t q = n_pairs - split_pairs; q < n_pairs; ++q) {
+            PairDesc& d = b->desc[order[q]];
+            // (a part is at least two 64-step chunks; narrow last strips and multi-strip pairs stay whole)
+            if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && need_of(d) <= kSlotCap && d.la + kWave >= 128 * parts) {
+                d.v_parts = static_cast<uint8_t>(parts);
+                cut.push_back(order[q]);
+            }
+        }
+        if(!cut.empty()) {  // the cut pairs go to the end of the order, still longest first
+            std::vector<uint32_t> whole;
+            for(const uint32_t p : order)
+                if(b->desc[p].v_parts < 2) whole.push_back(p);
+            whole.insert(whole.end(), cut.begin(), cut.end());
+            order.swap(whole);
+            b->ck_split_items = static_cast<uint32_t>(cut.size());
+        }
+        if(use_slots || !cut.empty()) {
             // re-lay the arena: [wave slots | pairs that keep their own storage]
-            uint64_t at = slots_total;
+            uint64_t at = use_slots ? slots_total : 0;
             for(uint64_t p = 0; p < n_pairs; ++p) {
                 PairDesc& d = b->desc[p];
                 if(!(d.la > 0 && d.lb > 0)) {
                     d.flags_off = at;
                     continue;
                 }
-                if(d.v_strips == 1 && need_of(d) <= kSlotCap) {
+                if(d.v_parts >= 2) {
+                    d.flags_off = at;
+                    at += ck_strip_dwords(d.la, d.v_wlast) + kCkPartStateDwords;
+                } else if(use_slots && d.v_strips == 1 && need_of(d) <= kSlotCap) {
                     d.flags_off = kCkWaveSlot;
                 } else {
                     d.flags_off = at;
@@ -847,7 +889,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                 }
             }
             b->flag_dwords = at;
-            b->ck_slot_dwords = slot;
+            b->ck_slot_dwords = use_slots ? slot : 0;
         }
     }
 
@@ -862,6 +904,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                                 "%s failed: %s", #expr, hipGetErrorString(e_)));                \
     } while(0)
     // work lists: one item per strip, pairs in LPT order
+    // (a pair cut into row parts -- they are the last ones of `order` -- contributes its part 0 here; parts 1.. of
+    // all of them follow in the same order, so that a part's predecessor is ck_split_items tickets before it)
     std::vector<WorkItem> items, fwd_items;
     for(const uint32_t p : order) {
         for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
@@ -871,6 +915,11 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact)
                                              : fwd_strips_w(b->desc[p].lb, 1u << b->desc[p].f_wlog2);
         for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
+    }
+    if(b->ck_split_items > 0) {
+        const uint32_t parts = b->desc[order[n_pairs - 1]].v_parts;
+        for(uint32_t part = 1; part < parts; ++part)
+            for(uint64_t q = n_pairs - b->ck_split_items; q < n_pairs; ++q) items.push_back(WorkItem{order[q], part << 16});
     }
     b->n_items = static_cast<uint32_t>(items.size());
     b->n_fwd_items = static_cast<uint32_t>(fwd_items.size());
@@ -1557,9 +1606,13 @@ bool is_pinned_host(const void* p) {
 // HBM workspace + page-locked staging a chunk of pairs [p0, p1) needs (upper bounds; the plan of
 // batch_create_impl is authoritative and fails cleanly if a chunk does not fit after all)
 struct ChunkNeed {
-    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, ck_own16 = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
+    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, ck_own16 = 0, pairs = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
     // checkpoints: per pair, or in per-wavefront slots when that is smaller (batch_create_impl decides the same way)
-    uint64_t arena() const { return fixed + std::min<uint64_t>(ck_sum, ck_max * ck_scratch_waves() + ck_sum / 64); }
+    // (+ the own storage of the pairs a large batch cuts into row parts: batch_create_impl, "the ragged end")
+    uint64_t arena() const {
+        const uint64_t cut = pairs > ck_scratch_waves() ? std::min<uint64_t>(ck_scratch_waves() / 2, (pairs - ck_scratch_waves()) / 2) : 0;
+        return fixed + std::min<uint64_t>(ck_sum, ck_max * (ck_scratch_waves() + cut) + ck_sum / 64);
+    }
     // chunk of a streamed call: wavefront slots and traceback scratch are the call's, not the chunk's
     uint64_t arena_streamed() const {
         return fixed - static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + ck_own16;
@@ -1586,9 +1639,10 @@ void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
         const uint64_t last = ck_strip_dwords(static_cast<uint32_t>(la), wl);
         if(ns > 1 || last > (1ull << 20)) nd.ck_own16 += ((ns - 1) * ck_strip_dwords(static_cast<uint32_t>(la), kW) + last) * 4;
     }
-    nd.fixed += 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 1024;
+    nd.fixed += 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 7 * 12 + 1024;
+    nd.pairs += 1;
     nd.seq_bytes += la + lb;
-    nd.meta_bytes += sizeof(PairDesc) + 4 + strips * 24 + 16;  // descriptor, order entry, work items (both lists), progress word
+    nd.meta_bytes += sizeof(PairDesc) + 4 + strips * 24 + 16 + 7 * 12;  // (+ the items and progress words of up to 8 row parts)  // descriptor, order entry, work items (both lists), progress word
     nd.ops += la + lb;
     nd.cells += la * lb;
 }

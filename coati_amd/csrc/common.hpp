@@ -59,8 +59,17 @@ struct PairDesc {
     // strips (forward_k.hip)
     uint16_t f_compact;
     uint8_t f_wlog2;  // log2 of the columns per lane of the Forward strips (2, 3, 4)
-    uint8_t reserved_;
+    // viterbi_ck: the pair's (single) strip is cut into this many ROW parts, each its own work item, continued by
+    // whichever wavefront takes the next part (0 or 1: not cut).  Finer items for the ragged end of a launch.
+    uint8_t v_parts;
 };
+// steps [begin, end) of row part `part` of `parts` of a strip of nsteps wavefront steps: whole 64-step chunks
+__host__ __device__ inline void ck_part_range(uint32_t nsteps, uint32_t parts, uint32_t part, uint32_t& begin, uint32_t& end) {
+    const uint32_t chunks = (nsteps + 63u) / 64u;
+    begin = 64u * (part * chunks / parts);
+    end = part + 1u == parts ? nsteps : 64u * ((part + 1u) * chunks / parts);
+}
+constexpr uint32_t kCkPartStateDwords = 3u * 64u;  // what a part leaves for the next besides the row checkpoint: per lane xlast_old, zlast, table row
 
 // HBM layout of the decision bits of one strip of one pair.  A strip is 64*W descendant
 // columns, W = 4, 8 or 16 columns per lane (W = 16 is the full-speed shape; narrower strips are
@@ -419,6 +428,7 @@ struct BatchDeviceView {
     uint32_t* ops_len;
     uint32_t* wscratch;  // viterbi_ck: per-wavefront scratch of the traceback (decision bits of one round)
     uint64_t ck_slot_dwords;  // viterbi_ck: size of one per-wavefront checkpoint slot (0: every pair has its own storage)
+    uint32_t ck_split_items;  // viterbi_ck: row part p > 0 of a cut pair waits for the item this many tickets before its own
     float* mdi;        // Forward: fp32 M/D/I of every body cell
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
 };

@@ -222,7 +222,11 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                                               uint32_t ticket, int lane, uint32_t lds_tab, const char* tab_bytes,
                                               const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
                                               uint32_t* __restrict__ ck, float* __restrict__ bnd,
-                                              float* __restrict__ scores, uint32_t* __restrict__ progress) {
+                                              float* __restrict__ scores, uint32_t* __restrict__ progress,
+                                              uint32_t kbegin = 0, uint32_t kend = 0xffffffffu) {
+    // [kbegin, kend): the steps of this item -- the whole strip, or one ROW PART of it (PairDesc::v_parts; whole
+    // 64-step chunks).  A part that does not start at 0 takes over the lane state its predecessor left behind the
+    // strip's checkpoints; one that does not end at the last step leaves it there.
     const uint32_t la = pd.la, lb = pd.lb;
     const uint32_t col0 = strip * (kWave * pd.v_wmain);  // every strip before this one has the main width
     const uint32_t ncol = min(static_cast<uint32_t>(kWave * W), lb - col0);
@@ -249,8 +253,24 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
     // ge*float(j-1)); a lane takes it again at its first step (ck_step)
+    kend = min(kend, nsteps);
+    uint32_t* __restrict__ part_state = ck_strip + ck_strip_dwords(la, W);  // [3][64]: xlast_old, zlast, table row
     CkLane<W> st;
-    {
+    uint32_t arow;
+    if(kbegin != 0) {
+        // a continuation: X, Y are the row checkpoint of the band that starts here (the predecessor wrote it early)
+        const float4* __restrict__ rq =
+            reinterpret_cast<const float4*>(rowck_strip + static_cast<uint64_t>(kbegin / kCkRows) * (2 * W * kWave));
+#pragma unroll
+        for(int q = 0; q < W / 4; ++q) {
+            const float4 x = rq[q * kWave + lane], y = rq[(W / 4 + q) * kWave + lane];
+            st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
+            st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
+        }
+        st.xlast_old = __builtin_bit_cast(float, part_state[lane]);
+        st.zlast = __builtin_bit_cast(float, part_state[kWave + lane]);
+        arow = part_state[2 * kWave + lane];
+    } else {
         const uint32_t bj0 = col0 + lane * W;
 #pragma unroll
         for(int c = 0; c < W; ++c) {
@@ -260,17 +280,17 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             st.Y[c] = i1 + k.go;
         }
         if(!last_strip && lane == kWave - 1) store_through(&bnd_x[0], st.X[W - 1]);
+        st.xlast_old = 0.0f;
+        st.zlast = 0.0f;
+        // table-row byte offset of the row this lane processes at the CURRENT step (every lane's first row is body row 0)
+        arow = static_cast<uint32_t>(a[0]) * (kTabStride * 4u);
     }
-    st.xlast_old = 0.0f;
-    st.zlast = 0.0f;
-    // table-row byte offset of the row this lane processes at the CURRENT step, and the W
-    // substitution scores gathered for it one step earlier (every lane's first row is body row 0)
-    uint32_t arow = static_cast<uint32_t>(a[0]) * (kTabStride * 4u);
+    // the W substitution scores of that row, gathered one step ahead
     float s[W];
 #pragma unroll
     for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
 
-    for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+    for(uint32_t kbase = kbegin; kbase < kend; kbase += kWave) {
         // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l (boundary
         // column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
         const uint32_t crow = kbase + lane;
@@ -304,6 +324,16 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
         }
+    }
+    if(kend < nsteps) {
+        // a row part ends here: the lane state for whoever continues (X, Y as the row checkpoint of the next band --
+        // the continuation stores the same values there again --, the rest behind the strip's checkpoints)
+        const CkChunkMem next{make_rsrc(ck_strip), make_rsrc(rowck_strip + static_cast<uint64_t>(kend / kCkRows) * (2 * W * kWave))};
+        store_rowck<W>(next, lane, st, 0);
+        part_state[lane] = fbits(st.xlast_old);
+        part_state[kWave + lane] = fbits(st.zlast);
+        part_state[2 * kWave + lane] = arow;
+        return handoff_ok;
     }
     // score = max(M,D,I) of the terminal-adjusted last cell (align_pair.cc:130-138,265) = X of the
     // last body cell, held by the lane that owns the last column after the strip's last step
@@ -652,7 +682,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ ck, float* __restrict__ bnd, float* __restrict__ scores, uint8_t* __restrict__ ops,
     uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t* __restrict__ wscratch,
-    uint64_t ck_slot_dwords, uint32_t dbg) {
+    uint64_t ck_slot_dwords, uint32_t split_items, uint32_t dbg) {
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[kSharedTab ? 0 : threadIdx.x / kWave];
@@ -692,7 +722,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
         if(ticket >= n_items) break;
         const WorkItem item = items[ticket];
-        const uint32_t pair = item.pair, strip = item.strip;
+        const uint32_t pair = item.pair, strip = item.strip & 0xffffu, part = item.strip >> 16;
         const PairDesc pd = pairs[pair];
         // the pair's checkpoint area: its own, or (single-strip pair of a large batch) this wavefront's slot
         uint32_t* __restrict__ ckp = ck + (pd.flags_off == kCkWaveSlot ? static_cast<uint64_t>(wave_id) * ck_slot_dwords : pd.flags_off);
@@ -709,9 +739,24 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         }
         const uint8_t* __restrict__ a = a_cat + pd.a_off;
         const uint8_t* __restrict__ b = b_cat + pd.b_off;
+        // a pair cut into row parts (the last pairs of a large batch: abi.hip, "the ragged end"): this item is steps
+        // [kbegin, kend) of the pair's one strip; part p > 0 continues where part p - 1 -- split_items tickets earlier,
+        // on whatever wavefront took it -- stopped
+        uint32_t kbegin = 0, kend = 0xffffffffu;
+        const bool cut = pd.v_parts >= 2;
+        if(cut) {
+            const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
+            ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
+            if(part > 0) {
+                handoff_ok = wait_progress(progress + ticket - split_items, kbegin);  // (acquires)
+                if(__hip_atomic_load(progress + ticket - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+            }
+        }
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-            if(w == 16)
+            if(cut)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend) && handoff_ok;
+            else if(w == 16)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
             else if(w == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
@@ -719,6 +764,14 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
         }
         COATI_CK_STAMP(0);  // fill of this item done
+        if(cut && part + 1 < pd.v_parts) {
+            // not the pair's last row part: release what this wavefront wrote for the pair (checkpoints, lane state),
+            // then say how far the pair has got (or that it is lost)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            publish_progress(progress + ticket, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
+            continue;
+        }
         if(strip + 1 < pd.v_strips || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
         // ---- traceback of this pair by the wavefront of its last strip.  What the wave wrote
         // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
@@ -1122,11 +1175,11 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     if(shared_tab)
         hipLaunchKernelGGL(viterbi_ck<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, dbg);
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg);
     else
         hipLaunchKernelGGL(viterbi_ck<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, dbg);
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg);
     if(dbg & 2u) {
         unsigned long long st[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
         e = hipStreamSynchronize(stream);

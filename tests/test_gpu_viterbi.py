@@ -434,3 +434,35 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
     model = hip.Model(tables, consts, 1)
     same(model.viterbi(a_cat, a_off, b_cat, b_off))
     model.close()
+
+
+@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8"])
+def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, plan):
+    """viterbi_ck cuts the last pairs of a large batch's LPT order into row parts (own work items; a part leaves
+    the lane state at a 64-step boundary, whichever wavefront takes the next part continues -- abi.hip "the ragged
+    end"; by itself from 4 352 pairs, forced here on a small batch): scores, ops and every decision byte as the
+    oracle has them, for 2, 3, 4 and 8 parts, with whole pairs, two-strip pairs, short pairs (too short to cut)
+    and empty sides in the same batch; twice on the same batch (the progress words are reset per launch)."""
+    if kernel_choice == "bits":
+        pytest.skip("viterbi_l1 forced: row parts are viterbi_ck's")
+    monkeypatch.setenv("COATI_HIP_CK_SPLIT", plan)
+    monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")  # (a batch this small would go to viterbi_l1's planner rule otherwise)
+    rng = np.random.default_rng(5)
+    table, consts = util.random_table(rng), oracle.gap_consts()
+    pairs = util.make_pairs(rng, 50, 100, 420, L=1, amb=0.03)  # 300 .. 1 260 nt
+    pairs += util.make_pairs(rng, 10, 0, 30, L=1)
+    pairs.append((util.random_anc(rng, 200), "".join(rng.choice(list(util.NT), 1500))))  # two strips
+    run_and_compare(hip, oracle, table, consts, pairs, check_flags=True)
+    # the same batch launched twice gives the same answer
+    enc = util.encode_pairs(pairs)
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc))
+    batch.viterbi_launch()
+    first = batch.viterbi_fetch()
+    batch.viterbi_launch()
+    second = batch.viterbi_fetch()
+    assert (bits(first[0]) == bits(second[0])).all() and (first[3] == second[3]).all()
+    for p in range(len(enc)):
+        assert (first[1][int(first[2][p]):int(first[2][p]) + int(first[3][p])] == second[1][int(second[2][p]):int(second[2][p]) + int(second[3][p])]).all()
+    batch.close()
+    model.close()

@@ -27,8 +27,11 @@ while time.time() < t_end:
     os.environ.pop("COATI_HIP_VITERBI_CK", None)
     os.environ.pop("COATI_HIP_VITERBI_BITS", None)
     forced = rng.choice(["auto", "ck", "ck", "bits"])
+    os.environ.pop("COATI_HIP_CK_SPLIT", None)
     if forced == "ck":
         os.environ["COATI_HIP_VITERBI_CK"] = "1"
+        if rng.random() < 0.5:  # the last pairs of the LPT order cut into row parts (default only from 4 352 pairs)
+            os.environ["COATI_HIP_CK_SPLIT"] = "%d,%d" % (int(rng.integers(1, 40)), int(rng.integers(2, 9)))
     elif forced == "bits":
         os.environ["COATI_HIP_VITERBI_BITS"] = "1"
     n_tables = int(rng.integers(1, 4))
