@@ -161,6 +161,8 @@ struct coati_hip_model {
         size_t pinned_bytes = 0;
     };
     StreamSlot sslots[kCkStreamSlots];
+    void* stream_tail_arena[2] = {nullptr, nullptr};  // workspaces of a call's last two chunks (their pairs keep their checkpoints)
+    size_t stream_tail_bytes = 0;
     void* d_stream_waves = nullptr;  // per-wavefront checkpoint slots + traceback scratch, shared by all chunks of a call
     size_t stream_waves_bytes = 0;
     hipEvent_t stream_events[kCkStreamSlots + 1] = {};  // [slot]: its download is done; [last]: an upload is done
@@ -406,6 +408,8 @@ void model_release(coati_hip_model* m) {
     if(m->d_stream_ctl != nullptr) (void)hipFree(m->d_stream_ctl);
     if(m->h_stream != nullptr) (void)hipHostFree(m->h_stream);
     if(m->d_stream_waves != nullptr) (void)hipFree(m->d_stream_waves);
+    for(void* t : m->stream_tail_arena)
+        if(t != nullptr) (void)hipFree(t);
     for(hipEvent_t e : m->stream_events)
         if(e != nullptr) (void)hipEventDestroy(e);
     for(auto& ss : m->sslots) {
@@ -471,6 +475,11 @@ int coati_hip_model_trim(coati_hip_model_t* m) {
         if(m->d_stream_waves != nullptr) (void)hipFree(m->d_stream_waves);
         m->d_stream_waves = nullptr;
         m->stream_waves_bytes = 0;
+        for(void*& t : m->stream_tail_arena) {
+            if(t != nullptr) (void)hipFree(t);
+            t = nullptr;
+        }
+        m->stream_tail_bytes = 0;
     }
     return COATI_HIP_OK;
 }
@@ -507,6 +516,7 @@ struct BatchOpts {
     // chunks of a streamed call: the per-wavefront checkpoint slots (this many dwords each) and the traceback
     // scratch live outside the chunk's workspace, shared by all chunks (viterbi_batch_stream)
     uint64_t wave_slot_dwords = 0;
+    uint32_t tail_parts = 0;  // one of the call's LAST chunks: every pair that can be is cut into this many row parts
 };
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                       const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
@@ -803,12 +813,34 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // the smaller arena (a 1 kb pair needs 1.09 MB: 10 000 pairs 10.9 GB per pair, 4.5 GB in 4 096 slots; a
     // batch of a few pairs keeps per-pair storage).  Pairs above kSlotCap keep their own storage either way.
     if(b->ck && opts != nullptr && opts->wave_slot_dwords != 0) {
-        // streamed chunk: every single-strip pair that fits the call's shared slots uses them; the workspace keeps the rest
+        // streamed chunk: every single-strip pair that fits the call's shared slots uses them; the workspace keeps the rest.
+        // One of the call's last chunks: its pairs are cut into row parts (the ragged end, below) and keep their checkpoints.
+        if(opts->tail_parts >= 2) {
+            std::vector<uint32_t> whole, cut;
+            for(const uint32_t p : order) {
+                PairDesc& d = b->desc[p];
+                if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && ck_strip_dwords(d.la, kW) <= (1ull << 20) &&
+                   d.la + kWave >= 128 * opts->tail_parts) {
+                    d.v_parts = static_cast<uint8_t>(opts->tail_parts);
+                    cut.push_back(p);
+                } else {
+                    whole.push_back(p);
+                }
+            }
+            if(!cut.empty()) {
+                whole.insert(whole.end(), cut.begin(), cut.end());
+                order.swap(whole);
+                b->ck_split_items = static_cast<uint32_t>(cut.size());
+            }
+        }
         uint64_t at = 0;
         for(uint64_t p = 0; p < n_pairs; ++p) {
             PairDesc& d = b->desc[p];
             if(!(d.la > 0 && d.lb > 0)) {
                 d.flags_off = at;
+            } else if(d.v_parts >= 2) {
+                d.flags_off = at;
+                at += ck_strip_dwords(d.la, d.v_wlast) + kCkPartStateDwords;
             } else if(d.v_strips == 1 && ck_strip_dwords(d.la, d.v_wlast) <= opts->wave_slot_dwords) {
                 d.flags_off = kCkWaveSlot;
             } else {
@@ -1606,7 +1638,7 @@ bool is_pinned_host(const void* p) {
 // HBM workspace + page-locked staging a chunk of pairs [p0, p1) needs (upper bounds; the plan of
 // batch_create_impl is authoritative and fails cleanly if a chunk does not fit after all)
 struct ChunkNeed {
-    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, ck_own16 = 0, pairs = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
+    uint64_t fixed = 0, ck_sum = 0, ck_max = 0, ck_own16 = 0, ck_cut16 = 0, pairs = 0, seq_bytes = 0, meta_bytes = 0, ops = 0, cells = 0;
     // checkpoints: per pair, or in per-wavefront slots when that is smaller (batch_create_impl decides the same way)
     // (+ the own storage of the pairs a large batch cuts into row parts: batch_create_impl, "the ragged end")
     uint64_t arena() const {
@@ -1614,8 +1646,8 @@ struct ChunkNeed {
         return fixed + std::min<uint64_t>(ck_sum, ck_max * (ck_scratch_waves() + cut) + ck_sum / 64);
     }
     // chunk of a streamed call: wavefront slots and traceback scratch are the call's, not the chunk's
-    uint64_t arena_streamed() const {
-        return fixed - static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + ck_own16;
+    uint64_t arena_streamed(bool tail = false) const {
+        return fixed - static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + ck_own16 + (tail ? ck_cut16 : 0);
     }
 };
 void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
@@ -1637,7 +1669,10 @@ void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
         uint32_t ns = 1, wl = kW;
         viterbi_strip_plan(static_cast<uint32_t>(lb), kW, ns, wl);
         const uint64_t last = ck_strip_dwords(static_cast<uint32_t>(la), wl);
-        if(ns > 1 || last > (1ull << 20)) nd.ck_own16 += ((ns - 1) * ck_strip_dwords(static_cast<uint32_t>(la), kW) + last) * 4;
+        if(ns > 1 || last > (1ull << 20))
+            nd.ck_own16 += ((ns - 1) * ck_strip_dwords(static_cast<uint32_t>(la), kW) + last) * 4;
+        else if(wl == kW)
+            nd.ck_cut16 += (last + kCkPartStateDwords) * 4;  // (what it keeps if the chunk is one of the call's last: row parts)
     }
     nd.fixed += 3 * (la + lb) + 16 * (la + 1) + sizeof(PairDesc) + 32 + strips * 24 + 7 * 12 + 1024;
     nd.pairs += 1;
@@ -1719,6 +1754,19 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             if(!soft(hipHostMalloc(&ss.pinned, kSlotStaging, hipHostMallocDefault))) return COATI_HIP_ESTATE;
             ss.pinned_bytes = kSlotStaging;
         }
+    }
+    // the call's last two chunks are cut into row parts (finer items for the ragged end of the kernel, as a resident
+    // batch's last pairs are): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- two larger workspaces
+    const uint64_t tail_bytes = std::min<uint64_t>(3ull << 30, std::max<uint64_t>(kSlotArena, 1250 * (wave_slot_bytes + 4096) + (64ull << 20)));
+    if(model->stream_tail_bytes < tail_bytes) {
+        for(void*& t : model->stream_tail_arena) {
+            if(t != nullptr) (void)hipFree(t);
+            t = nullptr;
+        }
+        model->stream_tail_bytes = 0;
+        bool ok = true;
+        for(void*& t : model->stream_tail_arena) ok = ok && soft(hipMalloc(&t, tail_bytes));
+        if(ok) model->stream_tail_bytes = tail_bytes;  // (else: no row parts in this call)
     }
     void* hs = model->h_stream;
     std::memset(hs, 0, host_bytes);
@@ -1850,6 +1898,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     uint32_t published = 0;
     uint64_t p0 = 0, ops_base = 0;
     long double cells_done = 0;
+    int tails_used = 0;
+    const char* const no_tail_parts = std::getenv("COATI_HIP_STREAM_NO_PARTS");  // (A/B)
     for(size_t ci = 0; p0 < n_pairs && rc == COATI_HIP_OK; ++ci) {
         const int q = static_cast<int>(ci % kSlots);
         coati_hip_model::StreamSlot& sl = model->sslots[q];
@@ -1858,13 +1908,17 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         rc = wait_free(q);
         if(rc != COATI_HIP_OK) break;
         const long double target = ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
+        // the last two chunks (~2 000 pairs of 1 kb): row parts, in the two large workspaces
+        const bool tail = ci >= 2 && total_cells - cells_done <= 2.2L * kUnit && tails_used < 2 && model->stream_tail_bytes != 0 && no_tail_parts == nullptr;
+        void* const arena = tail ? model->stream_tail_arena[tails_used] : sl.arena;
+        const uint64_t arena_bytes = tail ? model->stream_tail_bytes : sl.arena_bytes;
         ChunkNeed nd;
         nd.fixed = static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + (64u << 10);
         uint64_t p1 = p0;
         while(p1 < n_pairs) {
             ChunkNeed with = nd;
             chunk_need_add(with, a_off[p1 + 1] - a_off[p1], b_off[p1 + 1] - b_off[p1], gap_len);
-            if(p1 > p0 && (static_cast<long double>(with.cells) > target || with.arena_streamed() + with.arena_streamed() / 8 + (1u << 20) > sl.arena_bytes ||
+            if(p1 > p0 && (static_cast<long double>(with.cells) > target || with.arena_streamed(tail) + with.arena_streamed(tail) / 8 + (1u << 20) > arena_bytes ||
                            staging_of(with, p1 + 1 - p0) > sl.pinned_bytes))
                 break;
             nd = with;
@@ -1878,13 +1932,17 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         const uint64_t out_off = (sl.pinned_bytes - out_bytes_of(n, c.ops_bytes)) / 256 * 256;
         BatchOpts bo;
         bo.stream = up_stream;
-        bo.arena = sl.arena;
-        bo.arena_bytes = sl.arena_bytes;
+        bo.arena = arena;
+        bo.arena_bytes = arena_bytes;
         bo.staging = static_cast<char*>(sl.pinned);
         bo.staging_bytes = out_off;
         bo.seqs_pinned = in_pinned;
         bo.force_ck = true;
         bo.force_w_main = kW;  // (a small chunk is not a small batch: no narrowed strips)
+        if(tail) {
+            bo.tail_parts = 3;
+            ++tails_used;
+        }
         bo.wave_slot_dwords = wave_slot_bytes / 4;
         rc = batch_create_impl(model, n, a_cat, a_off + c.p0, b_cat, b_off + c.p0, nullptr, &bo, &f.batch);
         if(rc != COATI_HIP_OK) {  // (ENOMEM: the slot's workspace cannot grow while the kernel runs)

@@ -811,7 +811,8 @@ struct CkStreamChunk {
     // every array of a chunk is a 256-byte aligned part of ONE arena (abi.hip): base + 32-bit offsets in units
     // of 256 bytes keep the entry small enough to live in SGPRs while a wavefront works on an item
     uint64_t arena;
-    uint32_t off_pairs, off_items, off_a, off_b, off_ck, off_bnd, off_scores, off_ops, off_start, off_len, off_progress, pad0_;
+    uint32_t off_pairs, off_items, off_a, off_b, off_ck, off_bnd, off_scores, off_ops, off_start, off_len, off_progress;
+    uint32_t split_items;  // row part p > 0 of a cut pair waits for the item this many (chunk-local) tickets before its own
     uint32_t* host_flag;   // page-locked host memory: set to chunk_no + 1 when the chunk is complete
     uint32_t n_pairs, n_items, first_ticket, chunk_no;
     uint32_t done, pad_[3];  // pairs finished (device atomics)
@@ -962,23 +963,25 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         auto u32 = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
         auto u64 = [&](uint64_t v) { return static_cast<uint64_t>(u32(static_cast<uint32_t>(v))) | (static_cast<uint64_t>(u32(static_cast<uint32_t>(v >> 32))) << 32); };
         char* const arena = reinterpret_cast<char*>(u64(chp->arena));
-        auto part = [&](uint32_t off256) { return arena + (static_cast<uint64_t>(u32(off256)) << 8); };
+        auto arr = [&](uint32_t off256) { return arena + (static_cast<uint64_t>(u32(off256)) << 8); };
         const uint32_t first_ticket = u32(chp->first_ticket), n_pairs_chunk = u32(chp->n_pairs), chunk_no = u32(chp->chunk_no);
         uint32_t* const host_flag = reinterpret_cast<uint32_t*>(u64(reinterpret_cast<uint64_t>(chp->host_flag)));
-        const PairDesc* __restrict__ ch_pairs = reinterpret_cast<const PairDesc*>(part(chp->off_pairs));
-        const WorkItem* __restrict__ ch_items = reinterpret_cast<const WorkItem*>(part(chp->off_items));
-        const uint8_t* __restrict__ ch_a = reinterpret_cast<const uint8_t*>(part(chp->off_a));
-        const uint8_t* __restrict__ ch_b = reinterpret_cast<const uint8_t*>(part(chp->off_b));
-        uint32_t* __restrict__ ch_ck = reinterpret_cast<uint32_t*>(part(chp->off_ck));
-        float* __restrict__ ch_bnd = reinterpret_cast<float*>(part(chp->off_bnd));
-        float* __restrict__ ch_scores = reinterpret_cast<float*>(part(chp->off_scores));
-        uint8_t* __restrict__ ch_ops = reinterpret_cast<uint8_t*>(part(chp->off_ops));
-        uint64_t* __restrict__ ch_start = reinterpret_cast<uint64_t*>(part(chp->off_start));
-        uint32_t* __restrict__ ch_len = reinterpret_cast<uint32_t*>(part(chp->off_len));
-        uint32_t* __restrict__ ch_progress = reinterpret_cast<uint32_t*>(part(chp->off_progress));
+        const PairDesc* __restrict__ ch_pairs = reinterpret_cast<const PairDesc*>(arr(chp->off_pairs));
+        const WorkItem* __restrict__ ch_items = reinterpret_cast<const WorkItem*>(arr(chp->off_items));
+        const uint8_t* __restrict__ ch_a = reinterpret_cast<const uint8_t*>(arr(chp->off_a));
+        const uint8_t* __restrict__ ch_b = reinterpret_cast<const uint8_t*>(arr(chp->off_b));
+        uint32_t* __restrict__ ch_ck = reinterpret_cast<uint32_t*>(arr(chp->off_ck));
+        float* __restrict__ ch_bnd = reinterpret_cast<float*>(arr(chp->off_bnd));
+        float* __restrict__ ch_scores = reinterpret_cast<float*>(arr(chp->off_scores));
+        uint8_t* __restrict__ ch_ops = reinterpret_cast<uint8_t*>(arr(chp->off_ops));
+        uint64_t* __restrict__ ch_start = reinterpret_cast<uint64_t*>(arr(chp->off_start));
+        uint32_t* __restrict__ ch_len = reinterpret_cast<uint32_t*>(arr(chp->off_len));
+        uint32_t* __restrict__ ch_progress = reinterpret_cast<uint32_t*>(arr(chp->off_progress));
         const uint32_t local = ticket - first_ticket;
         const WorkItem item = ch_items[local];
-        const uint32_t pair = u32(item.pair), strip = u32(item.strip);
+        const uint32_t pair = u32(item.pair), strip_word = u32(item.strip);
+        const uint32_t strip = strip_word & 0xffffu, part = strip_word >> 16;  // (row part of a cut pair: the call's last chunks)
+        const uint32_t split_items = u32(chp->split_items);
         // (loaded through a pointer the compiler cannot trace to a kernel argument, i.e. with vector loads: made
         // wave-uniform word by word, or every address derived from it -- buffer descriptors included -- counts as
         // divergent)
@@ -1009,14 +1012,32 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         }
         const uint8_t* __restrict__ a = ch_a + pd.a_off;
         const uint8_t* __restrict__ b = ch_b + pd.b_off;
+        uint32_t kbegin = 0, kend = 0xffffffffu;
+        const bool cut = pd.v_parts >= 2;
+        if(cut) {  // (as in viterbi_ck)
+            const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
+            ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
+            if(part > 0) {
+                handoff_ok = wait_progress(ch_progress + local - split_items, kbegin);
+                if(__hip_atomic_load(ch_progress + local - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+            }
+        }
         if(pd.la > 0 && pd.lb > 0) {
             const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-            if(w == 16)
+            if(cut)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend) && handoff_ok;
+            else if(w == 16)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
             else if(w == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+        }
+        if(cut && part + 1 < pd.v_parts) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            publish_progress(ch_progress + local, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
+            continue;
         }
         if(strip + 1 < pd.v_strips) continue;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1217,6 +1238,7 @@ void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* aren
     c.off_pairs = off(v.pairs), c.off_items = off(v.items), c.off_a = off(v.a_cat), c.off_b = off(v.b_cat), c.off_ck = off(v.flags);
     c.off_bnd = off(v.bnd), c.off_scores = off(v.scores), c.off_ops = off(v.ops), c.off_start = off(v.ops_start), c.off_len = off(v.ops_len);
     c.off_progress = off(v.progress);
+    c.split_items = v.ck_split_items;
     c.host_flag = host_flag_dev;
     c.n_pairs = n_pairs, c.n_items = v.n_items, c.first_ticket = first_ticket, c.chunk_no = chunk_no, c.done = 0;
     std::memcpy(host_entry, &c, sizeof c);
