@@ -64,3 +64,35 @@ for pl in np.unique(place):
         percu[pl] = fill1[m].mean()
 v = np.array(list(percu.values()))
 print("per-CU mean of item-1 fill: min %.1f p50 %.1f max %.1f" % (v.min(), np.median(v), v.max()))
+
+# ---- utilisation over time: wavefronts that hold an item (between a stamp pair), per 250 us
+t_end = us(last).max()
+edges = np.arange(0.0, t_end + 250.0, 250.0)
+busy = np.zeros(len(edges) - 1)
+filling = np.zeros(len(edges) - 1)
+for i in range(tr.shape[0]):
+    n = int(n_items[i])
+    if n == 0:
+        continue
+    b, e = us(tr[i, 0]), us(tr[i, 2 * n])  # a wavefront is busy from its start to its last stamp
+    lo, hi = np.clip(np.searchsorted(edges, [b, e]) - 1, 0, len(busy) - 1)
+    for k in range(lo, hi + 1):
+        busy[k] += max(0.0, min(e, edges[k + 1]) - max(b, edges[k])) / 250.0
+print("busy wavefronts per 250 us bin:", " ".join("%d" % x for x in busy))
+# when does each SIMD go idle for good?
+simd_last = {}
+for i in range(tr.shape[0]):
+    if n_items[i] > 0:
+        simd_last[key[i]] = max(simd_last.get(key[i], 0.0), us(tr[i, 2 * int(n_items[i])]))
+sl = np.array(list(simd_last.values()))
+print("SIMD's last stamp (us): p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f max %.0f; mean idle before the end %.0f us" %
+      (*np.percentile(sl, [5, 25, 50, 75, 95, 100]), (sl.max() - sl).mean()))
+
+# which wavefronts (launch index = blockIdx * waves per workgroup + wave) are the starved ones (one item in the whole launch)?
+idx = np.nonzero(used)[0]
+starved = idx[n_items == 1]
+if len(starved):
+    print("wavefronts with ONE item: %d; launch index quartiles %s; share with index >= 3072: %.2f" %
+          (len(starved), np.percentile(starved, [0, 25, 50, 75, 100]).astype(int), float((starved >= 3072).mean())))
+    rich = idx[n_items >= 3]
+    print("wavefronts with >= 3 items: %d; launch index quartiles %s" % (len(rich), np.percentile(rich, [0, 25, 50, 75, 100]).astype(int)))
