@@ -466,3 +466,35 @@ def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, 
         assert (first[1][int(first[2][p]):int(first[2][p]) + int(first[3][p])] == second[1][int(second[2][p]):int(second[2][p]) + int(second[3][p])]).all()
     batch.close()
     model.close()
+
+
+def test_streamed_call_reports_bad_input_and_recovers(hip, kernel_choice, monkeypatch):
+    """An invalid pair deep inside a streamed call (the persistent kernel is already running when its chunk is
+    planned): the call returns the reference's error (process_marginal, src/lib/utils.cc:822-835), the kernel is
+    told to finish and the model is usable again -- the next call gives the resident batch's results."""
+    from coati_amd import host
+
+    if kernel_choice == "bits":
+        pytest.skip("viterbi_l1 forced: the streamed form is viterbi_ck only")
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 900)
+    model = hip.Model(table, consts, 1)
+    monkeypatch.setenv("COATI_HIP_PIPE", "stream")
+    monkeypatch.setenv("COATI_HIP_STREAM_UNIT", "60000000")  # ~15 chunks
+    bad = b_cat.copy()
+    bad[int(b_off[700]) + 3] = 15  # a descendant code the table has no column for
+    with pytest.raises(hip.CoatiHipError) as err:
+        model.viterbi(a_cat, a_off, bad, b_off)
+    assert "descendant code 15 out of range" in str(err.value)
+    short = a_off.copy()
+    short[-1] -= 1  # the last ancestor is no longer a whole number of codons
+    with pytest.raises(hip.CoatiHipError) as err:
+        model.viterbi(a_cat, short, b_cat, b_off)
+    assert "multiple of 3" in str(err.value)
+    got = model.viterbi(a_cat, a_off, b_cat, b_off)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    want = batch.viterbi_fetch()
+    assert (bits(got[0]) == bits(want[0])).all() and (got[3] == want[3]).all() and (got[2] == want[2]).all()
+    batch.close()
+    model.close()
