@@ -517,6 +517,7 @@ struct BatchOpts {
     // scratch live outside the chunk's workspace, shared by all chunks (viterbi_batch_stream)
     uint64_t wave_slot_dwords = 0;
     uint32_t tail_parts = 0;  // one of the call's LAST chunks: every pair that can be is cut into this many row parts
+    bool device_validates = false;  // the kernel checks the sequence codes it loads (viterbi_ck_stream): do not read them here
 };
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
                       const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
@@ -540,6 +541,36 @@ inline uint8_t max_byte(const uint8_t* p, uint64_t n) {
     uint8_t m = 0;
     for(uint64_t i = 0; i < n; ++i) m = p[i] > m ? p[i] : m;
     return m;
+}
+
+// Pair indices, most cells first: exactly (equal pairs in input order), or -- `quick`, the chunks of a streamed
+// call, where planning is on the critical path -- by a counting sort on the cell count's exponent and top six
+// mantissa bits (1.6 % classes, input order inside a class).  The order only decides which wavefront takes which
+// pair when; an exact sort of the 2 000 pairs of a streamed chunk was a third of its planning time (45 ns per
+// pair), and costs a resident 10 000-pair launch 0.5 % if replaced by the classes (4.98 vs 5.01 ms).
+void lpt_order(const std::vector<PairDesc>& desc, std::vector<uint32_t>& order, bool quick) {
+    const size_t n = desc.size();
+    auto cells_of = [&](size_t p) { return static_cast<uint64_t>(desc[p].la) * desc[p].lb; };
+    if(n < 256 || !quick) {
+        for(size_t p = 0; p < n; ++p) order[p] = static_cast<uint32_t>(p);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
+        return;
+    }
+    constexpr uint32_t kClasses = 65 * 64;
+    auto class_of = [&](size_t p) -> uint32_t {  // larger pairs -> smaller class number
+        const uint64_t c = cells_of(p);
+        if(c == 0) return kClasses - 1;
+        const uint32_t e = 63u - static_cast<uint32_t>(__builtin_clzll(c));                          // exponent 0..63
+        const uint32_t m = e >= 6 ? static_cast<uint32_t>((c >> (e - 6)) & 63u) : static_cast<uint32_t>((c << (6 - e)) & 63u);  // top six bits below the leading one
+        return kClasses - 2 - (e * 64 + m);
+    };
+    std::vector<uint32_t> start(kClasses + 1, 0), cls(n);
+    for(size_t p = 0; p < n; ++p) {
+        cls[p] = class_of(p);
+        ++start[cls[p] + 1];
+    }
+    for(uint32_t q = 0; q < kClasses; ++q) start[q + 1] += start[q];
+    for(size_t p = 0; p < n; ++p) order[start[cls[p]]++] = static_cast<uint32_t>(p);
 }
 
 int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
@@ -623,14 +654,17 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                                 "Length of descendant sequence must be multiple of gap unit length. "
                                 "(pair %llu)",
                                 static_cast<unsigned long long>(p)));
-        // code ranges: a branch-free max over the bytes (vectorises); the offender is only looked up on failure
-        if(max_byte(a_cat + a_off[p], la) >= kTabRows) {
+        // code ranges: a branch-free max over the bytes (vectorises); the offender is only looked up on failure.
+        // (Reading every byte once from DRAM is most of the planning time of a 1 kb pair: the chunks of a streamed
+        // call leave the check to the kernel, which reports through the same error.)
+        if(opts != nullptr && opts->device_validates) {
+        } else if(max_byte(a_cat + a_off[p], la) >= kTabRows) {
             uint64_t q = a_off[p];
             while(a_cat[q] < kTabRows) ++q;
             return cleanup(fail(COATI_HIP_EINVAL, "batch_create: ancestor code %u out of range (pair %llu)", a_cat[q],
                                 static_cast<unsigned long long>(p)));
         }
-        if(max_byte(b_cat + b_off[p], lb) >= kTabCols) {
+        if(!(opts != nullptr && opts->device_validates) && max_byte(b_cat + b_off[p], lb) >= kTabCols) {
             uint64_t q = b_off[p];
             while(b_cat[q] < kTabCols) ++q;
             return cleanup(fail(COATI_HIP_EINVAL, "batch_create: descendant code %u out of range (pair %llu)", b_cat[q],
@@ -655,6 +689,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         b->cells += la * lb;
     }
 
+    stage("plan: checks + descriptors");
     // ---- Viterbi strip plan (common.hpp).  Full-speed strips are 16 columns per lane; the last
     // strip of a pair takes the narrowest shape that holds the remainder.  When the whole batch
     // has fewer strips than the GPU has SIMDs (a few long pairs), narrower strips everywhere put
@@ -667,10 +702,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     const bool ck_shared = model->n_tables == 1;
     // longest-processing-time-first order for the dynamic queue
     std::vector<uint32_t> order(n_pairs);
-    for(uint64_t p = 0; p < n_pairs; ++p) order[p] = static_cast<uint32_t>(p);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        return static_cast<uint64_t>(b->desc[x].la) * b->desc[x].lb > static_cast<uint64_t>(b->desc[y].la) * b->desc[y].lb;
-    });
+    lpt_order(b->desc, order, opts != nullptr && opts->device_validates);
+    stage("plan: longest-first order");
     // Ragged end of the queue.  The persistent kernel runs kFillSlots wavefronts, three per SIMD, and
     // the SIMD's issue arbitration favours the oldest: in the trace build one 1 kb item takes a
     // wavefront between 1.15 and 3.4 ms (mean 2.1; `make trace`, tools/trace_fill.py).  The SIMD as a
@@ -742,6 +775,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         if(cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]))
             for(uint64_t q = n_pairs - 3 * 1024 / 4; q < n_pairs; ++q) b->desc[order[q]].f_wlog2 = 3;
     }
+    stage("plan: strip shapes");
     // Forward M/D/I arena, now that every pair's strip shape is known
     for(uint64_t p = 0; p < n_pairs; ++p) {
         PairDesc& d = b->desc[p];
@@ -925,7 +959,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         }
     }
 
-    stage("plan");
+    stage("plan: layout");
     if(hipSetDevice(model->device) != hipSuccess)
         return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice failed"));
 #define B_TRY(expr)                                                                             \
@@ -955,6 +989,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     }
     b->n_items = static_cast<uint32_t>(items.size());
     b->n_fwd_items = static_cast<uint32_t>(fwd_items.size());
+    stage("work lists");
     // ONE workspace for everything but the Forward M/D/I arena, carved into 256-byte aligned parts
     uint64_t arena_need = 0;
     auto carve = [&](uint64_t bytes) {
@@ -1842,6 +1877,11 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             if(!f.d2h_submitted) {
                 if(*ck_stream_host_done_flag(hs, q) != f.chunk_no + 1u) continue;
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                if(const unsigned long long bad = ck_stream_host_bad(hs, q)) {  // (the kernel's check of the codes: ck_report_bad)
+                    const uint64_t pair = f.chunk.p0 + (bad & 0xffffffffull);
+                    return fail(COATI_HIP_EINVAL, "batch_create: %s code %u out of range (pair %llu)", (bad >> 40) & 1 ? "descendant" : "ancestor",
+                                static_cast<unsigned>((bad >> 32) & 0xff), static_cast<unsigned long long>(pair));
+                }
                 const hipError_t e = submit_d2h(f, q);
                 if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
             }
@@ -1939,6 +1979,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         bo.seqs_pinned = in_pinned;
         bo.force_ck = true;
         bo.force_w_main = kW;  // (a small chunk is not a small batch: no narrowed strips)
+        bo.device_validates = true;
         if(tail) {
             bo.tail_parts = 3;
             ++tails_used;

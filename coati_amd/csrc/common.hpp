@@ -449,6 +449,7 @@ void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* aren
                           uint32_t first_ticket, uint32_t chunk_no);
 void ck_stream_host_announce(void* host, uint32_t chunks, uint32_t items);
 void ck_stream_host_close(void* host);
+unsigned long long ck_stream_host_bad(void* host, int slot);  // (0, or the kernel's report of a code out of range: viterbi_ck.hip ck_report_bad)
 double ck_stream_host_done_ms(void* host, int slot);  // (ms after the kernel started: when the slot's chunk was complete)
 volatile uint32_t* ck_stream_host_done_flag(void* host, int slot);
 // wave_ck: ck_scratch_waves() checkpoint slots of wave_slot_dwords each; wave_scratch: as many traceback scratch areas

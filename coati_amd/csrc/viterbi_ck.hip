@@ -215,6 +215,17 @@ __device__ __forceinline__ uint64_t ck_strip_base(const PairDesc& pd, uint32_t s
     return strip * ck_strip_dwords(pd.la, pd.v_wmain);
 }
 
+// The chunks of a streamed call are not read by the host before they go up (reading every sequence byte once
+// from DRAM was most of the host's planning time): the fill checks the codes it loads anyway and reports the
+// first it finds out of range -- one 64-bit word in page-locked host memory: bit 63 set, bit 40 = descendant
+// (else ancestor), bits 32-39 the code, bits 0-31 the chunk's pair.  (A code out of range cannot fault: it only
+// indexes the LDS table, where a read past the allocation returns 0; the pair's result is garbage and the call
+// fails.)  One plain store: whoever is last wins, every candidate is a true report.
+__device__ __forceinline__ void ck_report_bad(unsigned long long* bad, uint32_t pair, uint32_t code, bool descendant) {
+    const unsigned long long word = (1ull << 63) | (descendant ? 1ull << 40 : 0ull) | (static_cast<unsigned long long>(code & 0xffu) << 32) | pair;
+    __hip_atomic_store(bad, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
 // the left neighbour's boundary column did not arrive within the spin bound.
 template <int W>
@@ -223,7 +234,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                                               const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
                                               uint32_t* __restrict__ ck, float* __restrict__ bnd,
                                               float* __restrict__ scores, uint32_t* __restrict__ progress,
-                                              uint32_t kbegin = 0, uint32_t kend = 0xffffffffu) {
+                                              uint32_t kbegin = 0, uint32_t kend = 0xffffffffu,
+                                              unsigned long long* bad = nullptr) {
     // [kbegin, kend): the steps of this item -- the whole strip, or one ROW PART of it (PairDesc::v_parts; whole
     // 64-step chunks).  A part that does not start at 0 takes over the lane state its predecessor left behind the
     // strip's checkpoints; one that does not end at the last step leaves it there.
@@ -244,10 +256,17 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     bool handoff_ok = true;
 
     uint32_t boff[W];  // byte offsets of this lane's W table columns
+    {
+        uint32_t worst = 0;
 #pragma unroll
-    for(int c = 0; c < W; ++c) {
-        const uint32_t bj = col0 + lane * W + c;
-        boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+        for(int c = 0; c < W; ++c) {
+            const uint32_t bj = col0 + lane * W + c;
+            const uint32_t code = bj < lb ? static_cast<uint32_t>(b[bj]) : 0u;
+            worst = max(worst, code);
+            boff[c] = code * 4u;
+        }
+        if(bad != nullptr && worst >= static_cast<uint32_t>(kTabCols)) ck_report_bad(bad, pair, worst, true);
+        if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
     }
     const CkCtx cx{k, la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
@@ -296,7 +315,11 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         const uint32_t crow = kbase + lane;
         uint32_t a_chunk = 0;
         float bx = kLowest, bz = kLowest;
-        if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+        if(crow + 1 < la) {
+            const uint32_t code = a[crow + 1];
+            if(bad != nullptr && code >= static_cast<uint32_t>(kTabRows)) ck_report_bad(bad, pair, code, false);  // (streamed chunks)
+            a_chunk = code * (kTabStride * 4u);
+        }
         if(crow < la && strip == 0) {
             // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
             if(crow == 0) {
@@ -814,8 +837,9 @@ struct CkStreamChunk {
     uint32_t off_pairs, off_items, off_a, off_b, off_ck, off_bnd, off_scores, off_ops, off_start, off_len, off_progress;
     uint32_t split_items;  // row part p > 0 of a cut pair waits for the item this many (chunk-local) tickets before its own
     uint32_t* host_flag;   // page-locked host memory: set to chunk_no + 1 when the chunk is complete
+    unsigned long long* host_bad;  // page-locked host memory: a code out of range (ck_report_bad), 0 = none
     uint32_t n_pairs, n_items, first_ticket, chunk_no;
-    uint32_t done, pad_[3];  // pairs finished (device atomics)
+    uint32_t done, pad_[5];  // pairs finished (device atomics)
 };
 static_assert(sizeof(CkStreamChunk) % 16 == 0, "chunk table entries are copied as a block");
 struct CkStreamCtl {
@@ -842,6 +866,7 @@ struct CkStreamHost {
     uint32_t closed, pad_[13];
     uint32_t done_flag[16];
     uint64_t t_start, t_done[16];  // device clock (100 MHz) when the pilot started / when a slot's chunk was complete
+    unsigned long long bad[16];    // per slot: a sequence code out of range in the chunk (ck_report_bad)
     CkStreamChunk chunk[kCkStreamSlots];
 };
 static_assert(kCkStreamSlots <= 16 && sizeof(CkStreamChunk) <= 4 * kWave, "the pilot mirrors an entry a word per lane");
@@ -966,6 +991,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         auto arr = [&](uint32_t off256) { return arena + (static_cast<uint64_t>(u32(off256)) << 8); };
         const uint32_t first_ticket = u32(chp->first_ticket), n_pairs_chunk = u32(chp->n_pairs), chunk_no = u32(chp->chunk_no);
         uint32_t* const host_flag = reinterpret_cast<uint32_t*>(u64(reinterpret_cast<uint64_t>(chp->host_flag)));
+        unsigned long long* const host_bad = reinterpret_cast<unsigned long long*>(u64(reinterpret_cast<uint64_t>(chp->host_bad)));
         const PairDesc* __restrict__ ch_pairs = reinterpret_cast<const PairDesc*>(arr(chp->off_pairs));
         const WorkItem* __restrict__ ch_items = reinterpret_cast<const WorkItem*>(arr(chp->off_items));
         const uint8_t* __restrict__ ch_a = reinterpret_cast<const uint8_t*>(arr(chp->off_a));
@@ -1025,13 +1051,13 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         if(pd.la > 0 && pd.lb > 0) {
             const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
             if(cut)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend) && handoff_ok;
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad) && handoff_ok;
             else if(w == 16)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
             else if(w == 8)
-                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
             else
-                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress);
+                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
         }
         if(cut && part + 1 < pd.v_parts) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1225,6 +1251,7 @@ double ck_stream_host_done_ms(void* host, int slot) {
     const CkStreamHost* h = static_cast<const CkStreamHost*>(host);
     return static_cast<double>(static_cast<int64_t>(h->t_done[slot] - h->t_start)) * 1e-5;
 }
+unsigned long long ck_stream_host_bad(void* host, int slot) { return __atomic_load_n(&static_cast<CkStreamHost*>(host)->bad[slot], __ATOMIC_ACQUIRE); }
 void ck_stream_host_close(void* host) { __atomic_store_n(&static_cast<CkStreamHost*>(host)->closed, 1u, __ATOMIC_SEQ_CST); }
 
 void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* arena, const BatchDeviceView& v, uint32_t n_pairs,
@@ -1240,6 +1267,8 @@ void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* aren
     c.off_progress = off(v.progress);
     c.split_items = v.ck_split_items;
     c.host_flag = host_flag_dev;
+    c.host_bad = &static_cast<CkStreamHost*>(host_dev)->bad[slot];
+    static_cast<CkStreamHost*>(host)->bad[slot] = 0;
     c.n_pairs = n_pairs, c.n_items = v.n_items, c.first_ticket = first_ticket, c.chunk_no = chunk_no, c.done = 0;
     std::memcpy(host_entry, &c, sizeof c);
 }
