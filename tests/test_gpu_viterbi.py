@@ -485,7 +485,12 @@ def test_streamed_call_reports_bad_input_and_recovers(hip, kernel_choice, monkey
     bad[int(b_off[700]) + 3] = 15  # a descendant code the table has no column for
     with pytest.raises(hip.CoatiHipError) as err:
         model.viterbi(a_cat, a_off, bad, b_off)
-    assert "descendant code 15 out of range" in str(err.value)
+    assert "descendant code 15 out of range (pair 700)" in str(err.value)
+    bad_a = a_cat.copy()
+    bad_a[int(a_off[350]) + 500] = 200  # an ancestor code past the table's 183 rows, deep inside a pair
+    with pytest.raises(hip.CoatiHipError) as err:
+        model.viterbi(bad_a, a_off, b_cat, b_off)
+    assert "ancestor code 200 out of range (pair 350)" in str(err.value)
     short = a_off.copy()
     short[-1] -= 1  # the last ancestor is no longer a whole number of codons
     with pytest.raises(hip.CoatiHipError) as err:
