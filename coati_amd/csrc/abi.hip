@@ -630,9 +630,14 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             return n;
         };
         while(fwd_wlog2 > 2 && count_strips(1u << fwd_wlog2) < kFwdSlots) --fwd_wlog2;
+        // a handful of pairs (`coati sample` works on ONE): 2 and 1 columns per lane put 8 and 16 wavefronts on a 1 kb
+        // pair.  Measured, 1 kb pairs, 4 / 2 / 1 columns: 1 or 16 pairs 6.2 / 4.5 / 3.75 ms, 64 pairs 6.45 / 4.65 / 3.95,
+        // 256 pairs 7.1 / 6.0 / 7.1, 1 024 pairs 15 / 16 / 19.6 -- i.e. while the strips still fit ~2 per SIMD.
+        if(fwd_wlog2 == 2 && count_strips(2) <= 2304) fwd_wlog2 = 1;
+        if(fwd_wlog2 == 1 && count_strips(1) <= 1536) fwd_wlog2 = 0;
         if(const char* e = std::getenv("COATI_HIP_FWD_W")) {
             const int w = std::atoi(e);
-            if(w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 4 ? 2u : (w == 8 ? 3u : 4u);
+            if(w == 1 || w == 2 || w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 1 ? 0u : w == 2 ? 1u : w == 4 ? 2u : (w == 8 ? 3u : 4u);
         }
     }
     for(uint64_t p = 0; p < n_pairs; ++p) {

@@ -58,7 +58,7 @@ struct PairDesc {
     // 16 columns per lane; dp_generic: 16); L (2 or 3) = live cells only, forward_k's block-column
     // strips (forward_k.hip)
     uint16_t f_compact;
-    uint8_t f_wlog2;  // log2 of the columns per lane of the Forward strips (2, 3, 4)
+    uint8_t f_wlog2;  // log2 of the columns per lane of the Forward strips (0 .. 4)
     // viterbi_ck: the pair's (single) strip is cut into this many ROW parts, each its own work item, continued by
     // whichever wavefront takes the next part (0 or 1: not cut).  Finer items for the ragged end of a launch.
     uint8_t v_parts;

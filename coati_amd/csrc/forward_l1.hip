@@ -303,6 +303,8 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 2 : 3) void forward_l1(
         }
         // strips are 64 * W columns, W = 16 unless the batch has too few pairs to fill the GPU (abi.hip)
         switch(pd.f_wlog2) {
+            case 0: forward_strip<1, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
+            case 1: forward_strip<2, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
             case 2: forward_strip<4, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
             case 3: forward_strip<8, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
             default: forward_strip<16, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;

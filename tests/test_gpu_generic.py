@@ -115,11 +115,11 @@ def test_fast_forward_mode_within_tolerance():
     assert out.returncode == 0, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("w", [8, 16])
+@pytest.mark.parametrize("w", [2, 4, 8, 16])
 def test_forward_strip_shapes(w):
-    """forward_l1 narrows its strips (16 -> 8 -> 4 columns per lane) while a batch has fewer strips
-    than the GPU has SIMDs, so the small batches of this suite run the 4-column shape.
-    COATI_HIP_FWD_W forces the other two: same bits (matrices, final cells, samples)."""
+    """forward_l1 narrows its strips (16 -> 8 -> 4 -> 2 -> 1 columns per lane) while a batch has few
+    strips for the GPU's SIMDs, so the small batches of this suite run the 1-column shape.
+    COATI_HIP_FWD_W forces the others: same bits (matrices, final cells, samples)."""
     if os.environ.get("COATI_HIP_FWD_W") or os.environ.get("COATI_HIP_FORCE_GENERIC") or os.environ.get("COATI_HIP_FORWARD_FAST"):
         pytest.skip("already inside a child run")
     env = dict(os.environ, COATI_HIP_FWD_W=str(w))
