@@ -219,7 +219,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
     return BatchDeviceView{m->d_table,  m->k,      static_cast<uint32_t>(m->gap_len),
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
-                           b->d_flags,  b->d_bnd,  b->d_scores,
+                           b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
                            b->d_mdi,    b->d_final_mdi};
 }

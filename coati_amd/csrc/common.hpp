@@ -422,6 +422,7 @@ struct BatchDeviceView {
     const uint8_t *a_cat, *b_cat;
     uint32_t* flags;
     float* bnd;
+    uint64_t bnd_bytes;
     float* scores;
     uint8_t* ops;
     uint64_t* ops_start;
