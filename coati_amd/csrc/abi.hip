@@ -167,6 +167,8 @@ struct coati_hip_model {
     size_t stream_waves_bytes = 0;
     hipEvent_t stream_events[kCkStreamSlots + 1] = {};  // [slot]: its download is done; [last]: an upload is done
     std::mutex pipeline_lock;  // one pipelined call at a time per model
+    bool stream_unusable = false;  // the persistent kernel's first upload did not arrive in time once (copies not on the copy engine): never again on this model
+    bool stream_forbidden = false;  // coati_hip_model_set_option(COATI_HIP_OPT_PERSISTENT_CALL, 0): the embedder shares the GPU
 };
 
 struct coati_hip_batch {
@@ -484,6 +486,16 @@ int coati_hip_model_trim(coati_hip_model_t* m) {
     return COATI_HIP_OK;
 }
 
+int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t value) {
+    if(model == nullptr) return fail(COATI_HIP_EINVAL, "model_set_option: model is NULL");
+    if(option == COATI_HIP_OPT_PERSISTENT_CALL) {
+        std::lock_guard<std::mutex> one_call(model->pipeline_lock);
+        model->stream_forbidden = value == 0;
+        return COATI_HIP_OK;
+    }
+    return fail(COATI_HIP_EINVAL, "model_set_option: unknown option %d", option);
+}
+
 int coati_hip_batch_create(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                            const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                            coati_hip_batch_t** out) {
@@ -733,7 +745,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             for(uint64_t p = 0; p < n_pairs; ++p) items += items_of(p, w);
             return items;
         };
-        constexpr uint64_t kSimds = 1024;
+        const uint64_t kSimds = 4ull * device_cu_count();
         while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
         if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
             const int w = std::atoi(e);
@@ -1725,6 +1737,29 @@ void chunk_need_add(ChunkNeed& nd, uint64_t la, uint64_t lb, uint32_t gap_len) {
 struct PipeChunk {
     uint64_t p0 = 0, p1 = 0, ops_base = 0, ops_bytes = 0;
 };
+
+// Streamed form (viterbi_batch_stream): fixed slot sizes -- nothing can grow while the persistent kernel runs, the
+// chunks are cut to fit.  Workspace: room for the largest pair this form accepts with its own checkpoints; staging
+// block [what goes up | short result arrays, and the ops when the caller's array is pageable].
+constexpr uint64_t kStreamSlotArena = 192ull << 20, kStreamSlotStaging = 48ull << 20;
+uint64_t stream_out_bytes(uint64_t n, uint64_t ops_bytes, bool out_pinned) {
+    return 4 * 256 + 2 * kMinDmaBytes + n * (sizeof(float) + sizeof(uint64_t) + sizeof(uint32_t)) + (out_pinned ? uint64_t{0} : ops_bytes);
+}
+uint64_t stream_staging_bytes(const ChunkNeed& nd, uint64_t n, bool in_pinned, bool out_pinned) {
+    return nd.meta_bytes + 8 * 256 + 2 * kMinDmaBytes + (in_pinned ? std::min<uint64_t>(nd.seq_bytes, 2 * kMinDmaBytes) : nd.seq_bytes) + 512 +
+           stream_out_bytes(n, nd.ops, out_pinned) + 512;
+}
+uint64_t stream_chunk_fixed() { return static_cast<uint64_t>(ck_scratch_waves()) * ck_scratch_dwords_per_wave() * sizeof(uint32_t) + (64u << 10); }
+// Does a chunk made of this ONE pair fit a stream slot (workspace and staging)?  The chunk cutter always accepts
+// the first pair of a chunk, so every pair of a streamed call must pass this (a long-thin pair -- la = 50 M,
+// lb = 1 -- has few cells but 19 bytes of workspace and 2 bytes of staging per ancestor position).
+bool stream_pair_fits(uint64_t la, uint64_t lb, uint32_t gap_len, bool in_pinned, bool out_pinned) {
+    ChunkNeed one;
+    one.fixed = stream_chunk_fixed();
+    chunk_need_add(one, la, lb, gap_len);
+    const uint64_t arena = one.arena_streamed(true);
+    return arena + arena / 8 + (1u << 20) <= kStreamSlotArena && stream_staging_bytes(one, 1, in_pinned, out_pinned) <= kStreamSlotStaging;
+}
 }  // namespace
 
 namespace {
@@ -1771,14 +1806,9 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // slots: fixed sizes (nothing can grow while the kernel runs; the chunks are cut to fit).  Workspace: room for
     // the largest pair this form accepts (kStreamPairCells) with its own checkpoints; staging block
     // [what goes up | short result arrays, and the ops when the caller's array is pageable]
-    constexpr uint64_t kSlotArena = 192ull << 20, kSlotStaging = 48ull << 20;
-    auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) {
-        return 4 * 256 + 2 * kMinDmaBytes + n * (sizeof(float) + sizeof(uint64_t) + sizeof(uint32_t)) + (out_pinned ? uint64_t{0} : ops_bytes);
-    };
-    auto staging_of = [&](const ChunkNeed& nd, uint64_t n) {
-        return nd.meta_bytes + 8 * 256 + 2 * kMinDmaBytes + (in_pinned ? std::min<uint64_t>(nd.seq_bytes, 2 * kMinDmaBytes) : nd.seq_bytes) + 512 +
-               out_bytes_of(n, nd.ops) + 512;
-    };
+    constexpr uint64_t kSlotArena = kStreamSlotArena, kSlotStaging = kStreamSlotStaging;
+    auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) { return stream_out_bytes(n, ops_bytes, out_pinned); };
+    auto staging_of = [&](const ChunkNeed& nd, uint64_t n) { return stream_staging_bytes(nd, n, in_pinned, out_pinned); };
     for(auto& ss : model->sslots) {
         if(ss.arena_bytes < kSlotArena) {
             if(ss.arena != nullptr) (void)hipFree(ss.arena);
@@ -1852,8 +1882,13 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     const bool pipe_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;
     auto t_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: schedule made, kernel launched at %.2f ms\n", t_ms());
-    constexpr int kGaveUp = -1000;  // (private to this function)
-    auto kernel_gone = [&]() { return hipStreamQuery(kernel_stream) == hipSuccess; };  // (it only ends after `closed`: early = gave up)
+    constexpr int kGaveUp = -1000, kRedo = -1001;  // (private to this function)
+    // (the kernel only ends after `closed`: early = it gave up; a stream in an error state is gone too -- never spin on it)
+    auto kernel_gone = [&]() {
+        const hipError_t q = hipStreamQuery(kernel_stream);
+        if(q != hipSuccess && q != hipErrorNotReady) (void)hipGetLastError();
+        return q != hipErrorNotReady;
+    };
 
     // results: [scores | ops offsets | ops lengths | ops] are one contiguous group of the workspace.  Pageable
     // destination: one copy of the group into the slot's page-locked block.  Page-locked destination: the three
@@ -1974,6 +2009,14 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         ops_base += nd.ops;
         cells_done += static_cast<long double>(nd.cells);
         const uint64_t n = c.p1 - c.p0;
+        // (the cutter takes the first pair of a chunk unseen: one that does not fit a slot ends the streamed form --
+        // the kernel is closed below and the chunk pipeline, whose workspaces grow, does the call; never compute the
+        // staging split from an unchecked subtraction)
+        if(staging_of(nd, n) > sl.pinned_bytes || out_bytes_of(n, c.ops_bytes) > sl.pinned_bytes ||
+           nd.arena_streamed(tail) + nd.arena_streamed(tail) / 8 + (1u << 20) > arena_bytes) {
+            rc = kRedo;
+            break;
+        }
         const uint64_t out_off = (sl.pinned_bytes - out_bytes_of(n, c.ops_bytes)) / 256 * 256;
         BatchOpts bo;
         bo.stream = up_stream;
@@ -2010,7 +2053,28 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         // the chunk's data (with its zeroed progress words) is on its way; once it is in HBM the kernel may know
         hipError_t e = hipEventRecord(up_done, up_stream);
         ck_stream_fill_chunk(hs, hs_dev, q, b->arena, device_view(b), static_cast<uint32_t>(n), published, static_cast<uint32_t>(ci));
-        if(e == hipSuccess) e = hipEventSynchronize(up_done);
+        // Every copy under the persistent kernel must be done by the copy ENGINE: a copy the runtime does with a blit
+        // kernel (HSA_ENABLE_SDMA=0, or its own choice) cannot start while viterbi_ck_stream holds every wavefront
+        // slot.  So the wait is bounded -- 100 ms for the call's first chunk (a copy engine delivers it in well under
+        // a millisecond), 5 s later on -- and a miss closes the kernel, hands the call to the chunk pipeline and is
+        // remembered on the model (no later call tries the streamed form again).
+        if(e == hipSuccess) {
+            const auto t_up = std::chrono::steady_clock::now();
+            const double bound_ms = ci == 0 ? 100.0 : 5000.0;
+            for(uint64_t spins = 0;; ++spins) {
+                e = hipEventQuery(up_done);
+                if(e != hipErrorNotReady) break;
+                if(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count() > bound_ms) break;
+                if(spins > 256) sched_yield();
+            }
+            if(e == hipErrorNotReady) {
+                (void)hipGetLastError();
+                model->stream_unusable = true;
+                if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: upload of chunk %zu not done after %.0f ms; falling back\n", ci, bound_ms);
+                rc = kRedo;
+                break;
+            }
+        }
         if(e != hipSuccess) {
             rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
             break;
@@ -2038,6 +2102,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     }
     if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: done at %.2f ms\n", t_ms());
     if(rc == COATI_HIP_OK && es != hipSuccess) rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(es));
+    if(es == hipSuccess && rc == kRedo) return COATI_HIP_ESTATE;  // (a pair or an upload the streamed form cannot serve: the chunk pipeline does the call)
+    if(rc == kRedo) rc = COATI_HIP_OK;                            // (and the stream failed on top of it: reported just below)
     if(es == hipSuccess && (rc == kGaveUp || (rc == COATI_HIP_OK && dev_error != 0))) {
         // the kernel's waits are bounded (a host thread that was stopped for seconds must not hang the GPU): it gave
         // up, some chunks are incomplete.  Everything is quiet now; the chunk pipeline does the call again.
@@ -2069,7 +2135,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
     // ---- the input once: valid offsets, cells, what decides the form of the call
     long double total_cells = 0;
-    uint64_t widest = 0, max_pair_cells = 0, longest_single = 0;
+    uint64_t widest = 0, max_pair_cells = 0, longest_single = 0, longest_a = 0;
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
             return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p));
@@ -2080,6 +2146,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         total_cells += static_cast<long double>(cells);
         widest = std::max(widest, lb);
         max_pair_cells = std::max(max_pair_cells, cells);
+        longest_a = std::max(longest_a, la);
         if(lb > 0 && lb <= static_cast<uint64_t>(kStrip)) longest_single = std::max(longest_single, la);
     }
     const uint64_t ops_total = (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]);
@@ -2098,6 +2165,21 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
                         !(pipe_env != nullptr && std::strcmp(pipe_env, "chunks") == 0) && widest <= 8 * kStrip && max_pair_cells <= kStreamPairCells;
         if(streamed && !(pipe_env != nullptr && std::strcmp(pipe_env, "stream") == 0))
             streamed = n_pairs >= 4096 && total_cells / n_pairs >= 250.0L * 250.0L;
+        // the persistent kernel owns the GPU for the length of the call: not when the embedder said no
+        // (coati_hip_model_set_option), not where it failed before, and not where copies are done by kernels
+        if(streamed && (model->stream_forbidden || model->stream_unusable)) streamed = false;
+        if(streamed) {
+            const char* sdma = std::getenv("HSA_ENABLE_SDMA");
+            if(sdma != nullptr && std::atoi(sdma) == 0) streamed = false;
+        }
+        // every pair must fit a stream slot on its own (the chunk cutter takes the first pair of a chunk unseen).
+        // Ordinary pairs pass by two comparisons; the few long or wide ones are priced exactly.
+        if(streamed && (longest_a > 32768 || widest > static_cast<uint64_t>(kStrip))) {
+            for(uint64_t p = 0; p < n_pairs && streamed; ++p) {
+                const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+                if((la > 32768 || lb > static_cast<uint64_t>(kStrip)) && !stream_pair_fits(la, lb, gap_len, in_pinned, out_pinned)) streamed = false;
+            }
+        }
         if(streamed) {
             const int rc_stream = viterbi_batch_stream(model, n_pairs, a_cat, a_off, b_cat, b_off, scores, ops, ops_off, ops_len, in_pinned,
                                                        out_pinned, total_cells, longest_single, t_entry);

@@ -434,6 +434,17 @@ struct BatchDeviceView {
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
 };
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount), at most 256: the persistent
+// kernels size their grids to what is RESIDENT (a partitioned or CU-masked device has fewer than the MI355X's
+// 256; a grid sized for 256 would oversubscribe it and the residency the queue discipline assumes would not
+// hold), and the per-wavefront scratch areas are sized for 256 CUs.
+inline uint32_t device_cu_count() {
+    int dev = 0, n = 0;
+    if(hipGetDevice(&dev) != hipSuccess) return 256u;
+    if(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256u;
+    return static_cast<uint32_t>(n < 256 ? n : 256);
+}
+
 // viterbi_ck.hip: lean fill + checkpoint traceback (`flags` is the checkpoint arena); shared_tab: the
 // model has one substitution table.  The scratch is ck_scratch_waves() x ck_scratch_dwords_per_wave().
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream);

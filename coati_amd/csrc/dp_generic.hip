@@ -306,7 +306,7 @@ hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t
         if(e != hipSuccess) return e;
     }
     const uint32_t per_cu = static_cast<uint32_t>(std::min<size_t>(8, (160 * 1024) / lds));
-    const uint32_t grid = std::min<uint32_t>(v.n_pairs, 256u * std::max(1u, per_cu));
+    const uint32_t grid = std::min<uint32_t>(v.n_pairs, device_cu_count() * std::max(1u, per_cu));
     if(forward)
         hipLaunchKernelGGL(dp_generic<true>, dim3(grid), dim3(kWave), lds, stream, v.table, v.k, v.gap_len, v.pairs, v.order,
                            v.n_pairs, v.queue, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops, v.ops_start, v.ops_len,

@@ -321,7 +321,8 @@ hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream) {
     if(e != hipSuccess) return e;
     // two workgroups (8 wavefronts) per CU; fewer when there are fewer items than wavefronts
     const uint32_t per_cu = forward_fast_math() ? 2u : 3u;  // (the exact build fits 3 wavefronts per SIMD)
-    const uint32_t blocks = std::min<uint32_t>(256u * per_cu, std::max<uint32_t>(256u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
+    const uint32_t cus = device_cu_count();
+    const uint32_t blocks = std::min<uint32_t>(cus * per_cu, std::max<uint32_t>(cus, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
     if(forward_fast_math())
         hipLaunchKernelGGL(forward_l1<true>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,
                            v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);

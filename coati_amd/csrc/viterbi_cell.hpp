@@ -11,6 +11,22 @@
 namespace coati_hip_detail {
 namespace {
 
+// The four gap constants in VECTOR registers.  On gfx950 a v_add_f32 whose constant operand is an SGPR issues
+// at the 4-cycle rate of v_max_f32, not at the 2-cycle rate of an add between VGPRs (round 3,
+// tools/ubench/gen_issue.py -> profiles/r03/ubench_issue_model.txt: "pure v_add_f32" 2.5 cycles per
+// instruction and SIMD, "pure v_add_f32 sgpr" 4.4; the 15-instruction cell 3.03 cycles per instruction with
+// SGPR constants, 2.03 with VGPR constants).  Ten of the cell's adds take a constant, so the cells read them
+// from four VGPRs that are loaded once per work item and made opaque (or the compiler re-materialises the
+// v_mov from the SGPR inside the loop when registers are short).
+struct GapVec {
+    float ng, gs, go, ge;
+};
+__device__ __forceinline__ GapVec gap_vec(const GapConsts& k) {
+    GapVec v{k.ng, k.gs, k.go, k.ge};
+    asm volatile("" : "+v"(v.ng), "+v"(v.gs), "+v"(v.go), "+v"(v.ge));
+    return v;
+}
+
 // Register state of one lane: its W columns (W = 16, 8 or 4) of the row it processed last.
 template <int W>
 struct LaneState {
@@ -85,7 +101,7 @@ struct LaneState {
     "v_alignbit_b32 %[aB], %[aB], %[t7], 31"    /* S  D1                                   */
 
 template <int C, int W>
-__device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState<W>& st, float& diag, float& zl, float& pend,
+__device__ __forceinline__ void cell_l1(const GapVec& k, LaneState<W>& st, float& diag, float& zl, float& pend,
                                         float& s, uint32_t lds_next_row, uint32_t boff) {
     float x_new, t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10;
     uint32_t addr;
@@ -94,8 +110,8 @@ __device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState<W>& st, fl
       [aB] "+v"(st.acc[ACC_B]), [aC] "+v"(st.acc[ACC_C]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), \
       [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7), [t8] "=&v"(t8),     \
       [t9] "=&v"(t9), [t10] "=&v"(t10), [addr] "=&v"(addr)                                                \
-    : [diag] "v"(diag), [s] "v"(s), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng),          \
-      [gs] "s"(k.gs), [go] "s"(k.go), [ge] "s"(k.ge)
+    : [diag] "v"(diag), [s] "v"(s), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "v"(k.ng),          \
+      [gs] "v"(k.gs), [go] "v"(k.go), [ge] "v"(k.ge)
     if constexpr(C > 0) {
         asm volatile(COATI_CELL_FAST_A COATI_CELL_PEND COATI_CELL_TAIL COATI_CELL_OPERANDS);
     } else {
@@ -109,7 +125,7 @@ __device__ __forceinline__ void cell_l1(const GapConsts& k, LaneState<W>& st, fl
 }
 
 template <int W, int... C>
-__device__ __forceinline__ void row_l1(const GapConsts& k, LaneState<W>& st, float diag, float zl,
+__device__ __forceinline__ void row_l1(const GapVec& k, LaneState<W>& st, float diag, float zl,
                                        float (&s)[W], uint32_t lds_next_row, const uint32_t (&boff)[W],
                                        std::integer_sequence<int, C...>) {
     st.xlast_old = st.X[W - 1];

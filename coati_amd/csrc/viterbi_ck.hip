@@ -81,14 +81,14 @@ struct CkLane {
 // same rate whatever the order of the 15 instructions, so the order is the one with the shortest
 // live ranges.  `s` is consumed by the first instruction and then carries the LDS address.)
 template <int C, int W>
-__device__ __forceinline__ void cell_lean(const GapConsts& k, CkLane<W>& st, float& diag, float& zl, float& s,
+__device__ __forceinline__ void cell_lean(const GapVec& k, CkLane<W>& st, float& diag, float& zl, float& s,
                                           uint32_t lds_next_row, uint32_t boff) {
     float x_new, t0, t1, t2, t3, t4;
     asm volatile(COATI_CELL_LEAN
                  : [x] "=&v"(x_new), [y] "+v"(st.Y[C]), [zl] "+v"(zl), [s] "+v"(s), [t0] "=&v"(t0), [t1] "=&v"(t1),
                    [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
-                 : [diag] "v"(diag), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "s"(k.ng), [gs] "s"(k.gs),
-                   [go] "s"(k.go), [ge] "s"(k.ge));
+                 : [diag] "v"(diag), [lds] "v"(lds_next_row), [boff] "v"(boff), [ng] "v"(k.ng), [gs] "v"(k.gs),
+                   [go] "v"(k.go), [ge] "v"(k.ge));
     diag = st.X[C];  // the next column's diagonal input is this column's previous-row X
     st.X[C] = x_new;
     // next step's score (s holds its LDS byte address now).  volatile: the read is issued HERE, a step
@@ -97,7 +97,7 @@ __device__ __forceinline__ void cell_lean(const GapConsts& k, CkLane<W>& st, flo
 }
 
 template <int W, int... C>
-__device__ __forceinline__ void row_lean(const GapConsts& k, CkLane<W>& st, float diag, float zl, float (&s)[W],
+__device__ __forceinline__ void row_lean(const GapVec& k, CkLane<W>& st, float diag, float zl, float (&s)[W],
                                          uint32_t lds_next_row, const uint32_t (&boff)[W],
                                          std::integer_sequence<int, C...>) {
     st.xlast_old = st.X[W - 1];
@@ -119,6 +119,7 @@ __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(u
 // Read-only per-strip context of one wavefront.
 struct CkCtx {
     GapConsts k;
+    GapVec kv;  // the same four values in VGPRs, for the cells (viterbi_cell.hpp)
     uint32_t la, col0, nsteps, lds_tab;
     int lane;
     bool last_strip;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, static_cast<uint32_t>(lane) * 8u,
                                           kk * (kWave * 8u), 0);
     // ---- the W cells (and the LDS gather for the next step)
-    row_lean<W>(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
+    row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
     // lane 63 just did body row kstep - 63: its last column is the next strip's boundary
     if(!cx.last_strip && lane == kWave - 1 && kstep >= static_cast<uint32_t>(kWave - 1) && kstep - (kWave - 1) < cx.la) {
@@ -268,7 +269,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         if(bad != nullptr && worst >= static_cast<uint32_t>(kTabCols)) ck_report_bad(bad, pair, worst, true);
         if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
     }
-    const CkCtx cx{k, la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z};
+    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
     // ge*float(j-1)); a lane takes it again at its first step (ck_step)
@@ -532,13 +533,14 @@ __device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc&
     float2 in_next;
     uint32_t code_next;
     inputs_of(0, in_next, code_next);
+    const GapVec kv = gap_vec(k);
     for(int32_t ks = 0; ks < static_cast<int32_t>(kCkRows); ++ks) {
         const int32_t kstep = k0 + ks, r = kstep - t;
         const float2 in = in_next;
         const uint32_t arow_next = code_next;
         inputs_of(ks + 1, in_next, code_next);
         if(valid && r >= 0 && r < la) {
-            row_l1<W>(k, st, in.x, in.y, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
+            row_l1<W>(kv, st, in.x, in.y, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
             bits[(0 * kCkRows + ks) * kWave] = st.acc[ACC_A];
             bits[(1 * kCkRows + ks) * kWave] = st.acc[ACC_B];
             bits[(2 * kCkRows + ks) * kWave] = st.acc[ACC_C];
@@ -1167,7 +1169,7 @@ struct CkShape {
     size_t dynamic_lds;
 };
 CkShape ck_launch_shape(uint32_t n_items, bool shared_tab) {
-    constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
+    const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
     const int max_blocks = shared_tab ? 4 : 3;  // wavefronts per SIMD: <= 128 VGPRs -> 4; per-wavefront tables (12.4 KB each): 12 per CU
     static const int forced = [] {
         const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");

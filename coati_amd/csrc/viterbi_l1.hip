@@ -47,6 +47,7 @@ namespace {
 // Read-only per-strip context of one wavefront.
 struct StripCtx {
     GapConsts k;
+    GapVec kv;  // the same four values in VGPRs, for the cell (viterbi_cell.hpp)
     uint32_t la, col0, nsteps, pair, lds_tab;
     int lane, last_lane, last_c;
     bool last_strip;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void one_step(const StripCtx& cx, LaneState<W>& st, u
         const float zl = shift_in(st.zlast, read_lane(bz, kk));
         const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
         // ---- the W cells (and the LDS gather for the next step)
-        row_l1<W>(k, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
+        row_l1<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
         arow = arow_next;
         // ---- decision bits (layout in common.hpp): coalesced 256-byte rows, A and B whenever 32
         // bits are complete (every 16/W steps), C every 32/W steps
@@ -162,7 +163,7 @@ __device__ __forceinline__ bool fill_strip(const GapConsts& k, const PairDesc& p
         boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
     }
 
-    const StripCtx cx{k, la, col0, nsteps, pair, lds_tab, lane,
+    const StripCtx cx{k, gap_vec(k), la, col0, nsteps, pair, lds_tab, lane,
                       static_cast<int>((lb - 1 - col0) / W), static_cast<int>((lb - 1 - col0) % W),
                       last_strip, fout, bnd_x, bnd_z, scores};
     LaneState<W> st;
@@ -378,7 +379,7 @@ struct FillShape {
     size_t dynamic_lds;
 };
 FillShape fill_launch_shape(uint32_t n_items) {
-    constexpr uint32_t kCUs = 256, kSimds = kCUs * 4;
+    const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
     constexpr int kMaxBlocks = 3;  // <= 168 VGPRs -> 3 waves per SIMD
     static const int forced = [] {
         const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");

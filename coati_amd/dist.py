@@ -24,6 +24,10 @@ EXPORTS = (
     "coati_hip_dist_broadcast_model",
     "coati_hip_dist_gather",
     "coati_hip_dist_viterbi",
+    "coati_hip_dist_viterbi_shard",
+    "coati_hip_dist_chunk_plan",
+    "coati_hip_dist_landing_plan",
+    "coati_hip_dist_simulate",
 )
 
 _lib = None
@@ -49,6 +53,10 @@ def load() -> C.CDLL:
     lib.coati_hip_dist_broadcast_model.argtypes = [vp, i32, vp, C.c_uint32, vp, vp, vp]
     lib.coati_hip_dist_gather.argtypes = [vp, i32, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_dist_viterbi.argtypes = [vp, i32, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
+    lib.coati_hip_dist_viterbi_shard.argtypes = [vp, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, vp, u64, vp, vp]
+    lib.coati_hip_dist_chunk_plan.argtypes = [u64, vp, vp, i32, u64, vp, vp, u64, vp]
+    lib.coati_hip_dist_landing_plan.argtypes = [i32, i32, vp, vp, vp]
+    lib.coati_hip_dist_simulate.argtypes = [i32, i32, u64, vp, vp, u64, vp, vp, vp, vp, vp, u64, vp, vp]
     _lib = lib
     return lib
 
@@ -119,3 +127,41 @@ class Comm:
         _check(load().coati_hip_dist_viterbi(self._h, root, model._h, n, hip._ptr(a_cat), hip._ptr(a_off), hip._ptr(b_cat),
                                              hip._ptr(b_off), hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln)))
         return (scores, ops, off, ln) if self.rank == root else None
+
+
+def chunk_plan(a_off, b_off, world: int, chunk_cells: int = 0):
+    """coati_hip_dist_chunk_plan: ([per-rank chunk boundaries], rounds).  Pure host arithmetic."""
+    a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+    n = len(a_off) - 1
+    idx = np.zeros(world + 1, np.uint64)
+    rounds = C.c_uint64(0)
+    cap = n + 2 * world + 2
+    cuts = np.zeros(cap, np.uint64)
+    _check(load().coati_hip_dist_chunk_plan(n, hip._ptr(a_off), hip._ptr(b_off), world, chunk_cells, hip._ptr(idx), hip._ptr(cuts), cap,
+                                            C.byref(rounds)))
+    return [cuts[int(idx[r]):int(idx[r + 1])].copy() for r in range(world)], int(rounds.value)
+
+
+def landing_plan(counts, root: int = 0):
+    """coati_hip_dist_landing_plan: (land[world, 4] byte offsets of scores/ops/off/len, need)."""
+    counts = np.ascontiguousarray(counts, np.uint64).reshape(-1)
+    world = len(counts) // 2
+    land = np.zeros(4 * world, np.uint64)
+    need = C.c_uint64(0)
+    _check(load().coati_hip_dist_landing_plan(world, root, hip._ptr(counts), hip._ptr(land), C.byref(need)))
+    return land.reshape(world, 4), int(need.value)
+
+
+def simulate(world: int, root: int, a_off, b_off, pair_scores, pair_ops, pair_ops_len, chunk_cells: int = 0):
+    """coati_hip_dist_simulate: the sharded job of `world` ranks in host memory -> (scores, ops, ops_off, ops_len)."""
+    a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+    n = len(a_off) - 1
+    total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
+    ps = np.ascontiguousarray(pair_scores, np.float32)
+    po = np.ascontiguousarray(pair_ops, np.uint8)
+    pl = np.ascontiguousarray(pair_ops_len, np.uint32)
+    scores, ops = np.zeros(n, np.float32), np.full(max(total, 1), 0xCC, np.uint8)
+    off, ln = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    _check(load().coati_hip_dist_simulate(world, root, n, hip._ptr(a_off), hip._ptr(b_off), chunk_cells, hip._ptr(ps), hip._ptr(po), hip._ptr(pl),
+                                          hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln)))
+    return scores, ops, off, ln

@@ -26,6 +26,7 @@ EXPORTS = (
     "coati_hip_model_create_tables",
     "coati_hip_model_destroy",
     "coati_hip_model_trim",
+    "coati_hip_model_set_option",
     "coati_hip_batch_create",
     "coati_hip_batch_create_tables",
     "coati_hip_batch_destroy",
@@ -86,6 +87,8 @@ def load() -> C.CDLL:
     lib.coati_hip_model_destroy.restype = None
     if hasattr(lib, "coati_hip_model_trim"):
         lib.coati_hip_model_trim.argtypes = [vp]
+    if hasattr(lib, "coati_hip_model_set_option"):
+        lib.coati_hip_model_set_option.argtypes = [vp, C.c_int, C.c_int64]
     lib.coati_hip_batch_create.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(vp)]
     lib.coati_hip_batch_destroy.argtypes = [vp]
     lib.coati_hip_batch_destroy.restype = None
@@ -216,6 +219,10 @@ class Model:
     def trim(self):
         """Free the workspaces the model cached from destroyed batches."""
         _check(load().coati_hip_model_trim(self._h))
+
+    def set_option(self, option: int, value: int):
+        """coati_hip_model_set_option (OPT_PERSISTENT_CALL = 1: 0 forbids the device-owning one-shot form)."""
+        _check(load().coati_hip_model_set_option(self._h, int(option), int(value)))
 
     def close(self):
         if self._h:

@@ -15,6 +15,7 @@ int coati_hip_model_create(const float*, float, float, float, float, int, int, c
 int coati_hip_model_create_tables(const float*, uint32_t, float, float, float, float, int, int, coati_hip_model_t** out) { if(out) *out = nullptr; return kNo; }
 void coati_hip_model_destroy(coati_hip_model_t*) {}
 int coati_hip_model_trim(coati_hip_model_t*) { return kNo; }
+int coati_hip_model_set_option(coati_hip_model_t*, int, int64_t) { return kNo; }
 int coati_hip_batch_create(coati_hip_model_t*, uint64_t, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, coati_hip_batch_t** out) { if(out) *out = nullptr; return kNo; }
 int coati_hip_batch_create_tables(coati_hip_model_t*, uint64_t, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, const uint32_t*, coati_hip_batch_t** out) { if(out) *out = nullptr; return kNo; }
 void coati_hip_batch_destroy(coati_hip_batch_t*) {}

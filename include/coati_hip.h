@@ -103,6 +103,16 @@ void coati_hip_model_destroy(coati_hip_model_t* model);
  * 0.4 and 500 ms, which a loop over batches should not pay per batch.)  This call frees what is
  * cached; coati_hip_model_destroy does it too. */
 int coati_hip_model_trim(coati_hip_model_t* model);
+/* Per-model switches.  (No reference counterpart: they concern how this library shares the GPU with its
+ * embedder, which the CPU reference never has to.)
+ *   COATI_HIP_OPT_PERSISTENT_CALL (default 1): 0 forbids the device-owning form of coati_hip_viterbi_batch --
+ *     one persistent kernel per call that holds every wavefront slot of the GPU until the call returns, so that
+ *     any other kernel of the process (and any copy the runtime does with a kernel) waits for it.  With 0 every
+ *     call uses one launch per chunk (identical results, ~0.85 instead of ~0.95 of the resident kernel's rate)
+ *     and other streams of the embedder interleave normally.
+ * Returns COATI_HIP_EINVAL for an unknown option. */
+enum { COATI_HIP_OPT_PERSISTENT_CALL = 1 };
+int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t value);
 
 /* ---- batch -------------------------------------------------------------- *
  * Validates and uploads n_pairs encoded pairs (host pointers) and reserves the

@@ -66,6 +66,42 @@ int coati_hip_dist_viterbi(coati_hip_comm_t* comm, int root, coati_hip_model_t* 
                            const uint8_t* a_cat, const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                            float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len);
 
+/* The same for ranks that hold only THEIR part of the sequences (each process reads / generates its shard; the
+ * LENGTHS of all pairs -- a_off / b_off, 16 bytes per pair -- are still known everywhere, they are the plan):
+ * a_cat[0] is byte a_first of the concatenation that a_off indexes, b_cat[0] byte b_first; a rank's arrays must
+ * cover the pairs [bounds[rank], bounds[rank+1]) of coati_hip_shard_bounds.  a_first = b_first = 0 with whole
+ * arrays is coati_hip_dist_viterbi.  A rank that fails (allocation, bad codes, arrays that do not cover its
+ * shard) reports it in the round's count exchange: every rank returns an error from the same round, none is
+ * left waiting in a collective. */
+int coati_hip_dist_viterbi_shard(coati_hip_comm_t* comm, int root, coati_hip_model_t* model, uint64_t n_pairs,
+                                 const uint8_t* a_cat, uint64_t a_first, const uint64_t* a_off, const uint8_t* b_cat,
+                                 uint64_t b_first, const uint64_t* b_off, float* scores, uint8_t* ops,
+                                 uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len);
+
+/* ---- the plan, as pure host arithmetic (no device, no communicator: usable anywhere, and what the CPU tests
+ * of the multi-rank paths run on; the collectives above execute exactly these plans) ------------------------- *
+ * Chunk plan of the sharded job: rank r works on pairs [cuts[cut_index[r]], ...) in chunks whose boundaries are
+ * cuts[cut_index[r] .. cut_index[r+1]) (at least two entries per rank; chunks of at most chunk_cells DP cells,
+ * 0 = the library's default, and at least one pair); *rounds = the number of gather rounds (the largest chunk
+ * count of any rank).  cuts may be NULL to ask for the size (cut_index[world]). */
+int coati_hip_dist_chunk_plan(uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, int world,
+                              uint64_t chunk_cells, uint64_t* cut_index, uint64_t* cuts, uint64_t cuts_capacity,
+                              uint64_t* rounds);
+/* Landing zone of one gather on the root: counts[2 * world] as coati_hip_dist_gather returns them ->
+ * land4[4 * world] = byte offsets of rank r's scores, ops, op offsets, op lengths (256-byte aligned, rank
+ * order, nothing for the root itself), *need = bytes of HBM the zone takes. */
+int coati_hip_dist_landing_plan(int world, int root, const uint64_t* counts, uint64_t* land4, uint64_t* need);
+/* The whole sharded job with host memory in place of HBM and memcpy in place of ncclSend/ncclRecv, all ranks in
+ * the calling thread: the chunk plan, the per-round counts, the transfer lists of every sender matched against
+ * the root's receive list, the landing zone, the root's unpack / offset rebase / placement -- the code the
+ * collectives run, minus the device.  Input: per pair its score, its ops (pair p's slot of len_a+len_b bytes at
+ * the op prefix of p, ops right-aligned in the slot as the walkers leave them) and their number; output as
+ * coati_hip_dist_viterbi on the root.  Test infrastructure, exported so that tests reach it through the ABI. */
+int coati_hip_dist_simulate(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off,
+                            uint64_t chunk_cells, const float* pair_scores, const uint8_t* pair_ops,
+                            const uint32_t* pair_ops_len, float* scores, uint8_t* ops, uint64_t ops_capacity,
+                            uint64_t* ops_off, uint32_t* ops_len);
+
 #ifdef __cplusplus
 }
 #endif

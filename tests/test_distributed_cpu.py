@@ -119,3 +119,105 @@ def test_broadcast_and_gather_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ---- the native layer's plans (libcoati_hip_dist.so), world 2, 3, 8 without a GPU ---------------------------
+def _job(seed, n, max_cod=40, max_b=90, empty=True):
+    """lengths, per-pair scores and op slots (ops right-aligned in a slot of la+lb bytes, as the walkers leave them)"""
+    rng = np.random.default_rng(seed)
+    la = rng.integers(0 if empty else 1, max_cod, n) * 3
+    lb = rng.integers(0 if empty else 1, max_b, n)
+    a_off = np.concatenate([[0], np.cumsum(la)]).astype(np.uint64)
+    b_off = np.concatenate([[0], np.cumsum(lb)]).astype(np.uint64)
+    pref = np.concatenate([[0], np.cumsum(la + lb)]).astype(np.int64)
+    ln = np.array([rng.integers(max(la[i], lb[i]), la[i] + lb[i] + 1) for i in range(n)], np.uint32)
+    ops = np.full(max(int(pref[-1]), 1), 0xAA, np.uint8)
+    for i in range(n):
+        ops[pref[i + 1] - ln[i]:pref[i + 1]] = rng.integers(0, 3, ln[i])
+    scores = rng.normal(size=n).astype(np.float32)
+    return la, lb, a_off, b_off, pref, ln, ops, scores
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_native_chunk_plan_tiles_every_shard(world):
+    """coati_hip_dist_chunk_plan (what coati_hip_dist_viterbi runs on every rank): a rank's chunks tile its shard
+    of coati_hip_shard_bounds, no chunk is empty unless the shard is, none exceeds chunk_cells unless it is a
+    single pair, and the round count is the largest chunk count."""
+    from coati_amd import dist as nd
+    from coati_amd import hip
+
+    la, lb, a_off, b_off, *_ = _job(11 + world, 1500)
+    cells = (la * lb).astype(np.int64)
+    bounds = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
+    for chunk_cells in (1500, 40000, 0):
+        cuts, rounds = nd.chunk_plan(a_off, b_off, world, chunk_cells)
+        assert len(cuts) == world and rounds == max(len(c) - 1 for c in cuts)
+        for r, c in enumerate(cuts):
+            c = c.astype(np.int64)
+            assert len(c) >= 2 and c[0] == bounds[r] and c[-1] == bounds[r + 1] and (np.diff(c) >= 0).all()
+            if bounds[r + 1] > bounds[r]:
+                assert (np.diff(c) > 0).all()
+            if chunk_cells:
+                for k in range(len(c) - 1):
+                    assert cells[c[k]:c[k + 1]].sum() <= chunk_cells or c[k + 1] - c[k] == 1
+    # more ranks than pairs: the late ranks get empty shards, one (empty) round each
+    cuts, rounds = nd.chunk_plan(a_off[:3], b_off[:3], 8, 0)
+    assert rounds == 1 and sum(int(c[-1] - c[0]) for c in cuts) == 2
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (2, 1), (3, 1), (8, 0), (8, 5)])
+def test_native_landing_plan_blocks_are_disjoint(world, root):
+    """coati_hip_dist_landing_plan: the four arrays of every peer land 256-byte aligned, in rank order, without
+    overlap, inside `need`; the root itself takes nothing."""
+    from coati_amd import dist as nd
+
+    rng = np.random.default_rng(world * 10 + root)
+    counts = np.stack([rng.integers(0, 5000, world), rng.integers(0, 3_000_000, world)], axis=1).astype(np.uint64)
+    counts[rng.integers(0, world)] = 0  # a rank with nothing to send
+    land, need = nd.landing_plan(counts, root)
+    spans = []
+    for r in range(world):
+        if r == root:
+            continue
+        n, ob = int(counts[r, 0]), int(counts[r, 1])
+        for at, size in zip(land[r], (4 * n, ob, 8 * n, 4 * n)):
+            assert int(at) % 256 == 0
+            spans.append((int(at), int(at) + size))
+    spans.sort()
+    assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:]))
+    assert not spans or spans[-1][1] <= need
+    assert need <= sum(e - s for s, e in spans) + 256 * len(spans)
+
+
+@pytest.mark.parametrize("world,root", [(1, 0), (2, 0), (2, 1), (3, 2), (8, 0), (8, 3)])
+@pytest.mark.parametrize("chunk_cells", [0, 2500, 60000])
+def test_native_sharded_job_simulated_in_host_memory(world, root, chunk_cells):
+    """coati_hip_dist_simulate runs every rank's side of coati_hip_dist_viterbi in one thread with memcpy in
+    place of ncclSend / ncclRecv / hipMemcpyAsync: chunk plan, per-round counts, every sender's transfer list
+    against the root's receive list, landing zone, unpack, offset rebase, placement -- the functions the
+    collectives execute.  The root's arrays must equal the single-process answer for every pair, whatever the
+    world, the root, the number of rounds (ragged: ranks run out of chunks at different rounds)."""
+    from coati_amd import dist as nd
+
+    la, lb, a_off, b_off, pref, ln, ops, scores = _job(7 * world + root, 1200)
+    s, o, off, l = nd.simulate(world, root, a_off, b_off, scores, ops, ln, chunk_cells)
+    assert (s.view(np.uint32) == scores.view(np.uint32)).all() and (l == ln).all()
+    want_off = (pref[1:] - ln).astype(np.uint64)
+    assert (off == want_off).all()
+    for i in range(len(ln)):
+        assert (o[int(off[i]):int(off[i]) + int(l[i])] == ops[int(want_off[i]):pref[i + 1]]).all(), i
+
+
+def test_native_simulation_rejects_inconsistent_input():
+    from coati_amd import dist as nd
+    from coati_amd import hip
+
+    la, lb, a_off, b_off, pref, ln, ops, scores = _job(3, 50, empty=False)
+    bad = ln.copy()
+    bad[7] = la[7] + lb[7] + 1  # more ops than the pair's slot holds
+    with pytest.raises(hip.CoatiHipError):
+        nd.simulate(2, 0, a_off, b_off, scores, ops, bad)
+    dec = a_off.copy()
+    dec[5] = dec[4] - 3  # decreasing offsets: the partitioner refuses, the same way on every rank
+    with pytest.raises(hip.CoatiHipError):
+        nd.chunk_plan(dec, b_off, 2)

@@ -32,6 +32,44 @@ def test_golden_viterbi_cases_gap_len_1():
         assert int(np.float32(scores[p]).view(np.uint32)) == int(c["score_bits"], 16), c["name"]
 
 
+def test_golden_viterbi_cases_gap_len_3():
+    """The 51 gap_len == 3 cases of the compiled reference (`coati alignpair -k 3`; fixture from
+    oracle/_ref, tools/make_golden.py): aligned strings and score bits through the planner's kernel
+    (viterbi_k; dp_generic when COATI_HIP_FORCE_GENERIC is set -- see the next test)."""
+    from coati_amd import hip, host
+
+    doc = json.loads((GOLD / "viterbi_cases.json").read_text())
+    table = np.load(GOLD / "table_mg94_goldenP.npy")
+    consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])
+    cases = [c for c in doc["cases"] if c["gap_len"] == 3]
+    assert len(cases) >= 50
+    enc = [host.encode(c["anc"], c["des"]) for c in cases]
+    model = hip.Model(table, consts, 3)
+    scores, ops, ops_off, ops_len = model.viterbi(*hip.pack_pairs(enc))
+    for p, c in enumerate(cases):
+        got = ops[int(ops_off[p]):int(ops_off[p]) + int(ops_len[p])]
+        sa = "".join("-" if o == 2 else ch for o, ch in zip(got, _expand(got, c["anc"], 2)))
+        sb = "".join("-" if o == 1 else ch for o, ch in zip(got, _expand(got, c["des"], 1)))
+        assert (sa, sb) == (c["aln_anc"], c["aln_des"]), c["name"]
+        assert int(np.float32(scores[p]).view(np.uint32)) == int(c["score_bits"], 16), c["name"]
+
+
+def test_golden_viterbi_cases_gap_len_3_generic_kernel():
+    """The same fixtures through dp_generic (the library reads COATI_HIP_FORCE_GENERIC once: child process)."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("COATI_HIP_FORCE_GENERIC"):
+        pytest.skip("already inside the forced run")
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, COATI_HIP_FORCE_GENERIC="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", str(Path(__file__).resolve()),
+                          "-k", "test_golden_viterbi_cases_gap_len_3 and not generic"], env=env, capture_output=True,
+                         text=True, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
 def _expand(ops, seq, gap_op):
     """Characters of `seq` laid out along the alignment columns (placeholder where the op is a gap in seq)."""
     it = iter(seq)
