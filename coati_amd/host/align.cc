@@ -294,10 +294,10 @@ std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, 
     if(rc == COATI_HIP_OK) rc = coati_hip_viterbi_launch(batch);
     if(rc == COATI_HIP_OK)
         rc = coati_hip_viterbi_fetch(batch, scores.data(), ops.data(), a_cat.size() + b_cat.size(), off.data(), len.data());
-    if(rc == COATI_HIP_OK) check_scores(scores);
     if(batch != nullptr) coati_hip_batch_destroy(batch);
     coati_hip_model_destroy(model);
     hip_check(rc);
+    check_scores(scores);  // (after the handles are gone: it throws)
     stage("device (upload, plan, launch, fetch)");
     parallel_for(n, 256, [&](std::size_t p) {
         out[p].seqs.assign(2, std::string());
@@ -490,6 +490,9 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
                                ops.data(), in.a_cat.size() + in.b_cat.size(), off.data(), len.data());
     coati_hip_model_destroy(model);
     dist_check(rc);
+    // a pair whose strip hand-off timed out comes back with a NaN score (never a hang): an error here, as in the
+    // single-GPU driver -- not `"score": null` next to a garbage alignment
+    if(rank == 0) check_scores(scores);
     tm.stage("sharded Viterbi + gather");
     if(rank == 0) {
         write_batch_output(aln, in, scores, ops, off, len);
