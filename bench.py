@@ -7,10 +7,16 @@ Viterbi path (fill + traceback) on synthetic 1 kb x 1 kb pairs, mar-mg94
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path (fill kernel + traceback walker, and for
-N > 1 the gather of all results to rank 0 over RCCL) over one batch of
+N > 1 the gather of all results to rank 0's HBM over RCCL) over one batch of
 `--pairs` pairs PER GPU (weak scaling: the reference aligns one pair per
 process, pairs are independent, shards need no data-path collective).
-Rank 0 prints ONE JSON line.
+N > 1 runs on the product's own multi-GPU layer, libcoati_hip_dist.so (RCCL linked
+directly: coati_hip_dist_init / _broadcast_model / _gather / _viterbi_shard); the
+ncclUniqueId travels through the launcher's TCP store (MASTER_ADDR / MASTER_PORT)
+before anything touches a GPU.  torch is used for that store and for
+torch.cuda.synchronize() only.  The N > 1 line also carries `strong_1M`: BASELINE
+configs[4] (1 000 000 pairs, mar-ecm) as ONE sharded job, each rank generating
+only its shard.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -247,7 +253,58 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
                     "s": best, "pairs_per_s": n / best, "gcups_approx": cl / best / 1e9, "stage_ms": st,
                     "output_bytes": js.stat().st_size}
 
+    def reference_suite():
+        """The reference's own benchmark harness (benchmark/benchmark_main.cc.in:56-76, libcoati-benchmark-tests.txt:1-7):
+        the seven BM_marg_alignment inputs.  Per case: the GPU's kernel time for the pair alone and for a batch of 64
+        copies (HIP events, median of 3 launches; results checked against the fixture), next to the unmodified
+        reference engine on ONE host thread of this box (as its benchmark runs it), where it fits the time budget."""
+        from tests import util  # (fixture decoder only)
+        from oracle import pyoracle as orc  # the CPU side of the comparison -- never on the product path
+
+        keys = ["156", "1k", "2k", "4k", "8k", "16k", "32k"]
+        doc = util.load_bench_pair("156")[3]
+        tab = np.load(ROOT / "tests" / "golden" / doc["table"])
+        g, e = doc["gap_open"], doc["gap_extend"]
+        m = hip.Model(tab, host.gap_consts(g, e), 1)
+        rows, ref_ns_per_cell = [], None
+        for k in keys:
+            a, b, case, _ = util.load_bench_pair(k)
+            cl = len(a) * len(b)
+            row = {"case": "bm_" + k, "len_a": len(a), "len_b": len(b)}
+            for copies, tag in ((1, "pair"), (64, "batch64")):
+                bt = hip.Batch(m, *hip.pack_pairs([(a, b)] * copies))
+                ts = []
+                for _ in range(4):
+                    bt.viterbi_launch()
+                    bt.sync()
+                    ts.append(sum(bt.viterbi_timing()))
+                sc, ops, off, ln = bt.viterbi_fetch()
+                ok = all(int(np.float32(sc[p]).view(np.uint32)) == int(case["score_bits"], 16) and
+                         "%08x" % zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes()) == case["ops_crc32"] for p in (0, copies - 1))
+                ms = float(np.median(ts[1:]))
+                row[tag + "_ms"] = ms
+                row[tag + "_gcups"] = cl * copies / ms / 1e6
+                row[tag + "_bit_exact"] = bool(ok)
+                bt.close()
+            m.trim()
+            if orc.ref_available() and (ref_ns_per_cell is None or cl * ref_ns_per_cell * 2e-9 < 45.0):
+                letters = np.array(list("ACGT"))
+                des = "".join(letters[b])
+                codons = util.SENSE64  # encoded ancestor -> nucleotides: code = codon61 * 3 + phase
+                anc = "".join(util.codon_str(codons[int(c) // 3]) for c in a[0::3])
+                t0 = time.perf_counter()
+                orc.ref_viterbi(tab, np.float32(g), np.float32(e), 1, anc, des, a, b, want_matrices=False)
+                dt = time.perf_counter() - t0
+                ref_ns_per_cell = dt / cl * 1e9
+                row["reference_engine_ms_1_thread"] = dt * 1e3
+                row["pair_speedup_vs_reference"] = dt * 1e3 / row["pair_ms"]
+            rows.append(row)
+        m.close()
+        return {"what": "benchmark/benchmark_main.cc.in BM_marg_alignment inputs: kernel ms on the GPU (pair alone / 64 copies in one "
+                        "batch) and the unmodified reference engine (oracle/_ref, 1 host thread)", "cases": rows}
+
     guarded("pcie_inclusive", streamed)
+    guarded("reference_suite", reference_suite)
     guarded("cli_batch", cli_batch)
     guarded("long_pair", long_pair)
     guarded("sample", sample)
@@ -265,6 +322,8 @@ def main():
     ap.add_argument("--strong-total", type=int, default=0,
                     help="BASELINE configs[4] style: a FIXED total of pairs split over the ranks by the native "
                          "partitioner (coati_hip_shard_bounds), scaling 'strong'; default 0 = --pairs per GPU (weak)")
+    ap.add_argument("--strong-pairs", type=int, default=0,
+                    help="N > 1 only: size of the `strong_1M` job (default 1 000 000; 20 000 in the one-rank self-test)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the informational two_stream_pipeline and pcie_inclusive measurements (their extra "
                          "launches would be mixed into a rocprofv3 --stats summary of this command)")
@@ -274,39 +333,52 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    from coati_amd import distributed as cd
     from coati_amd import hip, host
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # COATI_BENCH_SELFTEST_GATHER=1 runs the N > 1 code path (second slot, packed gather, overlap)
-    # with a one-rank RCCL group: a functional check on a 1-GPU box, not a benchmark configuration
+    # COATI_BENCH_SELFTEST_GATHER=1 runs the N > 1 code path (rendezvous through a TCP store, native communicator,
+    # model broadcast, second slot, per-step gather, the sharded strong job) with a one-rank RCCL communicator:
+    # a functional check on a 1-GPU box, not a benchmark configuration
     selftest = world == 1 and os.environ.get("COATI_BENCH_SELFTEST_GATHER") == "1"
     multi = world > 1 or selftest
+    comm = None
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if selftest:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from datetime import timedelta
+
+        from torch.distributed import TCPStore
+
+        from coati_amd import dist as nd
+
+        # ---- rendezvous BEFORE any GPU call: rank 0 makes the ncclUniqueId, the launcher's store carries it.  Under
+        # torch.distributed.run the agent already serves a store on MASTER_PORT (workers are clients); launched by
+        # hand (or in the self-test) rank 0 serves it.
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29533"))
+        agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+        store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store), timeout=timedelta(seconds=300),
+                         wait_for_workers=False)
+        key = "coati_bench/uid/" + os.environ.get("TORCHELASTIC_RUN_ID", "0") + "/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+        if rank == 0:
+            store.set(key, nd.unique_id())
+        uid = bytes(store.get(key))
+        comm = nd.Comm(uid, world, rank, device=local_rank)
     if not torch.cuda.is_available() or hip.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no gfx950 device visible (there is no CPU fallback)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    # ---- model: built on rank 0, broadcast over RCCL --------------------------
+    # ---- model: built on rank 0, broadcast over RCCL (coati_hip_dist_broadcast_model) ----------------
     if rank == 0:
         table, consts, gap_len = host.set_subst(args.model), host.gap_consts(), 1
     else:
         table = consts = gap_len = None
     if multi:
-        table, consts, gap_len = cd.broadcast_model(table, consts, gap_len, device)
+        table, consts, gap_len = comm.broadcast_model(table, consts, gap_len, root=0)
+        table = table[0]
     model = hip.Model(table, consts, gap_len, device=local_rank)
 
     # ---- this rank's shard of the synthetic workload, uploaded once ------------
@@ -323,25 +395,20 @@ def main():
     cells = batch.cells
     seq_bytes = int(a_off[-1] + b_off[-1])
 
-    # N > 1: every step's results go to rank 0 (one packed RCCL gather per step).  Two resident
-    # copies of the shard alternate, so that the gather of step i runs on torch's collective stream
-    # while the kernel of step i+1 runs: nothing is skipped, K launches and K gathers happen inside
-    # the timed region.  By default both copies use ONE library stream (kernels never overlap each
-    # other; the gather waits for its own launch only, coati_hip_viterbi_wait); --streams 2 gives each
-    # copy its own stream.
+    # N > 1: every step's results go to rank 0's HBM (coati_hip_dist_gather without the download: an all-gather of
+    # the counts, then one group of ncclSend / ncclRecv out of the ranks' result arrays).  Two resident copies of
+    # the shard alternate, so that the gather of step i runs on the communicator's stream while the kernel of step
+    # i+1 runs: nothing is skipped, K launches and K gathers happen inside the timed region.  By default both
+    # copies use ONE library stream (kernels never overlap each other; the gather waits for its own launch only,
+    # coati_hip_viterbi_wait); --streams 2 gives each copy its own stream.
     slots = [(model, batch)]
-    gathers = []
     if multi or args.streams == 2:
         model2 = hip.Model(table, consts, gap_len, device=local_rank) if args.streams == 2 else model
         slots.append((model2, hip.Batch(model2, a_cat, a_off, b_cat, b_off)))
-    if multi:
-        gathers = [cd.PackedGather(cd.batch_result_tensors(bt, device), dst=0) for _, bt in slots]
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": None, "counts": None}
 
     def step():
         cur = state["i"] % len(slots)
-        if multi:
-            gathers[cur].wait_copies()  # its previous results have been read before the kernel overwrites them
         slots[cur][1].viterbi_launch()
         if multi:
             drain()
@@ -351,16 +418,13 @@ def main():
     def drain():
         pend = state["pending"]
         if pend is not None:
-            slots[pend][1].wait()  # its own launch only: the launch just issued keeps running
-            gathers[pend](async_op=True)
+            state["counts"] = comm.gather_device(slots[pend][1], root=0)  # (collective; waits for that launch only)
             state["pending"] = None
 
     def fence():
         if multi:
             drain()
-            for g in gathers:
-                g.finish()
-            dist.barrier()
+            comm.barrier()
         for _, bt in slots:
             bt.sync()
         torch.cuda.synchronize()
@@ -378,15 +442,12 @@ def main():
     n_timed = max(1, min(args.steps // len(slots), 64))
     timed = [bt.viterbi_timing(i) for _, bt in slots for i in range(n_timed)]
     fill_ms = [t[0] for t in timed]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([cells], dtype=torch.float64, device=device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = float(c.item())
+    if multi:
+        elapsed = float(comm.allreduce([elapsed], "max")[0])
+        total_cells = float(comm.allreduce([float(cells)], "sum")[0])
     else:
         total_cells = float(cells)
+    strong = strong_job(comm, hip, host, torch, world, rank, local_rank, args) if multi else None
 
     global_pairs = args.strong_total if args.strong_total > 0 else args.pairs * world
     # sanity: results are real (score of pair 0 finite, ops consume both sequences)
@@ -458,7 +519,8 @@ def main():
                                     f"{args.pairs} synthetic 1 kb x 1 kb pairs per GPU, {args.model} "
                                     "(BASELINE.json configs[1]; generator SURVEY.md §8(d))"),
                        "streams": args.streams, "pairs_per_gpu": n_mine, "global_pairs": global_pairs, "gap_len": 1,
-                       "parallelism": f"pairs sharded over {world} GPU(s), model broadcast + result gather (RCCL)"},
+                       "parallelism": f"pairs sharded over {world} GPU(s); model broadcast + per-step result gather to rank 0's HBM "
+                                      "through libcoati_hip_dist.so (RCCL linked directly)" if multi else "1 GPU"},
             "pairs_per_s": global_pairs * args.steps / elapsed,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -468,6 +530,7 @@ def main():
                          "note": "priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell); the limit this "
                                  "recurrence actually runs into is VALU issue -- valu_ceiling_gcups is the register-only "
                                  "replay of the 15-instruction fill cell, valu_frac the kernel against it (DESIGN.md 4)"},
+            "strong_1M": strong,
             "two_stream_pipeline": pipelined,
             "pcie_inclusive": extras.get("pcie_inclusive"),
             "extra": {k: v for k, v in extras.items() if k != "pcie_inclusive"} or None,
@@ -475,19 +538,72 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(table, consts, a_cat, a_off, b_cat, b_off)
         print(json.dumps(out), flush=True)
-    if multi and rank == 0:
-        # the gathered copy of the last step equals what a direct fetch returns
-        sc, ops, off, ln = gathers[(state["i"] - 1) % len(slots)].unpack(0)
-        f_sc, f_ops, f_off, f_ln = slots[(state["i"] - 1) % len(slots)][1].viterbi_fetch()
-        assert (sc.cpu().numpy().view(np.uint32) == f_sc.view(np.uint32)).all() and (ln.cpu().numpy() == f_ln).all()
-        assert (ops.cpu().numpy() == f_ops).all()
-        print("gathered results of rank 0 identical to a direct fetch", file=sys.stderr)
+    if multi:
+        # (untimed) one gather WITH the download: rank 0's part of the gathered arrays equals a direct fetch of its batch,
+        # the counts are every rank's pairs / op bytes
+        last = slots[(state["i"] - 1) % len(slots)][1]
+        got = comm.gather(last, root=0)
+        if rank == 0:
+            counts, sc, ops, off, ln = got
+            f_sc, f_ops, f_off, f_ln = last.viterbi_fetch()
+            n0 = int(counts[0, 0])
+            assert n0 == n_mine and int(counts[:, 0].sum()) == len(sc)
+            assert (sc[:n0].view(np.uint32) == f_sc.view(np.uint32)).all() and (ln[:n0] == f_ln).all() and (off[:n0] == f_off).all()
+            assert (ops[:int(counts[0, 1])] == f_ops[:int(counts[0, 1])]).all()
+            print("gathered results of rank 0 identical to a direct fetch", file=sys.stderr)
     for md, bt in slots:
         bt.close()
     for md in {id(m): m for m, _ in slots}.values():
         md.close()
-    if multi:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
+
+
+def strong_job(comm, hip, host, torch, world, rank, local_rank, args):
+    """BASELINE configs[4] as ONE sharded job through coati_hip_dist_viterbi_shard: `--strong-pairs` synthetic 1 kb
+    pairs (1 000 000 by default; 20 000 in the one-rank self-test), mar-ecm, split by coati_hip_shard_bounds; every
+    rank generates and encodes ONLY its shard (all ranks know all LENGTHS: they are the plan); the ECM model is built on
+    rank 0 and broadcast; results (scores, ops, offsets, lengths) end in rank 0's host arrays.  Wall time between two
+    barriers, max over ranks.  Returns the record for the JSON line (rank 0), None elsewhere."""
+    import zlib
+
+    total = args.strong_pairs if args.strong_pairs > 0 else (20000 if world == 1 else 1000000)
+    t_gen = time.perf_counter()
+    la, lb = host.synth_lengths(0, total)
+    a_off = np.concatenate([[0], np.cumsum(la)]).astype(np.uint64)
+    b_off = np.concatenate([[0], np.cumsum(lb)]).astype(np.uint64)
+    bounds = hip.shard_bounds(a_off, b_off, world)
+    first, n_mine = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+    a_cat, a_loc, b_cat, b_loc = host.synth_encoded(first, n_mine)
+    assert int(a_loc[-1]) == int(a_off[first + n_mine] - a_off[first]) and int(b_loc[-1]) == int(b_off[first + n_mine] - b_off[first])
+    t_gen = time.perf_counter() - t_gen
+    if rank == 0:
+        table, consts, gap_len = host.set_subst("mar-ecm"), host.gap_consts(), 1
+    else:
+        table = consts = gap_len = None
+    table, consts, gap_len = comm.broadcast_model(table, consts, gap_len, root=0)
+    model = hip.Model(table[0], consts, gap_len, device=local_rank)
+    times = []
+    res = None
+    for _ in range(2):  # (the first job pays the first-touch allocation of workspaces and result arrays)
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = comm.viterbi_shard(model, a_cat, int(a_off[first]), a_off, b_cat, int(b_off[first]), b_off, root=0, reuse=res)
+        comm.barrier()
+        torch.cuda.synchronize()
+        times.append(float(comm.allreduce([time.perf_counter() - t0], "max")[0]))
+    model.close()
+    if rank != 0:
+        return None
+    sc, ops, off, ln = res
+    cells = float((la.astype(np.float64) * lb).sum())
+    assert np.isfinite(sc).all() and int(ln.min()) >= 900 and (off.astype(np.int64) + ln <= np.cumsum(la + lb)).all()
+    return {"what": "BASELINE configs[4]: ONE sharded job (coati_hip_dist_viterbi_shard), shards by DP cells, each rank generated only "
+                    "its shard, results in rank 0's host memory; wall time between barriers, max over ranks, second of two jobs",
+            "pairs": total, "model": "mar-ecm", "n_gpus": world, "seconds": times[-1], "first_job_seconds": times[0],
+            "gcups": cells / times[-1] / 1e9, "pairs_per_s": total / times[-1], "scaling": "strong",
+            "shard_generation_seconds": t_gen, "scores_crc32": "%08x" % zlib.crc32(sc.tobytes()), "columns": int(ln.sum())}
 
 
 if __name__ == "__main__":

@@ -118,6 +118,27 @@ int coati_hip_dist_init(const void* id128, int world, int rank, int device, coat
 int coati_hip_dist_rank(const coati_hip_comm_t* c) { return c != nullptr ? c->rank : -1; }
 int coati_hip_dist_world(const coati_hip_comm_t* c) { return c != nullptr ? c->world : 0; }
 
+int coati_hip_dist_allreduce_f64(coati_hip_comm_t* c, int op, double* values, uint32_t n) {
+    if(c == nullptr || values == nullptr || n == 0 || n > 64 || (op != 0 && op != 1)) return fail(COATI_HIP_EINVAL, "dist_allreduce_f64: bad argument");
+    D_HIP(hipSetDevice(c->device));
+    double* d = nullptr;
+    D_HIP(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(double)));
+    struct Free {
+        void* p;
+        ~Free() { (void)hipFree(p); }
+    } free_d{d};
+    D_HIP(hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    D_NCCL(ncclAllReduce(d, d, n, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
+    D_HIP(hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    D_HIP(hipStreamSynchronize(c->stream));
+    return COATI_HIP_OK;
+}
+
+int coati_hip_dist_barrier(coati_hip_comm_t* c) {
+    double one = 1.0;
+    return coati_hip_dist_allreduce_f64(c, 0, &one, 1);
+}
+
 int coati_hip_dist_broadcast_model(coati_hip_comm_t* c, int root, float* tables, uint32_t table_capacity_tables,
                                    uint32_t* n_tables, float consts[4], int* gap_len) {
     if(c == nullptr || tables == nullptr || n_tables == nullptr || consts == nullptr || gap_len == nullptr || root < 0 || root >= c->world)

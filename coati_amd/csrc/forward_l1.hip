@@ -38,6 +38,7 @@ struct FwdLane {
 
 struct FwdCtx {
     GapConsts k;
+    GapVec kv;  // the same constants in VGPRs for the per-cell adds (an SGPR operand costs an add the slow issue cadence: common.hpp)
     uint32_t la, col0, nsteps, pair;
     int lane, last_lane, last_c;
     bool last_strip;
@@ -65,6 +66,7 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint3
                                          float chDM, float chDD, float chDI, float chLM, float chLI,
                                          const char* tab_bytes) {
     const GapConsts& k = cx.k;
+    const GapVec& kv = cx.kv;
     const int lane = cx.lane;
     {
         const uint32_t kstep = kbase + kk;
@@ -105,14 +107,14 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint3
             s[c] = *reinterpret_cast<const float*>(tab_bytes + arow_next + boff[c]);
             const float upM = st.M[c], upD = st.D[c], upI = st.I[c];
             // align_pair.cc:97-119 with look_back 1 (power(ge, 0) = -0.0f is the additive identity)
-            const float m2m = ((dgM + k.ng) + k.ng) + sc;
-            const float d2m = (dgD + k.gs) + sc;
-            const float i2m = ((dgI + k.gs) + k.ng) + sc;
-            const float m2d = (upM + k.ng) + k.go;
-            const float i2d = (upI + k.gs) + k.go;
-            const float d2d = upD + k.ge;
-            const float m2i = lfM + k.go;
-            const float i2i = lfI + k.ge;
+            const float m2m = ((dgM + kv.ng) + kv.ng) + sc;
+            const float d2m = (dgD + kv.gs) + sc;
+            const float i2m = ((dgI + kv.gs) + kv.ng) + sc;
+            const float m2d = (upM + kv.ng) + kv.go;
+            const float i2d = (upI + kv.gs) + kv.go;
+            const float d2d = upD + kv.ge;
+            const float m2i = lfM + kv.go;
+            const float i2i = lfI + kv.ge;
             const float M = plus2<kFast>(cx, plus2<kFast>(cx, m2m, d2m), i2m);
             const float D = plus2<kFast>(cx, plus2<kFast>(cx, m2d, d2d), i2d);
             const float I = plus2<kFast>(cx, m2i, i2i);
@@ -211,7 +213,7 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
         const uint32_t bj = col0 + lane * W + c;
         boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
     }
-    const FwdCtx cx{k, la, col0, nsteps, pair, lane,
+    const FwdCtx cx{k, gap_vec(k), la, col0, nsteps, pair, lane,
                     static_cast<int>(((lb - 1) & ((kWave * W) - 1)) / W), static_cast<int>((lb - 1) & (W - 1)),
                     last_strip, mdi + pd.mdi_off + strip * strip_mdi_floats_w(la, W) + 3 * lane, bnd_out, final_mdi, exp_tab};
     FwdLane<W> st;

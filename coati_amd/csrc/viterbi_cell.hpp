@@ -11,22 +11,6 @@
 namespace coati_hip_detail {
 namespace {
 
-// The four gap constants in VECTOR registers.  On gfx950 a v_add_f32 whose constant operand is an SGPR issues
-// at the 4-cycle rate of v_max_f32, not at the 2-cycle rate of an add between VGPRs (round 3,
-// tools/ubench/gen_issue.py -> profiles/r03/ubench_issue_model.txt: "pure v_add_f32" 2.5 cycles per
-// instruction and SIMD, "pure v_add_f32 sgpr" 4.4; the 15-instruction cell 3.03 cycles per instruction with
-// SGPR constants, 2.03 with VGPR constants).  Ten of the cell's adds take a constant, so the cells read them
-// from four VGPRs that are loaded once per work item and made opaque (or the compiler re-materialises the
-// v_mov from the SGPR inside the loop when registers are short).
-struct GapVec {
-    float ng, gs, go, ge;
-};
-__device__ __forceinline__ GapVec gap_vec(const GapConsts& k) {
-    GapVec v{k.ng, k.gs, k.go, k.ge};
-    asm volatile("" : "+v"(v.ng), "+v"(v.gs), "+v"(v.go), "+v"(v.ge));
-    return v;
-}
-
 // Register state of one lane: its W columns (W = 16, 8 or 4) of the row it processed last.
 template <int W>
 struct LaneState {

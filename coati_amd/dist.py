@@ -21,6 +21,8 @@ EXPORTS = (
     "coati_hip_dist_destroy",
     "coati_hip_dist_rank",
     "coati_hip_dist_world",
+    "coati_hip_dist_allreduce_f64",
+    "coati_hip_dist_barrier",
     "coati_hip_dist_broadcast_model",
     "coati_hip_dist_gather",
     "coati_hip_dist_viterbi",
@@ -51,6 +53,8 @@ def load() -> C.CDLL:
     lib.coati_hip_dist_rank.argtypes = [vp]
     lib.coati_hip_dist_world.argtypes = [vp]
     lib.coati_hip_dist_broadcast_model.argtypes = [vp, i32, vp, C.c_uint32, vp, vp, vp]
+    lib.coati_hip_dist_allreduce_f64.argtypes = [vp, i32, vp, C.c_uint32]
+    lib.coati_hip_dist_barrier.argtypes = [vp]
     lib.coati_hip_dist_gather.argtypes = [vp, i32, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_dist_viterbi.argtypes = [vp, i32, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     lib.coati_hip_dist_viterbi_shard.argtypes = [vp, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, vp, u64, vp, vp]
@@ -82,6 +86,45 @@ class Comm:
         if self._h:
             load().coati_hip_dist_destroy(self._h)
             self._h = C.c_void_p()
+
+    def barrier(self):
+        _check(load().coati_hip_dist_barrier(self._h))
+
+    def allreduce(self, values, op: str = "sum"):
+        """Element-wise all-reduce of up to 64 doubles ("sum" or "max"); returns the reduced array."""
+        v = np.ascontiguousarray(values, np.float64).reshape(-1).copy()
+        _check(load().coati_hip_dist_allreduce_f64(self._h, {"sum": 0, "max": 1}[op], hip._ptr(v), len(v)))
+        return v
+
+    def gather_device(self, batch, root: int = 0):
+        """The gather without the download: the peers' result arrays land in the root's HBM (the landing zone of the
+        communicator) and stay there; returns counts[world, 2].  What a multi-step driver times per step."""
+        counts = np.zeros(2 * self.world, np.uint64)
+        h = batch._h if batch is not None else None
+        _check(load().coati_hip_dist_gather(self._h, root, h, hip._ptr(counts), None, None, 0, None, None))
+        return counts.reshape(-1, 2)
+
+    def viterbi_shard(self, model, a_cat, a_first, a_off, b_cat, b_first, b_off, root: int = 0, reuse=None):
+        """coati_hip_dist_viterbi_shard: a_off / b_off describe ALL pairs, a_cat / b_cat hold this rank's part of the
+        concatenations starting at byte a_first / b_first.  Results on root (None elsewhere); `reuse` may pass an
+        earlier call's result arrays back in."""
+        a_cat, b_cat = np.ascontiguousarray(a_cat, np.uint8), np.ascontiguousarray(b_cat, np.uint8)
+        a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+        n = len(a_off) - 1
+        total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
+        if self.rank == root:
+            if reuse is not None and len(reuse[0]) == n and len(reuse[1]) >= max(total, 1):
+                scores, ops, off, ln = reuse
+            else:
+                scores, ops = np.zeros(n, np.float32), np.zeros(max(total, 1), np.uint8)
+                off, ln = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+            args = (hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln))
+        else:
+            scores = ops = off = ln = None
+            args = (None, None, 0, None, None)
+        _check(load().coati_hip_dist_viterbi_shard(self._h, root, model._h, n, hip._ptr(a_cat), int(a_first), hip._ptr(a_off), hip._ptr(b_cat),
+                                                   int(b_first), hip._ptr(b_off), *args))
+        return (scores, ops, off, ln) if self.rank == root else None
 
     def broadcast_model(self, tables=None, consts=None, gap_len=None, root: int = 0, capacity: int = 64):
         """Root passes (tables [n,183,15], consts[4], gap_len); every rank gets them back bit-identical."""

@@ -40,6 +40,12 @@ void coati_hip_dist_destroy(coati_hip_comm_t* comm);
 int coati_hip_dist_rank(const coati_hip_comm_t* comm);
 int coati_hip_dist_world(const coati_hip_comm_t* comm);
 
+/* Small collectives for drivers that time or sequence a multi-rank job (bench.py, the --devices launcher):
+ * an element-wise all-reduce of up to 64 doubles (op 0 = sum, 1 = max; ncclAllReduce) and a barrier (an
+ * all-reduce of one element, completed on the communicator's stream before the call returns). */
+int coati_hip_dist_allreduce_f64(coati_hip_comm_t* comm, int op, double* values, uint32_t n);
+int coati_hip_dist_barrier(coati_hip_comm_t* comm);
+
 /* Broadcast of the model from `root`.  On root: tables (n_tables * 183*15 floats), *n_tables, consts
  * (no_gap, gap_stop, gap_open, gap_extend), *gap_len are inputs; on the other ranks they are outputs
  * (`tables` must hold table_capacity_tables tables; fails if the root's model has more). */

@@ -73,3 +73,70 @@ def test_cli_rank_process_equals_single_gpu_batch(tmp_path):
     got = rank.stdout[rank.stdout.index("["):] if "[" in rank.stdout else rank.stdout  # (RCCL's banner precedes the JSON)
     assert json.loads(got) == json.loads(plain.stdout)
     assert len(json.loads(plain.stdout)) == 40
+
+
+def test_bench_multi_gpu_path_with_one_rank():
+    """bench.py's N > 1 code path on the 1-GPU box (COATI_BENCH_SELFTEST_GATHER=1): rendezvous through a TCP
+    store, the native communicator, model broadcast, two alternating resident batches with a per-step
+    coati_hip_dist_gather, barrier / max-over-ranks through the library, and the `strong_1M` job
+    (coati_hip_dist_viterbi_shard; reduced to 3 000 pairs here) -- no torch.distributed process group anywhere."""
+    import os
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, COATI_BENCH_SELFTEST_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "6", "--warmup", "2", "--pairs", "2000", "--no-cpu-baseline",
+                        "--no-extras", "--strong-pairs", "3000"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    doc = json.loads(line)
+    assert doc["n_gpus"] == 1 and doc["value"] > 100 and doc["scaling"] == "weak"
+    st = doc["strong_1M"]
+    assert st["pairs"] == 3000 and st["model"] == "mar-ecm" and st["gcups"] > 10 and st["columns"] > 3000 * 990
+    assert "gathered results of rank 0 identical to a direct fetch" in r.stderr
+    # the strong job's scores are the single-GPU one-shot call's (same generator, same ECM model)
+    sys.path.insert(0, str(root))
+    import zlib
+
+    import numpy as np
+
+    from coati_amd import hip, host
+
+    model = hip.Model(host.set_subst("mar-ecm"), host.gap_consts(), 1)
+    sc = model.viterbi(*host.synth_encoded(0, 3000))[0]
+    assert "%08x" % zlib.crc32(np.ascontiguousarray(sc).tobytes()) == st["scores_crc32"]
+    model.close()
+
+
+SHARD_CHILD = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from coati_amd import hip, host, dist
+comm = dist.Comm(dist.unique_id(), 1, 0, 0)
+model = hip.Model(host.set_subst("mar-mg"), host.gap_consts(), 1)
+a_cat, a_off, b_cat, b_off = host.synth_encoded(5, 200)
+want = comm.viterbi(model, a_cat, a_off, b_cat, b_off)
+# the same pairs described by offsets into a LARGER concatenation of which this rank holds only its part
+a_first, b_first = 123456, 7890
+got = comm.viterbi_shard(model, a_cat, a_first, a_off + np.uint64(a_first), b_cat, b_first, b_off + np.uint64(b_first))
+ok = all((g == w).all() for g, w in zip(got, want))
+# arrays that start behind the shard: an error on every rank, not a fault and not a hang
+try:
+    comm.viterbi_shard(model, a_cat, a_first + 3, a_off + np.uint64(a_first), b_cat, b_first, b_off + np.uint64(b_first))
+    ok = False
+except hip.CoatiHipError:
+    pass
+comm.barrier()
+ok = ok and comm.allreduce([2.5, -1.0], "max").tolist() == [2.5, -1.0] and comm.allreduce([2.5], "sum").tolist() == [2.5]
+comm.close(); model.close()
+print(json.dumps({"ok": bool(ok)}))
+'''
+
+
+def test_shard_entry_point_and_small_collectives():
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-c", SHARD_CHILD % str(root)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"ok"')]
+    assert lines and json.loads(lines[-1]) == {"ok": True}, r.stdout[-2000:]

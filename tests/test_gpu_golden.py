@@ -129,6 +129,45 @@ def test_long_sample_pairs(key, kernel, monkeypatch):
     assert "%08x" % zlib.crc32(got.tobytes()) == case["ops_crc32"]
 
 
+@pytest.mark.parametrize("kernel", ["auto", "ck", "bits"])
+def test_reference_benchmark_suite(kernel, monkeypatch):
+    """The reference's own benchmark inputs (benchmark/benchmark_main.cc.in:56-76: bm_156 ... bm_32k, seven
+    marginal alignments up to 29 394 x 29 295 nt): score bits, columns, op counts and CRC32 of the ops from the
+    unmodified reference engine (tests/golden/benchmark_suite.json) -- each pair alone (a lone long pair: narrowed
+    strips pipelined over wavefronts) and all seven in ONE batch with four copies each (multi-strip pairs of very
+    different sizes sharing the queue), under the planner's kernel and under each gap_len-1 kernel forced."""
+    import zlib
+
+    from coati_amd import hip, host
+
+    monkeypatch.delenv("COATI_HIP_VITERBI_BITS", raising=False)
+    monkeypatch.delenv("COATI_HIP_VITERBI_CK", raising=False)
+    if kernel == "ck":
+        monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")
+    elif kernel == "bits":
+        monkeypatch.setenv("COATI_HIP_VITERBI_BITS", "1")
+    keys = ["156", "1k", "2k", "4k", "8k", "16k", "32k"]
+    loaded = {k: util.load_bench_pair(k) for k in keys}
+    doc = loaded["156"][3]
+    model = hip.Model(np.load(GOLD / doc["table"]), host.gap_consts(doc["gap_open"], doc["gap_extend"]), 1)
+
+    def check(case, score, got):
+        assert int(np.float32(score).view(np.uint32)) == int(case["score_bits"], 16), case["key"]
+        assert len(got) == case["columns"], case["key"]
+        assert (int((got == 0).sum()), int((got == 1).sum()), int((got == 2).sum())) == (case["n_match"], case["n_del"], case["n_ins"])
+        assert "%08x" % zlib.crc32(got.tobytes()) == case["ops_crc32"], case["key"]
+
+    for k in keys:
+        a, b, case, _ = loaded[k]
+        scores, ops, off, ln = model.viterbi(*hip.pack_pairs([(a, b)]))
+        check(case, scores[0], ops[int(off[0]):int(off[0]) + int(ln[0])])
+    order = [k for k in keys for _ in range(4)]
+    scores, ops, off, ln = model.viterbi(*hip.pack_pairs([(loaded[k][0], loaded[k][1]) for k in order]))
+    for p, k in enumerate(order):
+        check(loaded[k][2], scores[p], ops[int(off[p]):int(off[p]) + int(ln[p])])
+    model.close()
+
+
 def test_full_baseline_workload_checksums():
     """BASELINE configs[1] at FULL size: all 10 000 synthetic 1 kb pairs through the C ABI; the CRC32
     of every op of every pair, the CRC32 of the fp32 score bits and the column total equal the CPU

@@ -123,6 +123,30 @@ def load_long_pair(key: str):
     return a, des_nt, case, doc
 
 
+def load_bench_pair(key: str):
+    """Encoded (a, b) of one input of the reference's benchmark suite (benchmark/data/benchmark_<key>.fasta, prepared
+    as marg_alignment prepares it) from tests/golden/benchmark_suite.npz, its expectation record and the fixture
+    document (tools/make_golden_bench.py)."""
+    import json
+    from pathlib import Path
+
+    gold = Path(__file__).resolve().parent / "golden"
+    doc = json.loads((gold / "benchmark_suite.json").read_text())
+    case = next(c for c in doc["cases"] if c["key"] == key)
+    z = np.load(gold / "benchmark_suite.npz")
+
+    def unpack(v, n):
+        return np.stack([v & 3, (v >> 2) & 3, (v >> 4) & 3, (v >> 6) & 3], axis=1).reshape(-1)[:n].astype(np.uint8)
+
+    anc_nt = unpack(z[f"anc_{key}"], case["len_a"])
+    des_nt = unpack(z[f"des_{key}"], case["len_b"])
+    cod = (anc_nt[0::3].astype(np.int32) << 4) | (anc_nt[1::3].astype(np.int32) << 2) | anc_nt[2::3]
+    assert not np.isin(cod, STOPS64).any()
+    c61 = cod - sum((cod > s).astype(np.int32) for s in STOPS64)
+    a = (c61[:, None] * 3 + np.arange(3)[None, :]).reshape(-1).astype(np.uint8)
+    return a, des_nt, case, doc
+
+
 def forward_exact() -> bool:
     """The Forward / sampling kernels run the bit-exact libm restatement unless the
     fast log-plus was asked for (COATI_HIP_FORWARD_FAST=1, 1e-5 relative)."""
