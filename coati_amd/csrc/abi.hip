@@ -167,6 +167,7 @@ struct coati_hip_model {
     size_t stream_waves_bytes = 0;
     hipEvent_t stream_events[kCkStreamSlots + 1] = {};  // [slot]: its download is done; [last]: an upload is done
     std::mutex pipeline_lock;  // one pipelined call at a time per model
+    uint32_t stream_calls = 0;     // streamed calls this model has served (the first one allocates lazily: a one-shot process pays for what it uses)
     bool stream_unusable = false;  // the persistent kernel's first upload did not arrive in time once (copies not on the copy engine): never again on this model
     bool stream_forbidden = false;  // coati_hip_model_set_option(COATI_HIP_OPT_PERSISTENT_CALL, 0): the embedder shares the GPU
 };
@@ -192,6 +193,7 @@ struct coati_hip_batch {
     WorkItem* d_items = nullptr;   // viterbi_l1 work list: (pair, strip), longest pairs first
     WorkItem* d_fwd_items = nullptr;  // forward_l1 work list (1024-column strips)
     uint32_t n_fwd_items = 0;
+    uint32_t fwd_wlog2_max = 4;  // widest Forward strip shape of the batch (forward_l1 has a leaner build for <= 8 columns per lane)
     uint32_t* d_progress = nullptr;
     uint32_t n_items = 0;
     uint8_t *d_a = nullptr, *d_b = nullptr, *d_ops = nullptr;
@@ -223,7 +225,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
-                           b->d_mdi,    b->d_final_mdi};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max};
 }
 }  // namespace
 
@@ -631,8 +633,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // (3 000 pairs: 41.7 ms at W = 16, 35.9 ms at W = 8).  A Forward cell is ~440 instructions, so the per-step overhead of a narrow strip is
     // small, unlike in viterbi_l1.  COATI_HIP_FWD_W=<4|8|16> overrides.
     constexpr uint64_t kFwdSlots = 3 * 1024 * 3 / 2;
-    uint32_t fwd_wlog2 = 4;
+    // The bit-exact build (glibc's expf / log1pf restated: ~440 instructions per cell) starts from 8 columns per lane:
+    // that shape fits 128 VGPRs without spills and runs 4 wavefronts per SIMD (forward_l1<false, true>), measured
+    // 6 144 pairs of 1 kb: 16 columns (168 VGPRs, 81 spilled values, 3 per SIMD) 68.7 ms, 8 columns in the same build 63.0 ms.
+    uint32_t fwd_wlog2 = 4;  // (dp_generic and forward_k lay their cells out for 16 columns per lane)
     if(L == 1 && !force_generic) {
+        if(!forward_fast_math()) fwd_wlog2 = 3;
         auto count_strips = [&](uint32_t w) {
             uint64_t n = 0;
             for(uint64_t p = 0; p < n_pairs && n < kFwdSlots; ++p) {
@@ -793,6 +799,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             for(uint64_t q = n_pairs - 3 * 1024 / 4; q < n_pairs; ++q) b->desc[order[q]].f_wlog2 = 3;
     }
     stage("plan: strip shapes");
+    b->fwd_wlog2_max = 0;
+    for(uint64_t p = 0; p < n_pairs; ++p) b->fwd_wlog2_max = std::max<uint32_t>(b->fwd_wlog2_max, b->desc[p].f_wlog2);
     // Forward M/D/I arena, now that every pair's strip shape is known
     for(uint64_t p = 0; p < n_pairs; ++p) {
         PairDesc& d = b->desc[p];
@@ -1237,7 +1245,7 @@ int coati_hip_forward_launch(coati_hip_batch_t* b) {
     if(b->n_pairs > 0) {
         static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
         if(m->gap_len == 1 && !force_generic)
-            HIP_TRY(launch_forward_l1(device_view(b), m->stream));
+            HIP_TRY(launch_forward_l1(device_view(b), m->n_tables == 1, m->stream));
         else if((m->gap_len == 2 || m->gap_len == 3) && !force_generic)
             HIP_TRY(launch_forward_k(device_view(b), m->stream));
         else
@@ -1809,7 +1817,25 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     constexpr uint64_t kSlotArena = kStreamSlotArena, kSlotStaging = kStreamSlotStaging;
     auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) { return stream_out_bytes(n, ops_bytes, out_pinned); };
     auto staging_of = [&](const ChunkNeed& nd, uint64_t n) { return stream_staging_bytes(nd, n, in_pinned, out_pinned); };
-    for(auto& ss : model->sslots) {
+    // How many slots can this call use?  The chunk targets below in cells: 1/2, 1, 2, then 3 units, and 1 unit each
+    // once four units are left.  A one-shot process (coati-alignpair --batch: ~0.1 ms per MB of fresh hipMalloc /
+    // hipHostMalloc, 12 slots are 2.9 GB) allocates what its input needs; a second call on the model takes the rest.
+    long double kUnitCells = 1000.0L * 1002 * 1002;
+    if(const char* e = std::getenv("COATI_HIP_STREAM_UNIT")) {
+        const long double forced = std::strtold(e, nullptr);
+        if(forced >= 1.0L) kUnitCells = forced;
+    }
+    int n_slots = kSlots;
+    if(model->stream_calls == 0) {
+        int est = 0;
+        for(long double done = 0; done < total_cells && est < kSlots; ++est)
+            done += est == 0 ? kUnitCells / 2 : (est == 1 || total_cells - done <= 4 * kUnitCells) ? kUnitCells : est == 2 ? 2 * kUnitCells : 3 * kUnitCells;
+        n_slots = std::min(kSlots, std::max(3, est + 1));  // (+1: a memory-bound cut may add a chunk; fewer slots than chunks only means reuse)
+        for(int q = 0; q < kSlots; ++q)
+            if(model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= kSlotStaging) n_slots = std::max(n_slots, q + 1);
+    }
+    for(int q = 0; q < n_slots; ++q) {
+        auto& ss = model->sslots[q];
         if(ss.arena_bytes < kSlotArena) {
             if(ss.arena != nullptr) (void)hipFree(ss.arena);
             ss.arena = nullptr;
@@ -1828,7 +1854,10 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // the call's last two chunks are cut into row parts (finer items for the ragged end of the kernel, as a resident
     // batch's last pairs are): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- two larger workspaces
     const uint64_t tail_bytes = std::min<uint64_t>(3ull << 30, std::max<uint64_t>(kSlotArena, 1250 * (wave_slot_bytes + 4096) + (64ull << 20)));
-    if(model->stream_tail_bytes < tail_bytes) {
+    // (a model's FIRST call on a small input runs without them: 2 x 1.4 GB of fresh allocation cost a one-shot process
+    // ~30 ms and buy its 10 000-pair kernel 0.5 ms)
+    const bool want_tails = model->stream_calls > 0 || total_cells >= 30 * kUnitCells;
+    if(want_tails && model->stream_tail_bytes < tail_bytes) {
         for(void*& t : model->stream_tail_arena) {
             if(t != nullptr) (void)hipFree(t);
             t = nullptr;
@@ -1840,6 +1869,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     }
     void* hs = model->h_stream;
     std::memset(hs, 0, host_bytes);
+    ck_stream_host_set_slots(hs, static_cast<uint32_t>(n_slots));
     void* hs_dev = nullptr;
     if(!soft(hipHostGetDevicePointer(&hs_dev, hs, 0))) return COATI_HIP_ESTATE;
     if(model->stream_events[0] == nullptr) {
@@ -1969,11 +1999,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // full rate, but a chunk occupies its slot for as long as its SLOWEST pair takes -- measured: 5 to 6 ms for a
     // 1 kb pair on a fully shared SIMD, three times the mean, the four wavefronts of a SIMD do not advance evenly --
     // so the slots together must hold well over 6 ms of work (12 300 pairs of 1 kb) or the GPU runs dry
-    long double kUnit = 1000.0L * 1002 * 1002;
-    if(const char* e = std::getenv("COATI_HIP_STREAM_UNIT")) {  // tests: many small chunks out of a small input (cells)
-        const long double forced = std::strtold(e, nullptr);
-        if(forced >= 1.0L) kUnit = forced;
-    }
+    const long double kUnit = kUnitCells;  // (COATI_HIP_STREAM_UNIT, tests: many small chunks out of a small input)
     const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
     uint32_t published = 0;
     uint64_t p0 = 0, ops_base = 0;
@@ -1981,7 +2007,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     int tails_used = 0;
     const char* const no_tail_parts = std::getenv("COATI_HIP_STREAM_NO_PARTS");  // (A/B)
     for(size_t ci = 0; p0 < n_pairs && rc == COATI_HIP_OK; ++ci) {
-        const int q = static_cast<int>(ci % kSlots);
+        const int q = static_cast<int>(ci % static_cast<size_t>(n_slots));
         coati_hip_model::StreamSlot& sl = model->sslots[q];
         InFlight& f = fl[q];
         const double t_begin = t_ms();
@@ -2087,6 +2113,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         rc = progress();
     }
     ck_stream_host_close(hs);
+    ++model->stream_calls;
     for(int q = 0; q < kSlots && rc == COATI_HIP_OK; ++q) rc = wait_free(q);
     // the kernel ends by itself once it has seen `closed`; then its verdict
     const hipError_t es = hipStreamSynchronize(kernel_stream);

@@ -410,6 +410,11 @@ __device__ __forceinline__ float log_plus(float a, float b) {
     const float u = 1.0f + e;
     const float resid = e - (u - 1.0f);            // exact
     const float l2 = __builtin_amdgcn_logf(u);     // v_log_f32: log2(u) in [0, 1]
+    // (gfx950's v_log_f32 is biased low by up to 2.9e-8 on [1.4, 2], v_exp_f32 is centred: tools/ubench/trans_err.hip ->
+    // profiles/r03/ubench_transcendental_error.txt.  Putting the measured bias back in -- three more instructions --
+    // changed NO figure of the fuzz campaign (tools/fuzz_sample.py, 900 000 samples: the same worst deviations to
+    // the digit): what separates this build from the CPU is not the accuracy of log1p(exp()) but the 1e-8 noise of the
+    // CPU's own libm against the rounding grid of values of magnitude ~100 -- DESIGN.md 3.2b.  Left out.)
     return hi + __builtin_fmaf(l2, kLn2, resid);
 }
 
@@ -448,6 +453,7 @@ struct BatchDeviceView {
     uint32_t ck_split_items;  // viterbi_ck: row part p > 0 of a cut pair waits for the item this many tickets before its own
     float* mdi;        // Forward: fp32 M/D/I of every body cell
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
+    uint32_t fwd_wlog2_max;  // forward_l1: the widest strip shape of the batch (log2 of the columns per lane)
 };
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 // Compute units of the current device (hipDeviceAttributeMultiprocessorCount), at most 256: the persistent
@@ -468,6 +474,7 @@ uint32_t ck_scratch_waves();
 uint64_t ck_scratch_dwords_per_wave();
 // viterbi_ck_stream (viterbi_ck.hip): one persistent launch fed chunk by chunk; the control block lives in HBM
 constexpr int kCkStreamSlots = 12;
+void ck_stream_host_set_slots(void* host, uint32_t n_slots);  // before the launch: chunk ci uses table entry ci % n_slots
 uint64_t ck_stream_ctl_bytes();
 uint64_t ck_stream_error_offset();
 // the page-locked, device-visible block host and kernel talk through (host = its host address, host_dev = its
@@ -486,7 +493,7 @@ hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared
 hipError_t launch_ck_all_flags(const BatchDeviceView& v, uint32_t pair, uint32_t* scratch, uint32_t n_waves, uint8_t* out,
                                hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
-hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream);
+hipError_t launch_forward_l1(const BatchDeviceView& v, bool one_table, hipStream_t stream);
 hipError_t launch_viterbi_k(const BatchDeviceView& v, bool narrow_only, hipStream_t stream);
 hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream);
 // COATI_HIP_FORWARD_FAST=1: Forward with the hardware exp2/log2 (fast, within 1e-5 of the CPU) instead

@@ -261,19 +261,28 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
     if(!ok && last_strip && lane == 0) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
 }
 
-template <bool kFast>
-__global__ __launch_bounds__(kFillWaves* kWave, kFast ? 2 : 3) void forward_l1(
+// kNarrow: strips of at most 8 columns per lane only -- half the lane state, so the build fits 128 VGPRs and four
+// wavefronts share a SIMD (the latency of the fp64 / reciprocal chains of the exact `plus` is what the wide build
+// cannot hide with three).
+template <bool kFast, bool kNarrow>
+__device__ __forceinline__ void forward_l1_body(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
-    float* __restrict__ bnd, float* __restrict__ mdi, float* __restrict__ final_mdi) {
-    __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];  // one table per wavefront (see viterbi_l1.hip)
-    __shared__ uint64_t exp_tab[32];
+    float* __restrict__ bnd, float* __restrict__ mdi, float* __restrict__ final_mdi, float (*tab_all)[kTabRows * kTabStride],
+    uint64_t* exp_tab) {
     load_exp_table(exp_tab, threadIdx.x);
-    __syncthreads();
     const int lane_id = threadIdx.x & (kWave - 1);
-    float* tab = tab_all[threadIdx.x / kWave];
+    float* tab = tab_all[kNarrow ? 0 : threadIdx.x / kWave];
     uint32_t tab_held = 0xffffffffu;
+    if constexpr(kNarrow) {  // (the narrow build serves models with ONE table: a copy per workgroup, not per wavefront)
+        for(int idx = threadIdx.x; idx < kTabFloats; idx += kFillWaves * kWave) {
+            const int r = idx / kTabCols, c = idx - r * kTabCols;
+            tab[r * kTabStride + c] = table[idx];
+        }
+        tab_held = 0u;
+    }
+    __syncthreads();
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     for(;;) {
         int lane = lane_id;  // opaque per iteration (see viterbi_l1.hip)
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 2 : 3) void forward_l1(
         const uint32_t pair = item.pair, strip = item.strip;
         const PairDesc pd = pairs[pair];
         const uint32_t la = pd.la, lb = pd.lb;
-        if(pd.table != tab_held) {
+        if(!kNarrow && pd.table != tab_held) {
             const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
             for(int idx = lane; idx < kTabFloats; idx += kWave) {
                 const int r = idx / kTabCols, c = idx - r * kTabCols;
@@ -309,28 +318,53 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 2 : 3) void forward_l1(
             case 1: forward_strip<2, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
             case 2: forward_strip<4, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
             case 3: forward_strip<8, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
-            default: forward_strip<16, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
+            default:
+                if constexpr(!kNarrow) forward_strip<16, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes);
+                break;
         }
     }
 }
 
+// The four builds.  The narrow ones are held to 128 VGPRs (amdgpu_num_vgpr: __launch_bounds__' second argument is only
+// a request -- left alone the compiler took 135-138 registers and with them the fourth wavefront per SIMD).
+#define COATI_FWD_KERNEL(NAME, FAST, NARROW, ATTR)                                                                       \
+    __global__ ATTR void NAME(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,          \
+                              const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,        \
+                              uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,                        \
+                              const uint8_t* __restrict__ b_cat, float* __restrict__ bnd, float* __restrict__ mdi,       \
+                              float* __restrict__ final_mdi) {                                                           \
+        __shared__ float tab_all[NARROW ? 1 : kFillWaves][kTabRows * kTabStride]; /* wide: one table per wavefront */     \
+        __shared__ uint64_t exp_tab[32];                                                                                 \
+        forward_l1_body<FAST, NARROW>(table, k, pairs, items, n_items, queue, progress, a_cat, b_cat, bnd, mdi, final_mdi, \
+                                      tab_all, exp_tab);                                                                 \
+    }
+COATI_FWD_KERNEL(forward_l1_exact_wide, false, false, __launch_bounds__(kFillWaves* kWave, 3))
+COATI_FWD_KERNEL(forward_l1_fast_wide, true, false, __launch_bounds__(kFillWaves* kWave, 2))
+COATI_FWD_KERNEL(forward_l1_exact_narrow, false, true, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
+COATI_FWD_KERNEL(forward_l1_fast_narrow, true, true, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
+#undef COATI_FWD_KERNEL
+
 }  // namespace
 
-hipError_t launch_forward_l1(const BatchDeviceView& v, hipStream_t stream) {
+hipError_t launch_forward_l1(const BatchDeviceView& v, bool one_table, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
     if(e != hipSuccess) return e;
     e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_fwd_items, 4u), stream);
     if(e != hipSuccess) return e;
-    // two workgroups (8 wavefronts) per CU; fewer when there are fewer items than wavefronts
-    const uint32_t per_cu = forward_fast_math() ? 2u : 3u;  // (the exact build fits 3 wavefronts per SIMD)
+    // workgroups of 4 wavefronts (one per SIMD); per CU: 2 (fast, 16 columns per lane), 3 (exact, 16 columns), 4 (at most
+    // 8 columns per lane: the narrow build); fewer when there are fewer items than wavefronts
+    const bool fast = forward_fast_math(), narrow = one_table && v.fwd_wlog2_max <= 3 && std::getenv("COATI_HIP_FWD_WIDE_BUILD") == nullptr;
+    const uint32_t per_cu = narrow ? 4u : (fast ? 2u : 3u);
     const uint32_t cus = device_cu_count();
     const uint32_t blocks = std::min<uint32_t>(cus * per_cu, std::max<uint32_t>(cus, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));
-    if(forward_fast_math())
-        hipLaunchKernelGGL(forward_l1<true>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,
-                           v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
-    else
-        hipLaunchKernelGGL(forward_l1<false>, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,
-                           v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.fwd_items, v.n_fwd_items,
+                           v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
+    };
+    if(fast && narrow) go(forward_l1_fast_narrow);
+    else if(fast) go(forward_l1_fast_wide);
+    else if(narrow) go(forward_l1_exact_narrow);
+    else go(forward_l1_exact_wide);
     return hipGetLastError();
 }
 

@@ -865,7 +865,9 @@ __device__ __forceinline__ T dev_load(const T* p) {
 // KERNEL, which could not start while viterbi_ck_stream owns every wavefront slot of the chip.
 struct CkStreamHost {
     uint64_t announced;  // (chunks << 32) | items
-    uint32_t closed, pad_[13];
+    uint32_t closed;
+    uint32_t n_slots;    // chunk number ci lives in table entry ci % n_slots (the host allocates only the slots a call can use)
+    uint32_t pad_[12];
     uint32_t done_flag[16];
     uint64_t t_start, t_done[16];  // device clock (100 MHz) when the pilot started / when a slot's chunk was complete
     unsigned long long bad[16];    // per slot: a sequence code out of range in the chunk (ck_report_bad)
@@ -898,6 +900,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         // entries and the item count into HBM, where the 4 095 workers poll.  (Four thousand wavefronts polling
         // host memory would compete with the uploads for the link.)
         uint32_t last = 0, mirrored = 0;
+        const uint32_t n_slots = min(static_cast<uint32_t>(kCkStreamSlots),
+                                     max(1u, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sys_load(&host->n_slots))))));
         if(lane_id == 0) __hip_atomic_store(const_cast<uint64_t*>(&host->t_start), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for(uint32_t idle = 0;; ++idle) {
             const uint64_t word = sys_load(&host->announced);
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
                 chunks = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(fin >> 32))));
             }
             for(; mirrored != chunks; ++mirrored) {  // entries first ...
-                const uint32_t q = mirrored % kCkStreamSlots;
+                const uint32_t q = mirrored % n_slots;
                 if(lane_id < static_cast<int>(sizeof(CkStreamChunk) / 4)) {
                     const uint32_t v = sys_load(reinterpret_cast<const uint32_t*>(&host->chunk[q]) + lane_id);
                     __hip_atomic_store(reinterpret_cast<uint32_t*>(&ctl->chunk[q]) + lane_id, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1254,6 +1258,7 @@ double ck_stream_host_done_ms(void* host, int slot) {
     return static_cast<double>(static_cast<int64_t>(h->t_done[slot] - h->t_start)) * 1e-5;
 }
 unsigned long long ck_stream_host_bad(void* host, int slot) { return __atomic_load_n(&static_cast<CkStreamHost*>(host)->bad[slot], __ATOMIC_ACQUIRE); }
+void ck_stream_host_set_slots(void* host, uint32_t n_slots) { static_cast<CkStreamHost*>(host)->n_slots = n_slots; }
 void ck_stream_host_close(void* host) { __atomic_store_n(&static_cast<CkStreamHost*>(host)->closed, 1u, __ATOMIC_SEQ_CST); }
 
 void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* arena, const BatchDeviceView& v, uint32_t n_pairs,

@@ -243,3 +243,11 @@ def merge_indels(sets):
     _check(load().coati_host_merge_indels(spec.encode(), buf, C.c_ulonglong(len(buf))))
     names, seqs, flags = buf.value.decode().split(";")
     return names.split(","), seqs.split(","), {int(kv.split("=")[0]): int(kv.split("=")[1]) for kv in flags.split(",") if kv}
+
+
+def batch_reader_check(path) -> int:
+    """The --batch driver's indexed FASTA reader against read_input on one file: 0 = identical records,
+    k + 1 = record k differs, -1 = the fast reader declines the file (not a FASTA path)."""
+    out = C.c_long(0)
+    _check(load().coati_host_batch_reader_check(str(path).encode(), C.byref(out)))
+    return int(out.value)

@@ -6,11 +6,15 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <dlfcn.h>
 #include <exception>
 #include <fstream>
+#include <future>
 #include <iostream>
+#include <memory>
 #include <mutex>
+#include <sstream>
 #include <stdexcept>
 #include <thread>
 
@@ -309,44 +313,214 @@ std::vector<data_t> align_leafs(alignment_t& input, const std::string& ref_seq, 
 }
 
 namespace {
-// The encoded pairs of a --batch input and what is needed to print them again.
-struct batch_input_t {
-    std::size_t n{0};
-    std::vector<data_t> pairs;
-    std::vector<std::string> ancs, dess;
+// ---------------------------------------------------------------------------------------------------------
+// --batch: the reference aligns ONE pair per process (utils.cc:809-812); here a file of 2n sequences is n pairs.
+// The driver is a three-stage pipeline over BLOCKS of pairs, so that a file of any size streams through bounded
+// memory and the host work either side of the GPU overlaps it:
+//   A  parse + process_marginal + encode   (block k+1, on the thread pool)
+//   B  coati_hip_viterbi_batch             (block k,   this thread; the library overlaps H2D / kernel / D2H inside)
+//   C  gapped strings + JSON text + write  (block k-1, on the thread pool; blocks leave in order)
+// The HIP runtime and the model are brought up on a helper thread while block 0 is parsed.
+// Input semantics are read_fasta's / process_marginal's / write_json's, byte for byte (tests: the CLI suite
+// compares this driver's output with per-pair runs).
+// ---------------------------------------------------------------------------------------------------------
+constexpr std::size_t kBatchBlockPairs = 32768;
+
+// A FASTA file in memory and where its records start ('>' at the beginning of a line; io.cc:read_fasta).
+struct fasta_index_t {
+    std::string buf;
+    std::vector<std::size_t> starts;  // offsets of the '>' of every record, then buf.size()
+};
+// false: not a plain FASTA file (stdin, "fmt:path" of another format, .phy, .json): the generic reader takes it
+bool load_fasta(const std::string& path, fasta_index_t& fi) {
+    const file_type_t type = path.empty() ? file_type_t{"-", ".json"} : extract_file_type(path);
+    if(type.path.empty() || type.path == "-" || !(type.type_ext == ".fa" || type.type_ext == ".fasta")) return false;
+    std::ifstream file(type.path, std::ios::binary);
+    if(!file) throw std::invalid_argument("Opening input file " + path + " failed.");
+    file.seekg(0, std::ios::end);
+    const std::streamoff size = file.tellg();
+    if(size < 0) return false;  // (not seekable: a pipe)
+    file.seekg(0);
+    fi.buf.resize(static_cast<std::size_t>(size));
+    file.read(fi.buf.data(), size);
+    if(file.gcount() != size) throw std::invalid_argument("Reading input file " + path + " failed.");
+    // record starts, found in parallel: every thread scans a slice for "\n>" (and the file's first byte)
+    const std::size_t n = fi.buf.size();
+    const std::size_t slices = std::max<std::size_t>(1, std::min<std::size_t>(64, n >> 20));
+    std::vector<std::vector<std::size_t>> found(slices);
+    parallel_for(slices, 1, [&](std::size_t k) {
+        const std::size_t lo = n * k / slices, hi = n * (k + 1) / slices;
+        const char* base = fi.buf.data();
+        for(const char* p = base + lo; p < base + hi;) {
+            p = static_cast<const char*>(std::memchr(p, '>', static_cast<std::size_t>(base + hi - p)));
+            if(p == nullptr) break;
+            if(p == base || p[-1] == '\n') found[k].push_back(static_cast<std::size_t>(p - base));
+            ++p;
+        }
+    });
+    for(const auto& f : found) fi.starts.insert(fi.starts.end(), f.begin(), f.end());
+    fi.starts.push_back(n);
+    return true;
+}
+// record `rec` as read_fasta reads it: the name is the rest of the '>' line (a trailing '\r' dropped), the sequence
+// the following lines without white space; empty lines and lines starting with ';' are skipped
+void fasta_record(const fasta_index_t& fi, std::size_t rec, std::string& name, std::string& seq) {
+    const char* p = fi.buf.data() + fi.starts[rec] + 1;
+    const char* const end = fi.buf.data() + fi.starts[rec + 1];
+    const char* eol = static_cast<const char*>(std::memchr(p, '\n', static_cast<std::size_t>(end - p)));
+    if(eol == nullptr) eol = end;
+    name.assign(p, eol);
+    if(!name.empty() && name.back() == '\r') name.pop_back();
+    if(name.empty()) throw std::invalid_argument("Input fasta file contains a sequence without a name.");
+    seq.clear();
+    seq.reserve(static_cast<std::size_t>(end - eol));
+    for(p = eol < end ? eol + 1 : end; p < end;) {
+        eol = static_cast<const char*>(std::memchr(p, '\n', static_cast<std::size_t>(end - p)));
+        if(eol == nullptr) eol = end;
+        if(p != eol && *p != ';')
+            for(const char* q = p; q < eol; ++q)
+                if(std::isspace(static_cast<unsigned char>(*q)) == 0) seq.push_back(*q);
+        p = eol < end ? eol + 1 : end;
+    }
+}
+
+// One block of pairs on its way through the pipeline.
+struct batch_block_t {
+    std::size_t p0{0}, n{0};
+    std::vector<data_t> pairs;  // processed (stops trimmed and remembered); seqs[0] = ancestor, seqs[1] = descendant
     std::vector<uint64_t> a_off, b_off;
     std::vector<unsigned char> a_cat, b_cat;
+    std::vector<float> scores;
+    std::vector<uint8_t> ops;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> len;
 };
-batch_input_t read_batch_input(alignment_t& aln) {
-    data_t all = read_input(aln.data.path);
-    if(all.size() == 0 || all.size() % 2 != 0) throw std::invalid_argument("Batch input needs an even number of sequences.");
-    batch_input_t in;
-    const std::size_t n = in.n = all.size() / 2;
-    in.pairs.resize(n), in.ancs.resize(n), in.dess.resize(n);
-    parallel_for(n, 256, [&](std::size_t p) {
-        in.pairs[p].names = {all.names[2 * p], all.names[2 * p + 1]};
-        in.pairs[p].seqs = {all.seqs[2 * p], all.seqs[2 * p + 1]};
-        process_marginal(in.pairs[p], aln.gap, std::string(), aln.rev);
-        in.ancs[p] = in.pairs[p].seqs[0];
-        in.dess[p] = in.pairs[p].seqs[1];
-    });
-    in.a_off.assign(n + 1, 0), in.b_off.assign(n + 1, 0);
-    for(std::size_t p = 0; p < n; ++p) {
-        in.a_off[p + 1] = in.a_off[p] + in.ancs[p].size();
-        in.b_off[p + 1] = in.b_off[p] + in.dess[p].size();
-    }
-    in.a_cat.resize(in.a_off[n]), in.b_cat.resize(in.b_off[n]);
-    parallel_for(n, 256, [&](std::size_t p) {
-        encode_ancestor(in.ancs[p], in.a_cat.data() + in.a_off[p]);
-        unsigned char* des = in.b_cat.data() + in.b_off[p];
-        encode_descendant(in.dess[p], des);
-        for(std::size_t i = 0; i < in.dess[p].size(); ++i)
-            if(des[i] >= kTableCols) throw std::invalid_argument("Invalid character in descendant sequence.");
-    });
-    return in;
+// Where the pairs come from: the indexed FASTA file, or (other formats, stdin) everything the generic reader returned.
+struct batch_source_t {
+    bool fast{false};
+    fasta_index_t fasta;
+    data_t all;
+    std::size_t n_pairs{0};
+};
+batch_source_t open_batch_source(const alignment_t& aln) {
+    batch_source_t src;
+    src.fast = load_fasta(aln.data.path, src.fasta);
+    const std::size_t n_seqs = src.fast ? src.fasta.starts.size() - 1 : (src.all = read_input(aln.data.path)).size();
+    if(n_seqs == 0 || n_seqs % 2 != 0) throw std::invalid_argument("Batch input needs an even number of sequences.");
+    src.n_pairs = n_seqs / 2;
+    return src;
 }
-void write_batch_output(alignment_t& aln, batch_input_t& in, const std::vector<float>& scores, const std::vector<uint8_t>& ops,
-                        const std::vector<uint64_t>& off, const std::vector<uint32_t>& len) {
+// stage A, first half: the pairs [p0, p0 + n) parsed and processed; offsets filled in
+void batch_block_parse(const alignment_t& aln, const batch_source_t& src, std::size_t p0, std::size_t n, batch_block_t& blk) {
+    blk.p0 = p0;
+    blk.n = n;
+    blk.pairs.assign(n, data_t());
+    parallel_for(n, 64, [&](std::size_t i) {
+        data_t& d = blk.pairs[i];
+        d.names.assign(2, std::string());
+        d.seqs.assign(2, std::string());
+        for(std::size_t s = 0; s < 2; ++s) {
+            const std::size_t rec = 2 * (p0 + i) + s;
+            if(src.fast) {
+                fasta_record(src.fasta, rec, d.names[s], d.seqs[s]);
+            } else {
+                d.names[s] = src.all.names[rec];
+                d.seqs[s] = src.all.seqs[rec];
+            }
+        }
+        process_marginal(d, aln.gap, std::string(), aln.rev);
+    });
+    blk.a_off.assign(n + 1, 0), blk.b_off.assign(n + 1, 0);
+    for(std::size_t i = 0; i < n; ++i) {
+        blk.a_off[i + 1] = blk.a_off[i] + blk.pairs[i].seqs[0].size();
+        blk.b_off[i + 1] = blk.b_off[i] + blk.pairs[i].seqs[1].size();
+    }
+}
+// stage A, second half: the pairs [i0, i1) of the block encoded (a rank of a multi-GPU run encodes its shard only)
+void batch_block_encode(batch_block_t& blk, std::size_t i0, std::size_t i1) {
+    // (a_cat / b_cat hold the bytes [a_off[i0], a_off[i1]) / [b_off[i0], b_off[i1]) of the block's concatenations)
+    const uint64_t a0 = blk.a_off[i0], b0 = blk.b_off[i0];
+    blk.a_cat.resize(blk.a_off[i1] - a0), blk.b_cat.resize(blk.b_off[i1] - b0);
+    parallel_for(i1 - i0, 64, [&](std::size_t k) {
+        const std::size_t i = i0 + k;
+        encode_ancestor(blk.pairs[i].seqs[0], blk.a_cat.data() + (blk.a_off[i] - a0));
+        unsigned char* des = blk.b_cat.data() + (blk.b_off[i] - b0);
+        const std::string& d = blk.pairs[i].seqs[1];
+        encode_descendant(d, des);
+        for(std::size_t c = 0; c < d.size(); ++c)
+            if(des[c] >= kTableCols) throw std::invalid_argument("Invalid character in descendant sequence.");
+    });
+}
+// stage C: the block's alignments as JSON text (write_json's bytes for elements p0 .. p0+n of an array of n_total), in order
+void batch_block_write(const alignment_t& aln, batch_block_t& blk, std::size_t n_total, std::ostream& out) {
+    constexpr std::size_t kSub = 128;  // pairs per text piece
+    const std::size_t pieces = (blk.n + kSub - 1) / kSub;
+    std::vector<std::string> text(pieces);
+    parallel_for(pieces, 1, [&](std::size_t k) {
+        std::ostringstream os;
+        for(std::size_t i = k * kSub; i < std::min(blk.n, (k + 1) * kSub); ++i) {
+            data_t& d = blk.pairs[i];
+            const std::string anc = std::move(d.seqs[0]), des = std::move(d.seqs[1]);
+            d.seqs.assign(2, std::string());
+            ops_to_alignment(blk.ops.data() + blk.off[i], blk.len[i], anc, des, d.seqs[0], d.seqs[1]);
+            d.score = blk.scores[i];
+            restore_end_stops(d, aln.gap);
+            write_json(d, os, blk.p0 + i, n_total);
+            d = data_t();  // (a block's strings are not kept once they are text)
+        }
+        text[k] = os.str();
+    });
+    for(const std::string& t : text) out.write(t.data(), static_cast<std::streamsize>(t.size()));
+}
+void check_block_scores(const batch_block_t& blk) {
+    for(std::size_t i = 0; i < blk.n; ++i)
+        if(std::isnan(blk.scores[i]))
+            throw std::runtime_error("The device did not finish pair " + std::to_string(blk.p0 + i) + " (strip hand-off timed out).");
+}
+bool g_fast_exit = false;
+}  // namespace
+
+void set_process_exits_after_call(bool on) { g_fast_exit = on; }
+
+// Test hook: the block driver's reader against the generic one (read_input) on the same file.  0 = the same names
+// and sequences in the same order; k + 1 = the first difference is record k; -1 = the fast reader does not take the file.
+long batch_reader_first_difference(const std::string& path) {
+    fasta_index_t fi;
+    if(!load_fasta(path, fi)) return -1;
+    const data_t all = read_input(path);
+    const std::size_t n = fi.starts.size() - 1;
+    std::string name, seq;
+    for(std::size_t r = 0; r < std::max(n, all.size()); ++r) {
+        if(r >= n || r >= all.size()) return static_cast<long>(r) + 1;
+        fasta_record(fi, r, name, seq);
+        if(name != all.names[r] || seq != all.seqs[r]) return static_cast<long>(r) + 1;
+    }
+    return 0;
+}
+
+bool marg_alignment_batch(alignment_t& aln) {
+    host_timer tm("alignpair --batch");
+    set_subst(aln);
+    // the HIP runtime, the model and (inside the first call) the pipeline's workspaces come up while the input is read
+    auto model_ready = std::async(std::launch::async, [&aln]() { return make_model(aln); });
+    struct model_guard {
+        std::future<coati_hip_model*>& f;
+        coati_hip_model* m{nullptr};
+        ~model_guard() {
+            if(m == nullptr && f.valid()) {
+                try {
+                    m = f.get();
+                } catch(...) {
+                }
+            }
+            // (a process that exits right after this call leaves the GBs of cached workspaces to the driver: freeing
+            // them one by one costs the one-shot tool ~65 ms)
+            if(m != nullptr && !g_fast_exit) coati_hip_model_destroy(m);
+        }
+    } guard{model_ready};
+    const batch_source_t src = open_batch_source(aln);
+    const std::size_t n_total = src.n_pairs;
+    tm.stage("read + index");
     std::ofstream file;
     std::ostream* out = &std::cout;
     if(!(aln.output.empty() || aln.output == "-")) {
@@ -354,37 +528,38 @@ void write_batch_output(alignment_t& aln, batch_input_t& in, const std::vector<f
         if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
         out = &file;
     }
-    // gapped strings for all pairs in parallel, then the (ordered) JSON stream
-    parallel_for(in.n, 64, [&](std::size_t p) {
-        in.pairs[p].seqs.assign(2, std::string());
-        ops_to_alignment(ops.data() + off[p], len[p], in.ancs[p], in.dess[p], in.pairs[p].seqs[0], in.pairs[p].seqs[1]);
-        in.pairs[p].score = scores[p];
-        restore_end_stops(in.pairs[p], aln.gap);
-    });
-    for(std::size_t p = 0; p < in.n; ++p) write_json(in.pairs[p], *out, p, in.n);
-}
-}  // namespace
-
-bool marg_alignment_batch(alignment_t& aln) {
-    host_timer tm("alignpair --batch");
-    batch_input_t in = read_batch_input(aln);
-    tm.stage("read + encode");
-    set_subst(aln);
-    coati_hip_model* model = make_model(aln);
-    tm.stage("model");
-    const std::size_t n = in.n;
-    std::vector<float> scores(n);
-    std::vector<uint8_t> ops(in.a_cat.size() + in.b_cat.size() + 1);
-    std::vector<uint64_t> off(n);
-    std::vector<uint32_t> len(n);
-    const int rc = coati_hip_viterbi_batch(model, n, in.a_cat.data(), in.a_off.data(), in.b_cat.data(), in.b_off.data(),
-                                           scores.data(), ops.data(), in.a_cat.size() + in.b_cat.size(), off.data(), len.data());
-    coati_hip_model_destroy(model);
-    hip_check(rc);
-    check_scores(scores);
-    tm.stage("device (upload, kernels, download)");
-    write_batch_output(aln, in, scores, ops, off, len);
-    tm.stage("gapped strings + output");
+    const std::size_t n_blocks = (n_total + kBatchBlockPairs - 1) / kBatchBlockPairs;
+    auto stage_a = [&](std::size_t k) {
+        auto blk = std::make_unique<batch_block_t>();
+        const std::size_t p0 = k * kBatchBlockPairs;
+        batch_block_parse(aln, src, p0, std::min(kBatchBlockPairs, n_total - p0), *blk);
+        batch_block_encode(*blk, 0, blk->n);
+        return blk;
+    };
+    std::future<std::unique_ptr<batch_block_t>> next = std::async(std::launch::async, stage_a, std::size_t{0});
+    std::future<void> writing;
+    for(std::size_t k = 0; k < n_blocks; ++k) {
+        std::unique_ptr<batch_block_t> blk = next.get();
+        if(k + 1 < n_blocks) next = std::async(std::launch::async, stage_a, k + 1);
+        if(k == 0) {
+            tm.stage("parse + encode (first block)");
+            guard.m = model_ready.get();
+            tm.stage("model (overlapped with the input)");
+        }
+        batch_block_t& b = *blk;
+        b.scores.resize(b.n), b.off.resize(b.n), b.len.resize(b.n);
+        b.ops.resize(b.a_cat.size() + b.b_cat.size() + 1);
+        hip_check(coati_hip_viterbi_batch(guard.m, b.n, b.a_cat.data(), b.a_off.data(), b.b_cat.data(), b.b_off.data(), b.scores.data(),
+                                          b.ops.data(), b.a_cat.size() + b.b_cat.size(), b.off.data(), b.len.data()));
+        check_block_scores(b);
+        if(k == 0) tm.stage("device (first block: workspaces, upload, kernels, download)");
+        if(writing.valid()) writing.get();  // (blocks leave in order)
+        std::shared_ptr<batch_block_t> held = std::move(blk);
+        writing = std::async(std::launch::async, [&aln, held, n_total, out]() { batch_block_write(aln, *held, n_total, *out); });
+    }
+    if(writing.valid()) writing.get();
+    out->flush();
+    tm.stage(n_blocks > 1 ? "remaining blocks (parse, device, output overlapped)" : "gapped strings + output");
     return true;
 }
 
@@ -398,8 +573,8 @@ struct dist_api_t {
     int (*init)(const void*, int, int, int, void**){nullptr};
     void (*destroy)(void*){nullptr};
     int (*broadcast_model)(void*, int, float*, uint32_t, uint32_t*, float*, int*){nullptr};
-    int (*viterbi)(void*, int, coati_hip_model*, uint64_t, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, float*,
-                   uint8_t*, uint64_t, uint64_t*, uint32_t*){nullptr};
+    int (*viterbi_shard)(void*, int, coati_hip_model*, uint64_t, const uint8_t*, uint64_t, const uint64_t*, const uint8_t*, uint64_t,
+                         const uint64_t*, float*, uint8_t*, uint64_t, uint64_t*, uint32_t*){nullptr};
 };
 dist_api_t load_dist_api() {
     dist_api_t api;
@@ -426,7 +601,7 @@ dist_api_t load_dist_api() {
     api.init = reinterpret_cast<decltype(api.init)>(sym("coati_hip_dist_init"));
     api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("coati_hip_dist_destroy"));
     api.broadcast_model = reinterpret_cast<decltype(api.broadcast_model)>(sym("coati_hip_dist_broadcast_model"));
-    api.viterbi = reinterpret_cast<decltype(api.viterbi)>(sym("coati_hip_dist_viterbi"));
+    api.viterbi_shard = reinterpret_cast<decltype(api.viterbi_shard)>(sym("coati_hip_dist_viterbi_shard"));
     return api;
 }
 }  // namespace
@@ -438,8 +613,16 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
     auto dist_check = [&](int rc) {
         if(rc != 0) throw std::runtime_error(api.last_error());
     };
-    batch_input_t in = read_batch_input(aln);  // every rank reads the same input: only results cross the links
-    tm.stage("read + encode");
+    // every rank reads and indexes the input (the LENGTHS of all pairs are the shard plan) but encodes only its shard;
+    // nothing but results crosses the links
+    const batch_source_t src = open_batch_source(aln);
+    batch_block_t in;
+    batch_block_parse(aln, src, 0, src.n_pairs, in);
+    std::vector<uint64_t> bounds(static_cast<std::size_t>(world) + 1, 0);
+    hip_check(coati_hip_shard_bounds(in.n, in.a_off.data(), in.b_off.data(), world, bounds.data()));
+    const std::size_t s0 = bounds[static_cast<std::size_t>(rank)], s1 = bounds[static_cast<std::size_t>(rank) + 1];
+    batch_block_encode(in, s0, s1);
+    tm.stage("read + encode (own shard)");
     // ---- rendezvous: rank 0 leaves the id in a file (written under another name, then renamed)
     unsigned char id[128];
     if(rank == 0) {
@@ -482,20 +665,27 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
     hip_check(coati_hip_model_create(table.data(), consts[0], consts[1], consts[2], consts[3], gap_len, aln.device, &model));
     tm.stage("model broadcast");
     const std::size_t n = in.n;
-    std::vector<float> scores(rank == 0 ? n : 0);
-    std::vector<uint8_t> ops(rank == 0 ? in.a_cat.size() + in.b_cat.size() + 1 : 1);
-    std::vector<uint64_t> off(rank == 0 ? n : 0);
-    std::vector<uint32_t> len(rank == 0 ? n : 0);
-    const int rc = api.viterbi(comm, 0, model, n, in.a_cat.data(), in.a_off.data(), in.b_cat.data(), in.b_off.data(), scores.data(),
-                               ops.data(), in.a_cat.size() + in.b_cat.size(), off.data(), len.data());
+    const uint64_t ops_total = in.a_off[n] + in.b_off[n];
+    in.scores.resize(rank == 0 ? n : 0), in.off.resize(rank == 0 ? n : 0), in.len.resize(rank == 0 ? n : 0);
+    in.ops.resize(rank == 0 ? ops_total + 1 : 1);
+    const int rc = api.viterbi_shard(comm, 0, model, n, in.a_cat.data(), in.a_off[s0], in.a_off.data(), in.b_cat.data(), in.b_off[s0],
+                                     in.b_off.data(), in.scores.data(), in.ops.data(), ops_total, in.off.data(), in.len.data());
     coati_hip_model_destroy(model);
     dist_check(rc);
     // a pair whose strip hand-off timed out comes back with a NaN score (never a hang): an error here, as in the
     // single-GPU driver -- not `"score": null` next to a garbage alignment
-    if(rank == 0) check_scores(scores);
+    if(rank == 0) check_block_scores(in);
     tm.stage("sharded Viterbi + gather");
     if(rank == 0) {
-        write_batch_output(aln, in, scores, ops, off, len);
+        std::ofstream file;
+        std::ostream* out = &std::cout;
+        if(!(aln.output.empty() || aln.output == "-")) {
+            file.open(extract_file_type(aln.output).path);
+            if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
+            out = &file;
+        }
+        batch_block_write(aln, in, n, *out);
+        out->flush();
         tm.stage("gapped strings + output");
     }
     return true;

@@ -89,6 +89,10 @@ void marg_sample(alignment_t& aln, std::size_t sample_size, random_t& rand);
 // Batch extension: the input holds 2n sequences, consecutive ones form a pair
 // (reference first unless rev); writes a JSON array of n alignments.
 bool marg_alignment_batch(alignment_t& aln);
+// A one-shot tool that exits right after the call says so: the model's cached HBM workspaces (several GB) are then
+// left to the driver instead of being freed one by one (~65 ms of a 0.3 s run).  Off by default (libraries clean up).
+void set_process_exits_after_call(bool on);
+long batch_reader_first_difference(const std::string& path);  // (test hook, align.cc)
 // The same over several GPUs, ONE PROCESS PER GPU (this process is rank `rank` of `world` and drives
 // aln.device): every rank reads the input, rank 0 computes the model and broadcasts it (ncclBroadcast),
 // each rank aligns its shard of coati_hip_shard_bounds, the results are gathered to rank 0 over RCCL

@@ -236,6 +236,10 @@ int coati_host_parse_matrix_csv(const char* path, float out[3721]) {
 
 // Encoded synthetic pairs [first, first+n): offsets have n+1 entries; call with
 // a_cat == NULL to size the buffers (offsets are filled either way).
+int coati_host_batch_reader_check(const char* path, long* first_difference) {
+    return guarded([&] { *first_difference = coati_amd::batch_reader_first_difference(path); });
+}
+
 int coati_host_synth_encoded(unsigned long long first, unsigned long long n, unsigned long long seed_base,
                              unsigned n_codons, unsigned char* a_cat, unsigned long long* a_off,
                              unsigned char* b_cat, unsigned long long* b_off) {

@@ -186,3 +186,46 @@ def test_batch_mode_reports_the_first_bad_pair(tmp_path):
     for _ in range(3):
         r = run("coati-alignpair", str(fa), "--batch")
         assert r.returncode == 1 and "Ambiguous nucleotides in ancestor" in r.stderr, r.stderr[-300:]
+
+
+def test_batch_driver_reader_equals_read_fasta(tmp_path):
+    """`coati-alignpair --batch` indexes a FASTA file in memory (record starts found in parallel, records parsed
+    per pair on the thread pool); every record must come out exactly as io.cc:read_fasta (fasta.cc:38-72 upstream)
+    returns it: comment and empty lines, CRLF, white space inside sequence lines, '>' inside a line, text before the
+    first record, no final newline, an empty sequence."""
+    import numpy as np
+
+    cases = {
+        "plain.fasta": ">a\nACGT\nACG\n>b\nTTT\n",
+        "crlf.fasta": ">a name\r\nAC GT\r\n\r\nAC\tG\r\n>b\r\nTT T\r\n",
+        "comments.fa": "; header comment\n>a\n;inside\nACG\n\n;x\nTTT\n>b\n\n>c\nA>C\nG>T\n",
+        "junk_first.fasta": "leading text\nmore\n>a\nACG\n>b\nTGA",
+        "nofinal.fasta": ">a\nACG\n>b\nTT",
+        "empty_seq.fasta": ">a\n>b\nACG\n>c\n\n\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_bytes(text.encode())
+        assert host.batch_reader_check(p) == 0, name
+    # a large random file: many records, random line lengths, random blank/comment lines
+    rng = np.random.default_rng(3)
+    parts = []
+    for r in range(3000):
+        parts.append(f">seq{r} d={rng.integers(0, 99)}\n")
+        seq = "".join(rng.choice(list("ACGT"), int(rng.integers(0, 400))))
+        while seq:
+            k = int(rng.integers(1, 90))
+            parts.append(seq[:k] + ("\r\n" if rng.random() < 0.1 else "\n"))
+            seq = seq[k:]
+            if rng.random() < 0.05:
+                parts.append(";c\n" if rng.random() < 0.5 else "\n")
+    big = tmp_path / "big.fasta"
+    big.write_text("".join(parts))
+    assert host.batch_reader_check(big) == 0
+    # not a FASTA path: declined (the generic reader takes it)
+    other = tmp_path / "x.json"
+    other.write_text("{}")
+    assert host.batch_reader_check(other) == -1
+    missing = tmp_path / "nope.fasta"
+    with pytest.raises(Exception):
+        host.batch_reader_check(missing)
