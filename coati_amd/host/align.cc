@@ -88,7 +88,8 @@ namespace {
 template <typename Fn>
 void parallel_for(std::size_t n, std::size_t min_per_thread, Fn&& fn) {
     const std::size_t want = std::max<std::size_t>(1, n / std::max<std::size_t>(1, min_per_thread));
-    const std::size_t n_threads = std::min<std::size_t>({want, std::max(1u, std::thread::hardware_concurrency()), 16});
+    // (at most 48: the block pipeline runs two or three of these loops at once on a 256-thread host)
+    const std::size_t n_threads = std::min<std::size_t>({want, std::max(1u, std::thread::hardware_concurrency()), 48});
     if(n_threads <= 1) {
         for(std::size_t i = 0; i < n; ++i) fn(i);
         return;
