@@ -193,6 +193,7 @@ struct coati_hip_batch {
     WorkItem* d_items = nullptr;   // viterbi_l1 work list: (pair, strip), longest pairs first
     WorkItem* d_fwd_items = nullptr;  // forward_l1 work list (1024-column strips)
     uint32_t n_fwd_items = 0;
+    bool ck_keep_all = false;    // viterbi_ck keeps every checkpoint (no band): the debug export decodes every tile
     uint32_t fwd_wlog2_max = 4;  // widest Forward strip shape of the batch (forward_l1 has a leaner build for <= 8 columns per lane)
     uint32_t* d_progress = nullptr;
     uint32_t n_items = 0;
@@ -225,7 +226,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
-                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? 1u : 0u};
 }
 }  // namespace
 
@@ -909,7 +910,9 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         }
         b->flag_dwords = at;
         b->ck_slot_dwords = opts->wave_slot_dwords;
-    } else if(b->ck && !(opts != nullptr && opts->ck_per_pair) && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
+    } else if(b->ck && opts != nullptr && opts->ck_per_pair) {
+        b->ck_keep_all = true;  // (the debug export: per-pair storage, every tile kept)
+    } else if(b->ck && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
         constexpr uint64_t kSlotCap = 1ull << 20;  // dwords (4 MB)
         uint64_t slot = 0, per_pair_total = 0;
         auto need_of = [&](const PairDesc& d) { return d.la > 0 && d.lb > 0 ? ck_strip_dwords(d.la, d.v_wlast) : 0; };
@@ -932,8 +935,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // 40 000: +0.8 %.  Their checkpoints must outlive the wavefront that wrote them: own storage.
         // COATI_HIP_CK_SPLIT="pairs,parts" forces a plan (0 = off).
         uint64_t split_pairs = 0, parts = 3;
+        // (round 3, with banded checkpoints -- a hand-over now writes back a fifth of the bytes -- and the band kept by
+        // cut pairs too: 10 000 pairs 2 048 / 4 096 / 5 904 / 8 000 / all pairs cut in 3: 2 320 / 2 423 / 2 495 / 2 488 /
+        // 2 404 GCUPS, in 2: 2 435 (5 904), in 4: 2 310 (all); 40 000 pairs 2 048 / 8 192 / 16 384 / all: 2 738 / 2 775 /
+        // 2 719 / 2 542; 6 000 pairs 1 904 / all: 2 272 / 2 158.  So: every pair beyond the first round of wavefronts, up to 8 192.)
         if(use_slots && n_pairs > ck_scratch_waves()) {
-            split_pairs = std::min<uint64_t>(ck_scratch_waves() / 2, (n_pairs - ck_scratch_waves()) / 2);
+            split_pairs = std::min<uint64_t>(2 * ck_scratch_waves(), n_pairs - ck_scratch_waves());
             if(split_pairs < 256) split_pairs = 0;
         }
         if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {
@@ -1702,7 +1709,7 @@ struct ChunkNeed {
     // checkpoints: per pair, or in per-wavefront slots when that is smaller (batch_create_impl decides the same way)
     // (+ the own storage of the pairs a large batch cuts into row parts: batch_create_impl, "the ragged end")
     uint64_t arena() const {
-        const uint64_t cut = pairs > ck_scratch_waves() ? std::min<uint64_t>(ck_scratch_waves() / 2, (pairs - ck_scratch_waves()) / 2) : 0;
+        const uint64_t cut = pairs > ck_scratch_waves() ? std::min<uint64_t>(2 * ck_scratch_waves(), pairs - ck_scratch_waves()) : 0;
         return fixed + std::min<uint64_t>(ck_sum, ck_max * (ck_scratch_waves() + cut) + ck_sum / 64);
     }
     // chunk of a streamed call: wavefront slots and traceback scratch are the call's, not the chunk's

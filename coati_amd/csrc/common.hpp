@@ -454,6 +454,7 @@ struct BatchDeviceView {
     float* mdi;        // Forward: fp32 M/D/I of every body cell
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
     uint32_t fwd_wlog2_max;  // forward_l1: the widest strip shape of the batch (log2 of the columns per lane)
+    uint32_t ck_keep_all;    // viterbi_ck: 1 = keep every checkpoint (debug export), 0 = the banded default
 };
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 // Compute units of the current device (hipDeviceAttributeMultiprocessorCount), at most 256: the persistent

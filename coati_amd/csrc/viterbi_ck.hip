@@ -111,8 +111,33 @@ __device__ __forceinline__ void row_lean(const GapVec& k, CkLane<W>& st, float d
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// (num_records = 2 GiB: a lane whose offset register holds kCkDropOffset is OUT OF RANGE and its part of the store is
+// discarded by the address unit -- how a lane that keeps no checkpoint for a band skips its stores without a branch)
+constexpr uint32_t kCkDropOffset = 0x80000000u;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffffu, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffff0u, 0x00020000);
+}
+
+// BANDED CHECKPOINTS (round 3).  The checkpoints are 1.09 bytes per cell written to HBM of which the traceback reads
+// ~6 %: the tiles along the path.  And the stores are what holds the clock down (the fill's loop holds
+// 2.35 GHz without them, 1.9 GHz with them).  A pair of related sequences is aligned near the straight line from
+// (0, 0) to (la, lb), so a lane keeps the checkpoints of a band (kCkRows wavefront steps) only when the band's middle
+// lies within `band` steps of the step at which that line crosses the middle of the lane's columns:
+//     kept(lane t, band c)  <=>  | c * kCkRows + kCkRows/2 - centre(t) | <= band
+// The FILL is unchanged -- every cell is computed, scores are the same bits; only which recompute hints exist changes.
+// A walk that asks for a tile that was not kept (it cannot know the decisions there) reports it, and the wavefront
+// fills the pair again with band = kCkBandOff (everything kept) and walks again: exact, at twice the cost for that
+// pair.  Single-strip pairs that are not cut into row parts only; COATI_HIP_CK_BAND=<steps> (0 = off) sets it.
+constexpr uint32_t kCkBandOff = 0xffffffffu;
+__device__ __forceinline__ uint32_t ck_lane_centre(uint32_t la, uint32_t lb, uint32_t w, uint32_t t) {
+    // body row of the line at the middle of the lane's columns, plus the lane's skew
+    const uint64_t col = static_cast<uint64_t>(t) * w + w / 2;
+    return static_cast<uint32_t>(col * la / max(lb, 1u)) + t;
+}
+__device__ __forceinline__ bool ck_tile_kept(uint32_t band, uint32_t centre, int32_t c) {
+    if(band == kCkBandOff) return true;
+    const int64_t d = static_cast<int64_t>(c) * kCkRows + kCkRows / 2 - static_cast<int64_t>(centre);
+    return (d < 0 ? -d : d) <= static_cast<int64_t>(band);
 }
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
 
@@ -124,6 +149,7 @@ struct CkCtx {
     int lane;
     bool last_strip;
     float *bnd_x, *bnd_z;  // (wave-uniform)
+    uint32_t band, centre;  // banded checkpoints: kCkBandOff or the half width in steps; this lane's centre step
 };
 // HBM windows of one 64-step chunk (rebased per chunk so that offsets stay far below 2^32)
 struct CkChunkMem {
@@ -133,11 +159,11 @@ struct CkChunkMem {
 
 // lane state -> row checkpoint of the band that starts at chunk step kb (state BEFORE that step)
 template <int W>
-__device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, const CkLane<W>& st, uint32_t kb) {
+__device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, const CkLane<W>& st, uint32_t kb, bool keep = true) {
     const uint32_t soff = (kb / kCkRows) * (ck_rowck_quads(W) * kWave * 16u);
     uint32_t voff = static_cast<uint32_t>(lane);
     asm volatile("" : "+v"(voff));  // (derived here, once per kCkRows steps: not another VGPR held across the hot loop)
-    voff *= 16u;
+    voff = keep ? voff * 16u : kCkDropOffset;
 #pragma unroll
     for(int q = 0; q < W / 4; ++q) {
         const u32x4 x = {fbits(st.X[4 * q]), fbits(st.X[4 * q + 1]), fbits(st.X[4 * q + 2]), fbits(st.X[4 * q + 3])};
@@ -154,7 +180,7 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
 template <int W>
 __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
-                                        uint32_t a_chunk, float bx, float bz) {
+                                        uint32_t a_chunk, float bx, float bz, uint32_t colin_voff) {
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
     const uint32_t kstep = kbase + kk;
@@ -176,8 +202,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     const float zl = shift_in(st.zlast, read_lane(bz, kk));
     const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
     // ---- checkpoint: what this lane received (one coalesced 512-byte row per wavefront step)
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, static_cast<uint32_t>(lane) * 8u,
-                                          kk * (kWave * 8u), 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, kk * (kWave * 8u), 0);
     // ---- the W cells (and the LDS gather for the next step)
     row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
@@ -196,17 +221,22 @@ __device__ __forceinline__ void ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
                                          float bx, float bz) {
     const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
     for(uint32_t kb = 0; kb < kend; kb += kCkRows) {
-        store_rowck<W>(mem, cx.lane, st, kb);
+        // (banded checkpoints: one comparison per lane and kCkRows steps; a lane outside the band stores nothing)
+        const bool keep = ck_tile_kept(cx.band, cx.centre, static_cast<int32_t>((kbase + kb) / kCkRows));
+        uint32_t colin_voff = static_cast<uint32_t>(cx.lane);
+        asm volatile("" : "+v"(colin_voff));
+        colin_voff = keep ? colin_voff * 8u : kCkDropOffset;
+        store_rowck<W>(mem, cx.lane, st, kb, keep);
         const uint32_t ke = min(kb + kCkRows, kend);
         // two steps per iteration: the new X of a column must not overwrite the old one before the
         // next column has taken it as its diagonal input; with two copies of the body the register
         // allocator ping-pongs X between two register sets instead of copying W values per step
         uint32_t kk = kb;
         for(; kk + 1 < ke; kk += 2) {
-            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
-            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz);
+            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
         }
-        if(kk < ke) ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz);
+        if(kk < ke) ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
     }
 }
 
@@ -236,7 +266,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                                               uint32_t* __restrict__ ck, float* __restrict__ bnd,
                                               float* __restrict__ scores, uint32_t* __restrict__ progress,
                                               uint32_t kbegin = 0, uint32_t kend = 0xffffffffu,
-                                              unsigned long long* bad = nullptr) {
+                                              unsigned long long* bad = nullptr, uint32_t band = kCkBandOff) {
     // [kbegin, kend): the steps of this item -- the whole strip, or one ROW PART of it (PairDesc::v_parts; whole
     // 64-step chunks).  A part that does not start at 0 takes over the lane state its predecessor left behind the
     // strip's checkpoints; one that does not end at the last step leaves it there.
@@ -269,7 +299,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         if(bad != nullptr && worst >= static_cast<uint32_t>(kTabCols)) ck_report_bad(bad, pair, worst, true);
         if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
     }
-    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z};
+    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z, band,
+                   band == kCkBandOff ? 0u : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane))};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
     // ge*float(j-1)); a lane takes it again at its first step (ck_step)
@@ -418,6 +449,7 @@ struct TileSet {
     int mode;  // COATI_HIP_OP_MATCH / _DEL / _INS
     uint32_t strip, w, lg, col0, t0;
     int32_t bi, bj, c0;
+    unsigned long long computed;  // slots whose tile was recomputed this round (a tile outside the kept band was not: its scratch is stale)
 };
 __device__ __forceinline__ int32_t tileset_cmid(const TileSet& ts, uint32_t dt) {
     const int32_t t = static_cast<int32_t>(ts.t0 - dt);
@@ -473,14 +505,17 @@ constexpr uint32_t kCkScratchDwords = 3u * kCkRows * kWave;
 // started inside the band), then kCkRows wavefront steps of W cells with the received values of
 // the fill as left inputs, depositing the five decision bits of every cell.
 template <int W>
-__device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc& pd, const CkStrip& sp, bool valid,
+__device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc& pd, const CkStrip& sp, bool valid,
                                              int32_t t, int32_t c, uint32_t lds_tab, const char* tab_bytes,
                                              const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                             uint32_t* __restrict__ bits /* wave scratch + lane */) {
+                                             uint32_t* __restrict__ bits /* wave scratch + lane */, uint32_t band = kCkBandOff) {
     const int32_t la = static_cast<int32_t>(pd.la);
     const int32_t k0 = c * static_cast<int32_t>(kCkRows);
     // rows this tile covers: k0 - t + [0, kCkRows)
     valid = valid && t >= 0 && t < static_cast<int32_t>(sp.nlanes) && k0 - t + static_cast<int32_t>(kCkRows) > 0 && k0 - t < la;
+    // (banded checkpoints: a tile the fill kept no checkpoints for cannot be recomputed)
+    if(band != kCkBandOff) valid = valid && ck_tile_kept(band, ck_lane_centre(pd.la, pd.lb, W, static_cast<uint32_t>(max(t, 0))), c);
+    const bool computed = valid;
     if(!valid) {
         t = 0;
         c = 0;
@@ -546,6 +581,7 @@ __device__ __forceinline__ void ck_recompute(const GapConsts& k, const PairDesc&
             bits[(2 * kCkRows + ks) * kWave] = st.acc[ACC_C];
         }
     }
+    return computed;
 }
 
 // Wavefronts per workgroup.  Two, not four: a workgroup's slot on its CU is only free for the next launch's
@@ -558,7 +594,7 @@ constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
 
 // COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
 // pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
-__device__ unsigned long long g_ck_stats[4];
+__device__ unsigned long long g_ck_stats[5];  // rounds, valid tiles, walker iterations, pairs, pairs filled twice (left the kept band)
 
 // State the walk is in after a move of kind `moved` arrives at body cell (bi, bj): from the
 // round's recomputed bits, or kWalkUnknown.
@@ -571,7 +607,7 @@ __device__ __forceinline__ int ck_state_after(const PairDesc& pd, const TileSet&
     const uint32_t colin = bj - ts.col0, t = colin >> ts.lg, cc = colin & (ts.w - 1u);
     const uint32_t kstep = bi + t;
     const int slot = tileset_slot(ts, t, static_cast<int32_t>(kstep >> kCkRowsLog2));
-    if(slot < 0) return kWalkUnknown;
+    if(slot < 0 || ((ts.computed >> slot) & 1ull) == 0ull) return kWalkUnknown;
     const uint32_t ks = kstep & (kCkRows - 1u);
     const uint32_t which = moved == COATI_HIP_OP_INS ? 2u : (moved == COATI_HIP_OP_DEL ? 1u : 0u);
     const uint32_t word = wbits[(which * kCkRows + ks) * kWave + static_cast<uint32_t>(slot)];
@@ -598,6 +634,7 @@ struct CkWalkArgs {
     const uint32_t* ck;
     uint32_t* wbits;  // this wavefront's scratch
     bool stats;
+    uint32_t band;    // banded checkpoints: what the fill of this pair kept (kCkBandOff: everything)
 };
 
 // traceback<tropical> (align_pair.cc:249-303) of one pair by one WAVEFRONT, in rounds (above).
@@ -621,7 +658,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
     uint32_t i = la, j = lb;  // matrix coordinates of the cell whose decision is pending
     int moved = COATI_HIP_OP_MATCH;  // max_mdi of the terminal-adjusted last cell == its "after match" decision
     uint64_t pos = pd.ops_off + la + lb;
-    TileSet ts{COATI_HIP_OP_MATCH, 0xffffffffu, 16u, 4u, 0u, 0u, 0, 0, 0};
+    TileSet ts{COATI_HIP_OP_MATCH, 0xffffffffu, 16u, 4u, 0u, 0u, 0, 0, 0, 0ull};
     bool ok = true;
     while(i >= 1 || j >= 1) {
         if(i >= 1 && j >= 1) {
@@ -643,18 +680,22 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             }
             // the previous round's lookups are done (their results were consumed by ballots);
             // this round's bits are written and then read by the same wavefront through L2
+            bool done;
             if(sp.w == 16)
-                ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane);
+                done = ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band);
             else if(sp.w == 8)
-                ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane);
+                done = ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band);
             else
-                ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane);
+                done = ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band);
+            ts.computed = __builtin_amdgcn_ballot_w64(done);
             // the wavefront reads back what it stored itself: once the stores are acknowledged its
             // loads see them (same L1, write-through)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         int st = __builtin_amdgcn_readfirstlane(ck_arrival_state(wa.k, pd, ts, wa.wbits, i, j, moved));
-        if(st == kWalkUnknown) {  // cannot happen: every round's set holds the tile of its pending cell.  Never spin.
+        if(st == kWalkUnknown) {
+            // the pending cell's own tile was not recomputed: with banded checkpoints the walk has left the kept band
+            // (the caller fills the pair again with everything kept); otherwise it cannot happen.  Never spin.
             ok = false;
             break;
         }
@@ -707,7 +748,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ ck, float* __restrict__ bnd, float* __restrict__ scores, uint8_t* __restrict__ ops,
     uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t* __restrict__ wscratch,
-    uint64_t ck_slot_dwords, uint32_t split_items, uint32_t dbg) {
+    uint64_t ck_slot_dwords, uint32_t split_items, uint32_t dbg, uint32_t band) {
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[kSharedTab ? 0 : threadIdx.x / kWave];
@@ -737,14 +778,18 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         g_ck_trace[trace_wave * 16 + 15] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
     }
 #endif
+    uint32_t redo_ticket = 0xffffffffu;
     for(;;) {
         // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
         // loop-invariant condition and may peel/unswitch this loop per lane, after which the
         // wave-level operations inside (readfirstlane, DPP, ballots) no longer see the whole wave.
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
-        uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);  // every lane takes part; lane 0 draws
+        const bool redo = redo_ticket != 0xffffffffu;  // (wave-uniform) the previous item again: its walk left the kept checkpoint band
+        uint32_t ticket = atomicAdd(queue, (lane == 0 && !redo) ? 1u : 0u);  // every lane takes part; lane 0 draws
         ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        if(redo) ticket = redo_ticket;
+        redo_ticket = 0xffffffffu;
         if(ticket >= n_items) break;
         const WorkItem item = items[ticket];
         const uint32_t pair = item.pair, strip = item.strip & 0xffffu, part = item.strip >> 16;
@@ -768,7 +813,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // [kbegin, kend) of the pair's one strip; part p > 0 continues where part p - 1 -- split_items tickets earlier,
         // on whatever wavefront took it -- stopped
         uint32_t kbegin = 0, kend = 0xffffffffu;
-        const bool cut = pd.v_parts >= 2;
+        const bool cut = pd.v_parts >= 2 && !redo;  // (redo: the wavefront of the last part fills the whole pair again, all rows)
         if(cut) {
             const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
             ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
@@ -777,13 +822,16 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
                 if(__hip_atomic_load(progress + ticket - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
             }
         }
+        // banded checkpoints (above): whole single-strip pairs of the full-width shape only; the second time round
+        // (redo: the walk left the kept band) everything is kept
+        const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
+        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? band : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
-            const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-            if(cut)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend) && handoff_ok;
-            else if(w == 16)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
-            else if(w == 8)
+            if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
+            else if(w_item == 16)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+            else if(w_item == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
@@ -809,9 +857,14 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             (void)terminal_state(k, m, d, in, score);
             if(lane == 0) scores[pair] = score;
         }
-        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u};
-        if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[3], 1ull);
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u, band_now};
+        if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[redo ? 4 : 3], 1ull);
         const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len);
+        if(!walk_ok && band_now != kCkBandOff) {
+            // the walk asked for a tile outside the kept band: the same item once more, with everything kept
+            redo_ticket = ticket;
+            continue;
+        }
         // NaN = "this pair failed": a producer strip never arrived (spin bound), or the walk lost its way
         if((!handoff_ok || !walk_ok) && lane == 0) scores[pair] = __builtin_nanf("");
         COATI_CK_STAMP(1);  // traceback done
@@ -881,7 +934,7 @@ template <bool kSharedTab>
 __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const float* __restrict__ table, GapConsts k,
                                                                           CkStreamCtl* ctl, const CkStreamHost* host,
                                                                           uint32_t* __restrict__ wave_ck, uint64_t wave_slot_dwords,
-                                                                          uint32_t* __restrict__ wave_scratch) {
+                                                                          uint32_t* __restrict__ wave_scratch, uint32_t band) {
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
 
@@ -940,11 +993,15 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));
     const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * kCkWaves + threadIdx.x / kWave)));
+    uint32_t redo_ticket = 0xffffffffu;
     for(;;) {
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
-        uint32_t ticket = atomicAdd(&ctl->queue, lane == 0 ? 1u : 0u);
+        const bool redo = redo_ticket != 0xffffffffu;  // (as in viterbi_ck; the ticket was published long ago: the wait below returns at once)
+        uint32_t ticket = atomicAdd(&ctl->queue, (lane == 0 && !redo) ? 1u : 0u);
         ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        if(redo) ticket = redo_ticket;
+        redo_ticket = 0xffffffffu;
         // ---- wait until the item is published, or the call is closed (bounded)
         bool mine = false;
         const uint64_t t_wait = __builtin_amdgcn_s_memrealtime();  // (100 MHz)
@@ -1045,7 +1102,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         const uint8_t* __restrict__ a = ch_a + pd.a_off;
         const uint8_t* __restrict__ b = ch_b + pd.b_off;
         uint32_t kbegin = 0, kend = 0xffffffffu;
-        const bool cut = pd.v_parts >= 2;
+        const bool cut = pd.v_parts >= 2 && !redo;
         if(cut) {  // (as in viterbi_ck)
             const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
             ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
@@ -1054,13 +1111,15 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
                 if(__hip_atomic_load(ch_progress + local - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
             }
         }
+        // (banded checkpoints: as in viterbi_ck)
+        const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
+        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? band : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {
-            const uint32_t w = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
             if(cut)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad) && handoff_ok;
-            else if(w == 16)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
-            else if(w == 8)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
+            else if(w_item == 16)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad, band_now);
+            else if(w_item == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
@@ -1080,8 +1139,12 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
             margin_mdi(k, 1u, pd.la, pd.lb, m, d, in);
             (void)terminal_state(k, m, d, in, score);
         }
-        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, false};
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, false, band_now};
         const bool walk_ok = ck_walk_pair<true>(lane, wa, pd, pair, ch_ops, ch_start, ch_len);
+        if(!walk_ok && band_now != kCkBandOff) {  // (left the kept band: the same item again, everything kept)
+            redo_ticket = ticket;
+            continue;
+        }
         if(lane == 0) {
             // the score (stored plainly by the lane that owned the last column; acknowledged above) goes out
             // write-through like the rest of the pair's results
@@ -1209,6 +1272,19 @@ extern "C" int coati_hip_debug_trace(unsigned long long* out) {
 uint32_t ck_scratch_waves() { return 256u * 4u * 4u; }  // 4 wavefronts on each of the 1 024 SIMDs
 uint64_t ck_scratch_dwords_per_wave() { return kCkScratchDwords; }
 
+// Half width of the kept checkpoint band in wavefront steps (COATI_HIP_CK_BAND; 0 = keep everything).  Default 96:
+// a lane keeps 13 of a 1 kb pair's 67 bands, the path may stray ~70 rows from the straight line before a pair is
+// filled twice.
+uint32_t ck_band_setting() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("COATI_HIP_CK_BAND");
+        if(e == nullptr) return 96u;
+        const long x = std::atol(e);
+        return x <= 0 ? kCkBandOff : static_cast<uint32_t>(x);
+    }();
+    return v;
+}
+
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
     if(e != hipSuccess) return e;
@@ -1220,6 +1296,8 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
         const char* e = std::getenv("COATI_HIP_CK_DEBUG");
         return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
     }();
+    // (the debug export of every cell's decisions decodes every tile: that batch keeps every checkpoint)
+    const uint32_t band = v.ck_keep_all != 0 ? kCkBandOff : ck_band_setting();
     const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck<true>) : reinterpret_cast<const void*>(viterbi_ck<false>);
     if(shape.dynamic_lds > 0) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));
@@ -1228,19 +1306,19 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     if(shared_tab)
         hipLaunchKernelGGL(viterbi_ck<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg);
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg, band);
     else
         hipLaunchKernelGGL(viterbi_ck<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg);
+                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg, band);
     if(dbg & 2u) {
-        unsigned long long st[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+        unsigned long long st[5] = {0, 0, 0, 0, 0}, zero[5] = {0, 0, 0, 0, 0};
         e = hipStreamSynchronize(stream);
         if(e == hipSuccess) e = hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ck_stats), sizeof st);
         if(e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ck_stats), zero, sizeof zero);
         if(e != hipSuccess) return e;
-        std::fprintf(stderr, "viterbi_ck: %llu pairs, %.2f rounds/pair, %.1f valid tiles/round, %.1f walker iterations/pair\n", st[3],
-                     st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0);
+        std::fprintf(stderr, "viterbi_ck: %llu pairs, %.2f rounds/pair, %.1f valid tiles/round, %.1f walker iterations/pair, %llu pairs filled twice (band %u)\n", st[3],
+                     st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0, st[4], band);
     }
     return hipGetLastError();
 }
@@ -1290,10 +1368,12 @@ hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared
     }
     if(shared_tab)
         hipLaunchKernelGGL(viterbi_ck_stream<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
-                           static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch);
+                           static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch,
+                           ck_band_setting());
     else
         hipLaunchKernelGGL(viterbi_ck_stream<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
-                           static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch);
+                           static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch,
+                           ck_band_setting());
     return hipGetLastError();
 }
 

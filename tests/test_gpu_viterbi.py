@@ -1,6 +1,10 @@
 """Parity of the HIP Viterbi path (through the C ABI) with the CPU oracle.
 Bit-exact: fp32 score bits, every alignment op, and every per-cell traceback
 decision byte."""
+import json
+import os
+import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -9,6 +13,7 @@ import pytest
 from tests import util
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 
 def bits(x):
@@ -503,3 +508,4 @@ def test_streamed_call_reports_bad_input_and_recovers(hip, kernel_choice, monkey
     assert (bits(got[0]) == bits(want[0])).all() and (got[3] == want[3]).all() and (got[2] == want[2]).all()
     batch.close()
     model.close()
+
