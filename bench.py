@@ -33,11 +33,11 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# Secondary (and for this recurrence the binding) ceiling, DESIGN.md §4: the gap_len-1 fill cell
-# (viterbi_ck) is 15 VALU instructions whose register-only replay issues at 18.9 ns per 64-lane cell per
-# SIMD with 4 wavefronts per SIMD (tools/ubench/gen_cell_pk.py `lean`, profiles/r02/ubench_cell_lean.txt):
-# 1024 SIMDs x 64 lanes / 18.9 ns = 3.47 TCUPS.
-VALU_PEAK_GCUPS = 1024 * 64 / 18.9
+# Secondary (and for this recurrence the binding) ceiling, DESIGN.md §4 / §5b: the gap_len-1 fill cell (viterbi_ck) is
+# 15 VALU instructions; its register-only replay with the constants in VGPRs issues at 13.2 ns per 64-lane cell per SIMD
+# with 4 wavefronts per SIMD at 2.35 GHz (tools/ubench/gen_step.py "cell vgpr", profiles/r03/ubench_step_model.txt;
+# round 2's 18.9 ns was the same cell with SGPR constants): 1024 SIMDs x 64 lanes / 13.2 ns = 4.96 TCUPS.
+VALU_PEAK_GCUPS = 1024 * 64 / 13.2
 ALGO_BYTES_PER_CELL = 1.0      # 1 B/cell packed traceback written ...
 # ... + (len_a + len_b) B of sequence read per pair (added per pair below)
 
@@ -134,16 +134,19 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
                 ac, ao, bc, bo = host.synth_encoded(0, n_pairs)
                 cl = int((np.diff(ao).astype(np.float64) * np.diff(bo)).sum())
             pa, pb = hip.pinned_copy(ac), hip.pinned_copy(bc)
-            best, outp = 1e30, None
-            for _ in range(4):
+            calls, outp = [], None
+            for _ in range(7):
                 t0 = time.perf_counter()
                 outp = model.viterbi(pa, ao, pb, bo, out=outp, pinned=True)
-                best = min(best, time.perf_counter() - t0)
-            pageable, outq = 1e30, None
-            for _ in range(3):
+                calls.append(time.perf_counter() - t0)
+            # (the first call of a model allocates slots and first-touches the result arrays: reported, not mixed in)
+            first_call, best, median = calls[0], min(calls[1:]), float(np.median(calls[1:]))
+            pcalls, outq = [], None
+            for _ in range(5):
                 t0 = time.perf_counter()
                 outq = model.viterbi(ac, ao, bc, bo, out=outq)
-                pageable = min(pageable, time.perf_counter() - t0)
+                pcalls.append(time.perf_counter() - t0)
+            pageable = float(np.median(pcalls[1:]))
             assert np.isfinite(outp[0]).all() and (outp[3] == outq[3]).all()
             # the same pairs resident in HBM (what `value` measures), in this process on this GPU: kernel time by HIP events
             bt = hip.Batch(model, ac, ao, bc, bo)
@@ -157,15 +160,18 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
             bt.close()
             model.trim()
             same = bool((outp[0].view(np.uint32) == want[0].view(np.uint32)).all() and (outp[3] == want[3]).all())
-            res[f"{n_pairs}_pairs"] = {"gcups": cl / best / 1e9, "pairs_per_s": n_pairs / best, "ms": best * 1e3,
+            res[f"{n_pairs}_pairs"] = {"gcups": cl / median / 1e9, "pairs_per_s": n_pairs / median, "ms": median * 1e3,
+                                       "best_ms": best * 1e3, "first_call_ms": first_call * 1e3, "calls": len(calls),
                                        "pageable_ms": pageable * 1e3, "pageable_gcups": cl / pageable / 1e9,
-                                       "resident_kernel_ms": resident * 1e3, "inclusive_over_resident": resident / best,
+                                       "resident_kernel_ms": resident * 1e3, "inclusive_over_resident": resident / median,
+                                       "best_over_resident": resident / best,
                                        "pageable_over_resident": resident / pageable, "scores_and_lengths_equal_resident": same}
         res["what"] = ("coati_hip_viterbi_batch, wall time of ONE call from Python: plan + H2D of the encoded pairs + kernel + D2H of "
                        "scores/ops; from 4 096 pairs of >= 250 x 250 cells ONE persistent kernel (viterbi_ck_stream) fed chunk by chunk "
                        "over 12 slots (HBM workspace + page-locked staging), copies on two other streams; caller arrays page-locked "
-                       "(coati_hip_host_alloc) resp. pageable; best of 4 / 3 calls (slots persist between calls); "
-                       "inclusive_over_resident = kernel time of the same pairs as one resident batch / this wall time")
+                       "(coati_hip_host_alloc) resp. pageable; `ms` / `gcups` = MEDIAN of calls 2..7 (4 of the pageable form), the first "
+                       "call -- slot allocation, first touch of the result arrays -- and the best one reported beside it; "
+                       "inclusive_over_resident = kernel time of the same pairs as one resident batch / the median wall time")
         return res
 
     def long_pair():
@@ -527,9 +533,12 @@ def main():
                          "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "viterbi_ck", "algorithmic_bytes_per_launch": algo_bytes,
                          "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
-                         "note": "priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell); the limit this "
-                                 "recurrence actually runs into is VALU issue -- valu_ceiling_gcups is the register-only "
-                                 "replay of the 15-instruction fill cell, valu_frac the kernel against it (DESIGN.md 4)"},
+                         "note": "priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell of traceback state); the "
+                                 "limit this recurrence runs into is SIMD instruction issue (19 instructions per cell at ~2.2 "
+                                 "cycles) and the clock the chip holds -- valu_ceiling_gcups is the register-only replay of the "
+                                 "15-instruction fill cell at 2.35 GHz, valu_frac the kernel against it (DESIGN.md 4, 5b).  "
+                                 "Since round 3 the kernel WRITES less than the algorithmic 1 B/cell: checkpoints are kept "
+                                 "in a band around each pair's straight line only (traffic = what the counters saw)"},
             "strong_1M": strong,
             "two_stream_pipeline": pipelined,
             "pcie_inclusive": extras.get("pcie_inclusive"),

@@ -161,7 +161,8 @@ struct coati_hip_model {
         size_t pinned_bytes = 0;
     };
     StreamSlot sslots[kCkStreamSlots];
-    void* stream_tail_arena[2] = {nullptr, nullptr};  // workspaces of a call's last two chunks (their pairs keep their checkpoints)
+    static constexpr int kStreamTails = 6;
+    void* stream_tail_arena[kStreamTails] = {};  // workspaces of a call's last chunks (their pairs are cut into row parts and keep their checkpoints)
     size_t stream_tail_bytes = 0;
     void* d_stream_waves = nullptr;  // per-wavefront checkpoint slots + traceback scratch, shared by all chunks of a call
     size_t stream_waves_bytes = 0;
@@ -1858,8 +1859,9 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             ss.pinned_bytes = kSlotStaging;
         }
     }
-    // the call's last two chunks are cut into row parts (finer items for the ragged end of the kernel, as a resident
-    // batch's last pairs are): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- two larger workspaces
+    // the call's last chunks -- everything behind the first round of 4 096 wavefronts, up to ~7 500 pairs of 1 kb -- are
+    // cut into row parts (finer items for the ragged end of the kernel, as a resident batch's later pairs are, abi.hip
+    // "the ragged end"): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- six larger workspaces of ~1 250 pairs
     const uint64_t tail_bytes = std::min<uint64_t>(3ull << 30, std::max<uint64_t>(kSlotArena, 1250 * (wave_slot_bytes + 4096) + (64ull << 20)));
     // (a model's FIRST call on a small input runs without them: 2 x 1.4 GB of fresh allocation cost a one-shot process
     // ~30 ms and buy its 10 000-pair kernel 0.5 ms)
@@ -2021,8 +2023,10 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         rc = wait_free(q);
         if(rc != COATI_HIP_OK) break;
         const long double target = ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
-        // the last two chunks (~2 000 pairs of 1 kb): row parts, in the two large workspaces
-        const bool tail = ci >= 2 && total_cells - cells_done <= 2.2L * kUnit && tails_used < 2 && model->stream_tail_bytes != 0 && no_tail_parts == nullptr;
+        // row parts, in the large workspaces: the chunks behind the first 4 100 pairs' worth of cells, while at most
+        // 8 300 pairs' worth are left
+        const bool tail = ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= 8.3L * kUnit &&
+                          tails_used < coati_hip_model::kStreamTails && model->stream_tail_bytes != 0 && no_tail_parts == nullptr;
         void* const arena = tail ? model->stream_tail_arena[tails_used] : sl.arena;
         const uint64_t arena_bytes = tail ? model->stream_tail_bytes : sl.arena_bytes;
         ChunkNeed nd;
