@@ -353,24 +353,11 @@ def main():
     comm = None
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        from datetime import timedelta
-
-        from torch.distributed import TCPStore
-
         from coati_amd import dist as nd
 
-        # ---- rendezvous BEFORE any GPU call: rank 0 makes the ncclUniqueId, the launcher's store carries it.  Under
-        # torch.distributed.run the agent already serves a store on MASTER_PORT (workers are clients); launched by
-        # hand (or in the self-test) rank 0 serves it.
-        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-        port = int(os.environ.get("MASTER_PORT", "29533"))
-        agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
-        store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store), timeout=timedelta(seconds=300),
-                         wait_for_workers=False)
-        key = "coati_bench/uid/" + os.environ.get("TORCHELASTIC_RUN_ID", "0") + "/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-        if rank == 0:
-            store.set(key, nd.unique_id())
-        uid = bytes(store.get(key))
+        # ---- rendezvous BEFORE any GPU call: rank 0 makes the ncclUniqueId, the launcher's TCP store carries it
+        # (coati_amd/dist.py: rendezvous_id; under torch.distributed.run the agent serves the store, by hand rank 0 does)
+        uid = nd.rendezvous_id(world, rank)
         comm = nd.Comm(uid, world, rank, device=local_rank)
     if not torch.cuda.is_available() or hip.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no gfx950 device visible (there is no CPU fallback)")

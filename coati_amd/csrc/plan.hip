@@ -1,0 +1,601 @@
+// plan.hip -- batch_create_impl: what coati_hip_batch_create does (and what every chunk of coati_hip_viterbi_batch
+// does with BatchOpts): validation of the input (process_marginal, src/lib/utils.cc:822-835), strip plans and kernel
+// choice, the LPT order and the row parts of the ragged end, the layout of the ONE workspace allocation, the upload.
+#include "abi_internal.hpp"
+
+using namespace coati_hip_abi;
+
+extern "C" {
+int coati_hip_batch_create_tables(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                                  const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
+                                  const uint32_t* table_index, coati_hip_batch_t** out) {
+    try {  // no C++ exception may cross the C ABI (host-side vectors can throw bad_alloc)
+        return batch_create_impl(model, n_pairs, a_cat, a_off, b_cat, b_off, table_index, nullptr, out);
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
+    } catch(const std::exception& ex) {
+        return fail(COATI_HIP_EHIP, "batch_create: %s", ex.what());
+    }
+}
+
+}  // extern "C"
+
+namespace coati_hip_abi {
+namespace {
+inline uint8_t max_byte(const uint8_t* p, uint64_t n) {
+    uint8_t m = 0;
+    for(uint64_t i = 0; i < n; ++i) m = p[i] > m ? p[i] : m;
+    return m;
+}
+
+// Pair indices, most cells first: exactly (equal pairs in input order), or -- `quick`, the chunks of a streamed
+// call, where planning is on the critical path -- by a counting sort on the cell count's exponent and top six
+// mantissa bits (1.6 % classes, input order inside a class).  The order only decides which wavefront takes which
+// pair when; an exact sort of the 2 000 pairs of a streamed chunk was a third of its planning time (45 ns per
+// pair), and costs a resident 10 000-pair launch 0.5 % if replaced by the classes (4.98 vs 5.01 ms).
+void lpt_order(const std::vector<PairDesc>& desc, std::vector<uint32_t>& order, bool quick) {
+    const size_t n = desc.size();
+    auto cells_of = [&](size_t p) { return static_cast<uint64_t>(desc[p].la) * desc[p].lb; };
+    if(n < 256 || !quick) {
+        for(size_t p = 0; p < n; ++p) order[p] = static_cast<uint32_t>(p);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cells_of(x) > cells_of(y); });
+        return;
+    }
+    constexpr uint32_t kClasses = 65 * 64;
+    auto class_of = [&](size_t p) -> uint32_t {  // larger pairs -> smaller class number
+        const uint64_t c = cells_of(p);
+        if(c == 0) return kClasses - 1;
+        const uint32_t e = 63u - static_cast<uint32_t>(__builtin_clzll(c));                          // exponent 0..63
+        const uint32_t m = e >= 6 ? static_cast<uint32_t>((c >> (e - 6)) & 63u) : static_cast<uint32_t>((c << (6 - e)) & 63u);  // top six bits below the leading one
+        return kClasses - 2 - (e * 64 + m);
+    };
+    std::vector<uint32_t> start(kClasses + 1, 0), cls(n);
+    for(size_t p = 0; p < n; ++p) {
+        cls[p] = class_of(p);
+        ++start[cls[p] + 1];
+    }
+    for(uint32_t q = 0; q < kClasses; ++q) start[q + 1] += start[q];
+    for(size_t p = 0; p < n; ++p) order[start[cls[p]]++] = static_cast<uint32_t>(p);
+}
+
+}  // namespace
+
+int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off,
+                      const uint8_t* b_cat, const uint64_t* b_off, const uint32_t* table_index, const BatchOpts* opts,
+                      coati_hip_batch_t** out) {
+    if(out == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: out is NULL");
+    *out = nullptr;
+    if(model == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: model is NULL");
+    if(a_off == nullptr || b_off == nullptr) return fail(COATI_HIP_EINVAL, "batch_create: offsets are NULL");
+    if(n_pairs > 0xffffffffull) return fail(COATI_HIP_EINVAL, "batch_create: too many pairs");
+    const uint64_t a_total = a_off[n_pairs] - a_off[0], b_total = b_off[n_pairs] - b_off[0];
+    if((a_total > 0 && a_cat == nullptr) || (b_total > 0 && b_cat == nullptr))
+        return fail(COATI_HIP_EINVAL, "batch_create: sequence data is NULL");
+
+    auto* b = new(std::nothrow) coati_hip_batch;
+    if(b == nullptr) return fail(COATI_HIP_ENOMEM, "batch_create: host allocation failed");
+    b->model = model;
+    model->refs.fetch_add(1);  // released by coati_hip_batch_destroy
+    b->n_pairs = n_pairs;
+    b->stream = opts != nullptr && opts->stream != nullptr ? opts->stream : model->stream;
+    // a chunk of a streamed Viterbi call never runs Forward: no Forward work items, no Forward boundary arrays
+    const bool viterbi_only = opts != nullptr && opts->wave_slot_dwords != 0;
+    struct Owner {  // destroys the half-built batch on every exit but the successful one
+        coati_hip_batch* b;
+        ~Owner() {
+            if(b != nullptr) coati_hip_batch_destroy(b);
+        }
+    } owner{b};
+    auto cleanup = [&](int rc) { return rc; };
+    // COATI_HIP_TIMING=1: host-side stage times of this call on stderr
+    static const bool timing = std::getenv("COATI_HIP_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if(!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "batch_create: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    b->desc.resize(n_pairs);
+    const uint64_t L = static_cast<uint64_t>(model->gap_len);
+    static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+    // Forward strip shape (forward_l1): 16 columns per lane, narrowed to 8 and 4 while the batch has
+    // fewer strips than 1.5 rounds of the kernel's wavefront slots (3 per SIMD) -- a wavefront per
+    // 1 024 columns leaves a small batch on a handful of SIMDs (16 pairs of 1 kb: 17.8 ms at W = 16,
+    // 6.3 ms at W = 4), and just over one round of full-width strips wastes most of a second one
+    // (3 000 pairs: 41.7 ms at W = 16, 35.9 ms at W = 8).  A Forward cell is ~440 instructions, so the per-step overhead of a narrow strip is
+    // small, unlike in viterbi_l1.  COATI_HIP_FWD_W=<4|8|16> overrides.
+    constexpr uint64_t kFwdSlots = 3 * 1024 * 3 / 2;
+    // The bit-exact build (glibc's expf / log1pf restated: ~440 instructions per cell) starts from 8 columns per lane:
+    // that shape fits 128 VGPRs without spills and runs 4 wavefronts per SIMD (forward_l1<false, true>), measured
+    // 6 144 pairs of 1 kb: 16 columns (168 VGPRs, 81 spilled values, 3 per SIMD) 68.7 ms, 8 columns in the same build 63.0 ms.
+    uint32_t fwd_wlog2 = 4;  // (dp_generic and forward_k lay their cells out for 16 columns per lane)
+    if(L == 1 && !force_generic) {
+        if(!forward_fast_math()) fwd_wlog2 = 3;
+        auto count_strips = [&](uint32_t w) {
+            uint64_t n = 0;
+            for(uint64_t p = 0; p < n_pairs && n < kFwdSlots; ++p) {
+                const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+                n += (la > 0 && lb > 0 && lb <= 0x7fffff00ull) ? fwd_strips_w(static_cast<uint32_t>(lb), w) : 1;
+            }
+            return n;
+        };
+        while(fwd_wlog2 > 2 && count_strips(1u << fwd_wlog2) < kFwdSlots) --fwd_wlog2;
+        // a handful of pairs (`coati sample` works on ONE): 2 and 1 columns per lane put 8 and 16 wavefronts on a 1 kb
+        // pair.  Measured, 1 kb pairs, 4 / 2 / 1 columns: 1 or 16 pairs 6.2 / 4.5 / 3.75 ms, 64 pairs 6.45 / 4.65 / 3.95,
+        // 256 pairs 7.1 / 6.0 / 7.1, 1 024 pairs 15 / 16 / 19.6 -- i.e. while the strips still fit ~2 per SIMD.
+        if(fwd_wlog2 == 2 && count_strips(2) <= 2304) fwd_wlog2 = 1;
+        if(fwd_wlog2 == 1 && count_strips(1) <= 1536) fwd_wlog2 = 0;
+        if(const char* e = std::getenv("COATI_HIP_FWD_W")) {
+            const int w = std::atoi(e);
+            if(w == 1 || w == 2 || w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 1 ? 0u : w == 2 ? 1u : w == 4 ? 2u : (w == 8 ? 3u : 4u);
+        }
+    }
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: offsets of pair %llu decrease",
+                                static_cast<unsigned long long>(p)));
+        const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+        if(la > 0x7fffff00ull || lb > 0x7fffff00ull)
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: pair %llu too long",
+                                static_cast<unsigned long long>(p)));
+        // process_marginal, src/lib/utils.cc:822-835
+        if(la % 3 != 0 || la % L != 0)
+            return cleanup(fail(COATI_HIP_EINVAL,
+                                "Length of reference sequence must be multiple of 3 and gap unit "
+                                "length. (pair %llu)",
+                                static_cast<unsigned long long>(p)));
+        if(lb % L != 0)
+            return cleanup(fail(COATI_HIP_EINVAL,
+                                "Length of descendant sequence must be multiple of gap unit length. "
+                                "(pair %llu)",
+                                static_cast<unsigned long long>(p)));
+        // code ranges: a branch-free max over the bytes (vectorises); the offender is only looked up on failure.
+        // (Reading every byte once from DRAM is most of the planning time of a 1 kb pair: the chunks of a streamed
+        // call leave the check to the kernel, which reports through the same error.)
+        if(opts != nullptr && opts->device_validates) {
+        } else if(max_byte(a_cat + a_off[p], la) >= kTabRows) {
+            uint64_t q = a_off[p];
+            while(a_cat[q] < kTabRows) ++q;
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: ancestor code %u out of range (pair %llu)", a_cat[q],
+                                static_cast<unsigned long long>(p)));
+        }
+        if(!(opts != nullptr && opts->device_validates) && max_byte(b_cat + b_off[p], lb) >= kTabCols) {
+            uint64_t q = b_off[p];
+            while(b_cat[q] < kTabCols) ++q;
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: descendant code %u out of range (pair %llu)", b_cat[q],
+                                static_cast<unsigned long long>(p)));
+        }
+        if(table_index != nullptr && table_index[p] >= model->n_tables)
+            return cleanup(fail(COATI_HIP_EINVAL, "batch_create: table index %u of pair %llu out of range [0,%u)",
+                                table_index[p], static_cast<unsigned long long>(p), model->n_tables));
+        PairDesc& d = b->desc[p];
+        d.table = static_cast<uint16_t>(table_index != nullptr ? table_index[p] : 0u);
+        d.a_off = a_off[p] - a_off[0];
+        d.b_off = b_off[p] - b_off[0];
+        d.la = static_cast<uint32_t>(la);
+        d.lb = static_cast<uint32_t>(lb);
+        d.ops_off = b->ops_total;
+        // Forward M/D/I arena: gap_len 2, 3 store the live cells only (forward_k.hip)
+        const bool fwd_k = (L == 2 || L == 3) && !force_generic;
+        d.f_compact = static_cast<uint16_t>(fwd_k ? L : 0u);
+        d.f_wlog2 = static_cast<uint8_t>(fwd_wlog2);
+        d.v_parts = 0;
+        b->ops_total += la + lb;
+        b->cells += la * lb;
+    }
+
+    stage("plan: checks + descriptors");
+    // ---- Viterbi strip plan (common.hpp).  Full-speed strips are 16 columns per lane; the last
+    // strip of a pair takes the narrowest shape that holds the remainder.  When the whole batch
+    // has fewer strips than the GPU has SIMDs (a few long pairs), narrower strips everywhere put
+    // more wavefronts to work on each pair.  dp_generic (gap_len > 1) writes 16-column strips only.
+    uint32_t w_main = kW;
+    const bool plan_l1 = L == 1 && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;  // viterbi_ck / viterbi_l1 will run
+    // COATI_HIP_VITERBI_BITS=1: the round-1 kernel (five decision bits per cell written by the fill), kept
+    // as the A/B partner and second implementation of viterbi_ck
+    b->ck = plan_l1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr;
+    const bool ck_shared = model->n_tables == 1;
+    // longest-processing-time-first order for the dynamic queue
+    std::vector<uint32_t> order(n_pairs);
+    lpt_order(b->desc, order, opts != nullptr && opts->device_validates);
+    stage("plan: longest-first order");
+    // Ragged end of the queue.  The persistent kernel runs kFillSlots wavefronts, three per SIMD, and
+    // the SIMD's issue arbitration favours the oldest: in the trace build one 1 kb item takes a
+    // wavefront between 1.15 and 3.4 ms (mean 2.1; `make trace`, tools/trace_fill.py).  The SIMD as a
+    // whole is work-conserving, but when the queue runs empty every SIMD still holds up to three
+    // items in different states of progress and drains them alone -- a batch of equal pairs ends
+    // raggedly however many rounds it has.  The last third of a round (1 024 pairs) of such a
+    // batch (the end of the LPT order) therefore gets 8-column-per-lane strips -- twice as many,
+    // half as long items that the early finishers pick up.  Measured (tools/ab_fill.py, 1 kb pairs):
+    // 9 216 pairs +11 %, 6 644 +6 %, 10 000 +3.7 %, 20 000 and 40 000 +2.3 %, 12 000 and 125 000 +-0.5 %; narrowing more
+    // than ~1 100 pairs (768 and 1 024 are within 1 %, 1 280 loses 3 %), or to 4 columns, loses (W = 8 runs at ~85 %, W = 4 at ~57 % of the W = 16
+    // rate per cell).  A mixed bag needs none of it: its short pairs already end the queue.
+    // COATI_HIP_TAIL_PAIRS=<n> overrides the count (0: off).
+    std::vector<uint8_t> pair_w(n_pairs, 0);
+    if(plan_l1) {
+        auto items_of = [&](uint64_t p, uint32_t w) {
+            uint32_t ns = 1, wl = w;
+            if(b->desc[p].la > 0 && b->desc[p].lb > 0) viterbi_strip_plan(b->desc[p].lb, w, ns, wl);
+            return static_cast<uint64_t>(ns);
+        };
+        auto count_items = [&](uint32_t w) {
+            uint64_t items = 0;
+            for(uint64_t p = 0; p < n_pairs; ++p) items += items_of(p, w);
+            return items;
+        };
+        const uint64_t kSimds = 4ull * device_cu_count();
+        while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
+        if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
+            const int w = std::atoi(e);
+            if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
+        }
+        if(opts != nullptr && opts->force_w_main != 0) w_main = opts->force_w_main;
+        // Which gap_len-1 kernel.  viterbi_ck (lean fill + checkpoint traceback) wins where the fill
+        // dominates; viterbi_l1 (decision bits written by the fill) keeps two regimes, both measured
+        // (profiles/r02/kernel_choice.txt): batches of SHORT pairs, where a traceback round recomputes a
+        // large share of the little matrix (150 nt pairs: 588 vs 440 GCUPS; from 300 nt on the two are level,
+        // at 750 nt viterbi_ck leads by 16 %), and a few LONG pairs cut into narrow strips, where every
+        // wavefront is alone on its SIMD and the 4x larger checkpoint stream of 4-column strips costs more
+        // than the shorter cell saves (160 kb pair: 86 vs 104 ms).  COATI_HIP_VITERBI_CK=1 / _BITS=1 force one.
+        if(b->ck && std::getenv("COATI_HIP_VITERBI_CK") == nullptr && !(opts != nullptr && (opts->force_w_main != 0 || opts->force_ck))) {
+            long double cells = 0;
+            uint64_t live = 0;
+            for(uint64_t p = 0; p < n_pairs; ++p)
+                if(b->desc[p].la > 0 && b->desc[p].lb > 0) {
+                    cells += static_cast<long double>(b->desc[p].la) * b->desc[p].lb;
+                    ++live;
+                }
+            constexpr long double kShortPair = 250.0L * 250.0L;
+            if(w_main < kW || (live > 0 && cells / live < kShortPair)) b->ck = false;
+        }
+        const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
+        uint64_t tail_pairs = 0;
+        if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {
+            tail_pairs = std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10));
+        } else if(w_main == kW && n_pairs > 0) {
+            // "equal pairs": the smallest has at least half the cells of the largest (LPT order);
+            // and the batch must be clearly longer than one round (3 500 pairs: -1 %, 6 644: +6 %)
+            auto cells_of = [&](uint64_t p) { return static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb; };
+            const bool homogeneous = cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]);
+            // (viterbi_ck: measured again with the lean fill, 10 000 pairs: 0 and 700 narrowed pairs within
+            // noise of each other, 1 365 -7 %, 2 730 -10 % -- the narrow strips cost more than they balance)
+            if(homogeneous && n_pairs > kFillSlots * 3 / 2 && !b->ck) tail_pairs = kFillSlots / 3;
+        }
+        for(uint64_t q = n_pairs - tail_pairs; q < n_pairs; ++q) pair_w[order[q]] = 8;
+    }
+    // the same remedy for forward_l1 (3 slots per SIMD as well): a batch of equal pairs that runs
+    // full-width strips ends with its last quarter round in 8-column strips
+    if(L == 1 && !force_generic && fwd_wlog2 == 4 && n_pairs > 3 * 1024 * 3 / 2 && std::getenv("COATI_HIP_FWD_W") == nullptr) {
+        auto cells_of = [&](uint64_t p) { return static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb; };
+        if(cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]))
+            for(uint64_t q = n_pairs - 3 * 1024 / 4; q < n_pairs; ++q) b->desc[order[q]].f_wlog2 = 3;
+    }
+    stage("plan: strip shapes");
+    b->fwd_wlog2_max = 0;
+    for(uint64_t p = 0; p < n_pairs; ++p) b->fwd_wlog2_max = std::max<uint32_t>(b->fwd_wlog2_max, b->desc[p].f_wlog2);
+    // Forward M/D/I arena, now that every pair's strip shape is known
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        PairDesc& d = b->desc[p];
+        d.mdi_off = b->mdi_floats;
+        if(d.la > 0 && d.lb > 0)
+            b->mdi_floats += d.f_compact != 0
+                                 ? fwd_compact_strips(d.lb, d.f_compact) * fwd_compact_strip_floats(d.la, d.f_compact)
+                                 : fwd_strips_w(d.lb, 1u << d.f_wlog2) * strip_mdi_floats_w(d.la, 1u << d.f_wlog2);
+    }
+    // gap_len 2 and 3: viterbi_k works on the live cells only, in block columns (lb / L), strips of
+    // 16 block columns per lane and a narrow shape (6 for L = 3, 8 for L = 2) for the last strip
+    const bool plan_k = (L == 2 || L == 3) && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;
+    b->compact = plan_k;
+    uint32_t k_main = L == 3 ? 12u : 16u;  // (viterbi_k.hip: kWMain / kWNarrow)
+    const uint32_t k_narrow = L == 3 ? 6u : 8u;
+    if(plan_k) {  // few long pairs: the narrow shape everywhere puts more wavefronts on each pair
+        uint64_t items_main = 0;
+        for(uint64_t p = 0; p < n_pairs; ++p)
+            items_main += (b->desc[p].la > 0 && b->desc[p].lb > 0) ? (b->desc[p].lb / L + kWave * k_main - 1) / (kWave * k_main) : 1;
+        if(items_main < 1024) k_main = k_narrow;
+    }
+    bool all_narrow = plan_k;
+    for(uint64_t p = 0; p < n_pairs; ++p) {
+        PairDesc& d = b->desc[p];
+        const uint64_t la = d.la;
+        const uint32_t w_main_p = pair_w[p] != 0 ? std::min<uint32_t>(pair_w[p], w_main) : w_main;
+        uint32_t w_main_q = w_main_p;  // columns per lane of every strip but the last
+        uint32_t ns = 1, wl = w_main_p;
+        d.v_compact = 0;
+        if(plan_l1) {
+            if(d.la > 0 && d.lb > 0) viterbi_strip_plan(d.lb, w_main_p, ns, wl);
+        } else if(plan_k) {
+            d.v_compact = static_cast<uint32_t>(L);
+            const uint32_t cols_b = static_cast<uint32_t>(d.lb / L), narrow = k_narrow;
+            w_main_q = k_main;
+            wl = w_main_q;
+            if(d.la > 0 && d.lb > 0) {
+                const uint32_t full = kWave * w_main_q, whole = cols_b / full, rem = cols_b % full;
+                ns = whole + (rem != 0 ? 1u : 0u);
+                if(rem != 0 && rem <= kWave * narrow) wl = narrow;
+            }
+        } else {
+            ns = std::max(1u, n_strips(d.lb));
+        }
+        d.v_strips = ns;
+        d.v_wmain = static_cast<uint8_t>(w_main_q);
+        d.v_wlast = static_cast<uint8_t>(wl);
+        if(plan_k && d.la > 0 && d.lb > 0 && (wl != k_narrow || (ns > 1 && w_main_q != k_narrow))) all_narrow = false;
+        d.flags_off = b->flag_dwords;
+        d.bnd_off = b->bnd_floats;
+        if(d.la > 0 && d.lb > 0)
+            b->flag_dwords += plan_k  ? ns * compact_strip_dwords(d.la, static_cast<uint32_t>(L))
+                              : b->ck ? (ns - 1) * ck_strip_dwords(d.la, w_main_p) + ck_strip_dwords(d.la, wl)
+                                      : (ns - 1) * strip_dwords(d.la, w_main_p) + strip_dwords(d.la, wl);
+        // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
+        // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
+        // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
+        const uint64_t nf = viterbi_only ? 1 : fwd_strips_w(d.lb, 1u << d.f_wlog2);
+        const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
+                                                  nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
+                                                  plan_k ? (ns - 1) * ((la / L + 1) + la) : 0,
+                                                  d.f_compact != 0 && d.lb > 0
+                                                      ? (fwd_compact_strips(d.lb, static_cast<uint32_t>(L)) - 1) * 3 * L * (la / L + 1)
+                                                      : 0});
+        b->bnd_floats += (need + 31) / 32 * 32;
+    }
+    b->compact_narrow_only = plan_k && all_narrow;
+    // viterbi_ck: checkpoints of single-strip pairs in per-wavefront slots instead of per pair, when that is
+    // the smaller arena (a 1 kb pair needs 1.09 MB: 10 000 pairs 10.9 GB per pair, 4.5 GB in 4 096 slots; a
+    // batch of a few pairs keeps per-pair storage).  Pairs above kSlotCap keep their own storage either way.
+    if(b->ck && opts != nullptr && opts->wave_slot_dwords != 0) {
+        // streamed chunk: every single-strip pair that fits the call's shared slots uses them; the workspace keeps the rest.
+        // One of the call's last chunks: its pairs are cut into row parts (the ragged end, below) and keep their checkpoints.
+        if(opts->tail_parts >= 2) {
+            std::vector<uint32_t> whole, cut;
+            for(const uint32_t p : order) {
+                PairDesc& d = b->desc[p];
+                if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && ck_strip_dwords(d.la, kW) <= (1ull << 20) &&
+                   d.la + kWave >= 128 * opts->tail_parts) {
+                    d.v_parts = static_cast<uint8_t>(opts->tail_parts);
+                    cut.push_back(p);
+                } else {
+                    whole.push_back(p);
+                }
+            }
+            if(!cut.empty()) {
+                whole.insert(whole.end(), cut.begin(), cut.end());
+                order.swap(whole);
+                b->ck_split_items = static_cast<uint32_t>(cut.size());
+            }
+        }
+        uint64_t at = 0;
+        for(uint64_t p = 0; p < n_pairs; ++p) {
+            PairDesc& d = b->desc[p];
+            if(!(d.la > 0 && d.lb > 0)) {
+                d.flags_off = at;
+            } else if(d.v_parts >= 2) {
+                d.flags_off = at;
+                at += ck_strip_dwords(d.la, d.v_wlast) + kCkPartStateDwords;
+            } else if(d.v_strips == 1 && ck_strip_dwords(d.la, d.v_wlast) <= opts->wave_slot_dwords) {
+                d.flags_off = kCkWaveSlot;
+            } else {
+                d.flags_off = at;
+                at += (d.v_strips - 1) * ck_strip_dwords(d.la, d.v_wmain) + ck_strip_dwords(d.la, d.v_wlast);
+            }
+        }
+        b->flag_dwords = at;
+        b->ck_slot_dwords = opts->wave_slot_dwords;
+    } else if(b->ck && opts != nullptr && opts->ck_per_pair) {
+        b->ck_keep_all = true;  // (the debug export: per-pair storage, every tile kept)
+    } else if(b->ck && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
+        constexpr uint64_t kSlotCap = 1ull << 20;  // dwords (4 MB)
+        uint64_t slot = 0, per_pair_total = 0;
+        auto need_of = [&](const PairDesc& d) { return d.la > 0 && d.lb > 0 ? ck_strip_dwords(d.la, d.v_wlast) : 0; };
+        for(uint64_t p = 0; p < n_pairs; ++p) {
+            const PairDesc& d = b->desc[p];
+            if(d.v_strips != 1) continue;
+            const uint64_t nd = need_of(d);
+            if(nd == 0 || nd > kSlotCap) continue;
+            slot = std::max(slot, nd);
+            per_pair_total += nd;
+        }
+        const uint64_t slots_total = slot * ck_scratch_waves();
+        const bool use_slots = slot > 0 && slots_total < per_pair_total;
+        // The ragged end: when the ticket queue runs dry every wavefront holds an item, and the launch lasts as long as
+        // the SIMD with the most left (10 000 pairs of 1 kb: 0.5 ms of 5.5).  The last pairs of the LPT order are
+        // therefore cut into ROW parts, each its own item at the end of the queue: a part leaves the lane state at a
+        // 64-step boundary and whichever wavefront takes the next part continues there (viterbi_ck.hip).  Measured
+        // (tools/split_ab.py, 10 000 pairs): 2 048 pairs in 3 parts 5.50 -> 4.95 ms; 2 parts 5.05; 4 parts 5.05;
+        // 8 parts or 4 096 pairs lose again (hand-overs, waits for the predecessor).  6 000 pairs: 1 024 x 3 +4 %;
+        // 40 000: +0.8 %.  Their checkpoints must outlive the wavefront that wrote them: own storage.
+        // COATI_HIP_CK_SPLIT="pairs,parts" forces a plan (0 = off).
+        uint64_t split_pairs = 0, parts = 3;
+        // (round 3, with banded checkpoints -- a hand-over now writes back a fifth of the bytes -- and the band kept by
+        // cut pairs too: 10 000 pairs 2 048 / 4 096 / 5 904 / 8 000 / all pairs cut in 3: 2 320 / 2 423 / 2 495 / 2 488 /
+        // 2 404 GCUPS, in 2: 2 435 (5 904), in 4: 2 310 (all); 40 000 pairs 2 048 / 8 192 / 16 384 / all: 2 738 / 2 775 /
+        // 2 719 / 2 542; 6 000 pairs 1 904 / all: 2 272 / 2 158.  So: every pair beyond the first round of wavefronts, up to 8 192.)
+        if(use_slots && n_pairs > ck_scratch_waves()) {
+            split_pairs = std::min<uint64_t>(2 * ck_scratch_waves(), n_pairs - ck_scratch_waves());
+            if(split_pairs < 256) split_pairs = 0;
+        }
+        if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {
+            char* rest = nullptr;
+            split_pairs = std::strtoull(e, &rest, 10);
+            if(rest != nullptr && *rest == ',') parts = std::strtoull(rest + 1, nullptr, 10);
+            if(parts < 2 || parts > 8) split_pairs = 0;
+        }
+        split_pairs = std::min<uint64_t>(split_pairs, n_pairs);
+        std::vector<uint32_t> cut;  // in LPT order
+        for(uint64_t q = n_pairs - split_pairs; q < n_pairs; ++q) {
+            PairDesc& d = b->desc[order[q]];
+            // (a part is at least two 64-step chunks; narrow last strips and multi-strip pairs stay whole)
+            if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && need_of(d) <= kSlotCap && d.la + kWave >= 128 * parts) {
+                d.v_parts = static_cast<uint8_t>(parts);
+                cut.push_back(order[q]);
+            }
+        }
+        if(!cut.empty()) {  // the cut pairs go to the end of the order, still longest first
+            std::vector<uint32_t> whole;
+            for(const uint32_t p : order)
+                if(b->desc[p].v_parts < 2) whole.push_back(p);
+            whole.insert(whole.end(), cut.begin(), cut.end());
+            order.swap(whole);
+            b->ck_split_items = static_cast<uint32_t>(cut.size());
+        }
+        if(use_slots || !cut.empty()) {
+            // re-lay the arena: [wave slots | pairs that keep their own storage]
+            uint64_t at = use_slots ? slots_total : 0;
+            for(uint64_t p = 0; p < n_pairs; ++p) {
+                PairDesc& d = b->desc[p];
+                if(!(d.la > 0 && d.lb > 0)) {
+                    d.flags_off = at;
+                    continue;
+                }
+                if(d.v_parts >= 2) {
+                    d.flags_off = at;
+                    at += ck_strip_dwords(d.la, d.v_wlast) + kCkPartStateDwords;
+                } else if(use_slots && d.v_strips == 1 && need_of(d) <= kSlotCap) {
+                    d.flags_off = kCkWaveSlot;
+                } else {
+                    d.flags_off = at;
+                    at += (d.v_strips - 1) * ck_strip_dwords(d.la, d.v_wmain) + ck_strip_dwords(d.la, d.v_wlast);
+                }
+            }
+            b->flag_dwords = at;
+            b->ck_slot_dwords = use_slots ? slot : 0;
+        }
+    }
+
+    stage("plan: layout");
+    if(hipSetDevice(model->device) != hipSuccess)
+        return cleanup(fail(COATI_HIP_EHIP, "hipSetDevice failed"));
+#define B_TRY(expr)                                                                             \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if(e_ != hipSuccess)                                                                    \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,  \
+                                "%s failed: %s", #expr, hipGetErrorString(e_)));                \
+    } while(0)
+    // work lists: one item per strip, pairs in LPT order
+    // (a pair cut into row parts -- they are the last ones of `order` -- contributes its part 0 here; parts 1.. of
+    // all of them follow in the same order, so that a part's predecessor is ck_split_items tickets before it)
+    std::vector<WorkItem> items, fwd_items;
+    for(const uint32_t p : order) {
+        for(uint32_t st = 0; st < b->desc[p].v_strips; ++st) items.push_back(WorkItem{p, st});
+        if(viterbi_only) continue;
+        uint32_t nf = 1;
+        if(b->desc[p].la > 0 && b->desc[p].lb > 0)
+            nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact)
+                                             : fwd_strips_w(b->desc[p].lb, 1u << b->desc[p].f_wlog2);
+        for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
+    }
+    if(b->ck_split_items > 0) {
+        const uint32_t parts = b->desc[order[n_pairs - 1]].v_parts;
+        for(uint32_t part = 1; part < parts; ++part)
+            for(uint64_t q = n_pairs - b->ck_split_items; q < n_pairs; ++q) items.push_back(WorkItem{order[q], part << 16});
+    }
+    b->n_items = static_cast<uint32_t>(items.size());
+    b->n_fwd_items = static_cast<uint32_t>(fwd_items.size());
+    stage("work lists");
+    // ONE workspace for everything but the Forward M/D/I arena, carved into 256-byte aligned parts
+    uint64_t arena_need = 0;
+    auto carve = [&](uint64_t bytes) {
+        const uint64_t at = arena_need;
+        arena_need += (std::max<uint64_t>(bytes, 16) + 255) / 256 * 256;
+        return at;
+    };
+    // [what goes up: descriptors, order, queue word, work items, progress words, sequences | what comes back: scores,
+    // ops offsets and lengths, ops | scratch]: each group contiguous, so that a pipeline slot moves it with ONE copy
+    const uint64_t o_desc = carve(n_pairs * sizeof(PairDesc)), o_order = carve(n_pairs * sizeof(uint32_t)), o_queue = carve(sizeof(uint32_t)),
+                   o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
+                   o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)),
+                   o_a = carve(a_total), o_b = carve(b_total), o_up_end = arena_need,
+                   o_scores = carve(n_pairs * sizeof(float)), o_start = carve(n_pairs * sizeof(uint64_t)),
+                   o_len = carve(n_pairs * sizeof(uint32_t)), o_ops = carve(b->ops_total),
+                   o_flags = carve(b->flag_dwords * sizeof(uint32_t)), o_bnd = carve(b->bnd_floats * sizeof(float)),
+                   o_wscratch = carve(b->ck && !(opts != nullptr && opts->wave_slot_dwords != 0)
+                                          ? ck_scratch_waves() * ck_scratch_dwords_per_wave() * sizeof(uint32_t) : 0);
+    arena_need = std::max<uint64_t>(arena_need, 2 * kMinDmaBytes);
+    if(opts != nullptr && opts->arena_need_out != nullptr) *opts->arena_need_out = arena_need;
+    if(opts != nullptr && opts->arena != nullptr) {
+        if(opts->arena_bytes < arena_need)
+            return cleanup(fail(COATI_HIP_ENOMEM, "batch_create: the slot's workspace (%llu bytes) is smaller than the chunk needs (%llu)",
+                                static_cast<unsigned long long>(opts->arena_bytes), static_cast<unsigned long long>(arena_need)));
+        b->arena = opts->arena;
+        b->arena_bytes = opts->arena_bytes;
+        b->arena_owned = false;
+    } else {
+        // a workspace a destroyed batch of this model left behind, or a fresh one
+        const hipError_t e = model_take_arena(model, arena_need, &b->arena, &b->arena_bytes);
+        if(e != hipSuccess)
+            return cleanup(fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP,
+                                "hipMalloc(workspace, %llu bytes) failed: %s", static_cast<unsigned long long>(arena_need),
+                                hipGetErrorString(e)));
+    }
+    b->device_bytes += arena_need;
+    auto at = [&](uint64_t off) { return static_cast<char*>(b->arena) + off; };
+    b->d_desc = reinterpret_cast<PairDesc*>(at(o_desc));
+    b->d_a = reinterpret_cast<uint8_t*>(at(o_a));
+    b->d_b = reinterpret_cast<uint8_t*>(at(o_b));
+    b->d_ops = reinterpret_cast<uint8_t*>(at(o_ops));
+    b->d_flags = reinterpret_cast<uint32_t*>(at(o_flags));
+    b->d_bnd = reinterpret_cast<float*>(at(o_bnd));
+    b->d_scores = reinterpret_cast<float*>(at(o_scores));
+    b->d_ops_start = reinterpret_cast<uint64_t*>(at(o_start));
+    b->d_ops_len = reinterpret_cast<uint32_t*>(at(o_len));
+    b->d_order = reinterpret_cast<uint32_t*>(at(o_order));
+    b->d_queue = reinterpret_cast<uint32_t*>(at(o_queue));
+    b->d_items = reinterpret_cast<WorkItem*>(at(o_items));
+    b->d_fwd_items = reinterpret_cast<WorkItem*>(at(o_fwd));
+    b->d_progress = reinterpret_cast<uint32_t*>(at(o_progress));
+    b->d_wscratch = reinterpret_cast<uint32_t*>(at(o_wscratch));
+    stage("workspace");
+    // uploads: blocking copies by default; for a pipeline slot asynchronous copies on its stream, out of
+    // page-locked memory (the slot's staging block, or the caller's arrays when those are page-locked)
+    const bool seqs_pinned = opts != nullptr && opts->seqs_pinned;
+    if(opts == nullptr || opts->staging == nullptr) {
+        if(n_pairs > 0) {
+            B_TRY(hipMemcpy(b->d_desc, b->desc.data(), n_pairs * sizeof(PairDesc), hipMemcpyHostToDevice));
+            B_TRY(hipMemcpy(b->d_order, order.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if(!items.empty()) B_TRY(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+            if(!fwd_items.empty()) B_TRY(hipMemcpy(b->d_fwd_items, fwd_items.data(), fwd_items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+        }
+        stage("descriptors + work items upload");
+        if(a_total > 0) B_TRY(hipMemcpy(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice));
+        if(b_total > 0) B_TRY(hipMemcpy(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice));
+    } else {
+        // a pipeline slot: the group is laid out in the slot's page-locked block exactly as in the workspace and goes
+        // up as one asynchronous copy (queue and progress words as zeros); page-locked caller sequences go directly.
+        // Copies of kMinDmaBytes or less are done by a kernel, not by the copy engine -- which must not happen while
+        // viterbi_ck_stream owns the chip -- so short groups are padded (what follows in the workspace is scratch).
+        const bool stage_a = !seqs_pinned || a_total <= kMinDmaBytes, stage_b = !seqs_pinned || b_total <= kMinDmaBytes;
+        const uint64_t group = stage_a ? (stage_b ? o_up_end : o_b) : o_a;
+        const uint64_t sent = std::max<uint64_t>(group, kMinDmaBytes + 256);
+        const uint64_t b_alone = stage_b && !stage_a ? std::min<uint64_t>(std::max<uint64_t>(b_total, kMinDmaBytes + 256), arena_need - o_b) : 0;
+        if(std::max(sent, o_a + b_alone) > opts->staging_bytes) B_TRY(hipErrorOutOfMemory);
+        char* st = opts->staging;
+        std::memset(st + o_queue, 0, o_items - o_queue);
+        std::memset(st + o_progress, 0, o_a - o_progress);
+        if(n_pairs > 0) {
+            std::memcpy(st + o_desc, b->desc.data(), n_pairs * sizeof(PairDesc));
+            std::memcpy(st + o_order, order.data(), n_pairs * sizeof(uint32_t));
+            if(!items.empty()) std::memcpy(st + o_items, items.data(), items.size() * sizeof(WorkItem));
+            if(!fwd_items.empty()) std::memcpy(st + o_fwd, fwd_items.data(), fwd_items.size() * sizeof(WorkItem));
+        }
+        if(stage_a && a_total > 0) std::memcpy(st + o_a, a_cat + a_off[0], a_total);
+        if(stage_a && stage_b && b_total > 0) std::memcpy(st + o_b, b_cat + b_off[0], b_total);
+        B_TRY(hipMemcpyAsync(at(0), st, sent, hipMemcpyHostToDevice, b->stream));
+        stage("descriptors + work items upload");
+        if(!stage_a) B_TRY(hipMemcpyAsync(b->d_a, a_cat + a_off[0], a_total, hipMemcpyHostToDevice, b->stream));
+        if(!stage_b) {
+            B_TRY(hipMemcpyAsync(b->d_b, b_cat + b_off[0], b_total, hipMemcpyHostToDevice, b->stream));
+        } else if(!stage_a && b_total > 0) {  // (short b beside long page-locked a: staged behind the group, after it has gone)
+            std::memcpy(st + o_a, b_cat + b_off[0], b_total);
+            B_TRY(hipMemcpyAsync(b->d_b, st + o_a, b_alone, hipMemcpyHostToDevice, b->stream));
+        }
+    }
+    stage("sequences upload");
+#undef B_TRY
+    owner.b = nullptr;
+    *out = b;
+    return COATI_HIP_OK;
+}
+
+}  // namespace coati_hip_abi

@@ -1,0 +1,367 @@
+// sample_host.hip -- coati_hip_sampleback: the host loop of the stochastic traceback (kernels and rationale:
+// sampleback.hip; reference: sampleback / marg_sample, src/lib/align_pair.cc:336-458, align_marginal.cc:590-593).
+#include "abi_internal.hpp"
+
+using namespace coati_hip_abi;
+
+namespace {
+// ---- exact-stream sampling in parallel (kernels and rationale: sampleback.hip) ------------------
+// Per chunk and pair: sample j of the chunk is expected to start j * mean draws after the chunk
+// origin; every offset within +-(z * sigma * sqrt(j) + 2), z = 2, of that is walked as a candidate.  The
+// true chain origin -> sample 0 -> sample 1 ... is then followed through the candidates' draw
+// counts; a sample whose true offset was not a candidate ends the chunk for its pair (it becomes
+// sample 0 of the next chunk, whose offset is always a candidate), so the loop always advances.
+using u128 = unsigned __int128;
+constexpr uint64_t kLehmerMult = 0xda942042e4dd58b5ULL;  // contrib/random/random.hpp:95
+
+u128 lehmer_pow(uint64_t n) {
+    u128 r = 1, bpow = kLehmerMult;
+    for(; n != 0; n >>= 1, bpow *= bpow)
+        if(n & 1u) r *= bpow;
+    return r;
+}
+
+hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const uint64_t* rng_state,
+                                  const std::vector<uint64_t>& base, uint8_t* d_ops, uint64_t* d_start, uint32_t* d_len,
+                                  float* d_lw, uint64_t* states_out) {
+    coati_hip_model* m = b->model;
+    const uint64_t n = b->n_pairs;
+    constexpr uint32_t kChunkMax = 512;
+    static const uint32_t kMaxCands = [] {
+        const char* e = std::getenv("COATI_HIP_SPEC_CANDS");
+        const long v = e != nullptr ? std::atol(e) : 0;
+        return v >= 1024 && v <= (1 << 22) ? static_cast<uint32_t>(v) : (1u << 17);  // measured best (tools/sample_bench.py)
+    }();
+    // half-width of a candidate window in standard deviations of the offset; too narrow only ends
+    // a chunk early (COATI_HIP_SPEC_Z overrides, for tuning)
+    static const double kZ = [] {
+        const char* e = std::getenv("COATI_HIP_SPEC_Z");
+        const double v = e != nullptr ? std::atof(e) : 0.0;
+        return v >= 0.25 && v <= 10.0 ? v : 2.0;  // measured (16 x 1 000 samples of 1 kb pairs): z = 5: 38.8 ms, 3: 30.9, 2: 25.9, 1.5: 26.0, 1: 35.9
+    }();
+    size_t free_b = 0, total_b = 0;
+    hipError_t e = hipMemGetInfo(&free_b, &total_b);
+    if(e != hipSuccess) return e;
+    {   // (cached blocks of this model count as free)
+        std::lock_guard<std::mutex> hold(m->arena_lock);
+        for(const auto& a : m->free_arenas) free_b += a.bytes;
+    }
+    // work arena for the candidates' ops: 2 GB, or a power of two below a quarter of the free HBM
+    // (a stable size, so that repeated calls find their block in the cache)
+    uint64_t tmp_budget = 2ull << 30;
+    while(tmp_budget > (1ull << 20) && tmp_budget > free_b / 4) tmp_budget >>= 1;
+
+    uint64_t dbg_rounds = 0, dbg_cands = 0;  // reported with COATI_HIP_TIMING=1
+    struct PairState {
+        u128 st0;
+        uint64_t origin = 0;  // draws consumed by the samples resolved so far
+        uint32_t done = 0, cnt = 0;
+        double mean = 0.0, m2 = 0.0;
+    };
+    std::vector<PairState> ps(n);
+    for(uint64_t p = 0; p < n; ++p) ps[p].st0 = (static_cast<u128>(rng_state[2 * p + 1]) << 64) | rng_state[2 * p];
+
+    uint64_t mult_pow[64];
+    {
+        u128 bpow = kLehmerMult;
+        for(int bit = 0; bit < 32; ++bit, bpow *= bpow) {
+            mult_pow[2 * bit] = static_cast<uint64_t>(bpow);
+            mult_pow[2 * bit + 1] = static_cast<uint64_t>(bpow >> 64);
+        }
+    }
+    // all temporaries in ONE block from the model's workspace cache (a 2 GB hipMalloc per call costs
+    // between 0.4 and several hundred ms, see coati_hip_model::free_arenas)
+    uint64_t *d_origin = nullptr, *d_pow = nullptr, *d_cstart = nullptr;
+    SpecCandidate* d_cands = nullptr;
+    SpecCommit* d_commits = nullptr;
+    uint8_t* d_tmp = nullptr;
+    uint32_t *d_clen = nullptr, *d_cdraws = nullptr;
+    float* d_clw = nullptr;
+    void* block = nullptr;
+    uint64_t block_bytes = 0;
+    auto carve = [&](Carver& cv) {
+        d_origin = cv.take<uint64_t>(2 * n);
+        d_pow = cv.take<uint64_t>(64);
+        d_cstart = cv.take<uint64_t>(kMaxCands);
+        d_cands = cv.take<SpecCandidate>(kMaxCands);
+        d_commits = cv.take<SpecCommit>(std::max<uint64_t>(std::min<uint64_t>(n * kChunkMax, kMaxCands), 1));
+        d_clen = cv.take<uint32_t>(kMaxCands);
+        d_cdraws = cv.take<uint32_t>(kMaxCands);
+        d_clw = cv.take<float>(kMaxCands);
+        d_tmp = cv.take<uint8_t>(tmp_budget);
+    };
+    auto release = [&]() {
+        if(block == nullptr) return;
+        if(hipStreamSynchronize(m->stream) == hipSuccess)
+            model_give_arena(m, block, block_bytes);
+        else
+            (void)hipFree(block);
+        block = nullptr;
+    };
+#define S_TRY(expr)                 \
+    do {                            \
+        e = (expr);                 \
+        if(e != hipSuccess) {       \
+            release();              \
+            return e;               \
+        }                           \
+    } while(0)
+    {
+        Carver sizing;
+        carve(sizing);
+        S_TRY(model_take_arena(m, sizing.used, &block, &block_bytes));
+        Carver cv{static_cast<char*>(block), 0};
+        carve(cv);
+    }
+    S_TRY(hipMemcpyAsync(d_pow, mult_pow, sizeof(mult_pow), hipMemcpyHostToDevice, m->stream));
+
+    struct Window {  // candidates of one (pair, sample-in-chunk)
+        uint32_t first_cand, lo, hi;
+    };
+    std::vector<std::vector<Window>> windows(n);
+    // host sides of the per-round copies, page-locked (a round adds at most one candidate per pair
+    // beyond kMaxCands before the overflow check below)
+    PinnedVec<SpecCandidate> cands;
+    PinnedVec<uint64_t> origin_states;
+    PinnedVec<uint32_t> draws;
+    PinnedVec<SpecCommit> commits;
+    {
+        const uint64_t cap_c = static_cast<uint64_t>(kMaxCands) + n + 16, cap_m = std::min<uint64_t>(n * kChunkMax, cap_c) + 16;
+        Carver sizing;
+        auto carve_host = [&](Carver& cv) {
+            cands.p = cv.take<SpecCandidate>(cap_c);
+            origin_states.p = cv.take<uint64_t>(2 * n);
+            draws.p = cv.take<uint32_t>(cap_c);
+            commits.p = cv.take<SpecCommit>(cap_m);
+        };
+        carve_host(sizing);
+        void* host_block = nullptr;
+        S_TRY(model_pinned(m, sizing.used, &host_block));
+        Carver cv{static_cast<char*>(host_block), 0};
+        carve_host(cv);
+        cands.cap = draws.cap = cap_c;
+        origin_states.cap = origin_states.n = 2 * n;
+        commits.cap = cap_m;
+    }
+    const BatchDeviceView view = device_view(b);
+    try {
+    for(;;) {
+        cands.clear();
+        uint64_t tmp_used = 0;
+        bool any = false;
+        uint64_t active = 0;
+        for(uint64_t p = 0; p < n; ++p) active += ps[p].done < n_samples ? 1 : 0;
+        // every unfinished pair gets an equal share of the candidate and work-arena budget; the chunk
+        // of a pair is as long as its share allows (windows grow with sqrt(j))
+        const uint64_t cand_share = kMaxCands / std::max<uint64_t>(active, 1), tmp_share = tmp_budget / std::max<uint64_t>(active, 1);
+        for(uint64_t p = 0; p < n; ++p) {
+            windows[p].clear();
+            PairState& s = ps[p];
+            if(s.done >= n_samples) continue;
+            any = true;
+            const uint64_t cand_begin = cands.size(), tmp_begin = tmp_used;
+            if(cand_begin + 1 > kMaxCands ||
+               tmp_used + static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb > tmp_budget)
+                continue;  // more unfinished pairs than one round holds: this pair waits for the next round
+            const uint64_t width = static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb;
+            const uint32_t remaining = n_samples - s.done;
+            const uint32_t want = s.cnt == 0 ? 1u : (s.cnt < 4 ? 4u : (s.cnt < 16 ? 16u : kChunkMax));
+            const uint32_t chunk = std::min(remaining, want);
+            // (few observations: widen, a window that is too narrow only ends the chunk early)
+            const double sigma = s.cnt >= 2 ? std::sqrt(s.m2 / (s.cnt - 1)) * (1.0 + 4.0 / s.cnt) + 1.0
+                                            : 0.02 * static_cast<double>(width) + 2.0;
+            for(uint32_t j = 0; j < chunk; ++j) {
+                const int64_t center = std::llround(j * s.mean);
+                const int64_t half = j == 0 ? 0 : static_cast<int64_t>(std::ceil(kZ * sigma * std::sqrt(static_cast<double>(j)))) + 2;
+                const int64_t lo = std::max<int64_t>(center - half, j), hi = std::max<int64_t>(center + half, lo);
+                const uint64_t count = static_cast<uint64_t>(hi - lo + 1);
+                if(j > 0 && (cands.size() - cand_begin + count > cand_share ||
+                            tmp_used - tmp_begin + count * std::max<uint64_t>(width, 1) > tmp_share))
+                    break;
+                windows[p].push_back(Window{static_cast<uint32_t>(cands.size()), static_cast<uint32_t>(lo), static_cast<uint32_t>(hi)});
+                for(int64_t off = lo; off <= hi; ++off) {
+                    cands.push_back(SpecCandidate{static_cast<uint32_t>(p), static_cast<uint32_t>(off), tmp_used});
+                    tmp_used += width;
+                }
+            }
+            const u128 st = s.st0 * lehmer_pow(s.origin);
+            origin_states[2 * p] = static_cast<uint64_t>(st);
+            origin_states[2 * p + 1] = static_cast<uint64_t>(st >> 64);
+        }
+        if(!any) break;
+        if(cands.size() > kMaxCands || tmp_used > tmp_budget) {  // a single sample does not fit the work arena
+            release();
+            return hipErrorOutOfMemory;
+        }
+        const uint32_t nc = static_cast<uint32_t>(cands.size());
+        ++dbg_rounds;
+        dbg_cands += nc;
+        S_TRY(hipMemcpyAsync(d_origin, origin_states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(hipMemcpyAsync(d_cands, cands.data(), nc * sizeof(SpecCandidate), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_spec_walk(view, d_origin, d_pow, d_cands, nc, d_tmp, d_cstart, d_clen, d_clw, d_cdraws, m->stream));
+        draws.resize(nc);
+        S_TRY(hipMemcpyAsync(draws.data(), d_cdraws, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));
+        // follow the chain of true offsets
+        commits.clear();
+        for(uint64_t p = 0; p < n; ++p) {
+            PairState& s = ps[p];
+            const uint64_t width = static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb;
+            uint64_t off = 0;
+            for(const Window& w : windows[p]) {
+                if(off < w.lo || off > w.hi) break;  // not speculated: first sample of the next chunk
+                const uint32_t cand = w.first_cand + static_cast<uint32_t>(off - w.lo);
+                const uint64_t out_index = p * n_samples + s.done;
+                commits.push_back(SpecCommit{cand, 0u, base[p] + (static_cast<uint64_t>(s.done) + 1) * width, out_index});
+                const double x = static_cast<double>(draws[cand]);
+                s.cnt += 1;  // Welford
+                const double d1 = x - s.mean;
+                s.mean += d1 / s.cnt;
+                s.m2 += d1 * (x - s.mean);
+                off += draws[cand];
+                s.done += 1;
+            }
+            s.origin += off;
+        }
+        const uint32_t ncm = static_cast<uint32_t>(commits.size());
+        S_TRY(hipMemcpyAsync(d_commits, commits.data(), ncm * sizeof(SpecCommit), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_spec_commit(d_commits, ncm, d_tmp, d_cstart, d_clen, d_clw, d_ops, d_start, d_len, d_lw, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));  // `commits`/`cands` are reused by the next round
+    }
+    } catch(...) {  // host-side allocation failure: free the device work areas, report at the ABI
+        release();
+        throw;
+    }
+#undef S_TRY
+    if(std::getenv("COATI_HIP_TIMING") != nullptr)
+        std::fprintf(stderr, "sampleback_speculative: %llu rounds, %llu candidate walks for %llu samples\n",
+                     static_cast<unsigned long long>(dbg_rounds), static_cast<unsigned long long>(dbg_cands),
+                     static_cast<unsigned long long>(n * n_samples));
+    for(uint64_t p = 0; p < n; ++p) {
+        const u128 st = ps[p].st0 * lehmer_pow(ps[p].origin);  // where n serial sampleback calls leave the stream
+        states_out[2 * p] = static_cast<uint64_t>(st);
+        states_out[2 * p + 1] = static_cast<uint64_t>(st >> 64);
+    }
+    release();
+    return hipSuccess;
+}
+}  // namespace
+
+namespace {
+int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
+                    float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                    uint64_t* rng_state_out);
+}
+
+int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
+                         float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                         uint64_t* rng_state_out) {
+    try {
+        return sampleback_impl(b, n_samples, rng_state, independent_streams, log_weights, ops, ops_capacity, ops_off, ops_len,
+                               rng_state_out);
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "sampleback: host allocation failed");
+    } catch(const std::exception& ex) {
+        return fail(COATI_HIP_EHIP, "sampleback: %s", ex.what());
+    }
+}
+
+namespace {
+int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
+                    float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                    uint64_t* rng_state_out) {
+    if(b == nullptr || rng_state == nullptr) return fail(COATI_HIP_EINVAL, "sampleback: NULL argument");
+    if(!b->forward_done) return fail(COATI_HIP_ESTATE, "sampleback: forward was not launched");
+    const uint64_t n = b->n_pairs;
+    if(n == 0 || n_samples == 0) return COATI_HIP_OK;
+    coati_hip_model* m = b->model;
+    HIP_TRY(hipSetDevice(m->device));
+    // ops slots: pair p, sample s at sample_base[p] + s * (la + lb)
+    std::vector<uint64_t> base(n);
+    uint64_t total = 0;
+    for(uint64_t p = 0; p < n; ++p) {
+        base[p] = total;
+        total += static_cast<uint64_t>(n_samples) * (static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb);
+    }
+    if(ops != nullptr && ops_capacity < total)
+        return fail(COATI_HIP_EINVAL, "sampleback: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
+                    static_cast<unsigned long long>(total));
+    const uint64_t walkers = independent_streams ? n * n_samples : n;
+    std::vector<uint64_t> states(2 * walkers);
+    if(independent_streams) {
+        // sample s of pair p starts s * 2^32 draws into the pair's stream: state * (MULT^(2^32))^s mod 2^128
+        using u128 = unsigned __int128;
+        u128 jump = static_cast<u128>(0xda942042e4dd58b5ULL);
+        for(int sq = 0; sq < 32; ++sq) jump *= jump;
+        for(uint64_t p = 0; p < n; ++p) {
+            u128 st = (static_cast<u128>(rng_state[2 * p + 1]) << 64) | rng_state[2 * p];
+            for(uint32_t sidx = 0; sidx < n_samples; ++sidx) {
+                states[2 * (p * n_samples + sidx)] = static_cast<uint64_t>(st);
+                states[2 * (p * n_samples + sidx) + 1] = static_cast<uint64_t>(st >> 64);
+                st *= jump;
+            }
+        }
+    } else {
+        std::memcpy(states.data(), rng_state, sizeof(uint64_t) * 2 * n);
+    }
+    const uint64_t n_out = n * n_samples;
+    uint64_t *d_states = nullptr, *d_base = nullptr, *d_start = nullptr;
+    uint8_t* d_ops = nullptr;
+    uint32_t* d_len = nullptr;
+    float* d_lw = nullptr;
+    void* block = nullptr;
+    uint64_t block_bytes = 0;
+    auto carve = [&](Carver& cv) {
+        d_states = cv.take<uint64_t>(states.size());
+        d_base = cv.take<uint64_t>(n);
+        d_start = cv.take<uint64_t>(n_out);
+        d_len = cv.take<uint32_t>(n_out);
+        d_lw = cv.take<float>(n_out);
+        d_ops = cv.take<uint8_t>(std::max<uint64_t>(total, 16));
+    };
+    auto release = [&]() {
+        if(block == nullptr) return;
+        if(hipStreamSynchronize(m->stream) == hipSuccess)
+            model_give_arena(m, block, block_bytes);
+        else
+            (void)hipFree(block);
+        block = nullptr;
+    };
+    auto attempt = [&]() -> hipError_t {
+        hipError_t e;
+        {
+            Carver sizing;
+            carve(sizing);
+            if((e = model_take_arena(m, sizing.used, &block, &block_bytes)) != hipSuccess) return e;
+            Carver cv{static_cast<char*>(block), 0};
+            carve(cv);
+        }
+        // exact stream with several samples per pair: walked in parallel by speculating the stream
+        // offsets (identical results); COATI_HIP_SAMPLE_SEQUENTIAL=1 keeps the one-walker-per-pair loop
+        static const bool sequential = std::getenv("COATI_HIP_SAMPLE_SEQUENTIAL") != nullptr;
+        if(!independent_streams && n_samples >= 4 && !sequential) {
+            if((e = sampleback_speculative(b, n_samples, rng_state, base, d_ops, d_start, d_len, d_lw, states.data())) != hipSuccess) return e;
+            if((e = hipMemcpy(d_states, states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        } else {
+            if((e = hipMemcpyAsync(d_states, states.data(), states.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
+            if((e = hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
+            if((e = launch_sampleback(device_view(b), n_samples, independent_streams != 0, d_states, d_base, d_ops, d_start, d_len,
+                                      d_lw, m->stream)) != hipSuccess) return e;
+            if((e = hipStreamSynchronize(m->stream)) != hipSuccess) return e;
+        }
+        if(log_weights != nullptr && (e = hipMemcpy(log_weights, d_lw, n_out * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(ops != nullptr && total > 0 && (e = hipMemcpy(ops, d_ops, total, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(ops_off != nullptr && (e = hipMemcpy(ops_off, d_start, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(ops_len != nullptr && (e = hipMemcpy(ops_len, d_len, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(rng_state_out != nullptr && !independent_streams &&
+           (e = hipMemcpy(rng_state_out, d_states, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        return hipSuccess;
+    };
+    const hipError_t e = attempt();
+    release();
+    if(e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? COATI_HIP_ENOMEM : COATI_HIP_EHIP, "sampleback: %s", hipGetErrorString(e));
+    return COATI_HIP_OK;
+}
+}  // namespace
+

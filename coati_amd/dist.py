@@ -208,3 +208,34 @@ def simulate(world: int, root: int, a_off, b_off, pair_scores, pair_ops, pair_op
     _check(load().coati_hip_dist_simulate(world, root, n, hip._ptr(a_off), hip._ptr(b_off), chunk_cells, hip._ptr(ps), hip._ptr(po), hip._ptr(pl),
                                           hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln)))
     return scores, ops, off, ln
+
+
+def rendezvous_id(world: int, rank: int, make_id=None, timeout_s: float = 300.0) -> bytes:
+    """The 128-byte communicator id for all ranks of a job started by `torch.distributed.run` (or by hand), through
+    the launcher's TCP store -- BEFORE anything touches a GPU: rank 0 makes the id (`make_id`, default
+    coati_hip_dist_unique_id) and sets it, everybody gets it.  Under torch.distributed.run the agent already serves a
+    store on MASTER_ADDR:MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE) and the workers are clients; otherwise rank 0 serves."""
+    from datetime import timedelta
+
+    from torch.distributed import TCPStore
+
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29533"))
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store), timeout=timedelta(seconds=timeout_s),
+                     wait_for_workers=False)
+    key = "coati/uid/" + os.environ.get("TORCHELASTIC_RUN_ID", "0") + "/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if rank == 0:
+        store.set(key, (make_id or unique_id)())
+    uid = bytes(store.get(key))
+    if len(uid) != ID_BYTES:
+        raise RuntimeError(f"rendezvous: got {len(uid)} bytes for the communicator id")
+    # (the store object must outlive the exchange on rank 0 when it serves: keep it until every rank has the id)
+    store.add(key + "/got", 1)
+    if rank == 0 and not agent_store:
+        import time
+
+        t0 = time.time()
+        while int(store.add(key + "/got", 0)) < world and time.time() - t0 < timeout_s:
+            time.sleep(0.01)
+    return uid

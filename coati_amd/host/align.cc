@@ -17,6 +17,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <unistd.h>
 
 #include "coati_hip.h"
 #include "codon.hpp"
@@ -643,7 +644,27 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
         if(!got) throw std::runtime_error("--devices: rank 0 never published the rendezvous id (" + id_file + ")");
     }
     void* comm = nullptr;
-    dist_check(api.init(id, world, rank, aln.device, &comm));
+    {
+        // RCCL prints its version banner on stdout when a communicator is created; rank 0's stdout is the JSON stream
+        // when no -o is given: send fd 1 to stderr for the duration
+        struct stdout_to_stderr {
+            int saved;
+            stdout_to_stderr() {
+                std::cout.flush();
+                std::fflush(stdout);
+                saved = dup(STDOUT_FILENO);
+                if(saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+            }
+            ~stdout_to_stderr() {
+                std::fflush(stdout);
+                if(saved >= 0) {
+                    dup2(saved, STDOUT_FILENO);
+                    close(saved);
+                }
+            }
+        } quiet;
+        dist_check(api.init(id, world, rank, aln.device, &comm));
+    }
     struct comm_guard {
         const dist_api_t& api;
         void* c;

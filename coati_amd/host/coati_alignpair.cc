@@ -23,11 +23,12 @@ namespace {
 // used the GPU).  Exit status: the first non-zero status of a rank, or 128 + signal.
 int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
     const int world = static_cast<int>(devices.size());
-    char id_path[] = "/tmp/coati-dist-XXXXXX";
-    const int fd = mkstemp(id_path);
-    if(fd < 0) throw std::runtime_error("--devices: cannot create a rendezvous file in /tmp");
-    close(fd);
-    std::remove(id_path);  // rank 0 creates it (by rename) once the id exists
+    // the rendezvous id travels through a file in a directory only this user can enter (mkdtemp: mode 0700), so
+    // that nobody else can plant the file -- or a symlink under the name rank 0 writes -- in /tmp
+    char id_dir[] = "/tmp/coati-dist-XXXXXX";
+    if(mkdtemp(id_dir) == nullptr) throw std::runtime_error("--devices: cannot create a rendezvous directory in /tmp");
+    const std::string id_path_s = std::string(id_dir) + "/id";
+    const char* const id_path = id_path_s.c_str();  // rank 0 creates it (by rename) once the id exists
     char self[4096];
     const ssize_t len = readlink("/proc/self/exe", self, sizeof self - 1);
     if(len <= 0) throw std::runtime_error("--devices: cannot resolve /proc/self/exe");
@@ -74,6 +75,8 @@ int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
         }
     }
     std::remove(id_path);
+    std::remove((id_path_s + ".tmp").c_str());
+    rmdir(id_dir);
     return status_all;
 }
 }  // namespace

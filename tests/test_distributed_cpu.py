@@ -221,3 +221,33 @@ def test_native_simulation_rejects_inconsistent_input():
     dec[5] = dec[4] - 3  # decreasing offsets: the partitioner refuses, the same way on every rank
     with pytest.raises(hip.CoatiHipError):
         nd.chunk_plan(dec, b_off, 2)
+
+
+def test_rendezvous_through_the_launcher_store(tmp_path):
+    """bench.py's N > 1 path gets its communicator id through torch.distributed.run's TCP store before any GPU call
+    (coati_amd/dist.py: rendezvous_id).  Two ranks under the real launcher, and one rank by hand (rank 0 serves)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rdv.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from coati_amd import dist\n"
+        "world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))\n"
+        "uid = dist.rendezvous_id(world, rank, make_id=lambda: bytes((7 * i + 3) % 256 for i in range(128)), timeout_s=60)\n"
+        "assert uid == bytes((7 * i + 3) % 256 for i in range(128))\n"
+        "print('rank', rank, 'ok', flush=True)\n")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 1))
+    for k in ("RANK", "WORLD_SIZE", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "rank 0 ok" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
