@@ -102,7 +102,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
-                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? 1u : 0u};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? 1u : 0u, b->long_pairs ? 1u : 0u};
 }
 
 
@@ -375,7 +375,7 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
         if(b->ck)
             HIP_TRY(launch_viterbi_ck(v, m->n_tables == 1, b->stream));
         else if(m->gap_len == 1 && !force_generic)
-            HIP_TRY(launch_viterbi_l1(v, b->stream));
+            HIP_TRY(v.long_pairs != 0 ? launch_viterbi_lp(v, b->stream) : launch_viterbi_l1(v, b->stream));
         else if(b->compact)
             HIP_TRY(launch_viterbi_k(v, b->compact_narrow_only, b->stream));
         else

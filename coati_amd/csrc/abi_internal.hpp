@@ -105,6 +105,7 @@ struct coati_hip_batch {
     WorkItem* d_items = nullptr;   // viterbi_l1 work list: (pair, strip), longest pairs first
     WorkItem* d_fwd_items = nullptr;  // forward_l1 work list (1024-column strips)
     uint32_t n_fwd_items = 0;
+    bool long_pairs = false;     // decision-bit plan with 4-column strips throughout (a few long pairs): viterbi_lp runs it
     bool ck_keep_all = false;    // viterbi_ck keeps every checkpoint (no band): the debug export decodes every tile
     uint32_t fwd_wlog2_max = 4;  // widest Forward strip shape of the batch (forward_l1 has a leaner build for <= 8 columns per lane)
     uint32_t* d_progress = nullptr;

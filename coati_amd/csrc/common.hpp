@@ -455,8 +455,12 @@ struct BatchDeviceView {
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
     uint32_t fwd_wlog2_max;  // forward_l1: the widest strip shape of the batch (log2 of the columns per lane)
     uint32_t ck_keep_all;    // viterbi_ck: 1 = keep every checkpoint (debug export), 0 = the banded default
+    uint32_t long_pairs;     // decision-bit plan of a few long pairs (every strip 4 columns per lane): viterbi_lp fills it
 };
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
+// viterbi_lp.hip: the same fill (same decision-bit layout, same strip pipeline) issued for wavefronts that are alone
+// on their SIMDs; 4-column strips only
+hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream);
 // Compute units of the current device (hipDeviceAttributeMultiprocessorCount), at most 256: the persistent
 // kernels size their grids to what is RESIDENT (a partitioned or CU-masked device has fewer than the MI355X's
 // 256; a grid sized for 256 would oversubscribe it and the residency the queue discipline assumes would not

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate coati_amd/csrc/viterbi_lp_block.inc: the hand-allocated gfx950 instruction text of
+viterbi_lp.hip's 16-step blocks (4 columns per lane), as two string-literal macros.
+
+Why generated text and not C++: a wavefront that is ALONE on its SIMD (a single long pair cut into
+strips: fewer strips than SIMDs) issues one instruction per ~4.3 cycles whatever the instruction
+(profiles/r03/ubench_issue_model.txt), so the only thing that counts is the NUMBER of
+instructions per step -- and there v_pk_add_f32 does two of the cell's additions for the price of
+one (profiles/r03/ubench_issue_model.txt, "pure v_pk_add_f32": 5.1 cycles alone, like v_add_f32).
+The packed form needs its operands in even-aligned register PAIRS and the maxima read the halves
+of those pairs: inline-asm operands cannot name half of a 64-bit operand, so the block names its
+registers itself (COATI_LP_* pins them in viterbi_lp.hip).
+
+One step of one lane (its 4 columns of one row), in the reference's evaluation order
+(src/lib/align_pair.cc:97-124, gap_len 1) -- the same fp32 operations as viterbi_cell.hpp's
+25-instruction cell, 19 instructions per cell:
+    M  = diag + s                         v_add_f32 (cell 0: DPP from the left lane)
+    [z1:m1] = M + [go:ng]                 v_pk_add_f32
+    [z2:i1] = I + [ge:gs]                 v_pk_add_f32
+    [x1:y1] = m1 + [ng:go]                v_pk_add_f32
+    [x2:y2] = D + [gs:ge]                 v_pk_add_f32
+    [x3:y3] = i1 + [ng:go]                v_pk_add_f32
+    Z = max(z1, z2); X = max3(x1, x2, x3); Y = max3(y1, y2, y3)
+    decision bits: signs of z2-z1, [x1-X : y1-Y], [x2-X : y2-Y] (v_sub_f32, 2 x v_pk_add_f32 with neg),
+    deposited with five v_alignbit_b32 -- the same five bits in the same accumulators and order as
+    viterbi_cell.hpp, so the traceback (common.hpp) reads the same layout.
+Hand-off between lanes: DPP wave_shr:1; lane 0 takes the strip's left boundary from lane j of the
+16-row chunk registers with a row_shl:j DPP confined to lanes 0-3 (the wave_shr that follows
+overwrites lanes 1-3).  The diagonal input is the left lane's X of its last column from BEFORE its
+previous step: cell 3 ping-pongs its [X:Y] pair between two register pairs instead of copying.
+
+usage: python coati_amd/csrc/gen_viterbi_lp.py   (writes viterbi_lp_block.inc next to itself)
+"""
+from pathlib import Path
+
+# ---- physical VGPRs (pairs must be even-aligned)
+CA, CB = 2, 4                  # [go:ng], [ge:gs]
+P = [8, 10, 12]                # [X:Y] of columns 0..2
+P3A, P3B = 14, 16              # column 3 ping-pong
+ZL = 28                        # v28 = Z carried along the row, v29 = Z handed in by the left lane
+M = 30                         # v30 (v31 unused)
+T1, T2, T3, T4, T5 = 32, 34, 36, 38, 40
+TS, ADDR = 42, 43
+PINNED_CLOBBERS = [29, 30, 31] + list(range(32, 44))
+
+
+def pair(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def step(j, first, bnd):
+    """step j (0..15) of a block; first: lanes take their margin-row state at step == lane;
+    bnd: lane 63 publishes the strip's right boundary (dropped by its offset register elsewhere)"""
+    L = []
+    even = j % 2 == 0
+    src3 = P3B if even else P3A    # the left lane's X of column 3 before its previous step
+    cur3 = P3A if even else P3B    # column 3's state entering this step
+    new3 = P3B if even else P3A    # ... and leaving it
+    ar_src, ar_dst = ("%[ara]", "%[arb]") if even else ("%[arb]", "%[ara]")
+    sel = f"row_shl:{j}" if j else "quad_perm:[0,1,2,3]"
+    lane0 = f"{sel} row_mask:0x1 bank_mask:0x1"
+    shr = "wave_shr:1 row_mask:0xf bank_mask:0xf"
+    L.append("s_waitcnt lgkmcnt(0)")
+    if first:
+        L.append(f"v_cmp_eq_u32_e32 vcc, {j}, %[lrel]")
+        for c in range(4):
+            r = P[c] if c < 3 else cur3
+            L.append(f"v_cndmask_b32_e32 v{r}, v{r}, %[mx{c}], vcc")
+            L.append(f"v_cndmask_b32_e32 v{r + 1}, v{r + 1}, %[my{c}], vcc")
+    # hand-off: M of column 0, the I input, the table row of the NEXT step
+    L.append(f"v_add_f32_dpp v{M}, %[bx], %[s0] {lane0}")
+    L.append(f"v_add_f32_dpp v{M}, v{src3}, %[s0] {shr}")
+    L.append(f"v_mov_b32_dpp v{ZL + 1}, %[bz] {lane0}")
+    L.append(f"v_mov_b32_dpp v{ZL + 1}, v{ZL} {shr}")
+    L.append(f"v_mov_b32_dpp {ar_dst}, %[ach] {lane0}")
+    L.append(f"v_mov_b32_dpp {ar_dst}, {ar_src} {shr}")
+    for c in range(4):
+        rd = P[c] if c < 3 else cur3
+        wr = P[c] if c < 3 else new3
+        zsel = "op_sel:[1,0] op_sel_hi:[1,1]" if c == 0 else "op_sel:[0,0] op_sel_hi:[0,1]"
+        L += [
+            f"v_pk_add_f32 {pair(T1)}, {pair(M)}, {pair(CA)} op_sel:[0,0] op_sel_hi:[0,1]",   # [z1:m1] = M + [go:ng]
+            f"v_pk_add_f32 {pair(T2)}, {pair(ZL)}, {pair(CB)} {zsel}",                       # [z2:i1] = I + [ge:gs]
+            f"v_pk_add_f32 {pair(T3)}, {pair(T1)}, {pair(CA)} op_sel:[1,1] op_sel_hi:[1,0]",  # [x1:y1] = m1 + [ng:go]
+            f"v_pk_add_f32 {pair(T4)}, {pair(rd)}, {pair(CB)} op_sel:[1,1] op_sel_hi:[1,0]",  # [x2:y2] = D + [gs:ge]
+            f"v_pk_add_f32 {pair(T5)}, {pair(T2)}, {pair(CA)} op_sel:[1,1] op_sel_hi:[1,0]",  # [x3:y3] = i1 + [ng:go]
+        ]
+        if c < 3:
+            L.append(f"v_add_f32 v{M}, v{rd}, %[s{c + 1}]")                                  # M of the next column
+        L += [
+            f"v_max_f32 v{ZL}, v{T1}, v{T2}",                                                 # Z
+            f"v_sub_f32 v{TS}, v{T2}, v{T1}",                                                 # z2 - z1
+            f"v_max3_f32 v{wr}, v{T3}, v{T4}, v{T5}",                                         # X
+            f"v_max3_f32 v{wr + 1}, v{T3 + 1}, v{T4 + 1}, v{T5 + 1}",                         # Y
+            f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{c}]",
+            f"ds_read_b32 %[s{c}], v{ADDR}",
+            f"v_alignbit_b32 %[ac], %[ac], v{TS}, 31",                                        # IM
+            f"v_pk_add_f32 {pair(T3)}, {pair(T3)}, {pair(wr)} neg_lo:[0,1] neg_hi:[0,1]",     # [x1-X : y1-Y]
+            f"v_pk_add_f32 {pair(T4)}, {pair(T4)}, {pair(wr)} neg_lo:[0,1] neg_hi:[0,1]",     # [x2-X : y2-Y]
+            f"v_alignbit_b32 %[aa], %[aa], v{T3}, 31",                                        # M1
+            f"v_alignbit_b32 %[aa], %[aa], v{T4}, 31",                                        # M2
+            f"v_alignbit_b32 %[ab], %[ab], v{T3 + 1}, 31",                                    # D1
+            f"v_alignbit_b32 %[ab], %[ab], v{T4 + 1}, 31",                                    # D2
+        ]
+    if bnd:
+        L.append(f"buffer_store_dword v{new3}, %[offx], %[rs_out], %[so_out] offen offset:{4 * j + 4} sc1")
+        L.append(f"buffer_store_dword v{ZL}, %[offz], %[rs_out], %[so_out] offen offset:{4 * j} sc1")
+    if j % 4 == 3:
+        base = (j // 8) * 1280 + ((j % 8) // 4) * 512
+        L.append(f"buffer_store_dword %[aa], %[offb], %[rs_bits], %[so_bits] offen offset:{base}")
+        L.append(f"buffer_store_dword %[ab], %[offb], %[rs_bits], %[so_bits] offen offset:{base + 256}")
+    if j % 8 == 7:
+        L.append(f"buffer_store_dword %[ac], %[offb], %[rs_bits], %[so_bits] offen offset:{(j // 8) * 1280 + 1024}")
+    return L
+
+
+def block(first):
+    bnd = not first
+    L = ["buffer_load_dword %[nx], %[vin_x], %[rs_in], 0 offen sc1",
+         "buffer_load_dword %[nz], %[vin_z], %[rs_in], 0 offen sc1",
+         "buffer_load_ubyte %[na], %[vin_a], %[rs_a], 0 offen"]
+    vmem_after = 0
+    for j in range(16):
+        s = step(j, first, bnd)
+        vmem_after += sum(1 for x in s if x.startswith("buffer_"))
+        L += s
+    # the chunk loads are the block's OLDEST vector-memory operations and the counter retires in issue order
+    L.append(f"s_waitcnt vmcnt({vmem_after}) lgkmcnt(0)")
+    return L, vmem_after
+
+
+def emit(name, lines):
+    out = [f"#define {name} \\"]
+    for i, x in enumerate(lines):
+        end = "" if i + 1 == len(lines) else " \\"
+        out.append(f'    "{x}\\n\\t"{end}')
+    return "\n".join(out) + "\n"
+
+
+def main():
+    first, n_first = block(True)
+    main_, n_main = block(False)
+    clob = ", ".join(f'"v{r}"' for r in PINNED_CLOBBERS)
+    text = ("// GENERATED by gen_viterbi_lp.py -- do not edit (see that script for what the text does)\n"
+            f"// instructions per 16-step block: first {len(first)}, main {len(main_)}\n"
+            + emit("COATI_LP_BLOCK_FIRST_ASM", first) + emit("COATI_LP_BLOCK_MAIN_ASM", main_)
+            + f"#define COATI_LP_SCRATCH_CLOBBERS {clob}\n")
+    Path(__file__).with_name("viterbi_lp_block.inc").write_text(text)
+    print(f"first block {len(first)} instructions ({n_first} stores), main block {len(main_)} ({n_main} stores)")
+
+
+if __name__ == "__main__":
+    main()

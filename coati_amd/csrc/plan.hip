@@ -249,6 +249,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             constexpr long double kShortPair = 250.0L * 250.0L;
             if(w_main < kW || (live > 0 && cells / live < kShortPair)) b->ck = false;
         }
+        // a decision-bit plan of 4-column strips throughout is the "few long pairs" regime: viterbi_lp fills it (the same
+        // layout, half the instructions per step; COATI_HIP_L1_LP=0 keeps viterbi_l1, the A/B partner)
+        const char* lp_env = std::getenv("COATI_HIP_L1_LP");
+        b->long_pairs = !b->ck && w_main == 4 && !(lp_env != nullptr && lp_env[0] == '0') && std::getenv("COATI_HIP_L1_PROGRESS") == nullptr;
         const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
         uint64_t tail_pairs = 0;
         if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {

@@ -1,0 +1,359 @@
+// viterbi_lp: the gap_len-1 Viterbi fill for a FEW LONG pairs (BASELINE configs[2]: one 160 kb pair) --
+// the batches whose strip plan has fewer strips than the GPU has SIMDs, so that every strip is 4 columns per
+// lane wide and every wavefront is alone on its SIMD.  Same recurrence, same five decision bits per cell in
+// the same HBM layout as viterbi_l1.hip (the traceback of common.hpp reads both), same strip pipeline through
+// self-validating boundary values; what differs is how a step is issued.
+//
+// What it replaces in the reference: forward_impl<tropical, align_pair_work_mem_t> (src/lib/align_pair.cc:62-139)
+// and traceback<tropical> (align_pair.cc:249-303) for one pair that the CPU tool cannot hold in memory.
+//
+// A lone wavefront issues one instruction per ~4.3 cycles WHATEVER the instruction
+// (profiles/r03/ubench_issue_model.txt), so its time is its instruction count.  viterbi_l1's 4-column step is
+// ~175 instructions (27 per cell + ~67 of hand-off, stores, bookkeeping); here a step is ~87:
+//   * the cell's eleven additions are six (v_pk_add_f32 does two fp32 additions -- IEEE, the same bits -- in one
+//     instruction) and the five sign differences of the decisions three: 19 instructions per cell, LDS gather
+//     included (gen_viterbi_lp.py has the list);
+//   * 16 steps are ONE block of hand-allocated instruction text: lane 0 takes the strip's left boundary straight
+//     from lane j of the chunk registers by a row_shl:j DPP, stores use immediate offsets, cell 3 ping-pongs its
+//     state between two register pairs so that the diagonal hand-off needs no copy;
+//   * the left boundary arrives in 16-row chunks that are loaded one block AHEAD (at the top of the block before)
+//     and checked after it, so a strip follows its left neighbour at 63 + 32 steps, not 63 + 64 + a memory round
+//     trip per chunk -- with 626 strips in a 160 kb pair the sum of those lags is a third of the time.
+// fp32 only, adds/max/compares in the reference's evaluation order; built with -ffp-contract=off.
+#include "viterbi_cell.hpp"
+
+#include "viterbi_lp_block.inc"
+
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
+namespace coati_hip_detail {
+namespace {
+
+constexpr int kLpW = 4;        // columns per lane
+constexpr uint32_t kLpRows = 16;  // steps per block = rows per boundary chunk
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor in four SGPRs: base, no stride, `bytes` valid (the VGPR offset is range-checked against it:
+// reads beyond return 0, writes beyond are dropped), 32-bit data format
+__device__ __forceinline__ u32x4 lp_rsrc(const void* p, uint64_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    u32x4 r;
+    r.x = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
+    r.y = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32))) & 0xffffu;
+    r.z = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(std::min<uint64_t>(bytes, 0x7ffffff0ull))));
+    r.w = 0x00020000u;
+    return r;
+}
+constexpr uint32_t kLpDrop = 0x80000000u;  // offset register of a lane that does not store (out of every range)
+
+// what one strip's wavefront keeps besides the LaneState: named operands of the blocks
+struct LpStrip {
+    GapVec kv;
+    uint32_t bl[kLpW];   // LDS byte address of the lane's column c in table row 0
+    uint32_t offx, offz, offb;  // per-lane offsets: boundary X / Z stores (lane 63, or kLpDrop), decision rows
+    u32x4 rs_in, rs_out, rs_bits, rs_a;
+    float mx[kLpW], my[kLpW];  // the lane's margin-row state (taken at step == lane)
+};
+
+// 16 wavefront steps from `kbase`.  In: the chunk (bx, bz, ach: lane j < 16 holds the strip's left boundary of row
+// kbase + j and the table row offset of ancestor row kbase + j + 1).  Out: the raw next chunk (rows kbase + 16 ...).
+template <bool kFirst>
+__device__ __forceinline__ void lp_block(const LpStrip& sp, LaneState<kLpW>& st, uint32_t& arow, float (&s)[kLpW], uint32_t kbase,
+                                         int lane, uint32_t la, float bx, float bz, uint32_t ach, uint32_t& nx, uint32_t& nz,
+                                         uint32_t& na) {
+    uint32_t arb;
+    const uint32_t next = kbase + kLpRows + static_cast<uint32_t>(lane);
+    const uint32_t vin_x = next * 4u, vin_z = (la + 1u + next) * 4u, vin_a = next + 1u;
+    const uint32_t so_bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase / 8u) * (kPairDwords * 4u))));
+#define COATI_LP_STATE                                                                                                        \
+    "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.X[2]), "+{v13}"(st.Y[2]),          \
+        "+{v14}"(st.X[3]), "+{v15}"(st.Y[3]), "+{v16}"(st.xlast_old), "+{v28}"(st.zlast), [s0] "+v"(s[0]), [s1] "+v"(s[1]), \
+        [s2] "+v"(s[2]), [s3] "+v"(s[3]), [ara] "+v"(arow), [arb] "=&v"(arb), [aa] "+v"(st.acc[ACC_A]),                       \
+        [ab] "+v"(st.acc[ACC_B]), [ac] "+v"(st.acc[ACC_C]), [nx] "=&v"(nx), [nz] "=&v"(nz), [na] "=&v"(na)
+#define COATI_LP_INPUTS                                                                                                       \
+    "{v2}"(sp.kv.go), "{v3}"(sp.kv.ng), "{v4}"(sp.kv.ge), "{v5}"(sp.kv.gs), [bx] "v"(bx), [bz] "v"(bz), [ach] "v"(ach),       \
+        [bl0] "v"(sp.bl[0]), [bl1] "v"(sp.bl[1]), [bl2] "v"(sp.bl[2]), [bl3] "v"(sp.bl[3]), [offb] "v"(sp.offb),              \
+        [vin_x] "v"(vin_x), [vin_z] "v"(vin_z), [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits),         \
+        [rs_a] "s"(sp.rs_a), [so_bits] "s"(so_bits)
+    if constexpr(kFirst) {
+        const uint32_t lrel = static_cast<uint32_t>(lane) - kbase;  // the lane starts at step kbase + lrel
+        asm volatile(COATI_LP_BLOCK_FIRST_ASM
+                     : COATI_LP_STATE
+                     : COATI_LP_INPUTS, [lrel] "v"(lrel), [mx0] "v"(sp.mx[0]), [mx1] "v"(sp.mx[1]), [mx2] "v"(sp.mx[2]),
+                       [mx3] "v"(sp.mx[3]), [my0] "v"(sp.my[0]), [my1] "v"(sp.my[1]), [my2] "v"(sp.my[2]), [my3] "v"(sp.my[3])
+                     : COATI_LP_SCRATCH_CLOBBERS, "v17", "vcc", "memory");
+    } else {
+        // lane 63 did body row kbase + j - 63 at step j: X of its last column goes to bnd_x[row + 1], Z to bnd_z[row]
+        const uint32_t so_out = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase - (kWave - 1u)) * 4u)));
+        asm volatile(COATI_LP_BLOCK_MAIN_ASM
+                     : COATI_LP_STATE
+                     : COATI_LP_INPUTS, [offx] "v"(sp.offx), [offz] "v"(sp.offz), [rs_out] "s"(sp.rs_out), [so_out] "s"(so_out)
+                     : COATI_LP_SCRATCH_CLOBBERS, "v17", "memory");
+    }
+#undef COATI_LP_STATE
+#undef COATI_LP_INPUTS
+}
+
+// One step in plain C++ (viterbi_cell.hpp's cell): the strip's last nsteps % 16 steps, and every step of a strip
+// shorter than a block.  kFirst: the lane takes its margin-row state when the step is its first.
+template <bool kFirst>
+__device__ __forceinline__ void lp_tail_step(const LpStrip& sp, LaneState<kLpW>& st, uint32_t& arow, float (&s)[kLpW],
+                                             const uint32_t (&boff)[kLpW], uint32_t lds_tab, uint32_t kstep, uint32_t kk, int lane,
+                                             uint32_t la, bool last_strip, uint32_t* fout, float* bnd_x, float* bnd_z, uint32_t ach,
+                                             float bx, float bz) {
+    constexpr uint32_t kMA = 16 / kLpW, kMC = 32 / kLpW;
+    if constexpr(kFirst) {
+        if(kstep == static_cast<uint32_t>(lane)) {
+#pragma unroll
+            for(int c = 0; c < kLpW; ++c) {
+                st.X[c] = sp.mx[c];
+                st.Y[c] = sp.my[c];
+            }
+        }
+    }
+    const float diag = shift_in(st.xlast_old, read_lane(bx, static_cast<int>(kk)));
+    const float zl = shift_in(st.zlast, read_lane(bz, static_cast<int>(kk)));
+    const uint32_t arow_next = shift_in(arow, read_lane(ach, static_cast<int>(kk)));
+    row_l1<kLpW>(sp.kv, st, diag, zl, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, kLpW>{});
+    arow = arow_next;
+    if((kstep & (kMA - 1u)) == kMA - 1u) {
+        const uint32_t q = kstep & (kMC - 1u);
+        uint32_t* dst = fout + static_cast<uint64_t>(kstep / kMC) * kPairDwords + (q / kMA) * (2 * kWave);
+        dst[0] = st.acc[ACC_A];
+        dst[kWave] = st.acc[ACC_B];
+        if(q == kMC - 1u) fout[static_cast<uint64_t>(kstep / kMC) * kPairDwords + 4 * kWave] = st.acc[ACC_C];
+    }
+    const int r = static_cast<int>(kstep) - lane;
+    if(!last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(la)) {
+        store_through(&bnd_x[r + 1], st.X[kLpW - 1]);
+        store_through(&bnd_z[r], st.zlast);
+    }
+}
+
+// One work item: one strip (256 descendant columns) of one pair, all its rows.  Returns false if the left neighbour's
+// boundary column did not arrive within the spin bound.
+__device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip, uint32_t ticket,
+                                              int lane, uint32_t lds_tab, const char* tab_bytes, const uint8_t* __restrict__ a,
+                                              const uint8_t* __restrict__ b, uint32_t* __restrict__ flags, float* __restrict__ bnd,
+                                              float* __restrict__ scores, uint32_t* __restrict__ progress) {
+    constexpr int W = kLpW;
+    const uint32_t la = pd.la, lb = pd.lb;
+    const uint32_t col0 = strip * (kWave * W);
+    const uint32_t ncol = min(static_cast<uint32_t>(kWave * W), lb - col0);
+    const uint32_t nlanes = (ncol + W - 1) / W;
+    const uint32_t nsteps = la + nlanes - 1;
+    const bool last_strip = strip + 1 == pd.v_strips;
+    uint32_t* __restrict__ fout_strip = flags + pd.flags_off + strip * strip_dwords(la, W);
+    uint32_t* __restrict__ fout = fout_strip + lane;
+    // strip-boundary columns (layout: viterbi_l1.hip fill_strip)
+    const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
+    float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
+    float* __restrict__ bnd_z = bnd_x + (la + 1);
+    const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
+    const float* __restrict__ in_z = in_x + (la + 1);
+    bool handoff_ok = true;
+
+    uint32_t boff[W];
+    LpStrip sp;
+    sp.kv = gap_vec(k);
+#pragma unroll
+    for(int c = 0; c < W; ++c) {
+        const uint32_t bj = col0 + lane * W + c;
+        boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+        sp.bl[c] = boff[c] + lds_tab;
+        // margin row (matrix row 0, align_pair.cc:88-90): M = D = lowest, I = go + ge*float(j-1)
+        const float im = k.go + k.ge * static_cast<float>(bj);
+        const float i1 = im + k.gs;
+        sp.mx[c] = i1 + k.ng;
+        sp.my[c] = i1 + k.go;
+    }
+    const bool publisher = !last_strip && lane == kWave - 1;
+    sp.offx = publisher ? 0u : kLpDrop;
+    sp.offz = publisher ? (la + 1u) * 4u : kLpDrop;
+    sp.offb = static_cast<uint32_t>(lane) * 4u;
+    sp.rs_in = lp_rsrc(in_x, strip > 0 ? bstride * 4u : 0u);
+    sp.rs_out = lp_rsrc(bnd_x, bstride * 4u);
+    sp.rs_bits = lp_rsrc(fout_strip, strip_dwords(la, W) * 4u);
+    sp.rs_a = lp_rsrc(a, la);
+    if(publisher) store_through(&bnd_x[0], sp.mx[W - 1]);  // (boundary index 0 is the margin row)
+
+    LaneState<W> st;
+#pragma unroll
+    for(int c = 0; c < W; ++c) st.X[c] = st.Y[c] = 0.0f;
+#pragma unroll
+    for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
+    st.xlast_old = 0.0f;
+    st.zlast = 0.0f;
+    uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+    float s[W];
+#pragma unroll
+    for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
+
+    // The chunk of rows r0 .. r0+15 from its raw loads (lanes 0..15): the left neighbour's values once they are all
+    // there (they were 0xffffffff before the launch; rows that are not come again, bypassing the L2, until they are),
+    // the matrix' column 0 for the first strip (align_pair.cc:82-86).
+    float bx = kLowest, bz = kLowest;
+    uint32_t ach = 0;
+    auto take_chunk = [&](uint32_t r0, uint32_t xb, uint32_t zb, uint32_t code) {
+        const uint32_t crow = r0 + static_cast<uint32_t>(lane);
+        const bool mine = lane < static_cast<int>(kLpRows) && crow < la;
+        bx = bz = kLowest;
+        if(strip == 0) {
+            if(mine) bx = crow == 0 ? (0.0f + k.ng) + k.ng : ((k.ng + k.go) + k.ge * static_cast<float>(crow - 1)) + k.gs;
+        } else {
+            // (the first test is on the values the block loaded; the loop's own loads -- and the waits for them, which
+            // also wait for the block's stores -- stay on the slow path)
+            auto all_there = [&] { return __builtin_amdgcn_ballot_w64(!mine || (xb != 0xffffffffu && zb != 0xffffffffu)) == ~0ull; };
+            if(__builtin_expect(!all_there(), 0)) {
+                for(uint32_t spins = 0;; ++spins) {
+                    if(spins > (1u << 24)) {
+                        handoff_ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    if(mine) {
+                        xb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(in_x) + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        zb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(in_z) + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if(all_there()) break;
+                }
+            }
+            if(mine) {
+                bx = __builtin_bit_cast(float, xb);
+                bz = __builtin_bit_cast(float, zb);
+            }
+        }
+        ach = code * (kTabStride * 4u);  // (0 beyond the last row: the load is range-checked)
+        asm volatile("" : "+v"(ach), "+v"(bx), "+v"(bz));
+    };
+    {
+        const uint32_t crow = static_cast<uint32_t>(lane);
+        take_chunk(0, 0xffffffffu, 0xffffffffu, crow + 1 < la ? static_cast<uint32_t>(a[crow + 1]) : 0u);
+    }
+    uint32_t kbase = 0;
+    // (two loops, not one with a branch: the state stays in the registers the blocks name)
+    for(; kbase < static_cast<uint32_t>(kWave) && kbase + kLpRows <= nsteps; kbase += kLpRows) {
+        uint32_t nx, nz, na;
+        lp_block<true>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
+        // step 63 is lane 63's first row
+        if(kbase + kLpRows == static_cast<uint32_t>(kWave) && publisher) {
+            store_through(&bnd_x[1], st.X[W - 1]);
+            store_through(&bnd_z[0], st.zlast);
+        }
+        take_chunk(kbase + kLpRows, nx, nz, na);
+    }
+    for(; kbase + kLpRows <= nsteps; kbase += kLpRows) {
+        uint32_t nx, nz, na;
+        lp_block<false>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
+        take_chunk(kbase + kLpRows, nx, nz, na);
+    }
+    for(uint32_t kk = 0; kbase + kk < nsteps; ++kk) {
+        if(kbase < static_cast<uint32_t>(kWave))
+            lp_tail_step<true>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
+        else
+            lp_tail_step<false>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
+    }
+    // score = X of the last body cell (align_pair.cc:130-138,265): held by the lane of the last column after the last step
+    const int last_lane = static_cast<int>((lb - 1 - col0) / W), last_c = static_cast<int>((lb - 1 - col0) % W);
+    if(last_strip && lane == last_lane) {
+        float sc = st.X[0];
+#pragma unroll
+        for(int c = 1; c < W; ++c) sc = (c == last_c) ? st.X[c] : sc;
+        scores[pair] = sc;
+    }
+    // flush the accumulators of an incomplete last dword, left-aligned (layout in common.hpp)
+    {
+        constexpr uint32_t kMA = 16 / W, kMC = 32 / W;
+        const uint32_t g = nsteps / kMC, q = nsteps & (kMC - 1u);
+        const uint32_t ra = nsteps & (kMA - 1u);
+        if(ra != 0) {
+            uint32_t* dst = fout + static_cast<uint64_t>(g) * kPairDwords + (q / kMA) * (2 * kWave);
+            dst[0] = st.acc[ACC_A] << (32u - 2u * W * ra);
+            dst[kWave] = st.acc[ACC_B] << (32u - 2u * W * ra);
+        }
+        if(q != 0) fout[static_cast<uint64_t>(g) * kPairDwords + 4 * kWave] = st.acc[ACC_C] << (32u - W * q);
+    }
+    if(strip > 0) {
+        // (the chain "every earlier strip has released its decision bits" runs through the progress words)
+        handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, la);
+        if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+    }
+    if(!last_strip) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        publish_progress(progress + ticket, handoff_ok ? la : kHandoffPoison, lane == kWave - 1);
+    }
+    return handoff_ok;
+}
+
+__global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
+    const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ items,
+    uint32_t n_items, uint32_t* __restrict__ queue, uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,
+    const uint8_t* __restrict__ b_cat, uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
+    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
+    __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];
+    const int lane_id = threadIdx.x & (kWave - 1);
+    float* tab = tab_all[threadIdx.x / kWave];
+    uint32_t tab_held = 0xffffffffu;
+    const char* tab_bytes = reinterpret_cast<const char*>(tab);
+    const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
+    for(;;) {
+        int lane = lane_id;
+        asm volatile("" : "+v"(lane));  // (see viterbi_l1)
+        uint32_t ticket = atomicAdd(queue, lane == 0 ? 1u : 0u);
+        ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+        if(ticket >= n_items) break;
+        const WorkItem item = items[ticket];
+        const uint32_t pair = item.pair, strip = item.strip;
+        const PairDesc pd = pairs[pair];
+        bool handoff_ok = true;
+        if(pd.table != tab_held) {  // (wave-uniform)
+            const float* __restrict__ src = table + static_cast<size_t>(pd.table) * kTabFloats;
+            for(int idx = lane; idx < kTabFloats; idx += kWave) {
+                const int r = idx / kTabCols, c = idx - r * kTabCols;
+                tab[r * kTabStride + c] = src[idx];
+            }
+            tab_held = pd.table;
+        }
+        if(pd.la > 0 && pd.lb > 0)
+            handoff_ok = fill_strip_lp(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off, flags,
+                                       bnd, scores, progress);
+        if(strip + 1 < pd.v_strips) continue;  // the pair's traceback runs on the wavefront of its LAST strip
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
+        if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
+    }
+}
+
+}  // namespace
+
+// The launch has one workgroup (one wavefront per SIMD) on every CU while the items fit, up to three after that,
+// enforced by LDS padding like viterbi_l1's.
+hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
+    if(e != hipSuccess) return e;
+    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);
+    if(e != hipSuccess) return e;
+    if(v.bnd_bytes != 0) {  // the boundary values validate themselves: everything starts as the NaN pattern 0xffffffff
+        e = hipMemsetAsync(v.bnd, 0xff, v.bnd_bytes, stream);
+        if(e != hipSuccess) return e;
+    }
+    const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
+    const int best = static_cast<int>(std::clamp<uint64_t>((static_cast<uint64_t>(v.n_items) + kSimds - 1) / kSimds, 1, 3));
+    constexpr size_t kStatic = kFillWaves * kTabRows * kTabStride * sizeof(float);
+    constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 52 * 1024};
+    const size_t dyn = kPerBlock[best] - ((kStatic + 255) / 256) * 256;
+    if(dyn > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_lp), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn));
+        if(e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(viterbi_lp, dim3(kCUs * static_cast<uint32_t>(best)), dim3(kFillWaves * kWave), dyn, stream, v.table, v.k, v.pairs,
+                       v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops, v.ops_start,
+                       v.ops_len);
+    return hipGetLastError();
+}
+
+}  // namespace coati_hip_detail

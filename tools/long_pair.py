@@ -42,13 +42,14 @@ model = hip.Model(table, consts, L)
 t0 = time.time()
 batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
 t_create = time.time() - t0
-ms = []
+ms, fw = [], []
 for r in range(args.reps + 1):
     batch.viterbi_launch()
     batch.sync()
     f, w = batch.viterbi_timing()
     if r:
         ms.append(f + w)
+        fw.append((f, w))
 scores, ops, off, ln = batch.viterbi_fetch()
 path = ops[int(off[0]):int(off[0]) + int(ln[0])]
 n_m, n_d, n_i = (int((path == k).sum()) for k in (0, 1, 2))
@@ -58,7 +59,7 @@ bit_equal = bool(np.float32(ps).view(np.uint32) == np.float32(scores[0]).view(np
 out = {
     "workload": f"1 pair {la} x {lb} nt, gap_len {L} (synthetic, configs[2])", "cells": la * lb,
     "device_bytes": batch.device_bytes, "batch_create_s": round(t_create, 3), "ms_median": float(np.median(ms)),
-    "ms_min": float(np.min(ms)), "gcups": la * lb / float(np.median(ms)) / 1e6, "score": float(scores[0]),
+    "ms_min": float(np.min(ms)), "fill_ms": float(np.median([x[0] for x in fw])), "traceback_ms": float(np.median([x[1] for x in fw])), "gcups": la * lb / float(np.median(ms)) / 1e6, "score": float(scores[0]),
     "columns": int(ln[0]), "ops_consume_both_sequences": consumed_ok, "path_score": float(ps),
     "path_score_bit_equal": bit_equal,
 }

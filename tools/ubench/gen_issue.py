@@ -149,6 +149,12 @@ def fmt(op, r, const):
         return f"v_mov_b32_dpp {r}, v14 wave_shr:1 row_mask:0xf bank_mask:0xf"
     if op == "v_pk_add_f32":
         return f"v_pk_add_f32 v[{20 + 2 * int(r[1:]) - 20}:{21 + 2 * int(r[1:]) - 20}], v[{20 + 2 * int(r[1:]) - 20}:{21 + 2 * int(r[1:]) - 20}], v[2:3]"
+    if op == "v_pk_add_f32_sel":  # (x, x) + (c0, c1), then sign differences with neg: the modifiers the DP cell would use
+        i = 2 * int(r[1:])
+        return f"v_pk_add_f32 v[{i}:{i + 1}], v[{i}:{i + 1}], v[2:3] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+    if op == "v_pk_mov_b32":
+        i = 2 * int(r[1:])
+        return f"v_pk_mov_b32 v[{i}:{i + 1}], v[{i + 8}:{i + 9}], v[{i + 8}:{i + 9}] op_sel:[0,1]"
     if op == "v_pk_max_f32":
         return f"v_pk_max_f32 v[{2 * int(r[1:])}:{2 * int(r[1:]) + 1}], v[{2 * int(r[1:])}:{2 * int(r[1:]) + 1}], v[2:3]"
     return f"{op} {r}, {const}, {r}"
@@ -164,6 +170,10 @@ def V(name, body):
 for op in ("v_add_f32", "v_max_f32", "v_max3_f32", "v_min_u32", "v_max_i32", "v_min3_u32", "v_max3_i32", "v_fma_f32",
            "v_mul_f32", "v_add_f32_dpp", "v_add_f32_dpp_row", "v_mov_b32_dpp", "v_med3_f32"):
     V("pure " + op, mix(1, op, 0, fast=op))
+for op in ("v_pk_add_f32", "v_pk_add_f32_sel", "v_pk_mov_b32"):
+    V("pure " + op, mix(1, op, 0, fast=op))
+V("add x3 : pk_add", mix(3, "v_pk_add_f32"))
+V("pk_add x3 : max3", mix(3, "v_max3_f32", fast="v_pk_add_f32"))
 V("pure v_add_f32 sgpr", mix(1, "v_add_f32", 0, const="s4"))
 V("pure v_max_f32 sgpr", mix(1, "v_max_f32", 0, fast="v_max_f32", const="s4"))
 for n in (1, 2, 3, 4):
