@@ -137,9 +137,14 @@ __host__ __device__ inline uint64_t compact_strip_dwords(uint32_t la, uint32_t L
 __host__ __device__ inline uint32_t n_strips(uint32_t lb) { return (lb + kStrip - 1) / kStrip; }
 // Viterbi strip plan of a descendant of lb columns with w_main columns per lane in every strip
 // but the last: the last strip takes the narrowest shape (4, 8, 16 columns per lane, at most
-// w_main) that holds the remainder.
+// w_main) that holds the remainder.  (w_main = 2: viterbi_lp, a few long pairs.)
 inline void viterbi_strip_plan(uint32_t lb, uint32_t w_main, uint32_t& strips, uint32_t& w_last) {
     const uint32_t full = kWave * w_main;
+    if(w_main < 4) {  // (viterbi_lp's 2-column strips: one shape throughout)
+        strips = (lb + full - 1) / full;
+        w_last = w_main;
+        return;
+    }
     const uint32_t whole = lb / full, rem = lb % full;
     if(rem == 0 && whole > 0) {
         strips = whole;

@@ -9,7 +9,7 @@ instructions per step -- and there v_pk_add_f32 does two of the cell's additions
 one (profiles/r03/ubench_issue_model.txt, "pure v_pk_add_f32": 5.1 cycles alone, like v_add_f32).
 The packed form needs its operands in even-aligned register PAIRS and the maxima read the halves
 of those pairs: inline-asm operands cannot name half of a 64-bit operand, so the block names its
-registers itself (COATI_LP_* pins them in viterbi_lp.hip).
+registers itself (COATI_LP_* pins them in viterbi_lp.hip).  Two shapes: 4 and 2 columns per lane.
 
 One step of one lane (its 4 columns of one row), in the reference's evaluation order
 (src/lib/align_pair.cc:97-124, gap_len 1) -- the same fp32 operations as viterbi_cell.hpp's
@@ -35,8 +35,7 @@ from pathlib import Path
 
 # ---- physical VGPRs (pairs must be even-aligned)
 CA, CB = 2, 4                  # [go:ng], [ge:gs]
-P = [8, 10, 12]                # [X:Y] of columns 0..2
-P3A, P3B = 14, 16              # column 3 ping-pong
+PBASE = 8                      # [X:Y] of columns 0..W-2 at v[8+2c]; the last column ping-pongs between the next two pairs
 ZL = 28                        # v28 = Z carried along the row, v29 = Z handed in by the left lane
 M = 30                         # v30 (v31 unused)
 T1, T2, T3, T4, T5 = 32, 34, 36, 38, 40
@@ -48,35 +47,44 @@ def pair(r):
     return f"v[{r}:{r + 1}]"
 
 
-def step(j, first, bnd):
-    """step j (0..15) of a block; first: lanes take their margin-row state at step == lane;
+def step(W, j, first, bnd):
+    """step j (0..15) of a block of W columns per lane; first: lanes take their margin-row state at step == lane;
     bnd: lane 63 publishes the strip's right boundary (dropped by its offset register elsewhere)"""
     L = []
+    P = [PBASE + 2 * c for c in range(W - 1)]
+    PA, PB = PBASE + 2 * (W - 1), PBASE + 2 * W
     even = j % 2 == 0
-    src3 = P3B if even else P3A    # the left lane's X of column 3 before its previous step
-    cur3 = P3A if even else P3B    # column 3's state entering this step
-    new3 = P3B if even else P3A    # ... and leaving it
+    src3 = PB if even else PA    # the left lane's X of its last column before its previous step
+    cur3 = PA if even else PB    # the last column's state entering this step
+    new3 = PB if even else PA    # ... and leaving it
     ar_src, ar_dst = ("%[ara]", "%[arb]") if even else ("%[arb]", "%[ara]")
     sel = f"row_shl:{j}" if j else "quad_perm:[0,1,2,3]"
     lane0 = f"{sel} row_mask:0x1 bank_mask:0x1"
     shr = "wave_shr:1 row_mask:0xf bank_mask:0xf"
+    # scores: this step reads the set the step before gathered, and gathers the next step's into the other set -- all
+    # W gathers right after the table row is known, a whole step ahead of their use
+    cur = (lambda c: f"%[s{c}]") if even else (lambda c: f"%[t{c}]")
+    nxt = (lambda c: f"%[t{c}]") if even else (lambda c: f"%[s{c}]")
     L.append("s_waitcnt lgkmcnt(0)")
     if first:
         L.append(f"v_cmp_eq_u32_e32 vcc, {j}, %[lrel]")
-        for c in range(4):
-            r = P[c] if c < 3 else cur3
+        for c in range(W):
+            r = P[c] if c < W - 1 else cur3
             L.append(f"v_cndmask_b32_e32 v{r}, v{r}, %[mx{c}], vcc")
             L.append(f"v_cndmask_b32_e32 v{r + 1}, v{r + 1}, %[my{c}], vcc")
     # hand-off: M of column 0, the I input, the table row of the NEXT step
-    L.append(f"v_add_f32_dpp v{M}, %[bx], %[s0] {lane0}")
-    L.append(f"v_add_f32_dpp v{M}, v{src3}, %[s0] {shr}")
-    L.append(f"v_mov_b32_dpp v{ZL + 1}, %[bz] {lane0}")
-    L.append(f"v_mov_b32_dpp v{ZL + 1}, v{ZL} {shr}")
     L.append(f"v_mov_b32_dpp {ar_dst}, %[ach] {lane0}")
     L.append(f"v_mov_b32_dpp {ar_dst}, {ar_src} {shr}")
-    for c in range(4):
-        rd = P[c] if c < 3 else cur3
-        wr = P[c] if c < 3 else new3
+    L.append(f"v_add_f32_dpp v{M}, %[bx], {cur(0)} {lane0}")
+    L.append(f"v_add_f32_dpp v{M}, v{src3}, {cur(0)} {shr}")
+    L.append(f"v_mov_b32_dpp v{ZL + 1}, %[bz] {lane0}")
+    L.append(f"v_mov_b32_dpp v{ZL + 1}, v{ZL} {shr}")
+    for c in range(W):
+        L.append(f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{c}]")
+        L.append(f"ds_read_b32 {nxt(c)}, v{ADDR}")
+    for c in range(W):
+        rd = P[c] if c < W - 1 else cur3
+        wr = P[c] if c < W - 1 else new3
         zsel = "op_sel:[1,0] op_sel_hi:[1,1]" if c == 0 else "op_sel:[0,0] op_sel_hi:[0,1]"
         L += [
             f"v_pk_add_f32 {pair(T1)}, {pair(M)}, {pair(CA)} op_sel:[0,0] op_sel_hi:[0,1]",   # [z1:m1] = M + [go:ng]
@@ -85,15 +93,13 @@ def step(j, first, bnd):
             f"v_pk_add_f32 {pair(T4)}, {pair(rd)}, {pair(CB)} op_sel:[1,1] op_sel_hi:[1,0]",  # [x2:y2] = D + [gs:ge]
             f"v_pk_add_f32 {pair(T5)}, {pair(T2)}, {pair(CA)} op_sel:[1,1] op_sel_hi:[1,0]",  # [x3:y3] = i1 + [ng:go]
         ]
-        if c < 3:
-            L.append(f"v_add_f32 v{M}, v{rd}, %[s{c + 1}]")                                  # M of the next column
+        if c < W - 1:
+            L.append(f"v_add_f32 v{M}, v{rd}, {cur(c + 1)}")                                  # M of the next column
         L += [
             f"v_max_f32 v{ZL}, v{T1}, v{T2}",                                                 # Z
             f"v_sub_f32 v{TS}, v{T2}, v{T1}",                                                 # z2 - z1
             f"v_max3_f32 v{wr}, v{T3}, v{T4}, v{T5}",                                         # X
             f"v_max3_f32 v{wr + 1}, v{T3 + 1}, v{T4 + 1}, v{T5 + 1}",                         # Y
-            f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{c}]",
-            f"ds_read_b32 %[s{c}], v{ADDR}",
             f"v_alignbit_b32 %[ac], %[ac], v{TS}, 31",                                        # IM
             f"v_pk_add_f32 {pair(T3)}, {pair(T3)}, {pair(wr)} neg_lo:[0,1] neg_hi:[0,1]",     # [x1-X : y1-Y]
             f"v_pk_add_f32 {pair(T4)}, {pair(T4)}, {pair(wr)} neg_lo:[0,1] neg_hi:[0,1]",     # [x2-X : y2-Y]
@@ -105,23 +111,26 @@ def step(j, first, bnd):
     if bnd:
         L.append(f"buffer_store_dword v{new3}, %[offx], %[rs_out], %[so_out] offen offset:{4 * j + 4} sc1")
         L.append(f"buffer_store_dword v{ZL}, %[offz], %[rs_out], %[so_out] offen offset:{4 * j} sc1")
-    if j % 4 == 3:
-        base = (j // 8) * 1280 + ((j % 8) // 4) * 512
+    # decision rows (layout: common.hpp): an A/B dword holds 16/W steps, a group of 32/W steps is 1280 bytes
+    ma, mc = 16 // W, 32 // W
+    group, q = j // mc, j % mc
+    if j % ma == ma - 1:
+        base = group * 1280 + (q // ma) * 512
         L.append(f"buffer_store_dword %[aa], %[offb], %[rs_bits], %[so_bits] offen offset:{base}")
         L.append(f"buffer_store_dword %[ab], %[offb], %[rs_bits], %[so_bits] offen offset:{base + 256}")
-    if j % 8 == 7:
-        L.append(f"buffer_store_dword %[ac], %[offb], %[rs_bits], %[so_bits] offen offset:{(j // 8) * 1280 + 1024}")
+    if q == mc - 1:
+        L.append(f"buffer_store_dword %[ac], %[offb], %[rs_bits], %[so_bits] offen offset:{group * 1280 + 1024}")
     return L
 
 
-def block(first):
+def block(W, first):
     bnd = not first
     L = ["buffer_load_dword %[nx], %[vin_x], %[rs_in], 0 offen sc1",
          "buffer_load_dword %[nz], %[vin_z], %[rs_in], 0 offen sc1",
          "buffer_load_ubyte %[na], %[vin_a], %[rs_a], 0 offen"]
     vmem_after = 0
     for j in range(16):
-        s = step(j, first, bnd)
+        s = step(W, j, first, bnd)
         vmem_after += sum(1 for x in s if x.startswith("buffer_"))
         L += s
     # the chunk loads are the block's OLDEST vector-memory operations and the counter retires in issue order
@@ -138,15 +147,16 @@ def emit(name, lines):
 
 
 def main():
-    first, n_first = block(True)
-    main_, n_main = block(False)
+    text = "// GENERATED by gen_viterbi_lp.py -- do not edit (see that script for what the text does)\n"
+    for W in (2, 4):
+        first, n_first = block(W, True)
+        main_, n_main = block(W, False)
+        text += (f"// {W} columns per lane: instructions per 16-step block: first {len(first)}, main {len(main_)}\n"
+                 + emit(f"COATI_LP{W}_BLOCK_FIRST_ASM", first) + emit(f"COATI_LP{W}_BLOCK_MAIN_ASM", main_))
+        print(f"W={W}: first block {len(first)} instructions ({n_first} stores), main block {len(main_)} ({n_main} stores)")
     clob = ", ".join(f'"v{r}"' for r in PINNED_CLOBBERS)
-    text = ("// GENERATED by gen_viterbi_lp.py -- do not edit (see that script for what the text does)\n"
-            f"// instructions per 16-step block: first {len(first)}, main {len(main_)}\n"
-            + emit("COATI_LP_BLOCK_FIRST_ASM", first) + emit("COATI_LP_BLOCK_MAIN_ASM", main_)
-            + f"#define COATI_LP_SCRATCH_CLOBBERS {clob}\n")
+    text += f"#define COATI_LP_SCRATCH_CLOBBERS {clob}\n"
     Path(__file__).with_name("viterbi_lp_block.inc").write_text(text)
-    print(f"first block {len(first)} instructions ({n_first} stores), main block {len(main_)} ({n_main} stores)")
 
 
 if __name__ == "__main__":

@@ -226,9 +226,20 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         };
         const uint64_t kSimds = 4ull * device_cu_count();
         while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
+        // While every wavefront is alone on its SIMD it issues one instruction per ~4.5 cycles whatever it is, so the time is
+        // (rows + strips x hand-off lag) x instructions per step -- and viterbi_lp's 2-column step is 52 instructions
+        // against 90 for 4 columns while the lag per column only doubles: 2-column strips as long as there are no more
+        // of them than SIMDs (80 kb pair, 626 strips: 22 -> 18 ms).  With more (160 kb pair: 1 252) some SIMDs hold two
+        // wavefronts, which then run at half speed each (the packed adds, maxima and bit deposits are limited by the
+        // SIMD, not by the wavefront: tools/ubench, "cell19 lp" 4.06 cycles per instruction alone, 4.03 per SIMD with two)
+        // and hold the whole pipeline back: 66 ms against 44.  viterbi_lp only (COATI_HIP_L1_LP=0 keeps viterbi_l1).
+        const char* lp_env = std::getenv("COATI_HIP_L1_LP");
+        const bool lp_allowed = !(lp_env != nullptr && lp_env[0] == '0') && std::getenv("COATI_HIP_L1_PROGRESS") == nullptr;
+        const bool ck_forced = std::getenv("COATI_HIP_VITERBI_CK") != nullptr || (opts != nullptr && (opts->force_w_main != 0 || opts->force_ck));
+        if(lp_allowed && !ck_forced && w_main == 4 && count_items(2) <= kSimds) w_main = 2;
         if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
             const int w = std::atoi(e);
-            if(w == 4 || w == 8 || w == 16) w_main = static_cast<uint32_t>(w);
+            if(w == 4 || w == 8 || w == 16 || (w == 2 && lp_allowed && !ck_forced)) w_main = static_cast<uint32_t>(w);
         }
         if(opts != nullptr && opts->force_w_main != 0) w_main = opts->force_w_main;
         // Which gap_len-1 kernel.  viterbi_ck (lean fill + checkpoint traceback) wins where the fill
@@ -251,8 +262,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         }
         // a decision-bit plan of 4-column strips throughout is the "few long pairs" regime: viterbi_lp fills it (the same
         // layout, half the instructions per step; COATI_HIP_L1_LP=0 keeps viterbi_l1, the A/B partner)
-        const char* lp_env = std::getenv("COATI_HIP_L1_LP");
-        b->long_pairs = !b->ck && w_main == 4 && !(lp_env != nullptr && lp_env[0] == '0') && std::getenv("COATI_HIP_L1_PROGRESS") == nullptr;
+        b->long_pairs = !b->ck && w_main <= 4 && lp_allowed;
         const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
         uint64_t tail_pairs = 0;
         if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {

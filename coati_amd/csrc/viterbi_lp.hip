@@ -29,9 +29,13 @@
 #include <utility>
 
 namespace coati_hip_detail {
+#ifdef COATI_FILL_TRACE
+// Debug build only (make trace): per wavefront {start, fill of its strip done, traceback done} in 100 MHz ticks and the
+// strip it took, read back by tools/trace_long.py through coati_hip_debug_trace_lp.
+__device__ unsigned long long g_lp_trace[4096 * 4];
+#endif
 namespace {
 
-constexpr int kLpW = 4;        // columns per lane
 constexpr uint32_t kLpRows = 16;  // steps per block = rows per boundary chunk
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -48,66 +52,83 @@ __device__ __forceinline__ u32x4 lp_rsrc(const void* p, uint64_t bytes) {
 }
 constexpr uint32_t kLpDrop = 0x80000000u;  // offset register of a lane that does not store (out of every range)
 
-// what one strip's wavefront keeps besides the LaneState: named operands of the blocks
+// what one strip's wavefront keeps besides the LaneState: named operands of the blocks (W = columns per lane: 4 or 2)
+template <int W>
 struct LpStrip {
     GapVec kv;
-    uint32_t bl[kLpW];   // LDS byte address of the lane's column c in table row 0
+    uint32_t bl[W];   // LDS byte address of the lane's column c in table row 0
     uint32_t offx, offz, offb;  // per-lane offsets: boundary X / Z stores (lane 63, or kLpDrop), decision rows
     u32x4 rs_in, rs_out, rs_bits, rs_a;
-    float mx[kLpW], my[kLpW];  // the lane's margin-row state (taken at step == lane)
+    float mx[W], my[W];  // the lane's margin-row state (taken at step == lane)
 };
 
 // 16 wavefront steps from `kbase`.  In: the chunk (bx, bz, ach: lane j < 16 holds the strip's left boundary of row
 // kbase + j and the table row offset of ancestor row kbase + j + 1).  Out: the raw next chunk (rows kbase + 16 ...).
-template <bool kFirst>
-__device__ __forceinline__ void lp_block(const LpStrip& sp, LaneState<kLpW>& st, uint32_t& arow, float (&s)[kLpW], uint32_t kbase,
+template <int W, bool kFirst>
+__device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st, uint32_t& arow, float (&s)[W], uint32_t kbase,
                                          int lane, uint32_t la, float bx, float bz, uint32_t ach, uint32_t& nx, uint32_t& nz,
                                          uint32_t& na) {
+    static_assert(W == 4 || W == 2, "gen_viterbi_lp.py writes these two shapes");
     uint32_t arb;
+    float t0, t1, t2, t3;  // the other set of scores (the steps alternate between s and t)
     const uint32_t next = kbase + kLpRows + static_cast<uint32_t>(lane);
     const uint32_t vin_x = next * 4u, vin_z = (la + 1u + next) * 4u, vin_a = next + 1u;
-    const uint32_t so_bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase / 8u) * (kPairDwords * 4u))));
-#define COATI_LP_STATE                                                                                                        \
-    "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.X[2]), "+{v13}"(st.Y[2]),          \
-        "+{v14}"(st.X[3]), "+{v15}"(st.Y[3]), "+{v16}"(st.xlast_old), "+{v28}"(st.zlast), [s0] "+v"(s[0]), [s1] "+v"(s[1]), \
-        [s2] "+v"(s[2]), [s3] "+v"(s[3]), [ara] "+v"(arow), [arb] "=&v"(arb), [aa] "+v"(st.acc[ACC_A]),                       \
+    const uint32_t so_bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase / (32u / W)) * (kPairDwords * 4u))));
+    const uint32_t lrel = static_cast<uint32_t>(lane) - kbase;  // (first blocks) the lane starts at step kbase + lrel
+    // (main blocks) lane 63 did body row kbase + j - 63 at step j: X of its last column goes to bnd_x[row + 1], Z to bnd_z[row]
+    const uint32_t so_out = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase - (kWave - 1u)) * 4u)));
+    // [X:Y] of column c in v[8+2c : 9+2c]; the last column's pair alternates with the pair after it, whose low half is
+    // xlast_old between blocks (gen_viterbi_lp.py)
+#define COATI_LP_COMMON_OUT                                                                                                   \
+    "+{v28}"(st.zlast), [s0] "+v"(s[0]), [s1] "+v"(s[1]), [ara] "+v"(arow), [arb] "=&v"(arb), [t0] "=&v"(t0), [t1] "=&v"(t1),  \
+        [aa] "+v"(st.acc[ACC_A]),                                                                                              \
         [ab] "+v"(st.acc[ACC_B]), [ac] "+v"(st.acc[ACC_C]), [nx] "=&v"(nx), [nz] "=&v"(nz), [na] "=&v"(na)
-#define COATI_LP_INPUTS                                                                                                       \
+#define COATI_LP_COMMON_IN                                                                                                    \
     "{v2}"(sp.kv.go), "{v3}"(sp.kv.ng), "{v4}"(sp.kv.ge), "{v5}"(sp.kv.gs), [bx] "v"(bx), [bz] "v"(bz), [ach] "v"(ach),       \
-        [bl0] "v"(sp.bl[0]), [bl1] "v"(sp.bl[1]), [bl2] "v"(sp.bl[2]), [bl3] "v"(sp.bl[3]), [offb] "v"(sp.offb),              \
-        [vin_x] "v"(vin_x), [vin_z] "v"(vin_z), [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits),         \
-        [rs_a] "s"(sp.rs_a), [so_bits] "s"(so_bits)
-    if constexpr(kFirst) {
-        const uint32_t lrel = static_cast<uint32_t>(lane) - kbase;  // the lane starts at step kbase + lrel
-        asm volatile(COATI_LP_BLOCK_FIRST_ASM
-                     : COATI_LP_STATE
-                     : COATI_LP_INPUTS, [lrel] "v"(lrel), [mx0] "v"(sp.mx[0]), [mx1] "v"(sp.mx[1]), [mx2] "v"(sp.mx[2]),
-                       [mx3] "v"(sp.mx[3]), [my0] "v"(sp.my[0]), [my1] "v"(sp.my[1]), [my2] "v"(sp.my[2]), [my3] "v"(sp.my[3])
-                     : COATI_LP_SCRATCH_CLOBBERS, "v17", "vcc", "memory");
+        [bl0] "v"(sp.bl[0]), [bl1] "v"(sp.bl[1]), [offb] "v"(sp.offb), [vin_x] "v"(vin_x), [vin_z] "v"(vin_z),                \
+        [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits), [rs_a] "s"(sp.rs_a), [so_bits] "s"(so_bits)
+#define COATI_LP_FIRST_IN [lrel] "v"(lrel), [mx0] "v"(sp.mx[0]), [mx1] "v"(sp.mx[1]), [my0] "v"(sp.my[0]), [my1] "v"(sp.my[1])
+#define COATI_LP_MAIN_IN [offx] "v"(sp.offx), [offz] "v"(sp.offz), [rs_out] "s"(sp.rs_out), [so_out] "s"(so_out)
+    if constexpr(W == 4) {
+#define COATI_LP4_OUT                                                                                                         \
+    "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.X[2]), "+{v13}"(st.Y[2]),          \
+        "+{v14}"(st.X[3]), "+{v15}"(st.Y[3]), "+{v16}"(st.xlast_old), [s2] "+v"(s[2]), [s3] "+v"(s[3]), [t2] "=&v"(t2), [t3] "=&v"(t3), COATI_LP_COMMON_OUT
+#define COATI_LP4_IN COATI_LP_COMMON_IN, [bl2] "v"(sp.bl[2]), [bl3] "v"(sp.bl[3])
+        if constexpr(kFirst)
+            asm volatile(COATI_LP4_BLOCK_FIRST_ASM
+                         : COATI_LP4_OUT
+                         : COATI_LP4_IN, COATI_LP_FIRST_IN, [mx2] "v"(sp.mx[2]), [mx3] "v"(sp.mx[3]), [my2] "v"(sp.my[2]), [my3] "v"(sp.my[3])
+                         : COATI_LP_SCRATCH_CLOBBERS, "v17", "vcc", "memory");
+        else
+            asm volatile(COATI_LP4_BLOCK_MAIN_ASM : COATI_LP4_OUT : COATI_LP4_IN, COATI_LP_MAIN_IN : COATI_LP_SCRATCH_CLOBBERS, "v17", "memory");
+#undef COATI_LP4_OUT
+#undef COATI_LP4_IN
     } else {
-        // lane 63 did body row kbase + j - 63 at step j: X of its last column goes to bnd_x[row + 1], Z to bnd_z[row]
-        const uint32_t so_out = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase - (kWave - 1u)) * 4u)));
-        asm volatile(COATI_LP_BLOCK_MAIN_ASM
-                     : COATI_LP_STATE
-                     : COATI_LP_INPUTS, [offx] "v"(sp.offx), [offz] "v"(sp.offz), [rs_out] "s"(sp.rs_out), [so_out] "s"(so_out)
-                     : COATI_LP_SCRATCH_CLOBBERS, "v17", "memory");
+#define COATI_LP2_OUT "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.xlast_old), COATI_LP_COMMON_OUT
+        if constexpr(kFirst)
+            asm volatile(COATI_LP2_BLOCK_FIRST_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_FIRST_IN : COATI_LP_SCRATCH_CLOBBERS, "v13", "vcc", "memory");
+        else
+            asm volatile(COATI_LP2_BLOCK_MAIN_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_MAIN_IN : COATI_LP_SCRATCH_CLOBBERS, "v13", "memory");
+#undef COATI_LP2_OUT
     }
-#undef COATI_LP_STATE
-#undef COATI_LP_INPUTS
+#undef COATI_LP_COMMON_OUT
+#undef COATI_LP_COMMON_IN
+#undef COATI_LP_FIRST_IN
+#undef COATI_LP_MAIN_IN
 }
 
 // One step in plain C++ (viterbi_cell.hpp's cell): the strip's last nsteps % 16 steps, and every step of a strip
 // shorter than a block.  kFirst: the lane takes its margin-row state when the step is its first.
-template <bool kFirst>
-__device__ __forceinline__ void lp_tail_step(const LpStrip& sp, LaneState<kLpW>& st, uint32_t& arow, float (&s)[kLpW],
-                                             const uint32_t (&boff)[kLpW], uint32_t lds_tab, uint32_t kstep, uint32_t kk, int lane,
+template <int W, bool kFirst>
+__device__ __forceinline__ void lp_tail_step(const LpStrip<W>& sp, LaneState<W>& st, uint32_t& arow, float (&s)[W],
+                                             const uint32_t (&boff)[W], uint32_t lds_tab, uint32_t kstep, uint32_t kk, int lane,
                                              uint32_t la, bool last_strip, uint32_t* fout, float* bnd_x, float* bnd_z, uint32_t ach,
                                              float bx, float bz) {
-    constexpr uint32_t kMA = 16 / kLpW, kMC = 32 / kLpW;
+    constexpr uint32_t kMA = 16 / W, kMC = 32 / W;
     if constexpr(kFirst) {
         if(kstep == static_cast<uint32_t>(lane)) {
 #pragma unroll
-            for(int c = 0; c < kLpW; ++c) {
+            for(int c = 0; c < W; ++c) {
                 st.X[c] = sp.mx[c];
                 st.Y[c] = sp.my[c];
             }
@@ -116,7 +137,7 @@ __device__ __forceinline__ void lp_tail_step(const LpStrip& sp, LaneState<kLpW>&
     const float diag = shift_in(st.xlast_old, read_lane(bx, static_cast<int>(kk)));
     const float zl = shift_in(st.zlast, read_lane(bz, static_cast<int>(kk)));
     const uint32_t arow_next = shift_in(arow, read_lane(ach, static_cast<int>(kk)));
-    row_l1<kLpW>(sp.kv, st, diag, zl, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, kLpW>{});
+    row_l1<W>(sp.kv, st, diag, zl, s, lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
     if((kstep & (kMA - 1u)) == kMA - 1u) {
         const uint32_t q = kstep & (kMC - 1u);
@@ -127,18 +148,18 @@ __device__ __forceinline__ void lp_tail_step(const LpStrip& sp, LaneState<kLpW>&
     }
     const int r = static_cast<int>(kstep) - lane;
     if(!last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(la)) {
-        store_through(&bnd_x[r + 1], st.X[kLpW - 1]);
+        store_through(&bnd_x[r + 1], st.X[W - 1]);
         store_through(&bnd_z[r], st.zlast);
     }
 }
 
-// One work item: one strip (256 descendant columns) of one pair, all its rows.  Returns false if the left neighbour's
+// One work item: one strip (64 W descendant columns) of one pair, all its rows.  Returns false if the left neighbour's
 // boundary column did not arrive within the spin bound.
+template <int W>
 __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip, uint32_t ticket,
                                               int lane, uint32_t lds_tab, const char* tab_bytes, const uint8_t* __restrict__ a,
                                               const uint8_t* __restrict__ b, uint32_t* __restrict__ flags, float* __restrict__ bnd,
                                               float* __restrict__ scores, uint32_t* __restrict__ progress) {
-    constexpr int W = kLpW;
     const uint32_t la = pd.la, lb = pd.lb;
     const uint32_t col0 = strip * (kWave * W);
     const uint32_t ncol = min(static_cast<uint32_t>(kWave * W), lb - col0);
@@ -156,7 +177,7 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     bool handoff_ok = true;
 
     uint32_t boff[W];
-    LpStrip sp;
+    LpStrip<W> sp;
     sp.kv = gap_vec(k);
 #pragma unroll
     for(int c = 0; c < W; ++c) {
@@ -236,7 +257,7 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     // (two loops, not one with a branch: the state stays in the registers the blocks name)
     for(; kbase < static_cast<uint32_t>(kWave) && kbase + kLpRows <= nsteps; kbase += kLpRows) {
         uint32_t nx, nz, na;
-        lp_block<true>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
+        lp_block<W, true>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
         // step 63 is lane 63's first row
         if(kbase + kLpRows == static_cast<uint32_t>(kWave) && publisher) {
             store_through(&bnd_x[1], st.X[W - 1]);
@@ -246,14 +267,14 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     }
     for(; kbase + kLpRows <= nsteps; kbase += kLpRows) {
         uint32_t nx, nz, na;
-        lp_block<false>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
+        lp_block<W, false>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
         take_chunk(kbase + kLpRows, nx, nz, na);
     }
     for(uint32_t kk = 0; kbase + kk < nsteps; ++kk) {
         if(kbase < static_cast<uint32_t>(kWave))
-            lp_tail_step<true>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
+            lp_tail_step<W, true>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
         else
-            lp_tail_step<false>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
+            lp_tail_step<W, false>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
     }
     // score = X of the last body cell (align_pair.cc:130-138,265): held by the lane of the last column after the last step
     const int last_lane = static_cast<int>((lb - 1 - col0) / W), last_c = static_cast<int>((lb - 1 - col0) % W);
@@ -299,6 +320,10 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
     uint32_t tab_held = 0xffffffffu;
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
+#ifdef COATI_FILL_TRACE
+    const uint32_t trace_wave = (blockIdx.x * kFillWaves + threadIdx.x / kWave) & 4095u;
+    if(lane_id == 0) g_lp_trace[trace_wave * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
     for(;;) {
         int lane = lane_id;
         asm volatile("" : "+v"(lane));  // (see viterbi_l1)
@@ -317,18 +342,43 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
             }
             tab_held = pd.table;
         }
-        if(pd.la > 0 && pd.lb > 0)
-            handoff_ok = fill_strip_lp(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off, flags,
-                                       bnd, scores, progress);
+        if(pd.la > 0 && pd.lb > 0) {  // (every strip of a pair has the pair's shape here)
+            if(pd.v_wmain == 2)
+                handoff_ok = fill_strip_lp<2>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
+                                              flags, bnd, scores, progress);
+            else
+                handoff_ok = fill_strip_lp<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
+                                              flags, bnd, scores, progress);
+        }
+#ifdef COATI_FILL_TRACE
+        if(lane_id == 0) {
+            g_lp_trace[trace_wave * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            g_lp_trace[trace_wave * 4 + 3] = strip;
+        }
+#endif
         if(strip + 1 < pd.v_strips) continue;  // the pair's traceback runs on the wavefront of its LAST strip
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
         if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
+#ifdef COATI_FILL_TRACE
+        if(lane_id == 0) g_lp_trace[trace_wave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 
 }  // namespace
+
+#ifdef COATI_FILL_TRACE
+extern "C" int coati_hip_debug_trace_lp(unsigned long long* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lp_trace), sizeof(g_lp_trace));
+    if(e != hipSuccess) return static_cast<int>(e);
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_lp_trace));
+    if(e != hipSuccess) return static_cast<int>(e);
+    return static_cast<int>(hipMemset(p, 0, sizeof(g_lp_trace)));  // next launch starts clean
+}
+#endif
 
 // The launch has one workgroup (one wavefront per SIMD) on every CU while the items fit, up to three after that,
 // enforced by LDS padding like viterbi_l1's.

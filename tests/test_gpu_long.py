@@ -1,0 +1,125 @@
+"""viterbi_lp (round 3): the decision-bit fill for batches with fewer strips than the GPU has SIMDs -- a few long
+pairs, and every small batch -- in 16-step blocks of hand-allocated instructions, 4 or 2 columns per lane.  It shares the
+decision-bit layout and the traceback with viterbi_l1; results must be the reference's bits (oracle) and equal to
+viterbi_l1's."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from coati_amd import hip as h
+
+    assert h.device_count() > 0, "no gfx950 device: the HIP path cannot run"
+    return h
+
+
+@pytest.fixture(autouse=True)
+def decision_bit_plan(monkeypatch):
+    for v in ("COATI_HIP_VITERBI_CK", "COATI_HIP_VITERBI_BITS", "COATI_HIP_L1_LP", "COATI_HIP_STRIP_W", "COATI_HIP_FORCE_GENERIC"):
+        monkeypatch.delenv(v, raising=False)
+
+
+def run(hip, table, consts, enc, flags_of=()):
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc))
+    batch.viterbi_launch()
+    scores, ops, off, ln = batch.viterbi_fetch()
+    flags = {p: batch.debug_flags(p) for p in flags_of}
+    batch.close()
+    model.close()
+    return scores.copy(), [ops[int(off[p]):int(off[p]) + int(ln[p])].copy() for p in range(len(enc))], flags
+
+
+@pytest.mark.parametrize("strip_w", ["2", "4"])
+def test_block_and_chunk_boundaries_against_the_oracle(hip, oracle, monkeypatch, strip_w):
+    """Ancestor lengths around the 16-step blocks, the 64 steps in which the lanes start and the 16-row boundary chunks;
+    descendant lengths around one, two and several strips of both shapes; ambiguous nucleotides; every pair against
+    the oracle (score bits, ops, and the five decision bits of every cell where the matrix is small)."""
+    monkeypatch.setenv("COATI_HIP_STRIP_W", strip_w)
+    rng = np.random.default_rng(2024)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    pairs = []
+    for la3 in (1, 5, 6, 15, 16, 17, 21, 22, 26, 27, 32, 43, 70):       # codons: 3 ... 210 rows
+        for nb in (1, 2, 7, 127, 128, 129, 255, 256, 257, 385, 520, 700):
+            anc = util.random_anc(rng, la3)
+            des = "".join(rng.choice(list(util.NT16 if nb % 5 == 0 else util.NT), nb))
+            pairs.append((anc, des))
+    enc = util.encode_pairs(pairs)
+    small = [p for p, (a, b) in enumerate(enc) if len(a) * len(b) <= 30_000][::3]
+    scores, ops, flags = run(hip, table, consts, enc, flags_of=small)
+    for p, (a, b) in enumerate(enc):
+        want_ops, want_score = oracle.viterbi(table, consts, 1, a, b)
+        assert bits(scores[p]) == bits(want_score), (p, len(a), len(b))
+        assert len(ops[p]) == len(want_ops) and (ops[p] == want_ops).all(), (p, len(a), len(b))
+    for p in small:
+        a, b = enc[p]
+        M, D, I = oracle.fill(oracle.TROPICAL, table, consts, 1, a, b)
+        want = oracle.tb_flags(M, D, I, consts)[1:, 1:].copy()
+        want[-1, -1] = flags[p][-1, -1]  # (the oracle's last cell is terminal-adjusted)
+        assert (flags[p] == want).all(), (p, len(a), len(b), np.argwhere(flags[p] != want)[:5])
+
+
+def test_long_pairs_equal_viterbi_l1_and_the_oracle(hip, oracle, monkeypatch):
+    """Three related pairs of 9-31 kb (2-column strips, then 4-column strips forced) with long indels and a stretch of
+    ambiguous nucleotides: identical to viterbi_l1 (COATI_HIP_L1_LP=0) and to the oracle's low-memory Viterbi."""
+    rng = np.random.default_rng(31)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    pairs = []
+    for codons in (3011, 6007, 10400):
+        a = util.random_anc(rng, codons)
+        d = list(util.mutate(rng, a, n_indel=30, mean_len=12))
+        at = int(rng.integers(0, len(d) - 400))
+        d[at:at + 40] = list(rng.choice(list(util.NT16[4:]), 40))
+        del d[at + 200:at + 200 + 333]
+        pairs.append((a, "".join(d)))
+    enc = util.encode_pairs(pairs)
+    got = {}
+    for name, env in (("lp2", {}), ("lp4", {"COATI_HIP_STRIP_W": "4"}), ("l1", {"COATI_HIP_L1_LP": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got[name] = run(hip, table, consts, enc)
+        for k in env:
+            monkeypatch.delenv(k)
+    for name in ("lp4", "l1"):
+        assert (bits(got[name][0]) == bits(got["lp2"][0])).all(), name
+        for p in range(len(enc)):
+            assert np.array_equal(got[name][1][p], got["lp2"][1][p]), (name, p)
+    for p, (a, b) in enumerate(enc):
+        want_ops, want_score = oracle.viterbi(table, consts, 1, a, b, lowmem=True)
+        assert bits(got["lp2"][0][p]) == bits(want_score), p
+        assert np.array_equal(got["lp2"][1][p], want_ops), p
+
+
+def test_several_long_pairs_with_their_own_tables(hip, oracle):
+    """Per-pair substitution tables (a wavefront reloads its LDS copy between strips of different pairs) and uneven
+    lengths in one small batch."""
+    rng = np.random.default_rng(5)
+    consts = oracle.gap_consts()
+    tables = np.stack([util.random_table(rng) for _ in range(3)])
+    pairs = []
+    for codons in (700, 1500, 90, 2600, 1):
+        a = util.random_anc(rng, codons)
+        pairs.append((a, util.mutate(rng, a, n_indel=8)))
+    enc = util.encode_pairs(pairs)
+    which = np.array([0, 2, 1, 2, 0], np.uint32)
+    model = hip.Model(tables, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc), table_index=which)
+    batch.viterbi_launch()
+    scores, ops, off, ln = batch.viterbi_fetch()
+    for p, (a, b) in enumerate(enc):
+        want_ops, want_score = oracle.viterbi(tables[which[p]], consts, 1, a, b, lowmem=len(a) * len(b) > 4_000_000)
+        assert bits(scores[p]) == bits(want_score), p
+        assert np.array_equal(ops[int(off[p]):int(off[p]) + int(ln[p])], want_ops), p
+    batch.close()
+    model.close()

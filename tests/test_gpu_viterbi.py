@@ -253,7 +253,7 @@ def test_long_pair_strips_pipelined_across_wavefronts(hip, oracle):
     run_and_compare(hip, oracle, table, consts, pairs, check_flags=False)
 
 
-@pytest.mark.parametrize("strip_w", ["4", "8", "16"])
+@pytest.mark.parametrize("strip_w", ["2", "4", "8", "16"])
 def test_strip_shapes_forced(oracle, strip_w):
     """The three strip shapes (4, 8, 16 columns per lane) produce the same bit-exact results;
     COATI_HIP_STRIP_W forces the main shape, the last strip of a pair picks its own.  Runs in a

@@ -116,6 +116,62 @@ def cell_15_wide(c, parity):
             f"v_max3_f32 {y}, {t0}, {t7}, {t2}"]
 
 
+def cell19_parts(c, parity):
+    """viterbi_lp's cell (gen_viterbi_lp.py): packed adds; returns (front, back): the recurrence and the decision bits"""
+    xin, xout, y = _regs(c, parity)
+    P = f"v[{YP + 2 * c}:{YP + 2 * c + 1}]"   # [Y:Xin] here (register roles do not matter for timing)
+    front = ["v_pk_add_f32 v[10:11], v[28:29], v[2:3] op_sel:[0,0] op_sel_hi:[0,1]",
+             "v_pk_add_f32 v[12:13], v[8:9], v[4:5] op_sel:[0,0] op_sel_hi:[0,1]",
+             "v_pk_add_f32 v[14:15], v[10:11], v[2:3] op_sel:[1,1] op_sel_hi:[1,0]",
+             f"v_pk_add_f32 v[16:17], {P}, v[4:5] op_sel:[1,1] op_sel_hi:[1,0]",
+             "v_pk_add_f32 v[18:19], v[12:13], v[2:3] op_sel:[1,1] op_sel_hi:[1,0]",
+             f"v_add_f32 v28, v{YP + 2 * c}, v{S + c}",
+             "v_max_f32 v8, v10, v12",
+             "v_sub_f32 v20, v12, v10",
+             f"v_max3_f32 v{YP + 2 * c}, v14, v16, v18",
+             f"v_max3_f32 v{YP + 2 * c + 1}, v15, v17, v19",
+             f"v_add_u32 v{S + c}, v{LDS}, v7"]
+    back = ["v_alignbit_b32 v24, v24, v20, 31",
+            f"v_pk_add_f32 v[14:15], v[14:15], {P} neg_lo:[0,1] neg_hi:[0,1]",
+            f"v_pk_add_f32 v[16:17], v[16:17], {P} neg_lo:[0,1] neg_hi:[0,1]",
+            "v_alignbit_b32 v25, v25, v14, 31", "v_alignbit_b32 v25, v25, v16, 31",
+            "v_alignbit_b32 v26, v26, v15, 31", "v_alignbit_b32 v26, v26, v17, 31"]
+    return front, back
+
+
+def cell19(c, parity):
+    f, b = cell19_parts(c, parity)
+    return f + b
+
+
+def cell19_interleaved(c, parity):
+    """the decision-bit instructions between the adds (a different temporary set would be needed in the kernel; here
+    only the issue pattern matters)"""
+    f, b = cell19_parts(c, parity)
+    out = []
+    for i in range(max(len(f), len(b))):
+        if i < len(f):
+            out.append(f[i])
+        if i < len(b):
+            out.append(b[i])
+    return out
+
+
+def cell19_fastsplit(c, parity):
+    """the three fast-class instructions spread evenly among the slow ones"""
+    f, b = cell19_parts(c, parity)
+    seq = f + b
+    fast = [x for x in seq if x.split()[0] in ("v_add_f32", "v_sub_f32", "v_add_u32")]
+    slow = [x for x in seq if x not in fast]
+    out, k = [], 0
+    for i, x in enumerate(slow):
+        out.append(x)
+        if (i + 1) % 5 == 0 and k < len(fast):
+            out.append(fast[k])
+            k += 1
+    return out + fast[k:]
+
+
 def mix(fast_n, slow, slow_n=1, fast="v_add_f32", const="v2"):
     """4 independent chains (v10..v13); per chain: fast_n fast ops then slow_n slow ops, chains interleaved
     instruction by instruction so that consecutive instructions are independent"""
@@ -192,6 +248,9 @@ V("cell15 kernel", cells(cell_lean_kernel))
 V("cell15 vgpr consts", cells(cell_15v))
 V("cell15 int maxima", cells(cell_15i))
 V("cell15 wide", cells(cell_15_wide))
+V("cell19 lp", cells(cell19))
+V("cell19 lp interleaved", cells(cell19_interleaved))
+V("cell19 lp fast spread", cells(cell19_fastsplit))
 V("cell17 order0", cells(lambda c, p: cell_17(c, p, 0)))
 V("cell17 order1", cells(lambda c, p: cell_17(c, p, 1)))
 V("cell17 order1 vgpr", cells(lambda c, p: cell_17(c, p, 1, vconst=True)))
