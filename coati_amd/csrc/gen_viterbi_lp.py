@@ -123,17 +123,28 @@ def step(W, j, first, bnd):
     return L
 
 
+# Step of the block before which the NEXT chunk's loads are issued: as late as the load latency (~0.6 us) allows, so
+# that a strip follows its left neighbour more closely (160 kb pair, 4 columns: at step 0 43.3 ms, 8: 42.5, 12: 42.4,
+# 14: 43.1, 15: 45.2 -- the block then ends waiting for them; 2-column steps are shorter: 8).
+LOAD_AT = {4: 12, 2: 8}
+
+
 def block(W, first):
     bnd = not first
-    L = ["buffer_load_dword %[nx], %[vin_x], %[rs_in], 0 offen sc1",
-         "buffer_load_dword %[nz], %[vin_z], %[rs_in], 0 offen sc1",
-         "buffer_load_ubyte %[na], %[vin_a], %[rs_a], 0 offen"]
+    loads = ["buffer_load_dword %[nx], %[vin_x], %[rs_in], 0 offen sc1",
+             "buffer_load_dword %[nz], %[vin_z], %[rs_in], 0 offen sc1",
+             "buffer_load_ubyte %[na], %[vin_a], %[rs_a], 0 offen"]
+    L = []
     vmem_after = 0
     for j in range(16):
+        if j == LOAD_AT[W]:
+            L += loads
+            vmem_after = 0
         s = step(W, j, first, bnd)
         vmem_after += sum(1 for x in s if x.startswith("buffer_"))
         L += s
-    # the chunk loads are the block's OLDEST vector-memory operations and the counter retires in issue order
+    # the counter retires in issue order: everything up to the chunk loads is done when at most the operations issued
+    # after them are outstanding
     L.append(f"s_waitcnt vmcnt({vmem_after}) lgkmcnt(0)")
     return L, vmem_after
 
@@ -147,6 +158,10 @@ def emit(name, lines):
 
 
 def main():
+    import os
+    if "COATI_LP_LOAD_AT" in os.environ:  # (experiment)
+        for w in LOAD_AT:
+            LOAD_AT[w] = int(os.environ["COATI_LP_LOAD_AT"])
     text = "// GENERATED by gen_viterbi_lp.py -- do not edit (see that script for what the text does)\n"
     for W in (2, 4):
         first, n_first = block(W, True)

@@ -392,7 +392,8 @@ hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
         if(e != hipSuccess) return e;
     }
     const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
-    const int best = static_cast<int>(std::clamp<uint64_t>((static_cast<uint64_t>(v.n_items) + kSimds - 1) / kSimds, 1, 3));
+    int best = static_cast<int>(std::clamp<uint64_t>((static_cast<uint64_t>(v.n_items) + kSimds - 1) / kSimds, 1, 3));
+    if(const char* e = std::getenv("COATI_HIP_LP_BLOCKS_PER_CU")) best = std::clamp(std::atoi(e), 1, 3);  // (experiment)
     constexpr size_t kStatic = kFillWaves * kTabRows * kTabStride * sizeof(float);
     constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 52 * 1024};
     const size_t dyn = kPerBlock[best] - ((kStatic + 255) / 256) * 256;
