@@ -120,6 +120,21 @@ __device__ __forceinline__ void row_l1(const GapVec& k, LaneState<W>& st, float 
 }
 
 
+// Raw buffer descriptor in four SGPRs for the hand-written blocks (viterbi_lp.hip, viterbi_ck.hip): base, no stride,
+// `bytes` valid (the VGPR offset is range-checked against it: reads beyond return 0, writes beyond are dropped), 32-bit
+// data format.  A lane whose offset register holds kDropOffset stores nothing.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kDropOffset = 0x80000000u;
+__device__ __forceinline__ u32x4_t raw_rsrc(const void* p, uint64_t bytes = 0x7ffffff0ull) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    u32x4_t r;
+    r.x = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
+    r.y = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32))) & 0xffffu;
+    r.z = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(bytes < 0x7ffffff0ull ? bytes : 0x7ffffff0ull)));
+    r.w = 0x00020000u;
+    return r;
+}
+
 // Strip-boundary hand-off between wavefronts (cdna_hip_programming.md Guideline 16, recipe R1):
 // the payload is stored write-through (agent-scope relaxed atomic store = `sc1`), the storing
 // wave drains (s_waitcnt vmcnt(0)) and ONE lane publishes a progress word; the consumer polls that

@@ -37,20 +37,9 @@ __device__ unsigned long long g_lp_trace[4096 * 4];
 namespace {
 
 constexpr uint32_t kLpRows = 16;  // steps per block = rows per boundary chunk
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// raw buffer descriptor in four SGPRs: base, no stride, `bytes` valid (the VGPR offset is range-checked against it:
-// reads beyond return 0, writes beyond are dropped), 32-bit data format
-__device__ __forceinline__ u32x4 lp_rsrc(const void* p, uint64_t bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(p);
-    u32x4 r;
-    r.x = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
-    r.y = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32))) & 0xffffu;
-    r.z = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(std::min<uint64_t>(bytes, 0x7ffffff0ull))));
-    r.w = 0x00020000u;
-    return r;
-}
-constexpr uint32_t kLpDrop = 0x80000000u;  // offset register of a lane that does not store (out of every range)
+typedef u32x4_t u32x4;
+constexpr uint32_t kLpDrop = kDropOffset;  // offset register of a lane that does not store (out of every range)
+__device__ __forceinline__ u32x4 lp_rsrc(const void* p, uint64_t bytes) { return raw_rsrc(p, bytes); }
 
 // what one strip's wavefront keeps besides the LaneState: named operands of the blocks (W = columns per lane: 4 or 2)
 template <int W>

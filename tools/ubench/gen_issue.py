@@ -208,6 +208,9 @@ def fmt(op, r, const):
     if op == "v_pk_add_f32_sel":  # (x, x) + (c0, c1), then sign differences with neg: the modifiers the DP cell would use
         i = 2 * int(r[1:])
         return f"v_pk_add_f32 v[{i}:{i + 1}], v[{i}:{i + 1}], v[2:3] op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+    if op in ("v_pk_fma_f32", "v_pk_mul_f32"):
+        i = 2 * int(r[1:])
+        return f"{op} v[{i}:{i + 1}], v[{i}:{i + 1}], v[2:3]" + (f", v[{i + 8}:{i + 9}]" if op == "v_pk_fma_f32" else "")
     if op == "v_pk_mov_b32":
         i = 2 * int(r[1:])
         return f"v_pk_mov_b32 v[{i}:{i + 1}], v[{i + 8}:{i + 9}], v[{i + 8}:{i + 9}] op_sel:[0,1]"
@@ -226,7 +229,9 @@ def V(name, body):
 for op in ("v_add_f32", "v_max_f32", "v_max3_f32", "v_min_u32", "v_max_i32", "v_min3_u32", "v_max3_i32", "v_fma_f32",
            "v_mul_f32", "v_add_f32_dpp", "v_add_f32_dpp_row", "v_mov_b32_dpp", "v_med3_f32"):
     V("pure " + op, mix(1, op, 0, fast=op))
-for op in ("v_pk_add_f32", "v_pk_add_f32_sel", "v_pk_mov_b32"):
+V("fma x1 : add x1", mix(1, "v_fma_f32"))
+V("pk_fma x1 : add x2", mix(2, "v_pk_fma_f32"))
+for op in ("v_pk_add_f32", "v_pk_add_f32_sel", "v_pk_mov_b32", "v_pk_fma_f32", "v_pk_mul_f32"):
     V("pure " + op, mix(1, op, 0, fast=op))
 V("add x3 : pk_add", mix(3, "v_pk_add_f32"))
 V("pk_add x3 : max3", mix(3, "v_max3_f32", fast="v_pk_add_f32"))
