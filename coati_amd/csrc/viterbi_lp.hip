@@ -298,6 +298,61 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     return handoff_ok;
 }
 
+// traceback<tropical> (align_pair.cc:249-303) for a pair whose strips all have W columns per lane: common.hpp's
+// wave-cooperative walk_pair (64 lanes look up the states after 1..64 more moves of the current kind, a ballot finds where
+// the run ends) with the cell address computed for this one shape -- shifts by constants, one strip size, no compact layout,
+// the kind of move as a wave-uniform branch.  A long pair's walk is a chain of ~(moves/64 + 2 x gap runs) such iterations on a
+// wavefront that is alone on its SIMD: their instruction count is its time (160 kb pair: 2.4 ms with the general walker).
+template <int W>
+__device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const PairDesc& pd, uint32_t pair, int start_state,
+                                             const uint32_t* __restrict__ flags, uint8_t* __restrict__ ops,
+                                             uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
+    constexpr uint32_t lgW = W == 4 ? 2u : 1u, lg_mc = 5u - lgW, lg_ma = 4u - lgW, lg_cols = 6u + lgW;
+    const uint32_t la = pd.la, lb = pd.lb;
+    const uint32_t* __restrict__ fl = flags + pd.flags_off;
+    const uint64_t sd = strip_dwords(la, W);
+    uint32_t i = la, j = lb;  // matrix coordinates of the last cell (gap_len 1: body cell (i-1, j-1))
+    uint64_t pos = pd.ops_off + la + lb;
+    int st = (i < 1 && j < 1) ? kWalkEnd : start_state;
+    while(st != kWalkEnd) {
+        const uint32_t di = st != COATI_HIP_OP_INS ? 1u : 0u, dj = st != COATI_HIP_OP_DEL ? 1u : 0u;
+        const uint32_t step = static_cast<uint32_t>(lane) + 1u;
+        const bool valid = di * step <= i && dj * step <= j;
+        const uint32_t ci = i - di * step, cj = j - dj * step;  // where the walk is after `step` more moves of kind st
+        int next = kWalkEnd;
+        if(valid && ci >= 1 && cj >= 1) {
+            const uint32_t bi = ci - 1, bj = cj - 1;
+            const uint32_t strip = bj >> lg_cols, colin = bj & ((1u << lg_cols) - 1u), t = colin >> lgW, c = colin & (W - 1u);
+            const uint32_t kstep = bi + t, g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
+            const uint32_t* __restrict__ grp = fl + (strip * sd + static_cast<uint64_t>(g) * kPairDwords + t);
+            if(st == COATI_HIP_OP_INS) {  // (wave-uniform)
+                next = ((grp[4 * kWave] >> (31u - ((q << lgW) + c))) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+            } else {
+                const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
+                const uint32_t two = (grp[half * (2u * kWave) + (st == COATI_HIP_OP_DEL ? kWave : 0)] >> (30u - 2u * ((tt << lgW) + c))) & 3u;
+                next = !(two & 2u) ? COATI_HIP_OP_MATCH : ((two & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL);
+            }
+        } else if(valid && (ci >= 1 || cj >= 1)) {  // a margin cell: by formula (align_pair.cc:82-91)
+            float m, d, in;
+            margin_mdi(k, 1u, ci, cj, m, d, in);
+            next = decide_after(k, st, m, d, in);
+        }
+        if(di > i || dj > j) break;  // (never walk off the matrix)
+        const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
+        const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));
+        const uint32_t moves = run == kWave ? kWave : run + 1u;
+        if(static_cast<uint32_t>(lane) < moves) ops[pos - 1 - static_cast<uint32_t>(lane)] = static_cast<uint8_t>(st);
+        pos -= moves;
+        i -= di * moves;
+        j -= dj * moves;
+        if(run < kWave) st = __builtin_amdgcn_readlane(next, static_cast<int>(run));
+    }
+    if(lane == 0) {
+        ops_start[pair] = pos;
+        ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
+    }
+}
+
 __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ items,
     uint32_t n_items, uint32_t* __restrict__ queue, uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,
@@ -348,7 +403,16 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
         if(strip + 1 < pd.v_strips) continue;  // the pair's traceback runs on the wavefront of its LAST strip
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);
+        if(pd.la > 0 && pd.lb > 0) {
+            // max_mdi of the terminal-adjusted last cell == its "after match" decision (common.hpp viterbi_finish)
+            const int start_state = __builtin_amdgcn_readfirstlane(state_after(flags, pd, pd.la - 1, pd.lb - 1, COATI_HIP_OP_MATCH));
+            if(pd.v_wmain == 2)
+                walk_pair_lp<2>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len);
+            else
+                walk_pair_lp<4>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len);
+        } else {
+            viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);  // (margins only)
+        }
         if(!handoff_ok && lane == 0) scores[pair] = __builtin_nanf("");  // a producer never arrived (spin bound)
 #ifdef COATI_FILL_TRACE
         if(lane_id == 0) g_lp_trace[trace_wave * 4 + 2] = __builtin_amdgcn_s_memrealtime();
