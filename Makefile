@@ -15,7 +15,7 @@ lib: $(BUILD)/libcoati_hip.so
 
 HIP_SRC = coati_amd/csrc/abi.hip coati_amd/csrc/plan.hip coati_amd/csrc/pipeline.hip coati_amd/csrc/sample_host.hip coati_amd/csrc/viterbi_ck.hip coati_amd/csrc/viterbi_l1.hip coati_amd/csrc/viterbi_lp.hip coati_amd/csrc/dp_generic.hip coati_amd/csrc/forward_l1.hip coati_amd/csrc/viterbi_k.hip coati_amd/csrc/forward_k.hip \
           coati_amd/csrc/sampleback.hip
-$(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/viterbi_lp_block.inc coati_amd/csrc/viterbi_ck_block.inc coati_amd/csrc/abi_internal.hpp coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
+$(BUILD)/libcoati_hip.so: $(HIP_SRC) coati_amd/csrc/viterbi_lp_block.inc coati_amd/csrc/abi_internal.hpp coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 

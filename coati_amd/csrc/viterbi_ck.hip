@@ -25,8 +25,6 @@
 // fp32 only, adds/max in the reference's evaluation order; -ffp-contract=off -fno-slp-vectorize.
 #include "viterbi_cell.hpp"
 
-#include "viterbi_ck_block.inc"
-
 #include <algorithm>
 #include <cstdio>
 #include <cstddef>
@@ -206,7 +204,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     // ---- checkpoint: what this lane received (one coalesced 512-byte row per wavefront step)
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, kk * (kWave * 8u), 0);
     // ---- the W cells (and the LDS gather for the next step)
-    row_lean<W>(cx.kv, st, diag, zl, s, arow_next, boff, std::make_integer_sequence<int, W>{});  // (boff includes the table's LDS address)
+    row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
     // lane 63 just did body row kstep - 63: its last column is the next strip's boundary
     if(!cx.last_strip && lane == kWave - 1 && kstep >= static_cast<uint32_t>(kWave - 1) && kstep - (kWave - 1) < cx.la) {
@@ -242,6 +240,12 @@ __device__ __forceinline__ void ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
     }
 }
 
+// Checkpoints of strip `strip` of a pair (dwords from the start of the PAIR's checkpoint area, which is
+// PairDesc::flags_off in the arena or the slot of the wavefront that processes the pair)
+__device__ __forceinline__ uint64_t ck_strip_base(const PairDesc& pd, uint32_t strip) {
+    return strip * ck_strip_dwords(pd.la, pd.v_wmain);
+}
+
 // The chunks of a streamed call are not read by the host before they go up (reading every sequence byte once
 // from DRAM was most of the host's planning time): the fill checks the codes it loads anyway and reports the
 // first it finds out of range -- one 64-bit word in page-locked host memory: bit 63 set, bit 40 = descendant
@@ -253,110 +257,6 @@ __device__ __forceinline__ void ck_report_bad(unsigned long long* bad, uint32_t 
     __hip_atomic_store(bad, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// 16 wavefront steps of a single-strip pair, 16 columns per lane, every lane started (kb >= 64): the hand-allocated
-// block of gen_viterbi_ck.py -- the same cell, the same checkpoints, 265 instructions per step instead of 297.
-// In: the 16-row chunk (lane j < 16: column 0 of the matrix for row kb + j, the table row offset of ancestor row
-// kb + j + 1).  Out: the ancestor codes of the next block's rows (loaded while this one computes).
-__device__ __forceinline__ void ck_block16(const GapVec& kv, CkLane<16>& st, uint32_t& arow, float (&s)[16], const uint32_t (&bl)[16],
-                                           uint32_t kb, uint32_t lane, float bx, float bz, uint32_t ach, uint32_t coloff, uint32_t rkoff,
-                                           u32x4_t rs_colin, u32x4_t rs_rk, u32x4_t rs_a, uint32_t& na) {
-    uint32_t arb;
-    float m, t0, t1, t2, t3, t4;
-    const uint32_t vin_a = kb + kCkRows + lane + 1u;
-    const uint32_t so_c0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(kb * (kWave * 8u))));
-    const uint32_t so_c1 = so_c0 + 4096u;
-    const uint32_t so_r0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kb / kCkRows) * (2u * 16u * kWave * 4u))));
-    const uint32_t so_r1 = so_r0 + 4096u;
-    asm volatile(COATI_CK16_BLOCK_ASM
-                 : "+{v8}"(st.X[0]), "+{v9}"(st.X[1]), "+{v10}"(st.X[2]), "+{v11}"(st.X[3]), "+{v12}"(st.X[4]), "+{v13}"(st.X[5]), "+{v14}"(st.X[6]), "+{v15}"(st.X[7]), "+{v16}"(st.X[8]), "+{v17}"(st.X[9]), "+{v18}"(st.X[10]), "+{v19}"(st.X[11]), "+{v20}"(st.X[12]), "+{v21}"(st.X[13]), "+{v22}"(st.X[14]), "+{v23}"(st.X[15]),
-                   "+{v28}"(st.Y[0]), "+{v29}"(st.Y[1]), "+{v30}"(st.Y[2]), "+{v31}"(st.Y[3]), "+{v32}"(st.Y[4]), "+{v33}"(st.Y[5]), "+{v34}"(st.Y[6]), "+{v35}"(st.Y[7]), "+{v36}"(st.Y[8]), "+{v37}"(st.Y[9]), "+{v38}"(st.Y[10]), "+{v39}"(st.Y[11]), "+{v40}"(st.Y[12]), "+{v41}"(st.Y[13]), "+{v42}"(st.Y[14]), "+{v43}"(st.Y[15]),
-                   [s0] "+{v46}"(s[0]), [s1] "+{v47}"(s[1]), [s2] "+{v48}"(s[2]), [s3] "+{v49}"(s[3]), [s4] "+{v50}"(s[4]), [s5] "+{v51}"(s[5]), [s6] "+{v52}"(s[6]), [s7] "+{v53}"(s[7]), [s8] "+{v54}"(s[8]), [s9] "+{v55}"(s[9]), [s10] "+{v56}"(s[10]), [s11] "+{v57}"(s[11]), [s12] "+{v58}"(s[12]), [s13] "+{v59}"(s[13]), [s14] "+{v60}"(s[14]), [s15] "+{v61}"(s[15]),
-                   [xb] "+{v24}"(st.xlast_old), [zl] "+{v25}"(st.zlast), [ara] "+{v26}"(arow), [arb] "=&{v27}"(arb), [m] "=&{v78}"(m),
-                   [t0] "=&{v79}"(t0), [t1] "=&{v80}"(t1), [t2] "=&{v81}"(t2), [t3] "=&{v82}"(t3), [t4] "=&{v83}"(t4), [na] "=&{v84}"(na)
-                 : [ng] "{v2}"(kv.ng), [gs] "{v3}"(kv.gs), [go] "{v4}"(kv.go), [ge] "{v5}"(kv.ge), [bx] "{v85}"(bx), [bz] "{v86}"(bz),
-                   [ach] "{v87}"(ach), [coloff] "{v88}"(coloff), [rkoff] "{v89}"(rkoff), [vin_a] "{v90}"(vin_a),
-                   [bl0] "{v62}"(bl[0]), [bl1] "{v63}"(bl[1]), [bl2] "{v64}"(bl[2]), [bl3] "{v65}"(bl[3]), [bl4] "{v66}"(bl[4]), [bl5] "{v67}"(bl[5]), [bl6] "{v68}"(bl[6]), [bl7] "{v69}"(bl[7]), [bl8] "{v70}"(bl[8]), [bl9] "{v71}"(bl[9]), [bl10] "{v72}"(bl[10]), [bl11] "{v73}"(bl[11]), [bl12] "{v74}"(bl[12]), [bl13] "{v75}"(bl[13]), [bl14] "{v76}"(bl[14]), [bl15] "{v77}"(bl[15]),
-                   [rs_colin] "s"(rs_colin), [rs_rk] "s"(rs_rk), [rs_a] "s"(rs_a), [so_c0] "s"(so_c0), [so_c1] "s"(so_c1), [so_r0] "s"(so_r0),
-                   [so_r1] "s"(so_r1)
-                 : COATI_CK16_SCRATCH_CLOBBERS, "memory");
-}
-
-// The run of blocks of one work item as a FUNCTION of its own (not inlined): the block pins 83 vector registers, and
-// inside the persistent kernel -- whose fill, traceback and queue loop keep another ~45 values alive -- the register
-// allocator answered with scratch reloads between blocks, each behind a wait for the block's 24 stores.  Here nothing
-// else is alive; the lane state crosses the call in private memory once per work item (~140 dwords).
-constexpr uint32_t kMinBlockRun = 64;  // steps: shorter runs stay in the C++ loop (the call and the state's round trip through memory cost ~400 scratch accesses)
-struct CkBlockIo {
-    float X[16], Y[16], s[16];
-    uint32_t boff[16];
-    float xlast_old, zlast;
-    uint32_t arow;
-};
-__device__ __forceinline__ uint32_t uniform_u32(uint32_t x) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x))); }
-template <typename T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-    const uint64_t a = reinterpret_cast<uint64_t>(p);
-    return reinterpret_cast<T*>(static_cast<uint64_t>(uniform_u32(static_cast<uint32_t>(a))) | (static_cast<uint64_t>(uniform_u32(static_cast<uint32_t>(a >> 32))) << 32));
-}
-__device__ __attribute__((noinline)) void ck_run_blocks(CkBlockIo* io, float ng, float gs, float go, float ge, uint32_t la_, uint32_t kb0_, uint32_t kb_end_,
-                                                        uint32_t band_, uint32_t centre, const uint32_t* ck_strip_, const uint32_t* rowck_strip_,
-                                                        const uint8_t* a_, unsigned long long* bad_, uint32_t pair_) {
-    // (arguments of a device function arrive in vector registers: what is wave-uniform goes back to scalars)
-    const GapConsts k{__builtin_bit_cast(float, uniform_u32(__builtin_bit_cast(uint32_t, ng))), __builtin_bit_cast(float, uniform_u32(__builtin_bit_cast(uint32_t, gs))),
-                      __builtin_bit_cast(float, uniform_u32(__builtin_bit_cast(uint32_t, go))), __builtin_bit_cast(float, uniform_u32(__builtin_bit_cast(uint32_t, ge)))};
-    const uint32_t la = uniform_u32(la_), kb0 = uniform_u32(kb0_), kb_end = uniform_u32(kb_end_), band = uniform_u32(band_), pair = uniform_u32(pair_);
-    const uint32_t* ck_strip = uniform_ptr(ck_strip_);
-    const uint32_t* rowck_strip = uniform_ptr(rowck_strip_);
-    const uint8_t* a = uniform_ptr(a_);
-    unsigned long long* bad = uniform_ptr(bad_);
-    const GapVec kv = gap_vec(k);
-    CkLane<16> st;
-    float s[16];
-    uint32_t boff[16];
-#pragma unroll
-    for(int c = 0; c < 16; ++c) st.X[c] = io->X[c], st.Y[c] = io->Y[c], s[c] = io->s[c], boff[c] = io->boff[c];
-    st.xlast_old = io->xlast_old;
-    st.zlast = io->zlast;
-    uint32_t arow = io->arow;
-    const u32x4_t rs_colin = raw_rsrc(ck_strip), rs_rk = raw_rsrc(rowck_strip), rs_a = raw_rsrc(a, la);
-    const float dm0 = __builtin_bit_cast(float, uniform_u32(__builtin_bit_cast(uint32_t, k.ng + k.go)));
-    uint32_t na_next;
-    {
-        uint32_t l32;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l32));
-        const uint32_t crow = kb0 + l32;
-        na_next = crow + 1 < la ? static_cast<uint32_t>(a[crow + 1]) : 0u;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(na_next));
-    }
-#pragma nounroll  // (one copy of the 4 200-instruction block)
-    for(uint32_t kb = kb0; kb < kb_end; kb += kCkRows) {
-        uint32_t l32;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l32));
-        const uint32_t crow = kb + l32;
-        const uint32_t code = na_next;
-        if(bad != nullptr && code >= static_cast<uint32_t>(kTabRows)) ck_report_bad(bad, pair, code, false);  // (streamed chunks)
-        uint32_t ach = code * (kTabStride * 4u);
-        // column 0 of the matrix (align_pair.cc:82-86), rows >= 64: the D margin
-        float bx = crow < la ? (dm0 + k.ge * static_cast<float>(crow - 1)) + k.gs : kLowest;
-        float bz = kLowest;
-        asm volatile("" : "+v"(ach), "+v"(bx), "+v"(bz));
-        const bool keep = ck_tile_kept(band, centre, static_cast<int32_t>(kb / kCkRows));
-        ck_block16(kv, st, arow, s, boff, kb, l32, bx, bz, ach, keep ? l32 * 8u : kCkDropOffset, keep ? l32 * 16u : kCkDropOffset, rs_colin, rs_rk, rs_a,
-                   na_next);
-    }
-#pragma unroll
-    for(int c = 0; c < 16; ++c) io->X[c] = st.X[c], io->Y[c] = st.Y[c], io->s[c] = s[c];
-    io->xlast_old = st.xlast_old;
-    io->zlast = st.zlast;
-    io->arow = arow;
-}
-
-// Checkpoints of strip `strip` of a pair (dwords from the start of the PAIR's checkpoint area, which is
-// PairDesc::flags_off in the arena or the slot of the wavefront that processes the pair)
-__device__ __forceinline__ uint64_t ck_strip_base(const PairDesc& pd, uint32_t strip) {
-    return strip * ck_strip_dwords(pd.la, pd.v_wmain);
-}
-
 // One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
 // the left neighbour's boundary column did not arrive within the spin bound.
 template <int W>
@@ -366,7 +266,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                                               uint32_t* __restrict__ ck, float* __restrict__ bnd,
                                               float* __restrict__ scores, uint32_t* __restrict__ progress,
                                               uint32_t kbegin = 0, uint32_t kend = 0xffffffffu,
-                                              unsigned long long* bad = nullptr, uint32_t band = kCkBandOff, bool blocks = false) {
+                                              unsigned long long* bad = nullptr, uint32_t band = kCkBandOff) {
     // [kbegin, kend): the steps of this item -- the whole strip, or one ROW PART of it (PairDesc::v_parts; whole
     // 64-step chunks).  A part that does not start at 0 takes over the lane state its predecessor left behind the
     // strip's checkpoints; one that does not end at the last step leaves it there.
@@ -386,7 +286,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     const float* __restrict__ in_z = in_x + (la + 1);
     bool handoff_ok = true;
 
-    uint32_t boff[W];  // LDS byte addresses of this lane's W columns in table row 0
+    uint32_t boff[W];  // byte offsets of this lane's W table columns
     {
         uint32_t worst = 0;
 #pragma unroll
@@ -394,7 +294,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             const uint32_t bj = col0 + lane * W + c;
             const uint32_t code = bj < lb ? static_cast<uint32_t>(b[bj]) : 0u;
             worst = max(worst, code);
-            boff[c] = code * 4u + lds_tab;
+            boff[c] = code * 4u;
         }
         if(bad != nullptr && worst >= static_cast<uint32_t>(kTabCols)) ck_report_bad(bad, pair, worst, true);
         if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
@@ -439,31 +339,9 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     // the W substitution scores of that row, gathered one step ahead
     float s[W];
 #pragma unroll
-    for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const __attribute__((address_space(3))) float*>(arow + boff[c]);
+    for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
 
-    // Whole 64-step chunks of a single-strip pair behind the first one (every lane has started) run as four blocks of
-    // hand-allocated instructions each (ck_block16); COATI_HIP_CK_BLOCKS=0: the C++ loop throughout (A/B).
     for(uint32_t kbase = kbegin; kbase < kend; kbase += kWave) {
-        if constexpr(W == 16) {
-            if(blocks && pd.v_strips == 1 && kbase >= static_cast<uint32_t>(kWave) && kbase + kWave <= kend && (kend - kbase >= kMinBlockRun)) {
-                // every whole chunk from here on: one run of blocks (ck_run_blocks)
-                const uint32_t kb_end = kbase + ((kend - kbase) / kWave) * kWave;
-                CkBlockIo io;
-#pragma unroll
-                for(int c = 0; c < W; ++c) io.X[c] = st.X[c], io.Y[c] = st.Y[c], io.s[c] = s[c], io.boff[c] = boff[c];
-                io.xlast_old = st.xlast_old;
-                io.zlast = st.zlast;
-                io.arow = arow;
-                ck_run_blocks(&io, k.ng, k.gs, k.go, k.ge, la, kbase, kb_end, cx.band, cx.centre, ck_strip, rowck_strip, a, bad, pair);
-#pragma unroll
-                for(int c = 0; c < W; ++c) st.X[c] = io.X[c], st.Y[c] = io.Y[c], s[c] = io.s[c];
-                st.xlast_old = io.xlast_old;
-                st.zlast = io.zlast;
-                arow = io.arow;
-                kbase = kb_end - kWave;
-                continue;
-            }
-        }
         // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l (boundary
         // column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
         const uint32_t crow = kbase + lane;
@@ -949,13 +827,11 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
         const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? band : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
-            if(cut || w_item == 16) {
-                // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own
-                // storage.  ONE call site: the fill's hot block is 34 KB of code)
-                const bool ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, cut ? kbegin : 0u,
-                                                  cut ? kend : 0xffffffffu, nullptr, band_now, (dbg & 0x80u) == 0u);
-                handoff_ok = cut ? ok && handoff_ok : ok;
-            } else if(w_item == 8)
+            if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
+            else if(w_item == 16)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+            else if(w_item == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
@@ -1058,8 +934,7 @@ template <bool kSharedTab>
 __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const float* __restrict__ table, GapConsts k,
                                                                           CkStreamCtl* ctl, const CkStreamHost* host,
                                                                           uint32_t* __restrict__ wave_ck, uint64_t wave_slot_dwords,
-                                                                          uint32_t* __restrict__ wave_scratch, uint32_t band, uint32_t flags) {
-    const bool blocks = (flags & 1u) != 0u;  // the hand-allocated 16-step blocks (ck_block16)
+                                                                          uint32_t* __restrict__ wave_scratch, uint32_t band) {
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
 
@@ -1240,11 +1115,11 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
         const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? band : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {
-            if(cut || w_item == 16) {
-                const bool ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress,
-                                                  cut ? kbegin : 0u, cut ? kend : 0xffffffffu, host_bad, band_now, blocks);
-                handoff_ok = cut ? ok && handoff_ok : ok;
-            } else if(w_item == 8)
+            if(cut)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
+            else if(w_item == 16)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad, band_now);
+            else if(w_item == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
@@ -1410,15 +1285,6 @@ uint32_t ck_band_setting() {
     return v;
 }
 
-// COATI_HIP_CK_BLOCKS=0: the C++ step loop throughout (the A/B partner of the hand-allocated blocks)
-bool ck_blocks_setting() {
-    static const bool v = [] {
-        const char* e = std::getenv("COATI_HIP_CK_BLOCKS");
-        return !(e != nullptr && e[0] == '0');
-    }();
-    return v;
-}
-
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
     if(e != hipSuccess) return e;
@@ -1428,7 +1294,7 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
     static const uint32_t dbg = [] {
         const char* e = std::getenv("COATI_HIP_CK_DEBUG");
-        return (e != nullptr ? static_cast<uint32_t>(std::atoi(e)) & ~0x80u : 0u) | (ck_blocks_setting() ? 0u : 0x80u);  // (bit 7: no blocks)
+        return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
     }();
     // (the debug export of every cell's decisions decodes every tile: that batch keeps every checkpoint)
     const uint32_t band = v.ck_keep_all != 0 ? kCkBandOff : ck_band_setting();
@@ -1503,11 +1369,11 @@ hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared
     if(shared_tab)
         hipLaunchKernelGGL(viterbi_ck_stream<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
                            static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch,
-                           ck_band_setting(), ck_blocks_setting() ? 1u : 0u);
+                           ck_band_setting());
     else
         hipLaunchKernelGGL(viterbi_ck_stream<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
                            static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch,
-                           ck_band_setting(), ck_blocks_setting() ? 1u : 0u);
+                           ck_band_setting());
     return hipGetLastError();
 }
 

@@ -14,7 +14,15 @@ Checkpoints as in viterbi_ck.hip: before the block's first step the lane state (
 checkpoint of this band), per step what the lane received (diagonal X, left Z: one 8-byte store); a lane outside the
 kept band has its offset registers out of range and stores nothing.
 
-usage: python coati_amd/csrc/gen_viterbi_ck.py   (writes viterbi_ck_block.inc next to itself)
+RESULT (round 3, measured, NOT kept in the product): bit-exact; but at four wavefronts per SIMD the instruction count
+is not what bounds the fill -- +4 % at 40 000 pairs, +1..3 % at 1 000-6 000, level at 10 000 (A/B in one process, box to
+box +-2.5 %).  And the block pins 83 vector registers: inside the persistent kernel (another ~45 live values at the
+128-register cap of four wavefronts per SIMD) the allocator reloads from scratch between blocks, each reload behind a
+wait for the block's 24 stores; as a non-inlined function the lane state crosses the call through memory, +27 % HBM
+traffic per launch (7.8 against 6.1 GB), or the whole item's fill moves into the function and its C++ chunks spill.
+History: git log -- coati_amd/csrc/gen_viterbi_ck.py (commit 515ea18 has the integrated version).
+
+usage: python tools/experiments/gen_viterbi_ck_block.py   (writes viterbi_ck_block.inc next to itself)
 """
 from pathlib import Path
 
