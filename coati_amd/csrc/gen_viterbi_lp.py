@@ -40,6 +40,7 @@ ZL = 28                        # v28 = Z carried along the row, v29 = Z handed i
 M = 30                         # v30 (v31 unused)
 T1, T2, T3, T4, T5 = 32, 34, 36, 38, 40
 TS, ADDR = 42, 43
+SA, SB = 44, 48                # the two score sets (v44.., v48..): a step reads one and gathers the next step's into the other
 PINNED_CLOBBERS = [29, 30, 31] + list(range(32, 44))
 
 
@@ -47,9 +48,11 @@ def pair(r):
     return f"v[{r}:{r + 1}]"
 
 
-def step(W, j, first, bnd):
+def step(W, j, first, bnd, pairtab):
     """step j (0..15) of a block of W columns per lane; first: lanes take their margin-row state at step == lane;
-    bnd: lane 63 publishes the strip's right boundary (dropped by its offset register elsewhere)"""
+    bnd: lane 63 publishes the strip's right boundary (dropped by its offset register elsewhere);
+    pairtab: the scores of two adjacent columns come from the 16-entry pair table (A/C/G/T descendants) with ONE
+    ds_read_b64 -- an LDS instruction costs a lone wavefront ~18 cycles of issue, four times a vector instruction"""
     L = []
     P = [PBASE + 2 * c for c in range(W - 1)]
     PA, PB = PBASE + 2 * (W - 1), PBASE + 2 * W
@@ -63,8 +66,8 @@ def step(W, j, first, bnd):
     shr = "wave_shr:1 row_mask:0xf bank_mask:0xf"
     # scores: this step reads the set the step before gathered, and gathers the next step's into the other set -- all
     # W gathers right after the table row is known, a whole step ahead of their use
-    cur = (lambda c: f"%[s{c}]") if even else (lambda c: f"%[t{c}]")
-    nxt = (lambda c: f"%[t{c}]") if even else (lambda c: f"%[s{c}]")
+    cur = (lambda c: f"v{SA + c}") if even else (lambda c: f"v{SB + c}")
+    nxt = (lambda c: f"v{SB + c}") if even else (lambda c: f"v{SA + c}")
     L.append("s_waitcnt lgkmcnt(0)")
     if first:
         L.append(f"v_cmp_eq_u32_e32 vcc, {j}, %[lrel]")
@@ -79,9 +82,14 @@ def step(W, j, first, bnd):
     L.append(f"v_add_f32_dpp v{M}, v{src3}, {cur(0)} {shr}")
     L.append(f"v_mov_b32_dpp v{ZL + 1}, %[bz] {lane0}")
     L.append(f"v_mov_b32_dpp v{ZL + 1}, v{ZL} {shr}")
-    for c in range(W):
-        L.append(f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{c}]")
-        L.append(f"ds_read_b32 {nxt(c)}, v{ADDR}")
+    if pairtab:
+        for h in range(W // 2):  # (pair table rows are twice as long: 2 x the row offset)
+            L.append(f"v_lshl_add_u32 v{ADDR}, {ar_dst}, 1, %[blp{h}]")
+            L.append(f"ds_read_b64 v[{nxt(2 * h)[1:]}:{int(nxt(2 * h)[1:]) + 1}], v{ADDR}")
+    else:
+        for c in range(W):
+            L.append(f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{c}]")
+            L.append(f"ds_read_b32 {nxt(c)}, v{ADDR}")
     for c in range(W):
         rd = P[c] if c < W - 1 else cur3
         wr = P[c] if c < W - 1 else new3
@@ -129,7 +137,7 @@ def step(W, j, first, bnd):
 LOAD_AT = {4: 12, 2: 8}
 
 
-def block(W, first):
+def block(W, first, pairtab):
     bnd = not first
     loads = ["buffer_load_dword %[nx], %[vin_x], %[rs_in], 0 offen sc1",
              "buffer_load_dword %[nz], %[vin_z], %[rs_in], 0 offen sc1",
@@ -140,7 +148,7 @@ def block(W, first):
         if j == LOAD_AT[W]:
             L += loads
             vmem_after = 0
-        s = step(W, j, first, bnd)
+        s = step(W, j, first, bnd, pairtab)
         vmem_after += sum(1 for x in s if x.startswith("buffer_"))
         L += s
     # the counter retires in issue order: everything up to the chunk loads is done when at most the operations issued
@@ -164,11 +172,13 @@ def main():
             LOAD_AT[w] = int(os.environ["COATI_LP_LOAD_AT"])
     text = "// GENERATED by gen_viterbi_lp.py -- do not edit (see that script for what the text does)\n"
     for W in (2, 4):
-        first, n_first = block(W, True)
-        main_, n_main = block(W, False)
-        text += (f"// {W} columns per lane: instructions per 16-step block: first {len(first)}, main {len(main_)}\n"
-                 + emit(f"COATI_LP{W}_BLOCK_FIRST_ASM", first) + emit(f"COATI_LP{W}_BLOCK_MAIN_ASM", main_))
-        print(f"W={W}: first block {len(first)} instructions ({n_first} stores), main block {len(main_)} ({n_main} stores)")
+        for pairtab in (False, True):
+            first, n_first = block(W, True, pairtab)
+            main_, n_main = block(W, False, pairtab)
+            tag = f"{W}P" if pairtab else f"{W}"
+            text += (f"// {W} columns per lane{', pair table' if pairtab else ''}: instructions per 16-step block: first {len(first)}, main {len(main_)}\n"
+                     + emit(f"COATI_LP{tag}_BLOCK_FIRST_ASM", first) + emit(f"COATI_LP{tag}_BLOCK_MAIN_ASM", main_))
+            print(f"W={W} pairtab={pairtab}: first block {len(first)} instructions ({n_first} stores), main block {len(main_)} ({n_main} stores)")
     clob = ", ".join(f'"v{r}"' for r in PINNED_CLOBBERS)
     text += f"#define COATI_LP_SCRATCH_CLOBBERS {clob}\n"
     Path(__file__).with_name("viterbi_lp_block.inc").write_text(text)

@@ -36,7 +36,10 @@ __device__ unsigned long long g_lp_trace[4096 * 4];
 #endif
 namespace {
 
-constexpr uint32_t kLpRows = 16;  // steps per block = rows per boundary chunk
+constexpr uint32_t kLpRows = 16;
+// Pair table: the scores of two adjacent descendant columns (A/C/G/T both) as one 8-byte entry, 16 entries per table row;
+// row stride 136 bytes = twice the single table's 68, so that the row offset the lanes hand along is simply doubled
+constexpr uint32_t kLpPairStride = 2u * kTabStride * 4u;  // steps per block = rows per boundary chunk
 typedef u32x4_t u32x4;
 constexpr uint32_t kLpDrop = kDropOffset;  // offset register of a lane that does not store (out of every range)
 __device__ __forceinline__ u32x4 lp_rsrc(const void* p, uint64_t bytes) { return raw_rsrc(p, bytes); }
@@ -46,6 +49,8 @@ template <int W>
 struct LpStrip {
     GapVec kv;
     uint32_t bl[W];   // LDS byte address of the lane's column c in table row 0
+    uint32_t blp[W / 2];  // ... of the lane's column pair (2h, 2h+1) in row 0 of the pair table
+    bool pairtab;     // (wave-uniform) the strip's descendant columns are all A/C/G/T and the launch has pair tables
     uint32_t offx, offz, offb;  // per-lane offsets: boundary X / Z stores (lane 63, or kLpDrop), decision rows
     u32x4 rs_in, rs_out, rs_bits, rs_a;
     float mx[W], my[W];  // the lane's margin-row state (taken at step == lane)
@@ -59,7 +64,6 @@ __device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st,
                                          uint32_t& na) {
     static_assert(W == 4 || W == 2, "gen_viterbi_lp.py writes these two shapes");
     uint32_t arb;
-    float t0, t1, t2, t3;  // the other set of scores (the steps alternate between s and t)
     const uint32_t next = kbase + kLpRows + static_cast<uint32_t>(lane);
     const uint32_t vin_x = next * 4u, vin_z = (la + 1u + next) * 4u, vin_a = next + 1u;
     const uint32_t so_bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase / (32u / W)) * (kPairDwords * 4u))));
@@ -67,38 +71,55 @@ __device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st,
     // (main blocks) lane 63 did body row kbase + j - 63 at step j: X of its last column goes to bnd_x[row + 1], Z to bnd_z[row]
     const uint32_t so_out = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase - (kWave - 1u)) * 4u)));
     // [X:Y] of column c in v[8+2c : 9+2c]; the last column's pair alternates with the pair after it, whose low half is
-    // xlast_old between blocks (gen_viterbi_lp.py)
+    // xlast_old between blocks; the scores in v44.. (the other set, v48.., is scratch) -- gen_viterbi_lp.py
 #define COATI_LP_COMMON_OUT                                                                                                   \
-    "+{v28}"(st.zlast), [s0] "+v"(s[0]), [s1] "+v"(s[1]), [ara] "+v"(arow), [arb] "=&v"(arb), [t0] "=&v"(t0), [t1] "=&v"(t1),  \
-        [aa] "+v"(st.acc[ACC_A]),                                                                                              \
+    "+{v28}"(st.zlast), "+{v44}"(s[0]), "+{v45}"(s[1]), [ara] "+v"(arow), [arb] "=&v"(arb), [aa] "+v"(st.acc[ACC_A]),          \
         [ab] "+v"(st.acc[ACC_B]), [ac] "+v"(st.acc[ACC_C]), [nx] "=&v"(nx), [nz] "=&v"(nz), [na] "=&v"(na)
 #define COATI_LP_COMMON_IN                                                                                                    \
     "{v2}"(sp.kv.go), "{v3}"(sp.kv.ng), "{v4}"(sp.kv.ge), "{v5}"(sp.kv.gs), [bx] "v"(bx), [bz] "v"(bz), [ach] "v"(ach),       \
-        [bl0] "v"(sp.bl[0]), [bl1] "v"(sp.bl[1]), [offb] "v"(sp.offb), [vin_x] "v"(vin_x), [vin_z] "v"(vin_z),                \
-        [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits), [rs_a] "s"(sp.rs_a), [so_bits] "s"(so_bits)
+        [bl0] "v"(sp.bl[0]), [bl1] "v"(sp.bl[1]), [blp0] "v"(sp.blp[0]), [offb] "v"(sp.offb), [vin_x] "v"(vin_x),             \
+        [vin_z] "v"(vin_z), [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits), [rs_a] "s"(sp.rs_a),        \
+        [so_bits] "s"(so_bits)
 #define COATI_LP_FIRST_IN [lrel] "v"(lrel), [mx0] "v"(sp.mx[0]), [mx1] "v"(sp.mx[1]), [my0] "v"(sp.my[0]), [my1] "v"(sp.my[1])
 #define COATI_LP_MAIN_IN [offx] "v"(sp.offx), [offz] "v"(sp.offz), [rs_out] "s"(sp.rs_out), [so_out] "s"(so_out)
     if constexpr(W == 4) {
 #define COATI_LP4_OUT                                                                                                         \
     "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.X[2]), "+{v13}"(st.Y[2]),          \
-        "+{v14}"(st.X[3]), "+{v15}"(st.Y[3]), "+{v16}"(st.xlast_old), [s2] "+v"(s[2]), [s3] "+v"(s[3]), [t2] "=&v"(t2), [t3] "=&v"(t3), COATI_LP_COMMON_OUT
-#define COATI_LP4_IN COATI_LP_COMMON_IN, [bl2] "v"(sp.bl[2]), [bl3] "v"(sp.bl[3])
-        if constexpr(kFirst)
-            asm volatile(COATI_LP4_BLOCK_FIRST_ASM
-                         : COATI_LP4_OUT
-                         : COATI_LP4_IN, COATI_LP_FIRST_IN, [mx2] "v"(sp.mx[2]), [mx3] "v"(sp.mx[3]), [my2] "v"(sp.my[2]), [my3] "v"(sp.my[3])
-                         : COATI_LP_SCRATCH_CLOBBERS, "v17", "vcc", "memory");
-        else
-            asm volatile(COATI_LP4_BLOCK_MAIN_ASM : COATI_LP4_OUT : COATI_LP4_IN, COATI_LP_MAIN_IN : COATI_LP_SCRATCH_CLOBBERS, "v17", "memory");
+        "+{v14}"(st.X[3]), "+{v15}"(st.Y[3]), "+{v16}"(st.xlast_old), "+{v46}"(s[2]), "+{v47}"(s[3]), COATI_LP_COMMON_OUT
+#define COATI_LP4_IN COATI_LP_COMMON_IN, [bl2] "v"(sp.bl[2]), [bl3] "v"(sp.bl[3]), [blp1] "v"(sp.blp[1])
+#define COATI_LP4_CLOBBERS COATI_LP_SCRATCH_CLOBBERS, "v17", "v48", "v49", "v50", "v51", "memory"
+#define COATI_LP4_FIRST_IN COATI_LP4_IN, COATI_LP_FIRST_IN, [mx2] "v"(sp.mx[2]), [mx3] "v"(sp.mx[3]), [my2] "v"(sp.my[2]), [my3] "v"(sp.my[3])
+        if(sp.pairtab) {  // (wave-uniform)
+            if constexpr(kFirst)
+                asm volatile(COATI_LP4P_BLOCK_FIRST_ASM : COATI_LP4_OUT : COATI_LP4_FIRST_IN : COATI_LP4_CLOBBERS, "vcc");
+            else
+                asm volatile(COATI_LP4P_BLOCK_MAIN_ASM : COATI_LP4_OUT : COATI_LP4_IN, COATI_LP_MAIN_IN : COATI_LP4_CLOBBERS);
+        } else {
+            if constexpr(kFirst)
+                asm volatile(COATI_LP4_BLOCK_FIRST_ASM : COATI_LP4_OUT : COATI_LP4_FIRST_IN : COATI_LP4_CLOBBERS, "vcc");
+            else
+                asm volatile(COATI_LP4_BLOCK_MAIN_ASM : COATI_LP4_OUT : COATI_LP4_IN, COATI_LP_MAIN_IN : COATI_LP4_CLOBBERS);
+        }
 #undef COATI_LP4_OUT
 #undef COATI_LP4_IN
+#undef COATI_LP4_CLOBBERS
+#undef COATI_LP4_FIRST_IN
     } else {
 #define COATI_LP2_OUT "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.xlast_old), COATI_LP_COMMON_OUT
-        if constexpr(kFirst)
-            asm volatile(COATI_LP2_BLOCK_FIRST_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_FIRST_IN : COATI_LP_SCRATCH_CLOBBERS, "v13", "vcc", "memory");
-        else
-            asm volatile(COATI_LP2_BLOCK_MAIN_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_MAIN_IN : COATI_LP_SCRATCH_CLOBBERS, "v13", "memory");
+#define COATI_LP2_CLOBBERS COATI_LP_SCRATCH_CLOBBERS, "v13", "v48", "v49", "memory"
+        if(sp.pairtab) {
+            if constexpr(kFirst)
+                asm volatile(COATI_LP2P_BLOCK_FIRST_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_FIRST_IN : COATI_LP2_CLOBBERS, "vcc");
+            else
+                asm volatile(COATI_LP2P_BLOCK_MAIN_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_MAIN_IN : COATI_LP2_CLOBBERS);
+        } else {
+            if constexpr(kFirst)
+                asm volatile(COATI_LP2_BLOCK_FIRST_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_FIRST_IN : COATI_LP2_CLOBBERS, "vcc");
+            else
+                asm volatile(COATI_LP2_BLOCK_MAIN_ASM : COATI_LP2_OUT : COATI_LP_COMMON_IN, COATI_LP_MAIN_IN : COATI_LP2_CLOBBERS);
+        }
 #undef COATI_LP2_OUT
+#undef COATI_LP2_CLOBBERS
     }
 #undef COATI_LP_COMMON_OUT
 #undef COATI_LP_COMMON_IN
@@ -146,7 +167,7 @@ __device__ __forceinline__ void lp_tail_step(const LpStrip<W>& sp, LaneState<W>&
 // boundary column did not arrive within the spin bound.
 template <int W>
 __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip, uint32_t ticket,
-                                              int lane, uint32_t lds_tab, const char* tab_bytes, const uint8_t* __restrict__ a,
+                                              int lane, uint32_t lds_tab, uint32_t lds_pair, const char* tab_bytes, const uint8_t* __restrict__ a,
                                               const uint8_t* __restrict__ b, uint32_t* __restrict__ flags, float* __restrict__ bnd,
                                               float* __restrict__ scores, uint32_t* __restrict__ progress) {
     const uint32_t la = pd.la, lb = pd.lb;
@@ -168,10 +189,12 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     uint32_t boff[W];
     LpStrip<W> sp;
     sp.kv = gap_vec(k);
+    uint32_t worst = 0;
 #pragma unroll
     for(int c = 0; c < W; ++c) {
         const uint32_t bj = col0 + lane * W + c;
         boff[c] = bj < lb ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+        worst = max(worst, boff[c]);
         sp.bl[c] = boff[c] + lds_tab;
         // margin row (matrix row 0, align_pair.cc:88-90): M = D = lowest, I = go + ge*float(j-1)
         const float im = k.go + k.ge * static_cast<float>(bj);
@@ -179,6 +202,10 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
         sp.mx[c] = i1 + k.ng;
         sp.my[c] = i1 + k.go;
     }
+    // pair table (kLpPairStride bytes per row, entry (b0, b1) at (b0 * 4 + b1) * 8): only if every column of the strip is A/C/G/T
+    sp.pairtab = lds_pair != 0 && __builtin_amdgcn_ballot_w64(worst < 16u) == ~0ull;
+#pragma unroll
+    for(int h = 0; h < W / 2; ++h) sp.blp[h] = lds_pair + (boff[2 * h] * 4u + boff[2 * h + 1]) * 2u;  // ((b0 * 4 + b1) * 8; boff = code * 4)
     const bool publisher = !last_strip && lane == kWave - 1;
     sp.offx = publisher ? 0u : kLpDrop;
     sp.offz = publisher ? (la + 1u) * 4u : kLpDrop;
@@ -357,10 +384,13 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ items,
     uint32_t n_items, uint32_t* __restrict__ queue, uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,
     const uint8_t* __restrict__ b_cat, uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
-    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
+    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t pair_tables) {
     __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];
+    extern __shared__ float lp_dynamic_lds[];  // pair_tables: one pair table per wavefront; else padding (launch_viterbi_lp)
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[threadIdx.x / kWave];
+    float* ptab = lp_dynamic_lds + (threadIdx.x / kWave) * (kTabRows * kLpPairStride / 4);
+    const uint32_t lds_pair = pair_tables != 0 ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ptab)) : 0u;
     uint32_t tab_held = 0xffffffffu;
     const char* tab_bytes = reinterpret_cast<const char*>(tab);
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address
@@ -384,14 +414,23 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
                 const int r = idx / kTabCols, c = idx - r * kTabCols;
                 tab[r * kTabStride + c] = src[idx];
             }
+            if(pair_tables != 0) {
+                // scores of two adjacent A/C/G/T columns side by side: [row][b0 * 4 + b1] = (s(row, b0), s(row, b1))
+                for(int idx = lane; idx < kTabRows * 16; idx += kWave) {
+                    const int r = idx >> 4, p = idx & 15;
+                    const float* __restrict__ row = src + r * kTabCols;
+                    ptab[r * (kLpPairStride / 4) + 2 * p] = row[p >> 2];
+                    ptab[r * (kLpPairStride / 4) + 2 * p + 1] = row[p & 3];
+                }
+            }
             tab_held = pd.table;
         }
         if(pd.la > 0 && pd.lb > 0) {  // (every strip of a pair has the pair's shape here)
             if(pd.v_wmain == 2)
-                handoff_ok = fill_strip_lp<2>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
+                handoff_ok = fill_strip_lp<2>(k, pd, pair, strip, ticket, lane, lds_tab, lds_pair, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
                                               flags, bnd, scores, progress);
             else
-                handoff_ok = fill_strip_lp<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
+                handoff_ok = fill_strip_lp<4>(k, pd, pair, strip, ticket, lane, lds_tab, lds_pair, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
                                               flags, bnd, scores, progress);
         }
 #ifdef COATI_FILL_TRACE
@@ -449,14 +488,21 @@ hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
     if(const char* e = std::getenv("COATI_HIP_LP_BLOCKS_PER_CU")) best = std::clamp(std::atoi(e), 1, 3);  // (experiment)
     constexpr size_t kStatic = kFillWaves * kTabRows * kTabStride * sizeof(float);
     constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 52 * 1024};
-    const size_t dyn = kPerBlock[best] - ((kStatic + 255) / 256) * 256;
+    // one workgroup per CU: the dynamic LDS holds a pair table per wavefront (99.6 KB, which also keeps a second workgroup
+    // off the CU); more: padding only, single-column gathers.  COATI_HIP_LP_PAIRTAB=0: never (A/B)
+    static const bool pair_ok = [] {
+        const char* e = std::getenv("COATI_HIP_LP_PAIRTAB");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    const bool pair_tables = best == 1 && pair_ok;
+    const size_t dyn = pair_tables ? static_cast<size_t>(kFillWaves) * kTabRows * kLpPairStride : kPerBlock[best] - ((kStatic + 255) / 256) * 256;
     if(dyn > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_lp), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn));
         if(e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(viterbi_lp, dim3(kCUs * static_cast<uint32_t>(best)), dim3(kFillWaves * kWave), dyn, stream, v.table, v.k, v.pairs,
                        v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops, v.ops_start,
-                       v.ops_len);
+                       v.ops_len, pair_tables ? 1u : 0u);
     return hipGetLastError();
 }
 
