@@ -27,6 +27,19 @@ def cell(c, parity, vconst, lds):
     t0, t1, t2, t3, t4, zl, s = "v10", "v11", "v12", "v13", "v14", f"v{ZL}", f"v{S+c}"
     ng, gs, go, ge = ("v2", "v3", "v4", "v5") if vconst else ("s4", "s5", "s6", "s7")
     L = []
+    if lds == 2:  # pair table: ONE ds_read_b64 per two columns (issued after the odd column's cell, address from the even one)
+        if c % 2 == 0:
+            L.append("s_waitcnt lgkmcnt(7)")
+        L += [f"v_add_f32 {t0}, {diag}, {s}", f"v_add_f32 {t1}, {ge}, {zl}", f"v_add_f32 {t2}, {gs}, {zl}",
+              f"v_add_f32 {t3}, {go}, {t0}", f"v_add_f32 {t0}, {ng}, {t0}"]
+        if c % 2 == 0:
+            L.append(f"v_add_lshl_u32 v21, v{LDS}, v7, 1")
+        L += [f"v_add_f32 {t4}, {ng}, {t2}", f"v_max_f32 {zl}, {t3}, {t1}", f"v_add_f32 {t1}, {gs}, {y}",
+              f"v_add_f32 {t3}, {ng}, {t0}", f"v_add_f32 {t2}, {go}, {t2}", f"v_max3_f32 {xout}, {t3}, {t1}, {t4}",
+              f"v_add_f32 {t1}, {ge}, {y}", f"v_add_f32 {t0}, {go}, {t0}", f"v_max3_f32 {y}, {t0}, {t1}, {t2}"]
+        if c % 2 == 1:
+            L.append(f"ds_read_b64 v[{S+c-1}:{S+c}], v21")
+        return L
     if lds:
         L.append("s_waitcnt lgkmcnt(15)")  # the read issued 16 cells ago (this column, previous step) has landed
     L += [f"v_add_f32 {t0}, {diag}, {s}", f"v_add_f32 {t1}, {ge}, {zl}", f"v_add_f32 {t2}, {gs}, {zl}",
@@ -173,6 +186,9 @@ VARIANTS = {
     "cell vgpr +stores half": body(True, False, False, 3),
     "cell vgpr +stores quarter": body(True, False, False, 4),
     "step vgpr (all)": body(True, True, True, 1),
+    "step vgpr, pair gathers": body(True, 2, True, 1),
+    "step vgpr, pair gathers, banded stores": body(True, 2, 1, 5),
+    "cell vgpr +pair gathers": body(True, 2, False, 0),
     "step sgpr (all)": body(False, True, True, 1),
     "step vgpr, lds cf": body(True, True, True, 1, cf=True),
     "step vgpr, stores half": body(True, True, True, 3),
