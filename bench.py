@@ -522,8 +522,11 @@ def main():
                          "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
                          "note": "priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell of traceback state); the "
                                  "limit this recurrence runs into is SIMD instruction issue (19 instructions per cell at ~2.2 "
-                                 "cycles) and the clock the chip holds -- valu_ceiling_gcups is the register-only replay of the "
-                                 "15-instruction fill cell at 2.35 GHz, valu_frac the kernel against it (DESIGN.md 4, 5b).  "
+                                 "cycles) and the clock the chip holds, which is the board's POWER limit: back-to-back launches "
+                                 "draw 1 335-1 350 W of the 1 400 W cap (tools/power_probe.sh, profiles/r03/power_probe.txt), and "
+                                 "cycles saved by a leaner step come back as a lower clock -- valu_ceiling_gcups is the "
+                                 "register-only replay of the 15-instruction fill cell at 2.35 GHz, valu_frac the kernel against it "
+                                 "(DESIGN.md 4, 5b).  "
                                  "Since round 3 the kernel WRITES less than the algorithmic 1 B/cell: checkpoints are kept "
                                  "in a band around each pair's straight line only (traffic = what the counters saw)"},
             "strong_1M": strong,

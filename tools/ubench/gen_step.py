@@ -27,6 +27,22 @@ def cell(c, parity, vconst, lds):
     t0, t1, t2, t3, t4, zl, s = "v10", "v11", "v12", "v13", "v14", f"v{ZL}", f"v{S+c}"
     ng, gs, go, ge = ("v2", "v3", "v4", "v5") if vconst else ("s4", "s5", "s6", "s7")
     L = []
+    if lds == 3:  # the cell with PACKED adds (viterbi_lp's form without the decision bits): is it cheaper in ENERGY? (the
+        # fill runs at the 1 400 W cap: tools/power_probe.sh)
+        P = f"v[{YP+2*c}:{YP+2*c+1}]"  # [Y : X] pair of this column (roles as in _regs: y = YP+2c, xin/xout alternate)
+        L.append("s_waitcnt lgkmcnt(15)")
+        L += [f"v_add_f32 v10, {diag}, {s}",
+              "v_pk_add_f32 v[12:13], v[10:11], v[2:3] op_sel:[0,0] op_sel_hi:[0,1]",
+              f"v_pk_add_f32 v[14:15], v[{ZL}:{ZL+1}], v[4:5] op_sel:[0,0] op_sel_hi:[0,1]",
+              f"v_add_u32 {s}, v{LDS}, v7",
+              "v_pk_add_f32 v[18:19], v[12:13], v[2:3] op_sel:[1,1] op_sel_hi:[1,0]",
+              f"v_pk_add_f32 v[20:21], {P}, v[4:5] op_sel:[0,0] op_sel_hi:[0,1]",
+              "v_pk_add_f32 v[22:23], v[14:15], v[2:3] op_sel:[1,1] op_sel_hi:[1,0]",
+              f"v_max_f32 {zl}, v12, v14",
+              f"v_max3_f32 {xout}, v18, v20, v22",
+              f"v_max3_f32 {y}, v19, v21, v23",
+              f"ds_read_b32 {s}, {s}"]
+        return L
     if lds == 2:  # pair table: ONE ds_read_b64 per two columns (issued after the odd column's cell, address from the even one)
         if c % 2 == 0:
             L.append("s_waitcnt lgkmcnt(7)")
@@ -186,6 +202,8 @@ VARIANTS = {
     "cell vgpr +stores half": body(True, False, False, 3),
     "cell vgpr +stores quarter": body(True, False, False, 4),
     "step vgpr (all)": body(True, True, True, 1),
+    "step vgpr, packed cell, banded stores": body(True, 3, 1, 5),
+    "cell vgpr packed +lds": body(True, 3, False, 0),
     "step vgpr, pair gathers": body(True, 2, True, 1),
     "step vgpr, pair gathers, banded stores": body(True, 2, 1, 5),
     "cell vgpr +pair gathers": body(True, 2, False, 0),
