@@ -29,7 +29,7 @@ Hand-off between lanes: DPP wave_shr:1; lane 0 takes the strip's left boundary f
 overwrites lanes 1-3).  The diagonal input is the left lane's X of its last column from BEFORE its
 previous step: cell 3 ping-pongs its [X:Y] pair between two register pairs instead of copying.
 
-usage: python coati_amd/csrc/gen_viterbi_lp.py   (writes viterbi_lp_block.inc next to itself)
+usage: python coati_amd/csrc/gen_viterbi_lp.py [out]   (default: viterbi_lp_block.inc next to itself)
 """
 from pathlib import Path
 
@@ -181,7 +181,9 @@ def main():
             print(f"W={W} pairtab={pairtab}: first block {len(first)} instructions ({n_first} stores), main block {len(main_)} ({n_main} stores)")
     clob = ", ".join(f'"v{r}"' for r in PINNED_CLOBBERS)
     text += f"#define COATI_LP_SCRATCH_CLOBBERS {clob}\n"
-    Path(__file__).with_name("viterbi_lp_block.inc").write_text(text)
+    import sys
+    out = Path(sys.argv[1]) if len(sys.argv) > 1 else Path(__file__).with_name("viterbi_lp_block.inc")
+    out.write_text(text)
 
 
 if __name__ == "__main__":
