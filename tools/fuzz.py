@@ -26,8 +26,18 @@ while time.time() < t_end:
     import os
     os.environ.pop("COATI_HIP_VITERBI_CK", None)
     os.environ.pop("COATI_HIP_VITERBI_BITS", None)
-    forced = rng.choice(["auto", "ck", "ck", "bits"])
+    forced = rng.choice(["auto", "auto", "ck", "ck", "bits", "l1"])
     os.environ.pop("COATI_HIP_CK_SPLIT", None)
+    os.environ.pop("COATI_HIP_L1_LP", None)
+    os.environ.pop("COATI_HIP_STRIP_W", None)
+    os.environ.pop("COATI_HIP_LP_PAIRTAB", None)
+    if forced in ("auto", "bits"):  # small batches run on viterbi_lp: both strip shapes, with and without the pair table
+        w = str(rng.choice(["", "", "2", "4"]))
+        if w:
+            os.environ["COATI_HIP_STRIP_W"] = w
+    if forced == "l1":  # the decision-bit kernel it replaced there
+        os.environ["COATI_HIP_VITERBI_BITS"] = "1"
+        os.environ["COATI_HIP_L1_LP"] = "0"
     if forced == "ck":
         os.environ["COATI_HIP_VITERBI_CK"] = "1"
         if rng.random() < 0.5:  # the last pairs of the LPT order cut into row parts (default only from 4 352 pairs)
