@@ -178,9 +178,16 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // cut into row parts (finer items for the ragged end of the kernel, as a resident batch's later pairs are, abi.hip
     // "the ragged end"): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- six larger workspaces of ~1 250 pairs
     const uint64_t tail_bytes = std::min<uint64_t>(3ull << 30, std::max<uint64_t>(kSlotArena, 1250 * (wave_slot_bytes + 4096) + (64ull << 20)));
+    // OFF by default since the banded checkpoints (round 3): a tail chunk has ~1 000 pairs, so part p of a pair is drawn only
+    // ~1 000 tickets after part p-1 -- by one of 4 096 wavefronts that then waits for it -- and the three parts of a pair
+    // run one after the other anyway; with the leaner fill that wait costs more than the finer items save (same process,
+    // page-locked arrays: 10 000 pairs 5.15 -> 4.92 ms, 40 000 pairs 16.55 -> 15.93 ms without them).  A resident batch
+    // keeps its row parts: there a part's predecessor is >= 4 096 tickets back.  COATI_HIP_STREAM_PARTS=1 turns them on
+    // (tests, A/B).
+    const bool tail_parts_on = std::getenv("COATI_HIP_STREAM_PARTS") != nullptr;  // (read per call: the tests switch it)
     // (a model's FIRST call on a small input runs without them: 2 x 1.4 GB of fresh allocation cost a one-shot process
-    // ~30 ms and buy its 10 000-pair kernel 0.5 ms)
-    const bool want_tails = model->stream_calls > 0 || total_cells >= 30 * kUnitCells;
+    // ~30 ms)
+    const bool want_tails = tail_parts_on && (model->stream_calls > 0 || total_cells >= 30 * kUnitCells);
     if(want_tails && model->stream_tail_bytes < tail_bytes) {
         for(void*& t : model->stream_tail_arena) {
             if(t != nullptr) (void)hipFree(t);
@@ -329,7 +336,6 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     uint64_t p0 = 0, ops_base = 0;
     long double cells_done = 0;
     int tails_used = 0;
-    const char* const no_tail_parts = std::getenv("COATI_HIP_STREAM_NO_PARTS");  // (A/B)
     for(size_t ci = 0; p0 < n_pairs && rc == COATI_HIP_OK; ++ci) {
         const int q = static_cast<int>(ci % static_cast<size_t>(n_slots));
         coati_hip_model::StreamSlot& sl = model->sslots[q];
@@ -341,7 +347,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         // row parts, in the large workspaces: the chunks behind the first 4 100 pairs' worth of cells, while at most
         // 8 300 pairs' worth are left
         const bool tail = ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= 8.3L * kUnit &&
-                          tails_used < coati_hip_model::kStreamTails && model->stream_tail_bytes != 0 && no_tail_parts == nullptr;
+                          tails_used < coati_hip_model::kStreamTails && model->stream_tail_bytes != 0 && tail_parts_on;
         void* const arena = tail ? model->stream_tail_arena[tails_used] : sl.arena;
         const uint64_t arena_bytes = tail ? model->stream_tail_bytes : sl.arena_bytes;
         ChunkNeed nd;

@@ -395,6 +395,8 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
 
     if kernel_choice == "bits":
         pytest.skip("viterbi_l1 forced: the streamed form is viterbi_ck only")
+    if kernel_choice == "ck":  # the last chunks cut into row parts (off by default since round 3: pipeline.hip)
+        monkeypatch.setenv("COATI_HIP_STREAM_PARTS", "1")
     table, consts = host.set_subst("mar-mg"), host.gap_consts()
     rng = np.random.default_rng(77)
     a_cat, a_off, b_cat, b_off = host.synth_encoded(0, 1500)

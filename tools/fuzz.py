@@ -104,6 +104,9 @@ while time.time() < t_end:
     # viterbi_ck_stream launch) with a small random unit so that a few dozen pairs make many chunks
     if L == 1 and rng.random() < 0.5:
         os.environ.pop("COATI_HIP_STREAM_UNIT", None)
+        os.environ.pop("COATI_HIP_STREAM_PARTS", None)
+        if rng.random() < 0.5:
+            os.environ["COATI_HIP_STREAM_PARTS"] = "1"  # (the call's last chunks cut into row parts: off by default)
         form = str(rng.choice(["stream", "stream", "chunks"]))
         os.environ["COATI_HIP_PIPE"] = form
         if form == "stream":
