@@ -309,7 +309,50 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
         return {"what": "benchmark/benchmark_main.cc.in BM_marg_alignment inputs: kernel ms on the GPU (pair alone / 64 copies in one "
                         "batch) and the unmodified reference engine (oracle/_ref, 1 host thread)", "cases": rows}
 
+    def power():
+        """Board power (rocm-smi) while the headline batch is launched back to back for ~2.5 s: the fill runs at the package
+        power cap.  Sampled from a thread of this process; rocm-smi is a child process."""
+        import re
+        import shutil
+        import threading
+
+        smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+        stop = threading.Event()
+
+        def burn():
+            while not stop.is_set():
+                for _ in range(20):
+                    batch.viterbi_launch()
+                batch.sync()
+
+        th = threading.Thread(target=burn)
+        th.start()
+        watts, cap, sclk = [], None, []
+        try:
+            time.sleep(0.8)
+            for _ in range(3):
+                pr = subprocess.run([smi, "--showpower", "--showmaxpower", "--showclocks"], capture_output=True, text=True, timeout=20)
+                m = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", pr.stdout)
+                if m:
+                    watts.append(float(m.group(1)))
+                m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", pr.stdout)
+                if m:
+                    cap = float(m.group(1))
+                m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", pr.stdout)
+                if m:
+                    sclk.append(int(m.group(1)))
+        finally:
+            stop.set()
+            th.join()
+            batch.close()
+        if not watts:
+            raise RuntimeError("rocm-smi reported no power")
+        return {"what": "rocm-smi while the headline batch is launched back to back (GPU 0 of this box)", "package_power_w": watts,
+                "package_power_cap_w": cap, "sclk_mhz": sclk, "frac_of_cap": (sum(watts) / len(watts) / cap) if cap else None}
+
     guarded("pcie_inclusive", streamed)
+    guarded("power", power)
     guarded("reference_suite", reference_suite)
     guarded("cli_batch", cli_batch)
     guarded("long_pair", long_pair)
