@@ -26,7 +26,7 @@ $(BUILD)/libcoati_hip_dist.so: coati_amd/csrc/dist.hip include/coati_hip_dist.h 
 
 # debug variant with per-wave clock stamps in the fill kernel (tools/trace_fill.py)
 trace: $(BUILD)/libcoati_hip_trace.so
-$(BUILD)/libcoati_hip_trace.so: $(HIP_SRC) coati_amd/csrc/abi_internal.hpp coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
+$(BUILD)/libcoati_hip_trace.so: $(HIP_SRC) coati_amd/csrc/viterbi_lp_block.inc coati_amd/csrc/abi_internal.hpp coati_amd/csrc/common.hpp coati_amd/csrc/viterbi_cell.hpp coati_amd/csrc/glibc_math.hpp include/coati_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -DCOATI_FILL_TRACE -shared -o $@ $(HIP_SRC)
 

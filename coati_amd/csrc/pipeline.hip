@@ -460,9 +460,13 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         }
     }
     if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: done at %.2f ms\n", t_ms());
+    if(rc == kRedo) {
+        // a pair or an upload the streamed form cannot serve: the chunk pipeline does the call -- unless the stream itself
+        // failed on top of it (a GPU fault is the likeliest reason for an upload to miss its bound): that is the error
+        if(es == hipSuccess) return COATI_HIP_ESTATE;
+        rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(es));
+    }
     if(rc == COATI_HIP_OK && es != hipSuccess) rc = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(es));
-    if(es == hipSuccess && rc == kRedo) return COATI_HIP_ESTATE;  // (a pair or an upload the streamed form cannot serve: the chunk pipeline does the call)
-    if(rc == kRedo) rc = COATI_HIP_OK;                            // (and the stream failed on top of it: reported just below)
     if(es == hipSuccess && (rc == kGaveUp || (rc == COATI_HIP_OK && dev_error != 0))) {
         // the kernel's waits are bounded (a host thread that was stopped for seconds must not hang the GPU): it gave
         // up, some chunks are incomplete.  Everything is quiet now; the chunk pipeline does the call again.

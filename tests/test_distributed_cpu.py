@@ -238,16 +238,18 @@ def test_rendezvous_through_the_launcher_store(tmp_path):
         "world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))\n"
         "uid = dist.rendezvous_id(world, rank, make_id=lambda: bytes((7 * i + 3) % 256 for i in range(128)), timeout_s=60)\n"
         "assert uid == bytes((7 * i + 3) % 256 for i in range(128))\n"
-        "print('rank', rank, 'ok', flush=True)\n")
+        # one file per rank: the launcher merges the ranks' stdout, and two concurrent prints interleave
+        f"open(os.path.join({str(tmp_path)!r}, 'rank%d.ok' % rank), 'w').write('ok')\n")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").read_text() == "ok" and (tmp_path / "rank1.ok").read_text() == "ok"
+    (tmp_path / "rank0.ok").unlink()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 1))
     for k in ("RANK", "WORLD_SIZE", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, env=env)
-    assert r.returncode == 0 and "rank 0 ok" in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]
+    assert r.returncode == 0 and (tmp_path / "rank0.ok").read_text() == "ok", r.stdout[-1000:] + r.stderr[-1000:]
