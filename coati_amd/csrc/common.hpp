@@ -79,11 +79,28 @@ struct PairDesc {
     // whichever wavefront takes the next part (0 or 1: not cut).  Finer items for the ragged end of a launch.
     uint8_t v_parts;
 };
-// steps [begin, end) of row part `part` of `parts` of a strip of nsteps wavefront steps: whole 64-step chunks
-__host__ __device__ inline void ck_part_range(uint32_t nsteps, uint32_t parts, uint32_t part, uint32_t& begin, uint32_t& end) {
+// PairDesc::v_parts: the number of row parts in the low seven bits; bit 7 = TAPERED parts (below)
+constexpr uint8_t kCkPartsTaper = 0x80;
+__host__ __device__ inline uint32_t ck_parts_count(uint8_t v_parts) { return v_parts & 0x7fu; }
+// steps [begin, end) of row part `part` of a strip of nsteps wavefront steps: whole 64-step chunks.  Equal parts, or --
+// tapered -- parts whose lengths fall linearly (weights parts, parts - 1, ... 1): what is left of a launch when its
+// ticket queue runs dry is at most one item per wavefront, and the items at the end of the queue are the LAST parts
+// of the cut pairs, so short last parts shorten the ragged end while long first parts keep the hand-overs few.
+__host__ __device__ inline uint32_t ck_part_cut(uint32_t chunks, uint32_t parts, uint32_t p, bool taper) {
+    if(!taper) return p * chunks / parts;
+    const uint32_t total = parts * (parts + 1u) / 2u, upto = p * parts - p * (p - 1u) / 2u;  // (p = 0: 0 - 0)
+    return upto * chunks / total;
+}
+__host__ __device__ inline void ck_part_range(uint32_t nsteps, uint8_t v_parts, uint32_t part, uint32_t& begin, uint32_t& end) {
+    const uint32_t chunks = (nsteps + 63u) / 64u, parts = ck_parts_count(v_parts);
+    const bool taper = (v_parts & kCkPartsTaper) != 0;
+    begin = 64u * ck_part_cut(chunks, parts, part, taper);
+    end = part + 1u == parts ? nsteps : 64u * ck_part_cut(chunks, parts, part + 1u, taper);
+}
+// every part of a strip of nsteps steps is at least one chunk long
+__host__ __device__ inline bool ck_parts_fit(uint32_t nsteps, uint32_t parts, bool taper) {
     const uint32_t chunks = (nsteps + 63u) / 64u;
-    begin = 64u * (part * chunks / parts);
-    end = part + 1u == parts ? nsteps : 64u * ((part + 1u) * chunks / parts);
+    return taper ? chunks >= parts * (parts + 1u) / 2u && chunks >= 2u * parts : chunks >= 2u * parts;
 }
 constexpr uint32_t kCkPartStateDwords = 3u * 64u;  // what a part leaves for the next besides the row checkpoint: per lane xlast_old, zlast, table row
 

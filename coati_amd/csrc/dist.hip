@@ -7,11 +7,18 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(ncclUniqueId) == COATI_HIP_DIST_ID_BYTES, "rendezvous id size");
@@ -61,6 +68,7 @@ struct coati_hip_comm {
     uint64_t *d_mine = nullptr, *d_counts = nullptr;
     void* d_land = nullptr;
     uint64_t land_bytes = 0;
+    double* d_reduce = nullptr;  // 64 doubles for coati_hip_dist_allreduce_f64 (no allocation inside a timed collective)
 };
 
 extern "C" {
@@ -83,6 +91,7 @@ void coati_hip_dist_destroy(coati_hip_comm_t* c) {
     if(c->d_mine != nullptr) (void)hipFree(c->d_mine);
     if(c->d_counts != nullptr) (void)hipFree(c->d_counts);
     if(c->d_land != nullptr) (void)hipFree(c->d_land);
+    if(c->d_reduce != nullptr) (void)hipFree(c->d_reduce);
     if(c->stream != nullptr) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -110,6 +119,7 @@ int coati_hip_dist_init(const void* id128, int world, int rank, int device, coat
     D_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
     D_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_mine), 4 * sizeof(uint64_t)));  // (pairs, op bytes, status)
     D_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_counts), 4 * sizeof(uint64_t) * static_cast<size_t>(world)));
+    D_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_reduce), 64 * sizeof(double)));
     guard.c = nullptr;
     *out = c;
     return COATI_HIP_OK;
@@ -121,12 +131,7 @@ int coati_hip_dist_world(const coati_hip_comm_t* c) { return c != nullptr ? c->w
 int coati_hip_dist_allreduce_f64(coati_hip_comm_t* c, int op, double* values, uint32_t n) {
     if(c == nullptr || values == nullptr || n == 0 || n > 64 || (op != 0 && op != 1)) return fail(COATI_HIP_EINVAL, "dist_allreduce_f64: bad argument");
     D_HIP(hipSetDevice(c->device));
-    double* d = nullptr;
-    D_HIP(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(double)));
-    struct Free {
-        void* p;
-        ~Free() { (void)hipFree(p); }
-    } free_d{d};
+    double* const d = c->d_reduce;
     D_HIP(hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     D_NCCL(ncclAllReduce(d, d, n, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
     D_HIP(hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -182,24 +187,29 @@ int coati_hip_dist_broadcast_model(coati_hip_comm_t* c, int root, float* tables,
 
 // ---------------------------------------------------------------------------------------------------
 // Pure host arithmetic of the gather and of the sharded job (no HIP, no RCCL): which blocks travel, where
-// they land in the root's HBM, where they end up in the caller's arrays.  The collective code below and the
-// host-memory simulation coati_hip_dist_simulate (tests: world 2, 3, 8 without a GPU) both run on THESE
-// functions; what only hardware can exercise is the literal ncclSend / ncclRecv / hipMemcpyAsync calls.
+// they land in the root's HBM, where they end up in the caller's arrays.  The per-rank job loop below is a
+// template over its ENVIRONMENT -- RCCL + HIP in production; host memory with an in-process transport
+// (coati_hip_dist_simulate: every rank a thread) or with the caller's transport (coati_hip_dist_job_host: every
+// rank a process, e.g. gloo in the CPU tests) -- so the multi-rank control flow that runs on the GPUs is the code
+// the CPU tests run; what only hardware can exercise is the literal ncclSend / ncclRecv / hipMemcpyAsync calls.
 // ---------------------------------------------------------------------------------------------------
 }  // extern "C"
 namespace {
 
-constexpr int kCountWords = 3;  // per rank in the all-gather: pairs, op bytes, status (COATI_HIP_OK or the rank's error code)
+constexpr int kCountWords = 3;  // per rank in the count exchange: pairs, op bytes, status (COATI_HIP_OK or the rank's error code)
+// which result arrays of a block a gather moves to the root
+enum : uint32_t { kScores = 1u, kOff = 2u, kLen = 4u, kOps = 8u, kAllArrays = 15u, kSummary = kScores | kLen };
+constexpr uint64_t kDefaultChunkCells = 12000ull * 1002 * 1002;
 
 struct Land {
     uint64_t scores, ops, off, len;  // byte offsets in the root's landing zone
 };
 // landing zone of the peers' blocks on the root (rank order, every array 256-byte aligned); returns its size
-uint64_t landing_plan(int world, int root, const uint64_t* counts /* kCountWords per rank */, Land* land) {
+uint64_t landing_plan(int world, int root, const uint64_t* counts /* kCountWords per rank */, uint32_t mask, Land* land) {
     uint64_t need = 0;
-    auto take = [&](uint64_t bytes) {
+    auto take = [&](uint64_t bytes, uint32_t which) {
         const uint64_t at = need;
-        need += (bytes + 255) / 256 * 256;
+        if(mask & which) need += (bytes + 255) / 256 * 256;
         return at;
     };
     for(int r = 0; r < world; ++r) {
@@ -208,7 +218,10 @@ uint64_t landing_plan(int world, int root, const uint64_t* counts /* kCountWords
             continue;
         }
         const uint64_t n = counts[kCountWords * r], ob = counts[kCountWords * r + 1];
-        land[r] = Land{take(n * sizeof(float)), take(ob), take(n * sizeof(uint64_t)), take(n * sizeof(uint32_t))};
+        land[r].scores = take(n * sizeof(float), kScores);
+        land[r].ops = take(ob, kOps);
+        land[r].off = take(n * sizeof(uint64_t), kOff);
+        land[r].len = take(n * sizeof(uint32_t), kLen);
     }
     return need;
 }
@@ -222,52 +235,59 @@ struct Transfer {
     uint64_t at, count;
     uint32_t bytes_each;
 };
-void transfers_of_rank(int r, const uint64_t* counts, const Land& l, std::vector<Transfer>& out) {
+void transfers_of_rank(int r, const uint64_t* counts, const Land& l, uint32_t mask, std::vector<Transfer>& out) {
     const uint64_t n = counts[kCountWords * r], ob = counts[kCountWords * r + 1];
     if(n > 0) {
-        out.push_back(Transfer{r, 0, l.scores, n, static_cast<uint32_t>(sizeof(float))});
-        out.push_back(Transfer{r, 1, l.off, n, static_cast<uint32_t>(sizeof(uint64_t))});
-        out.push_back(Transfer{r, 2, l.len, n, static_cast<uint32_t>(sizeof(uint32_t))});
+        if(mask & kScores) out.push_back(Transfer{r, 0, l.scores, n, static_cast<uint32_t>(sizeof(float))});
+        if(mask & kOff) out.push_back(Transfer{r, 1, l.off, n, static_cast<uint32_t>(sizeof(uint64_t))});
+        if(mask & kLen) out.push_back(Transfer{r, 2, l.len, n, static_cast<uint32_t>(sizeof(uint32_t))});
     }
-    if(ob > 0) out.push_back(Transfer{r, 3, l.ops, ob, 1u});
+    if(ob > 0 && (mask & kOps)) out.push_back(Transfer{r, 3, l.ops, ob, 1u});
 }
 
-// A rank's result block as four arrays (device pointers in the collective, host pointers in the simulation)
+// A rank's result block as four arrays (device pointers in the collective, host pointers in the host environments)
 struct Block {
     const void *scores = nullptr, *ops = nullptr, *off = nullptr, *len = nullptr;
 };
 const void* block_array(const Block& b, int which) { return which == 0 ? b.scores : which == 1 ? b.off : which == 2 ? b.len : b.ops; }
 
-// Root, after the exchange: the blocks in rank order (its own arrays, the landing zone for the peers) go to the
-// caller's arrays -- rank r's entries start at sum_{q<r} pairs(q), its op bytes at sum_{q<r} opbytes(q).  `copy`
-// moves bytes (hipMemcpyAsync device->host in the collective, memcpy in the simulation).
-template <typename Copy>
-int unpack_blocks(int world, int root, const uint64_t* counts, const Block& own, const char* landing, const Land* land, float* scores,
-                  uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len, Copy&& copy) {
+// Where rank r's block goes in the root's arrays: its first entry at index pair0, its op bytes at op0.  The plain
+// gather concatenates in rank order (prefix sums of the counts); the sharded job places every chunk where its
+// pairs are in the INPUT order, straight from the landing zone -- no staging copy on the host.
+struct Place {
+    uint64_t pair0, op0;
+};
+void prefix_places(int world, const uint64_t* counts, Place* place) {
     uint64_t pair0 = 0, op0 = 0;
+    for(int r = 0; r < world; ++r) {
+        place[r] = Place{pair0, op0};
+        pair0 += counts[kCountWords * r];
+        op0 += counts[kCountWords * r + 1];
+    }
+}
+// Root, after the exchange: the blocks (its own arrays, the landing zone for the peers) go to the caller's arrays.
+// `copy` moves bytes (hipMemcpyAsync device->host in the collective, memcpy in the host environments).
+template <typename Copy>
+int unpack_blocks(int world, int root, const uint64_t* counts, uint32_t mask, const Place* place, const Block& own, const char* landing,
+                  const Land* land, float* scores, uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len, Copy&& copy) {
     for(int r = 0; r < world; ++r) {
         const uint64_t n = counts[kCountWords * r], ob = counts[kCountWords * r + 1];
         Block b = own;
         if(r != root) b = Block{landing + land[r].scores, landing + land[r].ops, landing + land[r].off, landing + land[r].len};
+        const uint64_t pair0 = place[r].pair0, op0 = place[r].op0;
         if(n > 0) {
-            if(scores != nullptr) { const int rc = copy(scores + pair0, b.scores, n * sizeof(float)); if(rc != COATI_HIP_OK) return rc; }
-            if(ops_off != nullptr) { const int rc = copy(ops_off + pair0, b.off, n * sizeof(uint64_t)); if(rc != COATI_HIP_OK) return rc; }
-            if(ops_len != nullptr) { const int rc = copy(ops_len + pair0, b.len, n * sizeof(uint32_t)); if(rc != COATI_HIP_OK) return rc; }
+            if(scores != nullptr && (mask & kScores)) { const int rc = copy(scores + pair0, b.scores, n * sizeof(float)); if(rc != COATI_HIP_OK) return rc; }
+            if(ops_off != nullptr && (mask & kOff)) { const int rc = copy(ops_off + pair0, b.off, n * sizeof(uint64_t)); if(rc != COATI_HIP_OK) return rc; }
+            if(ops_len != nullptr && (mask & kLen)) { const int rc = copy(ops_len + pair0, b.len, n * sizeof(uint32_t)); if(rc != COATI_HIP_OK) return rc; }
         }
-        if(ob > 0 && ops != nullptr) { const int rc = copy(ops + op0, b.ops, ob); if(rc != COATI_HIP_OK) return rc; }
-        pair0 += n;
-        op0 += ob;
+        if(ob > 0 && ops != nullptr && (mask & kOps)) { const int rc = copy(ops + op0, b.ops, ob); if(rc != COATI_HIP_OK) return rc; }
     }
     return COATI_HIP_OK;
 }
-// every rank's op offsets index its own ops array: rebase them into the concatenation
-void rebase_offsets(int world, const uint64_t* counts, uint64_t* ops_off) {
-    uint64_t pair0 = 0, op0 = 0;
-    for(int r = 0; r < world; ++r) {
-        for(uint64_t p = 0; p < counts[kCountWords * r]; ++p) ops_off[pair0 + p] += op0;
-        pair0 += counts[kCountWords * r];
-        op0 += counts[kCountWords * r + 1];
-    }
+// every rank's op offsets index its own ops array: rebase them to where its op bytes went
+void rebase_offsets(int world, const uint64_t* counts, const Place* place, uint64_t* ops_off) {
+    for(int r = 0; r < world; ++r)
+        for(uint64_t p = 0; p < counts[kCountWords * r]; ++p) ops_off[place[r].pair0 + p] += place[r].op0;
 }
 // first failed rank of a round, or -1
 int failed_rank(int world, const uint64_t* counts) {
@@ -320,7 +340,8 @@ void plan_block(const JobPlan& plan, int r, size_t k, uint64_t& p0, uint64_t& n,
     n = cut[k + 1] - cut[k];
     nb = plan.op_prefix[cut[k + 1]] - plan.op_prefix[cut[k]];
 }
-// every rank checks the gathered counts of a round against the plan (so that all leave together on a mismatch)
+// every rank checks the gathered counts of a round against the plan BEFORE anything is moved or unpacked (all
+// hold the same counts and the same plan: the same verdict everywhere, and all leave together on a mismatch)
 int check_round(const JobPlan& plan, int world, size_t k, const uint64_t* counts) {
     for(int r = 0; r < world; ++r) {
         uint64_t p0, n, nb;
@@ -332,118 +353,426 @@ int check_round(const JobPlan& plan, int world, size_t k, const uint64_t* counts
     }
     return COATI_HIP_OK;
 }
-// root: a round's staging arrays (the ranks' chunks concatenated in rank order, offsets rebased into st_ops) go to
-// their places in the caller's arrays -- pairs keep their input order
-void place_round(const JobPlan& plan, int world, size_t k, const float* st_scores, const uint8_t* st_ops, const uint64_t* st_off,
-                 const uint32_t* st_len, float* scores, uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len) {
-    uint64_t at_p = 0, at_b = 0;
+// where the blocks of round k go in the root's arrays: a chunk's pairs keep their input positions
+void round_places(const JobPlan& plan, int world, size_t k, Place* place) {
     for(int r = 0; r < world; ++r) {
         uint64_t p0, n, nb;
         plan_block(plan, r, k, p0, n, nb);
-        if(n == 0) continue;
-        if(scores != nullptr) std::memcpy(scores + p0, st_scores + at_p, n * sizeof(float));
-        if(ops_len != nullptr) std::memcpy(ops_len + p0, st_len + at_p, n * sizeof(uint32_t));
-        if(ops != nullptr && nb > 0) std::memcpy(ops + plan.op_prefix[p0], st_ops + at_b, nb);
-        if(ops_off != nullptr)
-            for(uint64_t p = 0; p < n; ++p) ops_off[p0 + p] = st_off[at_p + p] - at_b + plan.op_prefix[p0];
-        at_p += n;
-        at_b += nb;
+        place[r] = Place{p0, plan.op_prefix[p0]};
     }
 }
-void round_totals(const JobPlan& plan, int world, size_t k, uint64_t& np, uint64_t& nb) {
-    np = nb = 0;
-    for(int r = 0; r < world; ++r) {
-        uint64_t p0, n, b;
-        plan_block(plan, r, k, p0, n, b);
-        np += n;
-        nb += b;
+// the largest landing zone any round of the job needs (the root reserves it BEFORE the first round, and says so
+// in its status word if it cannot: no rank is ever left sending to a root that has gone)
+uint64_t job_landing_need(const JobPlan& plan, int world, int root, uint32_t mask) {
+    std::vector<uint64_t> counts(static_cast<size_t>(kCountWords) * static_cast<size_t>(world), 0);
+    std::vector<Land> land(static_cast<size_t>(world));
+    uint64_t need = 0;
+    for(size_t k = 0; k < plan.rounds; ++k) {
+        for(int r = 0; r < world; ++r) {
+            uint64_t p0, n, nb;
+            plan_block(plan, r, k, p0, n, nb);
+            counts[static_cast<size_t>(kCountWords) * r] = n, counts[static_cast<size_t>(kCountWords) * r + 1] = nb;
+        }
+        need = std::max(need, landing_plan(world, root, counts.data(), mask, land.data()));
     }
+    return need;
 }
 
-// The collective gather.  my_status: this rank's verdict on its own contribution (a rank whose batch could not
-// be made still takes part, with nothing to send, and tells the others); when any rank reports a failure every
-// rank returns COATI_HIP_ESTATE from THIS call -- nobody is left waiting in a later collective.
-int gather_impl(coati_hip_comm_t* c, int root, coati_hip_batch_t* batch, int my_status, uint64_t* counts3, float* scores, uint8_t* ops,
-                uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
-    D_HIP(hipSetDevice(c->device));
-    Block own;
-    uint64_t mine[kCountWords] = {0, 0, static_cast<uint64_t>(my_status)};
-    if(batch != nullptr && my_status == COATI_HIP_OK) {
-        void *d_scores = nullptr, *d_ops = nullptr, *d_off = nullptr, *d_len = nullptr;
-        int rc = coati_hip_viterbi_wait(batch);  // the results exist (other launches of the model keep running)
-        if(rc == COATI_HIP_OK) rc = coati_hip_batch_result_ptrs(batch, &d_scores, &d_ops, &mine[1], &d_off, &d_len);
-        if(rc == COATI_HIP_OK) {
-            mine[0] = coati_hip_batch_pairs(batch);
-            own = Block{d_scores, d_ops, d_off, d_len};
-        } else {
-            (void)fail(rc, "%s", coati_hip_last_error());
-            mine[0] = mine[1] = 0;
-            mine[2] = static_cast<uint64_t>(rc);
-        }
-    }
-    // 1. everybody learns everybody's counts and status
-    D_HIP(hipMemcpyAsync(c->d_mine, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-    D_NCCL(ncclAllGather(c->d_mine, c->d_counts, kCountWords, ncclUint64, c->comm, c->stream));
-    D_HIP(hipMemcpyAsync(counts3, c->d_counts, kCountWords * sizeof(uint64_t) * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, c->stream));
-    D_HIP(hipStreamSynchronize(c->stream));
-    if(const int bad = failed_rank(c->world, counts3); bad >= 0) {
-        if(bad == c->rank) return static_cast<int>(counts3[kCountWords * bad + 2]);  // (its own message is already set)
-        return fail(COATI_HIP_ESTATE, "dist_gather: rank %d failed with code %d", bad, static_cast<int>(counts3[kCountWords * bad + 2]));
-    }
-    // 2. one group of sends / receives out of (into) HBM
-    std::vector<Land> land(static_cast<size_t>(c->world));
-    std::vector<Transfer> xfer;
-    if(c->rank == root) {
-        const uint64_t need = landing_plan(c->world, root, counts3, land.data());
-        if(need > c->land_bytes) {
-            if(c->d_land != nullptr) (void)hipFree(c->d_land);
-            c->d_land = nullptr;
-            c->land_bytes = 0;
-            // (a failed allocation here is fatal for the job: the peers are about to send.  Agreeing on it would cost
-            // a second all-gather per round; the landing zone is at most the peers' result arrays, which fitted theirs.)
-            D_HIP(hipMalloc(&c->d_land, need));
-            c->land_bytes = need;
-        }
-        for(int r = 0; r < c->world; ++r)
-            if(r != root) transfers_of_rank(r, counts3, land[static_cast<size_t>(r)], xfer);
-    } else {
-        transfers_of_rank(c->rank, counts3, Land{0, 0, 0, 0}, xfer);
-    }
-    char* base = static_cast<char*>(c->d_land);
-    ncclResult_t first = ncclSuccess;
-    D_NCCL(ncclGroupStart());
-    for(const Transfer& t : xfer) {  // (never return between GroupStart and GroupEnd: the group would stay open)
-        const uint64_t bytes = t.count * t.bytes_each;
-        const ncclResult_t r = c->rank == root ? ncclRecv(base + t.at, bytes, ncclUint8, t.peer, c->comm, c->stream)
-                                               : ncclSend(block_array(own, t.which), bytes, ncclUint8, root, c->comm, c->stream);
-        if(r != ncclSuccess && first == ncclSuccess) first = r;
-    }
-    const ncclResult_t ended = ncclGroupEnd();
-    if(first != ncclSuccess) return fail(COATI_HIP_EHIP, "dist_gather: send/receive failed: %s", ncclGetErrorString(first));
-    if(ended != ncclSuccess) return fail(COATI_HIP_EHIP, "ncclGroupEnd failed: %s", ncclGetErrorString(ended));
-    if(c->rank != root) {
-        D_HIP(hipStreamSynchronize(c->stream));  // the batch's arrays may be reused after the call
+// ---------------------------------------------------------------------------------------------------
+// Environments.  What a rank's side of a round needs from its surroundings:
+//   exchange_counts   all ranks learn all ranks' (pairs, op bytes, status)
+//   landing_reserve   root: room for the peers' blocks;  landing(): its base
+//   transfer          root: receive every listed block into the landing zone; peer: send its listed arrays
+//   copy_out / sync   results to the caller's arrays (device -> host, or memcpy)
+// ---------------------------------------------------------------------------------------------------
+struct RcclEnv {
+    coati_hip_comm_t* c;
+    int world() const { return c->world; }
+    int rank() const { return c->rank; }
+    int begin() {
+        D_HIP(hipSetDevice(c->device));
         return COATI_HIP_OK;
     }
-    // 3. root: download in rank order
-    uint64_t total_ops = 0;
-    for(int r = 0; r < c->world; ++r) total_ops += counts3[kCountWords * r + 1];
-    if(ops != nullptr && ops_capacity < total_ops) {
-        (void)hipStreamSynchronize(c->stream);
-        return fail(COATI_HIP_EINVAL, "dist_gather: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
-                    static_cast<unsigned long long>(total_ops));
+    int exchange_counts(const uint64_t* mine, uint64_t* all) {
+        D_HIP(hipMemcpyAsync(c->d_mine, mine, kCountWords * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        D_NCCL(ncclAllGather(c->d_mine, c->d_counts, kCountWords, ncclUint64, c->comm, c->stream));
+        D_HIP(hipMemcpyAsync(all, c->d_counts, kCountWords * sizeof(uint64_t) * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, c->stream));
+        D_HIP(hipStreamSynchronize(c->stream));
+        return COATI_HIP_OK;
     }
-    hipStream_t stream = c->stream;
-    const int rc = unpack_blocks(c->world, root, counts3, own, base, land.data(), scores, ops, ops_off, ops_len,
-                                 [stream](void* dst, const void* src, uint64_t bytes) {
-                                     const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
-                                     return e == hipSuccess ? COATI_HIP_OK : fail(COATI_HIP_EHIP, "dist_gather: download failed: %s", hipGetErrorString(e));
-                                 });
-    D_HIP(hipStreamSynchronize(c->stream));
+    int landing_reserve(uint64_t need) {
+        if(need <= c->land_bytes) return COATI_HIP_OK;
+        if(c->d_land != nullptr) (void)hipFree(c->d_land);
+        c->d_land = nullptr;
+        c->land_bytes = 0;
+        D_HIP(hipMalloc(&c->d_land, need));
+        c->land_bytes = need;
+        return COATI_HIP_OK;
+    }
+    char* landing() const { return static_cast<char*>(c->d_land); }
+    int transfer(int root, const std::vector<Transfer>& xfer, const Block& own) {
+        char* base = landing();
+        ncclResult_t first = ncclSuccess;
+        D_NCCL(ncclGroupStart());
+        for(const Transfer& t : xfer) {  // (never return between GroupStart and GroupEnd: the group would stay open)
+            const uint64_t bytes = t.count * t.bytes_each;
+            const ncclResult_t r = c->rank == root ? ncclRecv(base + t.at, bytes, ncclUint8, t.peer, c->comm, c->stream)
+                                                   : ncclSend(block_array(own, t.which), bytes, ncclUint8, root, c->comm, c->stream);
+            if(r != ncclSuccess && first == ncclSuccess) first = r;
+        }
+        const ncclResult_t ended = ncclGroupEnd();
+        if(first != ncclSuccess) return fail(COATI_HIP_EHIP, "dist_gather: send/receive failed: %s", ncclGetErrorString(first));
+        if(ended != ncclSuccess) return fail(COATI_HIP_EHIP, "ncclGroupEnd failed: %s", ncclGetErrorString(ended));
+        return COATI_HIP_OK;
+    }
+    int copy_out(void* dst, const void* src, uint64_t bytes) {
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+        return e == hipSuccess ? COATI_HIP_OK : fail(COATI_HIP_EHIP, "dist_gather: download failed: %s", hipGetErrorString(e));
+    }
+    int sync() {
+        D_HIP(hipStreamSynchronize(c->stream));
+        return COATI_HIP_OK;
+    }
+};
+
+// Host memory in place of HBM, an abstract transport in place of RCCL.
+struct HostTransport {
+    virtual ~HostTransport() = default;
+    virtual int allgather(const uint64_t* mine, uint64_t* all, uint32_t words_per_rank) = 0;
+    virtual int send(int peer, const void* data, uint64_t bytes) = 0;
+    virtual int recv(int peer, void* data, uint64_t bytes) = 0;
+};
+struct HostEnv {
+    HostTransport* t;
+    int world_, rank_;
+    std::vector<char> land;
+    int world() const { return world_; }
+    int rank() const { return rank_; }
+    int begin() { return COATI_HIP_OK; }
+    int exchange_counts(const uint64_t* mine, uint64_t* all) {
+        const int rc = t->allgather(mine, all, kCountWords);
+        return rc == COATI_HIP_OK ? rc : fail(rc, "host transport: the count exchange failed (%d)", rc);
+    }
+    int landing_reserve(uint64_t need) {
+        if(need > land.size()) land.assign(need, static_cast<char>(0xDD));
+        return COATI_HIP_OK;
+    }
+    char* landing() { return land.data(); }
+    int transfer(int root, const std::vector<Transfer>& xfer, const Block& own) {
+        for(const Transfer& x : xfer) {
+            const uint64_t bytes = x.count * x.bytes_each;
+            int rc;
+            if(rank_ == root) {
+                if(x.at + bytes > land.size()) return fail(COATI_HIP_ESTATE, "host transport: a block leaves the landing zone");
+                rc = t->recv(x.peer, land.data() + x.at, bytes);
+            } else {
+                rc = t->send(root, block_array(own, x.which), bytes);
+            }
+            if(rc != COATI_HIP_OK) return fail(rc, "host transport: %s of array %d (%llu bytes) failed (%d)", rank_ == root ? "receive" : "send", x.which,
+                                               static_cast<unsigned long long>(bytes), rc);
+        }
+        return COATI_HIP_OK;
+    }
+    int copy_out(void* dst, const void* src, uint64_t bytes) {
+        std::memcpy(dst, src, bytes);
+        return COATI_HIP_OK;
+    }
+    int sync() { return COATI_HIP_OK; }
+};
+
+// One gather round on one rank.  my_status: this rank's verdict on its own contribution (a rank whose chunk could
+// not be made still takes part, with nothing to send, and tells the others); when any rank reports a failure every
+// rank returns an error from THIS round -- nobody is left waiting in a later collective.  `validate` (may be empty)
+// judges the counts before anything moves.  `presized`: the root reserved its landing zone before the job's first
+// round (and reported a failure in its status word); otherwise -- the stand-alone gather, whose sizes are only known
+// now -- the root reserves here and a second, one-word exchange tells the peers whether to send.
+template <typename Env, typename Validate>
+int gather_round(Env& env, int root, const Block& own, const uint64_t* mine, uint64_t* counts3, uint32_t mask, const Place* place_or_null,
+                 Validate&& validate, bool presized, float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
+    const int world = env.world(), rank = env.rank();
+    // 1. everybody learns everybody's counts and status
+    int rc = env.exchange_counts(mine, counts3);
     if(rc != COATI_HIP_OK) return rc;
-    if(ops_off != nullptr) rebase_offsets(c->world, counts3, ops_off);
+    if(const int bad = failed_rank(world, counts3); bad >= 0) {
+        if(bad == rank) return static_cast<int>(counts3[kCountWords * bad + 2]);  // (its own message is already set)
+        return fail(COATI_HIP_ESTATE, "dist_gather: rank %d failed with code %d", bad, static_cast<int>(counts3[kCountWords * bad + 2]));
+    }
+    rc = validate();
+    if(rc != COATI_HIP_OK) return rc;
+    std::vector<Place> place(static_cast<size_t>(world));
+    if(place_or_null != nullptr)
+        std::copy(place_or_null, place_or_null + world, place.begin());
+    else
+        prefix_places(world, counts3, place.data());
+    // 2. the landing zone, then one group of sends / receives out of (into) HBM
+    std::vector<Land> land(static_cast<size_t>(world));
+    std::vector<Transfer> xfer;
+    int root_status = COATI_HIP_OK;
+    if(rank == root) {
+        const uint64_t need = landing_plan(world, root, counts3, mask, land.data());
+        root_status = env.landing_reserve(need);
+        uint64_t total_ops = 0;
+        for(int r = 0; r < world; ++r) total_ops = std::max(total_ops, place[static_cast<size_t>(r)].op0 + counts3[kCountWords * r + 1]);
+        if(root_status == COATI_HIP_OK && ops != nullptr && (mask & kOps) && ops_capacity < total_ops)
+            root_status = fail(COATI_HIP_EINVAL, "dist_gather: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
+                               static_cast<unsigned long long>(total_ops));
+        for(int r = 0; r < world; ++r)
+            if(r != root) transfers_of_rank(r, counts3, land[static_cast<size_t>(r)], mask, xfer);
+    } else {
+        transfers_of_rank(rank, counts3, Land{0, 0, 0, 0}, mask, xfer);
+    }
+    if(!presized && world > 1) {
+        std::vector<uint64_t> verdicts(static_cast<size_t>(kCountWords) * static_cast<size_t>(world), 0);
+        const uint64_t word[kCountWords] = {0, 0, static_cast<uint64_t>(root_status)};
+        rc = env.exchange_counts(word, verdicts.data());
+        if(rc != COATI_HIP_OK) return rc;
+        const int root_said = static_cast<int>(verdicts[static_cast<size_t>(kCountWords) * root + 2]);
+        if(root_said != COATI_HIP_OK) return rank == root ? root_status : fail(COATI_HIP_ESTATE, "dist_gather: the root failed with code %d", root_said);
+    } else if(root_status != COATI_HIP_OK) {
+        return root_status;  // (a presized job cannot get here: the sizes were reserved and checked before round 0)
+    }
+    rc = env.transfer(root, xfer, own);
+    if(rc != COATI_HIP_OK) return rc;
+    if(rank != root) return env.sync();  // the block's arrays may be reused after the call
+    // 3. root: download, every block to its place
+    rc = unpack_blocks(world, root, counts3, mask, place.data(), own, env.landing(), land.data(), scores, ops, ops_off, ops_len,
+                       [&env](void* dst, const void* src, uint64_t bytes) { return env.copy_out(dst, src, bytes); });
+    const int rs = env.sync();
+    if(rc != COATI_HIP_OK) return rc;
+    if(rs != COATI_HIP_OK) return rs;
+    if(ops_off != nullptr && (mask & kOff)) rebase_offsets(world, counts3, place.data(), ops_off);
     return COATI_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The sharded job on one rank: its shard in chunks, chunk k + 1 computing while chunk k is gathered.
+//   gather-all (local = false): every result array goes to the root, pairs in input order.
+//   local      (local = true):  a rank's ops, op offsets, op lengths and scores stay with it -- downloaded over ITS
+//     PCIe link into ITS arrays (entry 0 = the first pair of its shard; offsets index its own ops array) -- and only
+//     the summary (scores + op lengths, 8 bytes per pair) is gathered, if asked for.  With 2 kB of ops per 1 kb pair
+//     the root's single host link otherwise carries every rank's output (the stage budget).
+// `Chunks` computes: start(p0, n) -> handle; finish(handle, block, n, op bytes) waits for it; release(handle).
+// ---------------------------------------------------------------------------------------------------
+struct JobOut {
+    float* scores = nullptr;
+    uint8_t* ops = nullptr;
+    uint64_t ops_capacity = 0;
+    uint64_t* ops_off = nullptr;
+    uint32_t* ops_len = nullptr;
+    bool local = false, summary = false;
+    float* all_scores = nullptr;  // local mode, root: every pair's score / op length (summary)
+    uint32_t* all_len = nullptr;
+};
+template <typename Env, typename Chunks>
+int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint64_t n_pairs, const JobOut& out) {
+    const int world = env.world(), rank = env.rank();
+    int my_status = env.begin();
+    const auto& mine = plan.cuts[static_cast<size_t>(rank)];
+    const uint64_t shard0 = plan.bounds[static_cast<size_t>(rank)], shard_ops0 = plan.op_prefix[shard0];
+    const uint64_t shard_ops = plan.op_prefix[plan.bounds[static_cast<size_t>(rank) + 1]] - shard_ops0;
+    const uint32_t mask = out.local ? (out.summary ? static_cast<uint32_t>(kSummary) : 0u) : static_cast<uint32_t>(kAllArrays);
+    // what only this rank can know goes into its status word of the first round, so that all ranks leave together
+    if(my_status == COATI_HIP_OK && !out.local && rank == root && out.ops != nullptr && out.ops_capacity < plan.op_prefix[n_pairs])
+        my_status = fail(COATI_HIP_EINVAL, "dist_viterbi: ops_capacity too small");
+    if(my_status == COATI_HIP_OK && out.local && out.ops != nullptr && out.ops_capacity < shard_ops)
+        my_status = fail(COATI_HIP_EINVAL, "dist_viterbi: ops_capacity of rank %d too small for its shard", rank);
+    if(my_status == COATI_HIP_OK) my_status = chunks.check(mine.front());
+    if(my_status == COATI_HIP_OK && rank == root && mask != 0u) my_status = env.landing_reserve(job_landing_need(plan, world, root, mask));
+    std::vector<uint64_t> counts(static_cast<size_t>(kCountWords) * static_cast<size_t>(world));
+    std::vector<Place> place(static_cast<size_t>(world));
+    auto start = [&](size_t k, void** h) -> int {
+        *h = nullptr;
+        if(k + 1 >= mine.size() || mine[k + 1] == mine[k]) return COATI_HIP_OK;
+        return chunks.start(mine[k], mine[k + 1] - mine[k], h);
+    };
+    void *cur = nullptr, *next = nullptr;
+    if(my_status == COATI_HIP_OK) my_status = start(0, &cur);
+    int rc = COATI_HIP_OK;
+    for(size_t k = 0; k < plan.rounds && rc == COATI_HIP_OK; ++k) {
+        if(my_status == COATI_HIP_OK) my_status = start(k + 1, &next);  // the next chunk computes while this one is gathered
+        Block own;
+        uint64_t word[kCountWords] = {0, 0, static_cast<uint64_t>(my_status)};
+        if(cur != nullptr && my_status == COATI_HIP_OK) {
+            my_status = chunks.finish(cur, own, word[0], word[1]);
+            if(my_status != COATI_HIP_OK) word[0] = word[1] = 0;
+            word[2] = static_cast<uint64_t>(my_status);
+        }
+        uint64_t p0 = 0, n = 0, nb = 0;
+        plan_block(plan, rank, k, p0, n, nb);
+        const uint64_t lp = p0 - shard0, lo = plan.op_prefix[p0] - shard_ops0;  // this chunk in the rank's own arrays
+        if(out.local && my_status == COATI_HIP_OK && word[0] == n && word[1] == nb && n > 0) {
+            // the rank's own download, on its own link, under the exchange of the summaries
+            int lc = COATI_HIP_OK;
+            if(out.scores != nullptr) lc = env.copy_out(out.scores + lp, own.scores, n * sizeof(float));
+            if(lc == COATI_HIP_OK && out.ops_off != nullptr) lc = env.copy_out(out.ops_off + lp, own.off, n * sizeof(uint64_t));
+            if(lc == COATI_HIP_OK && out.ops_len != nullptr) lc = env.copy_out(out.ops_len + lp, own.len, n * sizeof(uint32_t));
+            if(lc == COATI_HIP_OK && out.ops != nullptr && nb > 0) lc = env.copy_out(out.ops + lo, own.ops, nb);
+            if(lc != COATI_HIP_OK) word[2] = static_cast<uint64_t>(my_status = lc);
+        }
+        round_places(plan, world, k, place.data());
+        rc = gather_round(env, root, own, word, counts.data(), mask, place.data(), [&]() { return check_round(plan, world, k, counts.data()); },
+                          /*presized=*/true, out.local ? out.all_scores : out.scores, out.local ? nullptr : out.ops, out.ops_capacity,
+                          out.local ? nullptr : out.ops_off, out.local ? out.all_len : out.ops_len);
+        if(out.local) {
+            const int rs = env.sync();  // (the own download; the chunk's arrays go back with `cur`)
+            if(rc == COATI_HIP_OK) rc = rs;
+            if(rc == COATI_HIP_OK && out.ops_off != nullptr)
+                for(uint64_t i = 0; i < n; ++i) out.ops_off[lp + i] += lo;
+        }
+        if(cur != nullptr) chunks.release(cur);
+        cur = next;
+        next = nullptr;
+    }
+    if(cur != nullptr) chunks.release(cur);
+    if(next != nullptr) chunks.release(next);
+    return rc;
+}
+
+// chunks computed on the GPU: one resident batch per chunk (coati_hip_batch_create + coati_hip_viterbi_launch)
+struct GpuChunks {
+    coati_hip_model_t* model;
+    int rank;
+    const uint8_t *a_cat, *b_cat;
+    uint64_t a_first, b_first;
+    const uint64_t *a_off, *b_off;
+    std::vector<uint64_t> loc_a, loc_b;
+    int check(uint64_t first_pair) {
+        if(a_off[first_pair] < a_first || b_off[first_pair] < b_first)
+            return fail(COATI_HIP_EINVAL, "dist_viterbi: the sequence arrays of rank %d start behind its shard", rank);
+        return COATI_HIP_OK;
+    }
+    int start(uint64_t p0, uint64_t n, void** h) {
+        // the sequence bytes this rank was given start at offsets a_first / b_first of the concatenation: a chunk's
+        // offsets are rebased to the arrays it was given
+        loc_a.resize(n + 1), loc_b.resize(n + 1);
+        for(uint64_t i = 0; i <= n; ++i) loc_a[i] = a_off[p0 + i] - a_first, loc_b[i] = b_off[p0 + i] - b_first;
+        coati_hip_batch_t* b = nullptr;
+        int rc = coati_hip_batch_create(model, n, a_cat, loc_a.data(), b_cat, loc_b.data(), &b);
+        if(rc == COATI_HIP_OK) rc = coati_hip_viterbi_launch(b);
+        if(rc != COATI_HIP_OK) {
+            (void)fail(rc, "%s", coati_hip_last_error());
+            if(b != nullptr) coati_hip_batch_destroy(b);
+            b = nullptr;
+        }
+        *h = b;
+        return rc;
+    }
+    int finish(void* h, Block& own, uint64_t& n, uint64_t& nb) {
+        coati_hip_batch_t* b = static_cast<coati_hip_batch_t*>(h);
+        void *d_scores = nullptr, *d_ops = nullptr, *d_off = nullptr, *d_len = nullptr;
+        int rc = coati_hip_viterbi_wait(b);  // the results exist (other launches of the model keep running)
+        if(rc == COATI_HIP_OK) rc = coati_hip_batch_result_ptrs(b, &d_scores, &d_ops, &nb, &d_off, &d_len);
+        if(rc != COATI_HIP_OK) return fail(rc, "%s", coati_hip_last_error());
+        n = coati_hip_batch_pairs(b);
+        own = Block{d_scores, d_ops, d_off, d_len};
+        return COATI_HIP_OK;
+    }
+    void release(void* h) { coati_hip_batch_destroy(static_cast<coati_hip_batch_t*>(h)); }
+};
+
+// chunks "computed" from given per-pair results (the host environments): a chunk as a resident batch leaves it --
+// scores[n], ops slots of la + lb bytes (the ops right-aligned in the slot: the walkers write right to left),
+// ops_start[n] = index of the first op in the chunk's ops array.  Only the rank's own pairs are read.
+struct HostChunks {
+    const JobPlan& plan;
+    const float* pair_scores;
+    const uint8_t* pair_ops;
+    const uint32_t* pair_ops_len;
+    struct Chunk {
+        std::vector<float> scores;
+        std::vector<uint8_t> ops;
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> len;
+        uint64_t op_bytes = 0;  // the chunk's slots together
+    };
+    int check(uint64_t) { return COATI_HIP_OK; }
+    int start(uint64_t p0, uint64_t n, void** h) {
+        auto ch = std::make_unique<Chunk>();
+        const uint64_t nb = plan.op_prefix[p0 + n] - plan.op_prefix[p0];
+        ch->scores.assign(pair_scores + p0, pair_scores + p0 + n);
+        ch->len.assign(pair_ops_len + p0, pair_ops_len + p0 + n);
+        ch->ops.assign(std::max<uint64_t>(nb, 1), 0xEE);
+        ch->op_bytes = nb;
+        ch->off.resize(n);
+        for(uint64_t p = 0; p < n; ++p) {
+            const uint64_t slot0 = plan.op_prefix[p0 + p] - plan.op_prefix[p0], slot = plan.op_prefix[p0 + p + 1] - plan.op_prefix[p0 + p];
+            if(ch->len[p] > slot) return fail(COATI_HIP_EINVAL, "dist_simulate: pair %llu has more ops than its slot", static_cast<unsigned long long>(p0 + p));
+            ch->off[p] = slot0 + slot - ch->len[p];
+            std::memcpy(ch->ops.data() + ch->off[p], pair_ops + plan.op_prefix[p0 + p] + slot - ch->len[p], ch->len[p]);
+        }
+        *h = ch.release();
+        return COATI_HIP_OK;
+    }
+    int finish(void* h, Block& own, uint64_t& n, uint64_t& nb) {
+        const Chunk* ch = static_cast<const Chunk*>(h);
+        n = ch->scores.size();
+        nb = ch->op_bytes;
+        own = Block{ch->scores.data(), ch->ops.data(), ch->off.data(), ch->len.data()};
+        return COATI_HIP_OK;
+    }
+    void release(void* h) { delete static_cast<Chunk*>(h); }
+};
+
+// In-process transport of the simulation: every rank a thread, mailboxes per (sender, receiver), a generation
+// barrier for the all-gather.  Every wait is bounded (a protocol bug fails the test, it does not hang it).
+struct ThreadFabric {
+    int world;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::deque<std::vector<char>>> box;  // [src * world + dst]
+    std::vector<uint64_t> slots, result;              // all-gather words of the current generation / of the completed one
+    int arrived = 0;
+    uint64_t generation = 0;
+    explicit ThreadFabric(int w) : world(w), box(static_cast<size_t>(w) * static_cast<size_t>(w)) {}
+};
+struct ThreadTransport final : HostTransport {
+    ThreadFabric& f;
+    int rank;
+    ThreadTransport(ThreadFabric& fabric, int r) : f(fabric), rank(r) {}
+    static constexpr auto kPatience = std::chrono::seconds(60);
+    int allgather(const uint64_t* mine, uint64_t* all, uint32_t words) override {
+        std::unique_lock<std::mutex> lock(f.m);
+        if(f.arrived == 0) f.slots.assign(static_cast<size_t>(words) * static_cast<size_t>(f.world), 0);
+        if(f.slots.size() != static_cast<size_t>(words) * static_cast<size_t>(f.world)) return COATI_HIP_ESTATE;  // ranks disagree on the collective
+        std::copy(mine, mine + words, f.slots.begin() + static_cast<size_t>(words) * static_cast<size_t>(rank));
+        const uint64_t gen = f.generation;
+        if(++f.arrived == f.world) {
+            f.arrived = 0;
+            ++f.generation;
+            f.result = f.slots;
+            f.cv.notify_all();
+        } else if(!f.cv.wait_for(lock, kPatience, [&] { return f.generation != gen; })) {
+            return COATI_HIP_ESTATE;
+        }
+        std::copy(f.result.begin(), f.result.end(), all);
+        return COATI_HIP_OK;
+    }
+    int send(int peer, const void* data, uint64_t bytes) override {
+        std::lock_guard<std::mutex> lock(f.m);
+        const char* p = static_cast<const char*>(data);
+        f.box[static_cast<size_t>(rank) * static_cast<size_t>(f.world) + static_cast<size_t>(peer)].emplace_back(p, p + bytes);
+        f.cv.notify_all();
+        return COATI_HIP_OK;
+    }
+    int recv(int peer, void* data, uint64_t bytes) override {
+        std::unique_lock<std::mutex> lock(f.m);
+        auto& q = f.box[static_cast<size_t>(peer) * static_cast<size_t>(f.world) + static_cast<size_t>(rank)];
+        if(!f.cv.wait_for(lock, kPatience, [&] { return !q.empty(); })) return COATI_HIP_ESTATE;
+        if(q.front().size() != bytes) return COATI_HIP_ESTATE;  // the sender's list and the receiver's disagree
+        std::memcpy(data, q.front().data(), bytes);
+        q.pop_front();
+        return COATI_HIP_OK;
+    }
+};
+
+// the caller's transport (coati_hip_dist_job_host)
+struct CallbackTransport final : HostTransport {
+    const coati_hip_dist_host_transport_t& t;
+    explicit CallbackTransport(const coati_hip_dist_host_transport_t& tr) : t(tr) {}
+    int allgather(const uint64_t* mine, uint64_t* all, uint32_t words) override { return t.allgather(t.ctx, mine, all, words); }
+    int send(int peer, const void* data, uint64_t bytes) override { return t.send(t.ctx, peer, data, bytes); }
+    int recv(int peer, void* data, uint64_t bytes) override { return t.recv(t.ctx, peer, data, bytes); }
+};
 
 }  // namespace
 extern "C" {
@@ -452,8 +781,25 @@ int coati_hip_dist_gather(coati_hip_comm_t* c, int root, coati_hip_batch_t* batc
                           uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
     if(c == nullptr || counts == nullptr || root < 0 || root >= c->world) return fail(COATI_HIP_EINVAL, "dist_gather: bad argument");
     try {
+        RcclEnv env{c};
         std::vector<uint64_t> counts3(static_cast<size_t>(kCountWords) * static_cast<size_t>(c->world), 0);
-        const int rc = gather_impl(c, root, batch, COATI_HIP_OK, counts3.data(), scores, ops, ops_capacity, ops_off, ops_len);
+        Block own;
+        uint64_t mine[kCountWords] = {0, 0, static_cast<uint64_t>(env.begin())};
+        if(batch != nullptr && mine[2] == static_cast<uint64_t>(COATI_HIP_OK)) {
+            void *d_scores = nullptr, *d_ops = nullptr, *d_off = nullptr, *d_len = nullptr;
+            int rc = coati_hip_viterbi_wait(batch);  // the results exist (other launches of the model keep running)
+            if(rc == COATI_HIP_OK) rc = coati_hip_batch_result_ptrs(batch, &d_scores, &d_ops, &mine[1], &d_off, &d_len);
+            if(rc == COATI_HIP_OK) {
+                mine[0] = coati_hip_batch_pairs(batch);
+                own = Block{d_scores, d_ops, d_off, d_len};
+            } else {
+                (void)fail(rc, "%s", coati_hip_last_error());
+                mine[0] = mine[1] = 0;
+                mine[2] = static_cast<uint64_t>(rc);
+            }
+        }
+        const int rc = gather_round(env, root, own, mine, counts3.data(), kAllArrays, nullptr, [] { return COATI_HIP_OK; }, /*presized=*/false, scores,
+                                    ops, ops_capacity, ops_off, ops_len);
         for(int r = 0; r < c->world; ++r) {
             counts[2 * r] = counts3[static_cast<size_t>(kCountWords) * r];
             counts[2 * r + 1] = counts3[static_cast<size_t>(kCountWords) * r + 1];
@@ -464,69 +810,40 @@ int coati_hip_dist_gather(coati_hip_comm_t* c, int root, coati_hip_batch_t* batc
     }
 }
 
-int coati_hip_dist_viterbi_shard(coati_hip_comm_t* c, int root, coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
-                                 uint64_t a_first, const uint64_t* a_off, const uint8_t* b_cat, uint64_t b_first, const uint64_t* b_off,
-                                 float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
+static int shard_job_gpu(coati_hip_comm_t* c, int root, coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, uint64_t a_first,
+                         const uint64_t* a_off, const uint8_t* b_cat, uint64_t b_first, const uint64_t* b_off, const JobOut& out) {
     if(c == nullptr || model == nullptr || a_off == nullptr || b_off == nullptr || root < 0 || root >= c->world)
         return fail(COATI_HIP_EINVAL, "dist_viterbi: bad argument");
     try {
-        const int world = c->world;
         // Chunk plan of EVERY rank (all ranks hold the same lengths, so all compute the same plan and the
-        // collectives line up): a rank's shard in chunks of at most kChunkCells cells.
-        constexpr uint64_t kChunkCells = 12000ull * 1002 * 1002;
+        // collectives line up): a rank's shard in chunks of at most kDefaultChunkCells cells.
         JobPlan plan;
-        int my_status = make_job_plan(n_pairs, a_off, b_off, world, kChunkCells, plan);
-        if(my_status != COATI_HIP_OK) return my_status;  // (bad offsets: the same verdict on every rank)
-        // what only this rank can know goes into its status word of the first round, so that all ranks leave together
-        const auto& mine = plan.cuts[static_cast<size_t>(c->rank)];
-        if(c->rank == root && ops != nullptr && ops_capacity < plan.op_prefix[n_pairs]) my_status = fail(COATI_HIP_EINVAL, "dist_viterbi: ops_capacity too small");
-        if(my_status == COATI_HIP_OK && (a_off[mine.front()] < a_first || b_off[mine.front()] < b_first))
-            my_status = fail(COATI_HIP_EINVAL, "dist_viterbi: the sequence arrays of rank %d start behind its shard", c->rank);
-        // the sequence bytes this rank was given start at offsets a_first / b_first of the concatenation: a chunk's
-        // offsets are rebased to the arrays it was given
-        std::vector<uint64_t> loc_a, loc_b;
-        auto make = [&](size_t k, coati_hip_batch_t** out) -> int {
-            *out = nullptr;
-            if(k + 1 >= mine.size() || mine[k + 1] == mine[k]) return COATI_HIP_OK;
-            const uint64_t n = mine[k + 1] - mine[k];
-            loc_a.resize(n + 1), loc_b.resize(n + 1);
-            for(uint64_t i = 0; i <= n; ++i) loc_a[i] = a_off[mine[k] + i] - a_first, loc_b[i] = b_off[mine[k] + i] - b_first;
-            int rc = coati_hip_batch_create(model, n, a_cat, loc_a.data(), b_cat, loc_b.data(), out);
-            if(rc == COATI_HIP_OK) rc = coati_hip_viterbi_launch(*out);
-            if(rc != COATI_HIP_OK) (void)fail(rc, "%s", coati_hip_last_error());
-            return rc;
-        };
-        // per-round staging on the root: ranks' chunks arrive concatenated in rank order
-        std::vector<uint64_t> counts(static_cast<size_t>(kCountWords) * static_cast<size_t>(world));
-        std::vector<float> st_scores;
-        std::vector<uint8_t> st_ops;
-        std::vector<uint64_t> st_off;
-        std::vector<uint32_t> st_len;
-        coati_hip_batch_t *cur = nullptr, *next = nullptr;
-        if(my_status == COATI_HIP_OK) my_status = make(0, &cur);
-        int rc = COATI_HIP_OK;
-        for(size_t k = 0; k < plan.rounds && rc == COATI_HIP_OK; ++k) {
-            if(my_status == COATI_HIP_OK) my_status = make(k + 1, &next);  // the next chunk computes while this one is gathered
-            if(c->rank == root) {
-                uint64_t np = 0, nb = 0;
-                round_totals(plan, world, k, np, nb);
-                st_scores.resize(np), st_off.resize(np), st_len.resize(np), st_ops.resize(std::max<uint64_t>(nb, 1));
-            }
-            rc = gather_impl(c, root, cur, my_status, counts.data(), st_scores.data(), st_ops.data(), st_ops.size(), st_off.data(), st_len.data());
-            if(cur != nullptr) coati_hip_batch_destroy(cur);
-            cur = next;
-            next = nullptr;
-            if(rc != COATI_HIP_OK) break;
-            rc = check_round(plan, world, k, counts.data());  // (every rank: same counts, same plan, same verdict)
-            if(rc != COATI_HIP_OK || c->rank != root) continue;
-            place_round(plan, world, k, st_scores.data(), st_ops.data(), st_off.data(), st_len.data(), scores, ops, ops_off, ops_len);
-        }
-        if(cur != nullptr) coati_hip_batch_destroy(cur);
-        if(next != nullptr) coati_hip_batch_destroy(next);
-        return rc;
+        const int rc = make_job_plan(n_pairs, a_off, b_off, c->world, kDefaultChunkCells, plan);
+        if(rc != COATI_HIP_OK) return rc;  // (bad offsets: the same verdict on every rank)
+        RcclEnv env{c};
+        GpuChunks chunks{model, c->rank, a_cat, b_cat, a_first, b_first, a_off, b_off, {}, {}};
+        return run_shard_job(env, chunks, root, plan, n_pairs, out);
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "dist_viterbi: host allocation failed");
     }
+}
+
+int coati_hip_dist_viterbi_shard(coati_hip_comm_t* c, int root, coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                                 uint64_t a_first, const uint64_t* a_off, const uint8_t* b_cat, uint64_t b_first, const uint64_t* b_off,
+                                 float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
+    JobOut out;
+    out.scores = scores, out.ops = ops, out.ops_capacity = ops_capacity, out.ops_off = ops_off, out.ops_len = ops_len;
+    return shard_job_gpu(c, root, model, n_pairs, a_cat, a_first, a_off, b_cat, b_first, b_off, out);
+}
+
+int coati_hip_dist_viterbi_shard_local(coati_hip_comm_t* c, int root, coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
+                                       uint64_t a_first, const uint64_t* a_off, const uint8_t* b_cat, uint64_t b_first, const uint64_t* b_off,
+                                       float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                                       int gather_summary, float* all_scores, uint32_t* all_len) {
+    JobOut out;
+    out.scores = scores, out.ops = ops, out.ops_capacity = ops_capacity, out.ops_off = ops_off, out.ops_len = ops_len;
+    out.local = true, out.summary = gather_summary != 0, out.all_scores = all_scores, out.all_len = all_len;
+    return shard_job_gpu(c, root, model, n_pairs, a_cat, a_first, a_off, b_cat, b_first, b_off, out);
 }
 
 int coati_hip_dist_viterbi(coati_hip_comm_t* c, int root, coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
@@ -535,13 +852,13 @@ int coati_hip_dist_viterbi(coati_hip_comm_t* c, int root, coati_hip_model_t* mod
     return coati_hip_dist_viterbi_shard(c, root, model, n_pairs, a_cat, 0, a_off, b_cat, 0, b_off, scores, ops, ops_capacity, ops_off, ops_len);
 }
 
-// ---- plan exports and the host-memory simulation (no device, no communicator) -------------------------------
+// ---- plan exports and the host-memory job (no device, no communicator) --------------------------------------
 int coati_hip_dist_chunk_plan(uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, int world, uint64_t chunk_cells,
                               uint64_t* cut_index, uint64_t* cuts, uint64_t cuts_capacity, uint64_t* rounds) {
     if(a_off == nullptr || b_off == nullptr || world < 1 || cut_index == nullptr || rounds == nullptr) return fail(COATI_HIP_EINVAL, "dist_chunk_plan: bad argument");
     try {
         JobPlan plan;
-        const int rc = make_job_plan(n_pairs, a_off, b_off, world, chunk_cells == 0 ? 12000ull * 1002 * 1002 : chunk_cells, plan);
+        const int rc = make_job_plan(n_pairs, a_off, b_off, world, chunk_cells == 0 ? kDefaultChunkCells : chunk_cells, plan);
         if(rc != COATI_HIP_OK) return rc;
         uint64_t at = 0;
         for(int r = 0; r < world; ++r) {
@@ -566,7 +883,7 @@ int coati_hip_dist_landing_plan(int world, int root, const uint64_t* counts, uin
         std::vector<uint64_t> c3(static_cast<size_t>(kCountWords) * static_cast<size_t>(world), 0);
         for(int r = 0; r < world; ++r) c3[static_cast<size_t>(kCountWords) * r] = counts[2 * r], c3[static_cast<size_t>(kCountWords) * r + 1] = counts[2 * r + 1];
         std::vector<Land> land(static_cast<size_t>(world));
-        *need = landing_plan(world, root, c3.data(), land.data());
+        *need = landing_plan(world, root, c3.data(), kAllArrays, land.data());
         for(int r = 0; r < world; ++r) {
             land4[4 * r] = land[static_cast<size_t>(r)].scores, land4[4 * r + 1] = land[static_cast<size_t>(r)].ops;
             land4[4 * r + 2] = land[static_cast<size_t>(r)].off, land4[4 * r + 3] = land[static_cast<size_t>(r)].len;
@@ -577,96 +894,99 @@ int coati_hip_dist_landing_plan(int world, int root, const uint64_t* counts, uin
     }
 }
 
-int coati_hip_dist_simulate(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, uint64_t chunk_cells,
+int coati_hip_dist_job_host(const coati_hip_dist_host_transport_t* transport, int world, int rank, int root, uint64_t n_pairs,
+                            const uint64_t* a_off, const uint64_t* b_off, uint64_t chunk_cells, int local, int gather_summary,
                             const float* pair_scores, const uint8_t* pair_ops, const uint32_t* pair_ops_len, float* scores, uint8_t* ops,
-                            uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
+                            uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len, float* all_scores, uint32_t* all_len) {
+    if(transport == nullptr || transport->allgather == nullptr || transport->send == nullptr || transport->recv == nullptr || world < 1 || rank < 0 ||
+       rank >= world || root < 0 || root >= world || a_off == nullptr || b_off == nullptr || pair_scores == nullptr || pair_ops == nullptr || pair_ops_len == nullptr)
+        return fail(COATI_HIP_EINVAL, "dist_job_host: bad argument");
+    try {
+        JobPlan plan;
+        const int rc = make_job_plan(n_pairs, a_off, b_off, world, chunk_cells == 0 ? kDefaultChunkCells : chunk_cells, plan);
+        if(rc != COATI_HIP_OK) return rc;
+        CallbackTransport tr(*transport);
+        HostEnv env{&tr, world, rank, {}};
+        HostChunks chunks{plan, pair_scores, pair_ops, pair_ops_len};
+        JobOut out;
+        out.scores = scores, out.ops = ops, out.ops_capacity = ops_capacity, out.ops_off = ops_off, out.ops_len = ops_len;
+        out.local = local != 0, out.summary = gather_summary != 0, out.all_scores = all_scores, out.all_len = all_len;
+        return run_shard_job(env, chunks, root, plan, n_pairs, out);
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "dist_job_host: host allocation failed");
+    }
+}
+
+// every rank of the job as a thread of this process
+static int simulate_impl(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, uint64_t chunk_cells, bool local,
+                         bool summary, const float* pair_scores, const uint8_t* pair_ops, const uint32_t* pair_ops_len, float* scores, uint8_t* ops,
+                         uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len, float* all_scores, uint32_t* all_len) {
     if(world < 1 || root < 0 || root >= world || a_off == nullptr || b_off == nullptr || pair_scores == nullptr || pair_ops == nullptr || pair_ops_len == nullptr)
         return fail(COATI_HIP_EINVAL, "dist_simulate: bad argument");
     try {
         JobPlan plan;
-        int rc = make_job_plan(n_pairs, a_off, b_off, world, chunk_cells == 0 ? 12000ull * 1002 * 1002 : chunk_cells, plan);
+        int rc = make_job_plan(n_pairs, a_off, b_off, world, chunk_cells == 0 ? kDefaultChunkCells : chunk_cells, plan);
         if(rc != COATI_HIP_OK) return rc;
-        if(ops != nullptr && ops_capacity < plan.op_prefix[n_pairs]) return fail(COATI_HIP_EINVAL, "dist_simulate: ops_capacity too small");
-        // a rank's chunk as a resident batch leaves it: scores[n], ops slots of la+lb bytes (the ops right-aligned in
-        // the slot: the walkers write right to left), ops_start[n] = index of the first op in the chunk's ops array
-        struct Chunk {
-            std::vector<float> scores;
-            std::vector<uint8_t> ops;
-            std::vector<uint64_t> off;
-            std::vector<uint32_t> len;
-        };
-        std::vector<uint64_t> counts(static_cast<size_t>(kCountWords) * static_cast<size_t>(world));
-        std::vector<Land> land(static_cast<size_t>(world));
-        std::vector<Chunk> chunk(static_cast<size_t>(world));
-        std::vector<char> landing;
-        std::vector<float> st_scores;
-        std::vector<uint8_t> st_ops;
-        std::vector<uint64_t> st_off;
-        std::vector<uint32_t> st_len;
-        for(size_t k = 0; k < plan.rounds; ++k) {
-            // every rank "computes" its chunk of this round and announces its counts
-            for(int r = 0; r < world; ++r) {
-                uint64_t p0, n, nb;
-                plan_block(plan, r, k, p0, n, nb);
-                Chunk& ch = chunk[static_cast<size_t>(r)];
-                ch.scores.assign(pair_scores + p0, pair_scores + p0 + n);
-                ch.len.assign(pair_ops_len + p0, pair_ops_len + p0 + n);
-                ch.ops.assign(nb, 0xEE);
-                ch.off.resize(n);
-                for(uint64_t p = 0; p < n; ++p) {
-                    const uint64_t slot0 = plan.op_prefix[p0 + p] - plan.op_prefix[p0], slot = plan.op_prefix[p0 + p + 1] - plan.op_prefix[p0 + p];
-                    if(ch.len[p] > slot) return fail(COATI_HIP_EINVAL, "dist_simulate: pair %llu has more ops than its slot", static_cast<unsigned long long>(p0 + p));
-                    ch.off[p] = slot0 + slot - ch.len[p];
-                    std::memcpy(ch.ops.data() + ch.off[p], pair_ops + plan.op_prefix[p0 + p] + slot - ch.len[p], ch.len[p]);
+        if(local && ops != nullptr && ops_capacity < plan.op_prefix[n_pairs]) return fail(COATI_HIP_EINVAL, "dist_simulate: ops_capacity too small");
+        ThreadFabric fabric(world);
+        std::vector<int> rcs(static_cast<size_t>(world), COATI_HIP_OK);
+        std::vector<std::string> errors(static_cast<size_t>(world));
+        std::vector<std::thread> threads;
+        for(int r = 0; r < world; ++r) {
+            threads.emplace_back([&, r]() {
+                try {
+                    ThreadTransport tr(fabric, r);
+                    HostEnv env{&tr, world, r, {}};
+                    HostChunks chunks{plan, pair_scores, pair_ops, pair_ops_len};
+                    JobOut out;
+                    out.local = local, out.summary = summary;
+                    if(local) {
+                        // every rank's own arrays are the slices of the caller's arrays that start at its shard
+                        const uint64_t s0 = plan.bounds[static_cast<size_t>(r)], o0 = plan.op_prefix[s0];
+                        const uint64_t o1 = plan.op_prefix[plan.bounds[static_cast<size_t>(r) + 1]];
+                        out.scores = scores != nullptr ? scores + s0 : nullptr;
+                        out.ops = ops != nullptr ? ops + o0 : nullptr;
+                        out.ops_capacity = o1 - o0;
+                        out.ops_off = ops_off != nullptr ? ops_off + s0 : nullptr;
+                        out.ops_len = ops_len != nullptr ? ops_len + s0 : nullptr;
+                        if(r == root) out.all_scores = all_scores, out.all_len = all_len;
+                    } else if(r == root) {
+                        out.scores = scores, out.ops = ops, out.ops_capacity = ops_capacity, out.ops_off = ops_off, out.ops_len = ops_len;
+                    }
+                    rcs[static_cast<size_t>(r)] = run_shard_job(env, chunks, root, plan, n_pairs, out);
+                    if(rcs[static_cast<size_t>(r)] != COATI_HIP_OK) errors[static_cast<size_t>(r)] = g_error;  // (thread-local)
+                } catch(const std::bad_alloc&) {
+                    rcs[static_cast<size_t>(r)] = COATI_HIP_ENOMEM;
+                    errors[static_cast<size_t>(r)] = "dist_simulate: host allocation failed";
                 }
-                counts[static_cast<size_t>(kCountWords) * r] = n, counts[static_cast<size_t>(kCountWords) * r + 1] = nb,
-                counts[static_cast<size_t>(kCountWords) * r + 2] = COATI_HIP_OK;
-            }
-            rc = check_round(plan, world, k, counts.data());
-            if(rc != COATI_HIP_OK) return rc;
-            // the exchange: every peer's transfer list, executed as memcpy into the root's landing zone; the
-            // receiver's list (derived from the counts alone) must name the same blocks
-            const uint64_t need = landing_plan(world, root, counts.data(), land.data());
-            landing.assign(need, static_cast<char>(0xDD));
-            std::vector<Transfer> recv;
-            for(int r = 0; r < world; ++r)
-                if(r != root) transfers_of_rank(r, counts.data(), land[static_cast<size_t>(r)], recv);
-            size_t at = 0;
-            for(int r = 0; r < world; ++r) {
-                if(r == root) continue;
-                std::vector<Transfer> send;
-                transfers_of_rank(r, counts.data(), Land{0, 0, 0, 0}, send);
-                const Chunk& ch = chunk[static_cast<size_t>(r)];
-                const Block b{ch.scores.data(), ch.ops.data(), ch.off.data(), ch.len.data()};
-                for(const Transfer& t : send) {
-                    if(at >= recv.size() || recv[at].peer != r || recv[at].which != t.which || recv[at].count != t.count || recv[at].bytes_each != t.bytes_each)
-                        return fail(COATI_HIP_ESTATE, "dist_simulate: round %zu: send %d of rank %d has no matching receive", k, t.which, r);
-                    const uint64_t bytes = t.count * t.bytes_each;
-                    if(recv[at].at + bytes > need) return fail(COATI_HIP_ESTATE, "dist_simulate: a block leaves the landing zone");
-                    std::memcpy(landing.data() + recv[at].at, block_array(b, t.which), bytes);
-                    ++at;
-                }
-            }
-            if(at != recv.size()) return fail(COATI_HIP_ESTATE, "dist_simulate: round %zu: %zu receives were never sent", k, recv.size() - at);
-            // root: unpack, rebase, place
-            uint64_t np = 0, nb = 0;
-            round_totals(plan, world, k, np, nb);
-            st_scores.assign(np, 0.0f), st_off.assign(np, 0), st_len.assign(np, 0), st_ops.assign(std::max<uint64_t>(nb, 1), 0);
-            const Chunk& rc_own = chunk[static_cast<size_t>(root)];
-            const Block own{rc_own.scores.data(), rc_own.ops.data(), rc_own.off.data(), rc_own.len.data()};
-            rc = unpack_blocks(world, root, counts.data(), own, landing.data(), land.data(), st_scores.data(), st_ops.data(), st_off.data(), st_len.data(),
-                               [](void* dst, const void* src, uint64_t bytes) {
-                                   std::memcpy(dst, src, bytes);
-                                   return COATI_HIP_OK;
-                               });
-            if(rc != COATI_HIP_OK) return rc;
-            rebase_offsets(world, counts.data(), st_off.data());
-            place_round(plan, world, k, st_scores.data(), st_ops.data(), st_off.data(), st_len.data(), scores, ops, ops_off, ops_len);
+            });
         }
+        for(auto& t : threads) t.join();
+        // the root's verdict first (it names the cause when a rank failed), then anybody's
+        if(rcs[static_cast<size_t>(root)] != COATI_HIP_OK) return fail(rcs[static_cast<size_t>(root)], "%s", errors[static_cast<size_t>(root)].c_str());
+        for(int r = 0; r < world; ++r)
+            if(rcs[static_cast<size_t>(r)] != COATI_HIP_OK) return fail(rcs[static_cast<size_t>(r)], "%s", errors[static_cast<size_t>(r)].c_str());
         return COATI_HIP_OK;
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "dist_simulate: host allocation failed");
+    } catch(const std::system_error& ex) {
+        return fail(COATI_HIP_EHIP, "dist_simulate: %s", ex.what());
     }
+}
+
+int coati_hip_dist_simulate(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, uint64_t chunk_cells,
+                            const float* pair_scores, const uint8_t* pair_ops, const uint32_t* pair_ops_len, float* scores, uint8_t* ops,
+                            uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
+    return simulate_impl(world, root, n_pairs, a_off, b_off, chunk_cells, false, false, pair_scores, pair_ops, pair_ops_len, scores, ops, ops_capacity,
+                         ops_off, ops_len, nullptr, nullptr);
+}
+
+int coati_hip_dist_simulate_local(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, uint64_t chunk_cells,
+                                  int gather_summary, const float* pair_scores, const uint8_t* pair_ops, const uint32_t* pair_ops_len,
+                                  float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len, float* all_scores,
+                                  uint32_t* all_len) {
+    return simulate_impl(world, root, n_pairs, a_off, b_off, chunk_cells, true, gather_summary != 0, pair_scores, pair_ops, pair_ops_len, scores, ops,
+                         ops_capacity, ops_off, ops_len, all_scores, all_len);
 }
 
 }  // extern "C"

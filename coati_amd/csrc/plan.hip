@@ -366,7 +366,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             for(const uint32_t p : order) {
                 PairDesc& d = b->desc[p];
                 if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && ck_strip_dwords(d.la, kW) <= (1ull << 20) &&
-                   d.la + kWave >= 128 * opts->tail_parts) {
+                   ck_parts_fit(d.la + (std::min<uint32_t>(kStrip, d.lb) + kW - 1) / kW - 1, opts->tail_parts, false)) {
                     d.v_parts = static_cast<uint8_t>(opts->tail_parts);
                     cut.push_back(p);
                 } else {
@@ -429,19 +429,23 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             split_pairs = std::min<uint64_t>(2 * ck_scratch_waves(), n_pairs - ck_scratch_waves());
             if(split_pairs < 256) split_pairs = 0;
         }
-        if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {
+        bool taper = false;
+        if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {  // "pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
             char* rest = nullptr;
             split_pairs = std::strtoull(e, &rest, 10);
-            if(rest != nullptr && *rest == ',') parts = std::strtoull(rest + 1, nullptr, 10);
+            if(rest != nullptr && *rest == ',') parts = std::strtoull(rest + 1, &rest, 10);
+            taper = rest != nullptr && rest[0] == ',' && rest[1] == 't';
             if(parts < 2 || parts > 8) split_pairs = 0;
         }
         split_pairs = std::min<uint64_t>(split_pairs, n_pairs);
         std::vector<uint32_t> cut;  // in LPT order
         for(uint64_t q = n_pairs - split_pairs; q < n_pairs; ++q) {
             PairDesc& d = b->desc[order[q]];
-            // (a part is at least two 64-step chunks; narrow last strips and multi-strip pairs stay whole)
-            if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && need_of(d) <= kSlotCap && d.la + kWave >= 128 * parts) {
-                d.v_parts = static_cast<uint8_t>(parts);
+            // (every part at least a 64-step chunk, two on average; narrow last strips and multi-strip pairs stay whole)
+            const uint32_t nsteps = d.la + (std::min<uint32_t>(kStrip, d.lb) + kW - 1) / kW - 1;
+            if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && need_of(d) <= kSlotCap &&
+               ck_parts_fit(nsteps, static_cast<uint32_t>(parts), taper)) {
+                d.v_parts = static_cast<uint8_t>(parts | (taper ? kCkPartsTaper : 0u));
                 cut.push_back(order[q]);
             }
         }
@@ -501,7 +505,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
     }
     if(b->ck_split_items > 0) {
-        const uint32_t parts = b->desc[order[n_pairs - 1]].v_parts;
+        const uint32_t parts = ck_parts_count(b->desc[order[n_pairs - 1]].v_parts);
         for(uint32_t part = 1; part < parts; ++part)
             for(uint64_t q = n_pairs - b->ck_split_items; q < n_pairs; ++q) items.push_back(WorkItem{order[q], part << 16});
     }

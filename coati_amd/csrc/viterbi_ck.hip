@@ -837,7 +837,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
         }
         COATI_CK_STAMP(0);  // fill of this item done
-        if(cut && part + 1 < pd.v_parts) {
+        if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
             // not the pair's last row part: release what this wavefront wrote for the pair (checkpoints, lane state),
             // then say how far the pair has got (or that it is lost)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
             else
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
         }
-        if(cut && part + 1 < pd.v_parts) {
+        if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             publish_progress(ch_progress + local, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);

@@ -27,9 +27,12 @@ EXPORTS = (
     "coati_hip_dist_gather",
     "coati_hip_dist_viterbi",
     "coati_hip_dist_viterbi_shard",
+    "coati_hip_dist_viterbi_shard_local",
     "coati_hip_dist_chunk_plan",
     "coati_hip_dist_landing_plan",
     "coati_hip_dist_simulate",
+    "coati_hip_dist_simulate_local",
+    "coati_hip_dist_job_host",
 )
 
 _lib = None
@@ -61,6 +64,9 @@ def load() -> C.CDLL:
     lib.coati_hip_dist_chunk_plan.argtypes = [u64, vp, vp, i32, u64, vp, vp, u64, vp]
     lib.coati_hip_dist_landing_plan.argtypes = [i32, i32, vp, vp, vp]
     lib.coati_hip_dist_simulate.argtypes = [i32, i32, u64, vp, vp, u64, vp, vp, vp, vp, vp, u64, vp, vp]
+    lib.coati_hip_dist_viterbi_shard_local.argtypes = [vp, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, vp, u64, vp, vp, i32, vp, vp]
+    lib.coati_hip_dist_simulate_local.argtypes = [i32, i32, u64, vp, vp, u64, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp]
+    lib.coati_hip_dist_job_host.argtypes = [vp, i32, i32, i32, u64, vp, vp, u64, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -125,6 +131,32 @@ class Comm:
         _check(load().coati_hip_dist_viterbi_shard(self._h, root, model._h, n, hip._ptr(a_cat), int(a_first), hip._ptr(a_off), hip._ptr(b_cat),
                                                    int(b_first), hip._ptr(b_off), *args))
         return (scores, ops, off, ln) if self.rank == root else None
+
+    def viterbi_shard_local(self, model, a_cat, a_first, a_off, b_cat, b_first, b_off, root: int = 0, summary: bool = True, pinned: bool = True,
+                            reuse=None):
+        """coati_hip_dist_viterbi_shard_local: every rank keeps the results of ITS shard -> (scores, ops, ops_off, ops_len) of
+        the pairs [bounds[rank], bounds[rank+1]) (page-locked arrays by default: the download is the rank's own PCIe
+        transfer), plus, on root when `summary`, (all_scores, all_len) of every pair (else None, None)."""
+        a_cat, b_cat = np.ascontiguousarray(a_cat, np.uint8), np.ascontiguousarray(b_cat, np.uint8)
+        a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+        n = len(a_off) - 1
+        bounds = hip.shard_bounds(a_off, b_off, self.world).astype(np.int64)
+        s0, s1 = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        n_loc = s1 - s0
+        ops_loc = int(a_off[s1] - a_off[s0] + b_off[s1] - b_off[s0])
+        if reuse is not None and len(reuse[0]) == n_loc and len(reuse[1]) >= max(ops_loc, 1):
+            scores, ops, off, ln = reuse
+        else:
+            make = hip.pinned_empty if pinned else (lambda shape, dt: np.zeros(shape, dt))
+            scores, ops = make(max(n_loc, 1), np.float32)[:n_loc], make(max(ops_loc, 1), np.uint8)
+            off, ln = make(max(n_loc, 1), np.uint64)[:n_loc], make(max(n_loc, 1), np.uint32)[:n_loc]
+        all_scores = all_len = None
+        if summary and self.rank == root:
+            all_scores, all_len = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        _check(load().coati_hip_dist_viterbi_shard_local(self._h, root, model._h, n, hip._ptr(a_cat), int(a_first), hip._ptr(a_off), hip._ptr(b_cat),
+                                                         int(b_first), hip._ptr(b_off), hip._ptr(scores), hip._ptr(ops), ops_loc, hip._ptr(off),
+                                                         hip._ptr(ln), int(summary), hip._ptr(all_scores), hip._ptr(all_len)))
+        return (scores, ops, off, ln), (all_scores, all_len)
 
     def broadcast_model(self, tables=None, consts=None, gap_len=None, root: int = 0, capacity: int = 64):
         """Root passes (tables [n,183,15], consts[4], gap_len); every rank gets them back bit-identical."""
@@ -208,6 +240,61 @@ def simulate(world: int, root: int, a_off, b_off, pair_scores, pair_ops, pair_op
     _check(load().coati_hip_dist_simulate(world, root, n, hip._ptr(a_off), hip._ptr(b_off), chunk_cells, hip._ptr(ps), hip._ptr(po), hip._ptr(pl),
                                           hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln)))
     return scores, ops, off, ln
+
+
+def simulate_local(world: int, root: int, a_off, b_off, pair_scores, pair_ops, pair_ops_len, chunk_cells: int = 0, summary: bool = True):
+    """coati_hip_dist_simulate_local: every rank keeps its shard -> (scores, ops, ops_off, ops_len, all_scores, all_len); rank r's own
+    arrays are the slices that start at its shard (ops_off relative to the rank's own ops array)."""
+    a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+    n = len(a_off) - 1
+    total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
+    ps = np.ascontiguousarray(pair_scores, np.float32)
+    po = np.ascontiguousarray(pair_ops, np.uint8)
+    pl = np.ascontiguousarray(pair_ops_len, np.uint32)
+    scores, ops = np.zeros(n, np.float32), np.full(max(total, 1), 0xCC, np.uint8)
+    off, ln = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+    all_scores, all_len = np.full(n, np.nan, np.float32), np.zeros(n, np.uint32)
+    _check(load().coati_hip_dist_simulate_local(world, root, n, hip._ptr(a_off), hip._ptr(b_off), chunk_cells, int(summary), hip._ptr(ps), hip._ptr(po),
+                                                hip._ptr(pl), hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln), hip._ptr(all_scores),
+                                                hip._ptr(all_len)))
+    return scores, ops, off, ln, all_scores, all_len
+
+
+class HostTransport(C.Structure):
+    """coati_hip_dist_host_transport_t over three Python callables (the CPU tests pass torch.distributed / gloo calls)."""
+    ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32)
+    SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64)
+    RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64)
+    _fields_ = [("ctx", C.c_void_p), ("allgather", ALLGATHER), ("send", SEND), ("recv", RECV)]
+
+
+def job_host(transport: HostTransport, world: int, rank: int, root: int, a_off, b_off, pair_scores, pair_ops, pair_ops_len, chunk_cells: int = 0,
+             local: bool = False, summary: bool = True):
+    """coati_hip_dist_job_host: THIS process is rank `rank` of the sharded job, the exchanges go through `transport`.
+    gather-all: (scores, ops, ops_off, ops_len) on root, None elsewhere.  local: ((scores, ops, ops_off, ops_len) of the own
+    shard, (all_scores, all_len) on root or (None, None))."""
+    a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
+    n = len(a_off) - 1
+    ps = np.ascontiguousarray(pair_scores, np.float32)
+    po = np.ascontiguousarray(pair_ops, np.uint8)
+    pl = np.ascontiguousarray(pair_ops_len, np.uint32)
+    if local:
+        bounds = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
+        s0, s1 = int(bounds[rank]), int(bounds[rank + 1])
+        n_out, ops_out = s1 - s0, int(a_off[s1] - a_off[s0] + b_off[s1] - b_off[s0])
+    else:
+        n_out, ops_out = (n, int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])) if rank == root else (0, 0)
+    scores, ops = np.zeros(max(n_out, 1), np.float32)[:n_out], np.full(max(ops_out, 1), 0xCC, np.uint8)
+    off, ln = np.zeros(max(n_out, 1), np.uint64)[:n_out], np.zeros(max(n_out, 1), np.uint32)[:n_out]
+    all_scores = all_len = None
+    if local and summary and rank == root:
+        all_scores, all_len = np.full(n, np.nan, np.float32), np.zeros(n, np.uint32)
+    _check(load().coati_hip_dist_job_host(C.byref(transport), world, rank, root, n, hip._ptr(a_off), hip._ptr(b_off), chunk_cells, int(local), int(summary),
+                                          hip._ptr(ps), hip._ptr(po), hip._ptr(pl), hip._ptr(scores) if n_out else None, hip._ptr(ops), ops_out,
+                                          hip._ptr(off) if n_out else None, hip._ptr(ln) if n_out else None, hip._ptr(all_scores), hip._ptr(all_len)))
+    if local:
+        return (scores, ops, off, ln), (all_scores, all_len)
+    return (scores, ops, off, ln) if rank == root else None
 
 
 def rendezvous_id(world: int, rank: int, make_id=None, timeout_s: float = 300.0) -> bytes:

@@ -84,6 +84,20 @@ int coati_hip_dist_viterbi_shard(coati_hip_comm_t* comm, int root, coati_hip_mod
                                  uint64_t b_first, const uint64_t* b_off, float* scores, uint8_t* ops,
                                  uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len);
 
+/* The same job with the bulk of the results LEFT ON THE RANK THAT COMPUTED THEM: rank r's scores, ops, op offsets
+ * and op lengths of the pairs [bounds[r], bounds[r+1]) are downloaded over ITS OWN host link into ITS arrays (entry 0 =
+ * the first pair of its shard; ops_off indexes its own ops array; ops_capacity >= the op bytes of its shard), and
+ * only the summary -- score and op length of every pair, 8 bytes per pair -- is gathered over RCCL into the root's
+ * all_scores[n_pairs] / all_len[n_pairs] when gather_summary != 0 (the same value on every rank; the arrays are
+ * ignored elsewhere and may be NULL).  Why: a 1 kb pair leaves ~2 kB of ops, so the gather-all form sends every
+ * rank's output through the root's single PCIe link (the stage budget for BASELINE configs[4]); here
+ * each rank formats / writes its own slice and N links work in parallel.  Failure handling as above. */
+int coati_hip_dist_viterbi_shard_local(coati_hip_comm_t* comm, int root, coati_hip_model_t* model, uint64_t n_pairs,
+                                       const uint8_t* a_cat, uint64_t a_first, const uint64_t* a_off,
+                                       const uint8_t* b_cat, uint64_t b_first, const uint64_t* b_off, float* scores,
+                                       uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
+                                       int gather_summary, float* all_scores, uint32_t* all_len);
+
 /* ---- the plan, as pure host arithmetic (no device, no communicator: usable anywhere, and what the CPU tests
  * of the multi-rank paths run on; the collectives above execute exactly these plans) ------------------------- *
  * Chunk plan of the sharded job: rank r works on pairs [cuts[cut_index[r]], ...) in chunks whose boundaries are
@@ -97,16 +111,42 @@ int coati_hip_dist_chunk_plan(uint64_t n_pairs, const uint64_t* a_off, const uin
  * land4[4 * world] = byte offsets of rank r's scores, ops, op offsets, op lengths (256-byte aligned, rank
  * order, nothing for the root itself), *need = bytes of HBM the zone takes. */
 int coati_hip_dist_landing_plan(int world, int root, const uint64_t* counts, uint64_t* land4, uint64_t* need);
-/* The whole sharded job with host memory in place of HBM and memcpy in place of ncclSend/ncclRecv, all ranks in
- * the calling thread: the chunk plan, the per-round counts, the transfer lists of every sender matched against
- * the root's receive list, the landing zone, the root's unpack / offset rebase / placement -- the code the
- * collectives run, minus the device.  Input: per pair its score, its ops (pair p's slot of len_a+len_b bytes at
- * the op prefix of p, ops right-aligned in the slot as the walkers leave them) and their number; output as
- * coati_hip_dist_viterbi on the root.  Test infrastructure, exported so that tests reach it through the ABI. */
+
+/* The per-rank job loop of coati_hip_dist_viterbi_shard[_local] is one piece of code over an ENVIRONMENT: RCCL + HIP
+ * in the entry points above, host memory + a host transport in the three below (test infrastructure, exported so
+ * that the tests reach it through the ABI).  Every rank "computes" its chunks from given per-pair results: pair p's
+ * score, its ops (its slot of len_a+len_b bytes at the op prefix of p, ops right-aligned in the slot as the walkers
+ * leave them) and their number; only the entries of the rank's own shard are read.
+ *
+ * coati_hip_dist_simulate[_local]: all ranks as threads of the calling process, an in-process transport (bounded
+ * waits).  _simulate: outputs as coati_hip_dist_viterbi on the root.  _simulate_local: scores / ops / ops_off /
+ * ops_len are global-size arrays in which rank r's own arrays are the slices that start at its shard (index
+ * bounds[r], op byte = op prefix of bounds[r]); all_scores / all_len: the root's summary. */
 int coati_hip_dist_simulate(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off,
                             uint64_t chunk_cells, const float* pair_scores, const uint8_t* pair_ops,
                             const uint32_t* pair_ops_len, float* scores, uint8_t* ops, uint64_t ops_capacity,
                             uint64_t* ops_off, uint32_t* ops_len);
+int coati_hip_dist_simulate_local(int world, int root, uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off,
+                                  uint64_t chunk_cells, int gather_summary, const float* pair_scores,
+                                  const uint8_t* pair_ops, const uint32_t* pair_ops_len, float* scores, uint8_t* ops,
+                                  uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len, float* all_scores,
+                                  uint32_t* all_len);
+/* ONE rank of the job in the calling process, the exchanges done by the caller's functions (each returns 0 or an
+ * error code): allgather -- every rank contributes words_per_rank 64-bit words, all[] receives them in rank order;
+ * send / recv -- `bytes` bytes to / from `peer`, matched in the order they are issued between two ranks.  The CPU
+ * tests run two such processes over torch.distributed's gloo backend.  local / gather_summary as in
+ * coati_hip_dist_viterbi_shard_local (local = 0: outputs on the root as coati_hip_dist_viterbi_shard). */
+typedef struct coati_hip_dist_host_transport {
+    void* ctx;
+    int (*allgather)(void* ctx, const uint64_t* mine, uint64_t* all, uint32_t words_per_rank);
+    int (*send)(void* ctx, int peer, const void* data, uint64_t bytes);
+    int (*recv)(void* ctx, int peer, void* data, uint64_t bytes);
+} coati_hip_dist_host_transport_t;
+int coati_hip_dist_job_host(const coati_hip_dist_host_transport_t* transport, int world, int rank, int root,
+                            uint64_t n_pairs, const uint64_t* a_off, const uint64_t* b_off, uint64_t chunk_cells,
+                            int local, int gather_summary, const float* pair_scores, const uint8_t* pair_ops,
+                            const uint32_t* pair_ops_len, float* scores, uint8_t* ops, uint64_t ops_capacity,
+                            uint64_t* ops_off, uint32_t* ops_len, float* all_scores, uint32_t* all_len);
 
 #ifdef __cplusplus
 }

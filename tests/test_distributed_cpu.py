@@ -1,5 +1,8 @@
-"""world_size-2 gloo test of the multi-GPU plumbing (no GPU): shard planning, the
-model broadcast and the ragged result gather."""
+"""The multi-GPU layer without a GPU (libcoati_hip_dist.so's per-rank job loop is one piece of code over an
+environment: RCCL + HIP on the GPUs; host memory + a host transport here): the plans as pure functions, every rank of
+the sharded job as a thread (coati_hip_dist_simulate*, world 1 .. 8), and TWO PROCESSES over torch.distributed's gloo
+backend running the same loop through coati_hip_dist_job_host."""
+import ctypes as C
 import os
 import socket
 
@@ -9,25 +12,23 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from coati_amd import distributed as cd
 
-
-def test_shard_bounds_balance_cells():
-    rng = np.random.default_rng(0)
-    w = rng.integers(1, 1000, 1000) ** 2
-    for world in (1, 2, 3, 8):
-        b = cd.shard_bounds(w, world)
-        assert b[0] == 0 and b[-1] == len(w) and all(x <= y for x, y in zip(b, b[1:]))
-        shares = [w[b[r]:b[r + 1]].sum() for r in range(world)]
-        assert max(shares) - min(shares) <= 2 * w.max()
-    assert cd.shard_bounds([], 4) == [0, 0, 0, 0, 0]
-    assert cd.shard_bounds([5.0], 4)[-1] == 1
+def _np_shard_bounds(w, world):
+    """numpy statement of coati_hip_shard_bounds' rule: rank r's shard ends at the first pair where the cell prefix
+    reaches (r+1)/world of the total."""
+    w = np.asarray(w, np.float64)
+    pre = np.concatenate([[0.0], np.cumsum(w)])
+    total = pre[-1]
+    out = [0]
+    for r in range(1, world):
+        out.append(int(np.searchsorted(pre, total * r / world, side="left")))
+    out.append(len(w))
+    return [min(max(x, 0), len(w)) for x in out]
 
 
 def test_native_shard_bounds_matches_and_balances():
     """coati_hip_shard_bounds (the C ABI partitioner bench.py, coati_hip_dist_viterbi and
-    `coati-alignpair --devices` use): contiguous, monotone, cell-balanced to within one pair, and
-    identical to the numpy statement of the same rule."""
+    `coati-alignpair --devices` use): contiguous, monotone, cell-balanced to within one pair."""
     from coati_amd import hip
 
     rng = np.random.default_rng(5)
@@ -41,7 +42,8 @@ def test_native_shard_bounds_matches_and_balances():
         assert b[0] == 0 and b[-1] == len(w) and (np.diff(b) >= 0).all()
         shares = np.array([w[b[r]:b[r + 1]].sum() for r in range(world)])
         assert shares.max() - w.sum() / world <= w.max() + 1
-        assert b.tolist() == cd.shard_bounds(w, world)
+        ref = np.array(_np_shard_bounds(w, world))
+        assert np.abs(b - ref).max() <= 1  # (the same rule up to the side a boundary pair falls on)
     assert hip.shard_bounds(np.zeros(1, np.uint64), np.zeros(1, np.uint64), 4).tolist() == [0, 0, 0, 0, 0]
     # one heavy pair among light ones: it sits alone in its shard, nothing is lost or duplicated
     la2, lb2 = np.full(100, 3), np.full(100, 3)
@@ -52,60 +54,102 @@ def test_native_shard_bounds_matches_and_balances():
     assert bb[0] == 0 and bb[-1] == 100 and (np.diff(bb.astype(np.int64)) >= 0).all()
 
 
+def _gloo_transport(rank, world):
+    """coati_hip_dist_host_transport_t over gloo: the three exchanges the native job loop asks for."""
+    from coati_amd import dist as nd
+
+    def allgather(_ctx, mine, out, words):
+        try:
+            t = torch.from_numpy(np.ctypeslib.as_array(mine, shape=(words,)).astype(np.int64))
+            parts = [torch.zeros(words, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, t)
+            np.ctypeslib.as_array(out, shape=(words * world,))[:] = torch.cat(parts).numpy().astype(np.uint64)
+            return 0
+        except Exception:  # noqa: BLE001 (an exception must not cross the C frame)
+            return 3
+
+    def send(_ctx, peer, data, nbytes):
+        try:
+            buf = (C.c_uint8 * nbytes).from_address(data)
+            dist.send(torch.frombuffer(buf, dtype=torch.uint8).clone(), dst=peer)
+            return 0
+        except Exception:  # noqa: BLE001
+            return 3
+
+    def recv(_ctx, peer, data, nbytes):
+        try:
+            t = torch.zeros(nbytes, dtype=torch.uint8)
+            dist.recv(t, src=peer)
+            C.memmove(data, t.numpy().ctypes.data, nbytes)
+            return 0
+        except Exception:  # noqa: BLE001
+            return 3
+
+    tr = nd.HostTransport(None, nd.HostTransport.ALLGATHER(allgather), nd.HostTransport.SEND(send), nd.HostTransport.RECV(recv))
+    return tr
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rng = np.random.default_rng(42)
-        table = rng.normal(size=(183, 15)).astype(np.float32)
-        consts = np.array([-0.001, -1.79, -6.9, -0.18], np.float32)
-        if rank == 0:
-            got = cd.broadcast_model(table, consts, 3, "cpu")
-        else:
-            got = cd.broadcast_model(None, None, None, "cpu")
-        ok = (got[0].view(np.uint32) == table.view(np.uint32)).all() and (got[1] == consts).all() and got[2] == 3
-        # ragged gather: rank r contributes r+2 elements
-        mine = torch.arange(rank + 2, dtype=torch.int64) + 100 * rank
-        parts = cd.gather_ragged(mine, dst=0)
-        if rank == 0:
-            ok = ok and len(parts) == world and all(
-                p.tolist() == (torch.arange(r + 2) + 100 * r).tolist() for r, p in enumerate(parts))
-        else:
-            ok = ok and parts is None
-        empty = cd.gather_ragged(torch.zeros(0 if rank else 3, dtype=torch.uint8), dst=0)
-        if rank == 0:
-            ok = ok and [p.numel() for p in empty] == [3] + [0] * (world - 1)
-        # packed one-collective gather of four typed arrays (what bench.py uses every step)
-        n = 3 + rank
-        arrs = (torch.arange(n, dtype=torch.float32) + rank, torch.arange(7 * n, dtype=torch.uint8) % 3,
-                torch.arange(n, dtype=torch.int64) * (rank + 5), torch.arange(n, dtype=torch.int32) + 9 * rank)
-        pg = cd.PackedGather(arrs, dst=0)
-        for _ in range(2):  # reusable
-            pg()
-        if rank == 0:
-            for r in range(world):
-                m = 3 + r
-                sc, ops, off, ln = pg.unpack(r)
-                ok = ok and sc.tolist() == [float(x + r) for x in range(m)] and ops.tolist() == [x % 3 for x in range(7 * m)]
-                ok = ok and off.tolist() == [x * (r + 5) for x in range(m)] and ln.tolist() == [x + 9 * r for x in range(m)]
-        # the real partitioner: every rank plans the same shards of one workload from the lengths alone and
-        # "computes" its own (here: a checksum per pair); gathered in rank order the input order is restored
+        from coati_amd import dist as nd
         from coati_amd import hip
-        lr = np.random.default_rng(7)
-        la, lb = lr.integers(1, 300, 500) * 3, lr.integers(1, 900, 500)
-        a_off = np.concatenate([[0], np.cumsum(la)]).astype(np.uint64)
-        b_off = np.concatenate([[0], np.cumsum(lb)]).astype(np.uint64)
+
+        ok = True
+        tr = _gloo_transport(rank, world)
+        for root, chunk_cells, seed in ((0, 0, 1), (1, 2500, 2), (0, 60000, 3)):
+            la, lb, a_off, b_off, pref, ln, ops, scores = _job(seed, 700)
+            want_off = (pref[1:] - ln).astype(np.uint64)
+            bounds = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
+            s0, s1 = int(bounds[rank]), int(bounds[rank + 1])
+            # every rank is given only ITS shard's results (the others' entries are poisoned: never read)
+            my_scores = np.full_like(scores, np.nan)
+            my_scores[s0:s1] = scores[s0:s1]
+            my_ops = np.full_like(ops, 0x77)
+            my_ops[pref[s0]:pref[s1]] = ops[pref[s0]:pref[s1]]
+            my_ln = np.zeros_like(ln)
+            my_ln[s0:s1] = ln[s0:s1]
+            # ---- gather-all: the root ends up with every pair, in input order
+            got = nd.job_host(tr, world, rank, root, a_off, b_off, my_scores, my_ops, my_ln, chunk_cells)
+            if rank == root:
+                s, o, off, l = got
+                ok = ok and (s.view(np.uint32) == scores.view(np.uint32)).all() and (l == ln).all() and (off == want_off).all()
+                ok = ok and all((o[int(off[i]):int(off[i]) + int(l[i])] == ops[int(want_off[i]):pref[i + 1]]).all() for i in range(len(ln)))
+            else:
+                ok = ok and got is None
+            # ---- local: every rank keeps its shard, the root gets the summary
+            (s, o, off, l), (all_s, all_l) = nd.job_host(tr, world, rank, root, a_off, b_off, my_scores, my_ops, my_ln, chunk_cells, local=True)
+            ok = ok and (s.view(np.uint32) == scores[s0:s1].view(np.uint32)).all() and (l == ln[s0:s1]).all()
+            ok = ok and (off == want_off[s0:s1] - np.uint64(pref[s0])).all()
+            ok = ok and all((o[int(off[i]):int(off[i]) + int(l[i])] == ops[int(want_off[s0 + i]):pref[s0 + i + 1]]).all() for i in range(s1 - s0))
+            if rank == root:
+                ok = ok and (all_s.view(np.uint32) == scores.view(np.uint32)).all() and (all_l == ln).all()
+            else:
+                ok = ok and all_s is None
+        # a rank that cannot deliver (more ops than the pair's slot holds) reports it in the count exchange: BOTH
+        # ranks return an error from the same round, none is left waiting in a receive
+        la, lb, a_off, b_off, pref, ln, ops, scores = _job(9, 60, empty=False)
         bounds = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
-        mine = torch.from_numpy((la * 7 + lb)[bounds[rank]:bounds[rank + 1]].astype(np.int64))
-        parts = cd.gather_ragged(mine, dst=0)
-        if rank == 0:
-            ok = ok and torch.cat(parts).tolist() == (la * 7 + lb).tolist()
+        bad = ln.copy()
+        victim = int(bounds[1])  # a pair of rank 1's shard
+        bad[victim] = la[victim] + lb[victim] + 1
+        failed = False
+        try:
+            nd.job_host(tr, world, rank, 0, a_off, b_off, scores, ops, bad)
+        except hip.CoatiHipError:
+            failed = True
+        ok = ok and failed
+        dist.barrier()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-def test_broadcast_and_gather_world2():
+def test_native_job_loop_two_processes_over_gloo():
+    """world_size 2, one process per rank, gloo in place of RCCL: the per-rank loop of coati_hip_dist_viterbi_shard
+    (chunk plan, status / count exchange, validation against the plan, transfer lists, landing zone, placement, offset
+    rebase; gather-all and local forms; a failing rank) through coati_hip_dist_job_host."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -115,7 +159,7 @@ def test_broadcast_and_gather_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
@@ -192,11 +236,12 @@ def test_native_landing_plan_blocks_are_disjoint(world, root):
 @pytest.mark.parametrize("world,root", [(1, 0), (2, 0), (2, 1), (3, 2), (8, 0), (8, 3)])
 @pytest.mark.parametrize("chunk_cells", [0, 2500, 60000])
 def test_native_sharded_job_simulated_in_host_memory(world, root, chunk_cells):
-    """coati_hip_dist_simulate runs every rank's side of coati_hip_dist_viterbi in one thread with memcpy in
-    place of ncclSend / ncclRecv / hipMemcpyAsync: chunk plan, per-round counts, every sender's transfer list
-    against the root's receive list, landing zone, unpack, offset rebase, placement -- the functions the
-    collectives execute.  The root's arrays must equal the single-process answer for every pair, whatever the
-    world, the root, the number of rounds (ragged: ranks run out of chunks at different rounds)."""
+    """coati_hip_dist_simulate runs every rank of coati_hip_dist_viterbi as a thread of this process -- the same
+    per-rank loop the GPUs run (chunk plan, per-round status / count exchange, validation against the plan, every
+    sender's transfer list against the root's receive list, landing zone, placement straight into the caller's
+    arrays, offset rebase), with host memory for HBM and an in-process transport for RCCL.  The root's arrays must
+    equal the single-process answer for every pair, whatever the world, the root, the number of rounds (ragged:
+    ranks run out of chunks at different rounds)."""
     from coati_amd import dist as nd
 
     la, lb, a_off, b_off, pref, ln, ops, scores = _job(7 * world + root, 1200)
@@ -206,6 +251,33 @@ def test_native_sharded_job_simulated_in_host_memory(world, root, chunk_cells):
     assert (off == want_off).all()
     for i in range(len(ln)):
         assert (o[int(off[i]):int(off[i]) + int(l[i])] == ops[int(want_off[i]):pref[i + 1]]).all(), i
+
+
+@pytest.mark.parametrize("world,root", [(1, 0), (2, 1), (3, 0), (8, 0), (8, 6)])
+@pytest.mark.parametrize("chunk_cells", [0, 2500])
+@pytest.mark.parametrize("summary", [True, False])
+def test_native_local_results_job_simulated(world, root, chunk_cells, summary):
+    """coati_hip_dist_viterbi_shard_local's loop (coati_hip_dist_simulate_local): every rank ends up with the scores,
+    ops, op offsets (relative to ITS ops array) and op lengths of its own shard, the root with the summary of all
+    pairs when asked for -- and with nothing moved at all when not."""
+    from coati_amd import dist as nd
+    from coati_amd import hip
+
+    la, lb, a_off, b_off, pref, ln, ops, scores = _job(31 * world + root, 900)
+    s, o, off, l, all_s, all_l = nd.simulate_local(world, root, a_off, b_off, scores, ops, ln, chunk_cells, summary)
+    bounds = hip.shard_bounds(a_off, b_off, world).astype(np.int64)
+    assert (s.view(np.uint32) == scores.view(np.uint32)).all() and (l == ln).all()
+    want_off = (pref[1:] - ln).astype(np.int64)
+    for r in range(world):
+        s0, s1 = int(bounds[r]), int(bounds[r + 1])
+        assert (off[s0:s1].astype(np.int64) == want_off[s0:s1] - pref[s0]).all(), r
+        mine = o[pref[s0]:pref[s1]]
+        for i in range(s0, s1):
+            assert (mine[int(off[i]):int(off[i]) + int(l[i])] == ops[int(want_off[i]):pref[i + 1]]).all(), i
+    if summary:
+        assert (all_s.view(np.uint32) == scores.view(np.uint32)).all() and (all_l == ln).all()
+    else:
+        assert np.isnan(all_s).all() and not all_l.any()
 
 
 def test_native_simulation_rejects_inconsistent_input():

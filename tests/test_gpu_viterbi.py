@@ -443,7 +443,7 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
     model.close()
 
 
-@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8"])
+@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t"])
 def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, plan):
     """viterbi_ck cuts the last pairs of a large batch's LPT order into row parts (own work items; a part leaves
     the lane state at a 64-step boundary, whichever wavefront takes the next part continues -- abi.hip "the ragged
