@@ -309,6 +309,75 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
         return {"what": "benchmark/benchmark_main.cc.in BM_marg_alignment inputs: kernel ms on the GPU (pair alone / 64 copies in one "
                         "batch) and the unmodified reference engine (oracle/_ref, 1 host thread)", "cases": rows}
 
+    def band_sensitivity():
+        """The banded checkpoints on inputs that are NOT the benign synthetic set: 10 000 synthetic 1 kb pairs of which 5 % /
+        25 % carry one 90-300 nt deletion or insertion in the descendant (a path that leaves a 96-step band is filled
+        twice), and the reference's own benchmark pair bm_1k (benchmark/data/benchmark_1k.fasta: 85 deletion and 46
+        insertion columns) x 10 000.  Per bag: kernel ms / GCUPS with the default band and with everything kept, the
+        number of pairs filled twice, and that both runs give the same bits."""
+        from tests import util  # (fixture decoder only)
+
+        rng = np.random.default_rng(2024)
+        n = 10000
+
+        def with_indels(frac):
+            a_parts, b_parts = [], []
+            for p in range(n):
+                a = a_cat[int(a_off[p]):int(a_off[p + 1])]
+                b = b_cat[int(b_off[p]):int(b_off[p + 1])]
+                if rng.random() < frac:
+                    size = int(rng.integers(90, 301))
+                    at = int(rng.integers(0, max(1, len(b) - size)))
+                    if rng.random() < 0.5:
+                        b = np.concatenate([b[:at], b[at + size:]])
+                    else:
+                        b = np.concatenate([b[:at], rng.integers(0, 4, size).astype(np.uint8), b[at:]])[:1020]
+                a_parts.append(a)
+                b_parts.append(b)
+            return hip.pack_pairs(list(zip(a_parts, b_parts)))
+
+        def run(packed, mdl):
+            bt = hip.Batch(mdl, *packed)
+            res = {}
+            crc = {}
+            for tag, band in (("band_default", None), ("band_off", 0)):
+                if band is not None:
+                    mdl.set_option(hip.OPT_CK_BAND, band)
+                ts = []
+                for i in range(6):
+                    bt.viterbi_launch()
+                    bt.sync()
+                    if i >= 2:
+                        ts.append(bt.viterbi_timing()[0])
+                steps, twice = bt.band_stats()
+                sc, ops, off, ln = bt.viterbi_fetch()
+                h = zlib.crc32(sc.tobytes())
+                h = zlib.crc32(ln.tobytes(), h)
+                for p in range(0, len(ln), 7):
+                    h = zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes(), h)
+                crc[tag] = h
+                ms = float(np.median(ts))
+                res[tag] = {"ms": ms, "gcups": bt.cells / ms / 1e6, "band_steps": steps, "pairs_filled_twice": twice}
+            mdl.set_option(hip.OPT_CK_BAND, default_band)
+            res["same_bits"] = crc["band_default"] == crc["band_off"]
+            bt.close()
+            return res
+
+        probe = hip.Batch(model, *hip.pack_pairs([(a_cat[:int(a_off[1])], b_cat[:int(b_off[1])])] * 8))
+        probe.viterbi_launch()
+        default_band = probe.band_stats()[0] or 96
+        probe.close()
+        out_b = {"what": "kernel time of 10 000-pair bags with the default checkpoint band and with everything kept; pairs filled "
+                         "twice = paths that left the band", "default_band_steps": default_band}
+        out_b["indel_5pct"] = run(with_indels(0.05), model)
+        out_b["indel_25pct"] = run(with_indels(0.25), model)
+        a, b, case, doc = util.load_bench_pair("1k")
+        tab = np.load(ROOT / "tests" / "golden" / doc["table"])
+        m2 = hip.Model(tab, host.gap_consts(doc["gap_open"], doc["gap_extend"]), 1)
+        out_b["bm_1k_x10000"] = run(hip.pack_pairs([(a, b)] * n), m2)
+        m2.close()
+        return out_b
+
     def power():
         """Board power (rocm-smi) while the headline batch is launched back to back for ~2.5 s: the fill runs at the package
         power cap.  Sampled from a thread of this process; rocm-smi is a child process."""
@@ -352,6 +421,7 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
                 "package_power_cap_w": cap, "sclk_mhz": sclk, "frac_of_cap": (sum(watts) / len(watts) / cap) if cap else None}
 
     guarded("pcie_inclusive", streamed)
+    guarded("band_sensitivity", band_sensitivity)
     guarded("power", power)
     guarded("reference_suite", reference_suite)
     guarded("cli_batch", cli_batch)
@@ -511,6 +581,32 @@ def main():
                     traffic = rec.get("viterbi_ck_bytes_per_launch_10000_pairs")
             except Exception:
                 traffic = None
+        # The headline kernel keeps its traceback checkpoints in a BAND around each pair's straight line; a pair whose
+        # path leaves it is filled twice (same bits).  What that did on THIS workload, and what the same launches cost
+        # with everything kept (COATI_HIP_OPT_CK_BAND = 0): part of the roofline record, measured here, never `value`.
+        band_rec = None
+        try:
+            band_steps, refilled = batch.band_stats()
+            if band_steps:
+                model.set_option(hip.OPT_CK_BAND, 0)
+                off_ms = []
+                for i in range(8):
+                    batch.viterbi_launch()
+                    batch.sync()
+                    if i >= 2:
+                        off_ms.append(batch.viterbi_timing()[0])
+                assert batch.band_stats() == (0, 0)
+                model.set_option(hip.OPT_CK_BAND, band_steps)
+                batch.viterbi_launch()
+                batch.sync()
+                band_rec = {"steps": band_steps, "pairs_filled_twice": refilled, "pairs": n_mine,
+                            "band_off_ms": float(np.median(off_ms)), "band_off_gcups": cells / float(np.median(off_ms)) / 1e6,
+                            "note": "the synthetic generator's indels (Poisson(2) per pair, mean 6 nt) keep every path inside the band; "
+                                    "extra.band_sensitivity runs bags with long indels and a real pair"}
+            else:
+                band_rec = {"steps": 0, "pairs_filled_twice": 0, "pairs": n_mine}
+        except Exception as exc:  # (never fails the line)
+            band_rec = {"error": repr(exc)}
         # Informational (never `value`): the same K steps alternating between two resident copies of the
         # batch on two library streams, i.e. how a pipeline of batches runs -- the ragged end of one
         # launch overlaps the start of the next.  Skipped when --streams 2 is the mode
@@ -561,7 +657,7 @@ def main():
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "viterbi_ck", "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel": "viterbi_ck", "algorithmic_bytes_per_launch": algo_bytes, "band": band_rec,
                          "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
                          "note": "priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell of traceback state); the "
                                  "limit this recurrence runs into is SIMD instruction issue (19 instructions per cell at ~2.2 "
@@ -635,17 +731,40 @@ def strong_job(comm, hip, host, torch, world, rank, local_rank, args):
         comm.barrier()
         torch.cuda.synchronize()
         times.append(float(comm.allreduce([time.perf_counter() - t0], "max")[0]))
+    # the same job with the results LEFT ON THE RANKS that computed them (coati_hip_dist_viterbi_shard_local: every rank
+    # downloads its shard over its own PCIe link into page-locked arrays; scores + op lengths of all pairs are gathered
+    # to rank 0 over RCCL) -- what `coati-alignpair --batch --devices` builds on: every rank formats its own slice
+    times_local = []
+    loc = None
+    for _ in range(2):
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loc, summary = comm.viterbi_shard_local(model, a_cat, int(a_off[first]), a_off, b_cat, int(b_off[first]), b_off, root=0, reuse=loc)
+        comm.barrier()
+        torch.cuda.synchronize()
+        times_local.append(float(comm.allreduce([time.perf_counter() - t0], "max")[0]))
     model.close()
+    # every rank's local results must be the gathered ones (rank 0 checks its own shard against the gather-all job)
+    if rank == 0:
+        sc, ops, off, ln = res
+        lsc, lops, loff, lln = loc
+        n0 = len(lsc)
+        same = bool((lsc.view(np.uint32) == sc[:n0].view(np.uint32)).all() and (lln == ln[:n0]).all() and (loff == off[:n0]).all()
+                    and (summary[0].view(np.uint32) == sc.view(np.uint32)).all() and (summary[1] == ln).all())
     if rank != 0:
         return None
-    sc, ops, off, ln = res
     cells = float((la.astype(np.float64) * lb).sum())
     assert np.isfinite(sc).all() and int(ln.min()) >= 900 and (off.astype(np.int64) + ln <= np.cumsum(la + lb)).all()
     return {"what": "BASELINE configs[4]: ONE sharded job (coati_hip_dist_viterbi_shard), shards by DP cells, each rank generated only "
                     "its shard, results in rank 0's host memory; wall time between barriers, max over ranks, second of two jobs",
             "pairs": total, "model": "mar-ecm", "n_gpus": world, "seconds": times[-1], "first_job_seconds": times[0],
             "gcups": cells / times[-1] / 1e9, "pairs_per_s": total / times[-1], "scaling": "strong",
-            "shard_generation_seconds": t_gen, "scores_crc32": "%08x" % zlib.crc32(sc.tobytes()), "columns": int(ln.sum())}
+            "shard_generation_seconds": t_gen, "scores_crc32": "%08x" % zlib.crc32(sc.tobytes()), "columns": int(ln.sum()),
+            "local_results": {"what": "the same job through coati_hip_dist_viterbi_shard_local: ops stay with the rank that computed them "
+                                      "(own PCIe link, page-locked arrays), scores + op lengths of all pairs gathered to rank 0 over RCCL",
+                              "seconds": times_local[-1], "first_job_seconds": times_local[0], "gcups": cells / times_local[-1] / 1e9,
+                              "pairs_per_s": total / times_local[-1], "equal_to_gathered": same}}
 
 
 if __name__ == "__main__":

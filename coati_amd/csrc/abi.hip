@@ -102,7 +102,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
-                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? 1u : 0u, b->long_pairs ? 1u : 0u};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u};
 }
 
 
@@ -126,6 +126,12 @@ hipError_t model_take_arena(coati_hip_model* m, uint64_t need, void** ptr, uint6
             return hipSuccess;
         }
     }
+    // A fresh block is a size CLASS, not the exact need (up to an eighth above it, in steps of at least 32 MB): consecutive chunks of one job
+    // differ by a few pairs, and a cached block that is a few KB short is a fresh multi-GB hipMalloc -- 0.25-0.5 s when
+    // the driver has to find the pages (round 4: a 1 000 000-pair sharded job in 48 000-pair chunks took 12 s that way)
+    uint64_t step = 32ull << 20;
+    while(step * 16 <= need) step *= 2;  // (a sixteenth to an eighth of the need)
+    need = (need + step - 1) / step * step;
     hipError_t e = hipMalloc(ptr, need);
     if(e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -230,6 +236,7 @@ int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float n
     if(m == nullptr) return fail(COATI_HIP_ENOMEM, "model_create: host allocation failed");
     m->device = device;
     m->gap_len = gap_len;
+    m->ck_band = ck_band_setting();
     m->n_tables = n_tables;
     m->k = GapConsts{no_gap, gap_stop, gap_open, gap_extend};
     auto cleanup = [&](int rc) {
@@ -347,6 +354,11 @@ int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t val
         model->stream_forbidden = value == 0;
         return COATI_HIP_OK;
     }
+    if(option == COATI_HIP_OPT_CK_BAND) {
+        if(value < 0 || value > 0x7fffffff) return fail(COATI_HIP_EINVAL, "model_set_option: band of %lld steps", static_cast<long long>(value));
+        model->ck_band = value == 0 ? kCkBandOff : static_cast<uint32_t>(value);
+        return COATI_HIP_OK;
+    }
     return fail(COATI_HIP_EINVAL, "model_set_option: unknown option %d", option);
 }
 
@@ -366,8 +378,8 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
     HIP_TRY(hipSetDevice(m->device));
     const uint32_t n = static_cast<uint32_t>(b->n_pairs);
     hipEvent_t* ev = b->ev[b->n_launches % coati_hip_batch::kTimingRing];
-    for(int q = 0; q < 3; ++q)
-        if(ev[q] == nullptr) HIP_TRY(hipEventCreate(&ev[q]));  // (created on first use: 192 events per batch cost 0.3 ms)
+    for(int q = 0; q < 2; ++q)
+        if(ev[q] == nullptr) HIP_TRY(hipEventCreate(&ev[q]));  // (created on first use: 128 events per batch cost 0.2 ms)
     HIP_TRY(hipEventRecord(ev[0], b->stream));
     if(n > 0) {
         const BatchDeviceView v = device_view(b);
@@ -381,8 +393,7 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
         else
             HIP_TRY(launch_dp_generic(v, /*forward=*/false, b->stream));
     }
-    HIP_TRY(hipEventRecord(ev[1], b->stream));
-    HIP_TRY(hipEventRecord(ev[2], b->stream));  // (the traceback is fused into the fill kernel)
+    HIP_TRY(hipEventRecord(ev[1], b->stream));  // (the traceback is fused into the fill kernel: one span per launch)
     b->n_launches += 1;
     b->launched = true;
     return COATI_HIP_OK;
@@ -400,7 +411,7 @@ int coati_hip_viterbi_wait(coati_hip_batch_t* b) {
     if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_wait: batch is NULL");
     if(!b->launched) return fail(COATI_HIP_ESTATE, "viterbi_wait: nothing was launched");
     HIP_TRY(hipSetDevice(b->model->device));
-    HIP_TRY(hipEventSynchronize(b->ev[(b->n_launches - 1) % coati_hip_batch::kTimingRing][2]));
+    HIP_TRY(hipEventSynchronize(b->ev[(b->n_launches - 1) % coati_hip_batch::kTimingRing][1]));
     return COATI_HIP_OK;
 }
 
@@ -445,10 +456,22 @@ int coati_hip_viterbi_timing(coati_hip_batch_t* b, uint32_t launches_back, float
     if(rc != COATI_HIP_OK) return rc;
     hipEvent_t* ev = b->ev[(b->n_launches - 1 - launches_back) % coati_hip_batch::kTimingRing];
     float f = 0.f, w = 0.f;
-    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&w, ev[1], ev[2]));
+    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));  // (w stays 0: the traceback is part of the fill kernel since round 1)
     if(fill_ms != nullptr) *fill_ms = f;
     if(walk_ms != nullptr) *walk_ms = w;
+    return COATI_HIP_OK;
+}
+
+int coati_hip_viterbi_band_stats(coati_hip_batch_t* b, uint32_t* band_steps, uint64_t* pairs_refilled) {
+    if(b == nullptr) return fail(COATI_HIP_EINVAL, "viterbi_band_stats: batch is NULL");
+    if(!b->launched) return fail(COATI_HIP_ESTATE, "viterbi_band_stats: nothing was launched");
+    const int rc = coati_hip_batch_sync(b);
+    if(rc != COATI_HIP_OK) return rc;
+    const bool banded = b->ck && !b->ck_keep_all && b->model->ck_band != kCkBandOff;
+    uint32_t refilled = 0;
+    if(banded && b->n_pairs > 0) HIP_TRY(hipMemcpy(&refilled, b->d_queue + 1, sizeof refilled, hipMemcpyDeviceToHost));  // (the word behind the ticket counter)
+    if(band_steps != nullptr) *band_steps = banded ? b->model->ck_band : 0u;
+    if(pairs_refilled != nullptr) *pairs_refilled = refilled;
     return COATI_HIP_OK;
 }
 

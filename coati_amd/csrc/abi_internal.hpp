@@ -81,6 +81,7 @@ struct coati_hip_model {
     std::mutex pipeline_lock;  // one pipelined call at a time per model
     uint32_t stream_calls = 0;     // streamed calls this model has served (the first one allocates lazily: a one-shot process pays for what it uses)
     bool stream_unusable = false;  // the persistent kernel's first upload did not arrive in time once (copies not on the copy engine): never again on this model
+    uint32_t ck_band = 96;  // viterbi_ck: half width of the kept checkpoint band, kCkBandOff = keep everything (COATI_HIP_OPT_CK_BAND; default: ck_band_setting())
     bool stream_forbidden = false;  // coati_hip_model_set_option(COATI_HIP_OPT_PERSISTENT_CALL, 0): the embedder shares the GPU
 };
 
@@ -126,7 +127,7 @@ struct coati_hip_batch {
     uint64_t* d_ops_start = nullptr;
     uint32_t* d_ops_len = nullptr;
     static constexpr int kTimingRing = 64;  // launches whose kernel times can still be read back
-    hipEvent_t ev[kTimingRing][3] = {};
+    hipEvent_t ev[kTimingRing][2] = {};  // around each launch
     uint64_t n_launches = 0;
     bool launched = false;
 };

@@ -134,6 +134,7 @@ constexpr uint32_t kCkRowsLog2 = 4, kCkRows = 1u << kCkRowsLog2;
 // the start of the arena).  Pairs of several strips (other wavefronts read their checkpoints) and the
 // pairs of small batches keep per-pair storage.
 constexpr uint64_t kCkWaveSlot = ~0ull;
+constexpr uint32_t kCkBandOff = 0xffffffffu;  // banded checkpoints (viterbi_ck.hip): no band, every tile keeps its checkpoints
 __host__ __device__ constexpr uint32_t ck_rowck_quads(uint32_t w) { return w / 2; }
 __host__ __device__ inline uint32_t ck_bands(uint32_t la) { return (la + kWave + kCkRows - 1) / kCkRows; }
 __host__ __device__ inline uint64_t ck_colin_dwords(uint32_t la) { return static_cast<uint64_t>(la + kWave) * (2 * kWave); }
@@ -476,9 +477,19 @@ struct BatchDeviceView {
     float* mdi;        // Forward: fp32 M/D/I of every body cell
     float* final_mdi;  // Forward: terminal-adjusted M, D, I of the last cell, 3 floats per pair
     uint32_t fwd_wlog2_max;  // forward_l1: the widest strip shape of the batch (log2 of the columns per lane)
-    uint32_t ck_keep_all;    // viterbi_ck: 1 = keep every checkpoint (debug export), 0 = the banded default
+    uint32_t ck_band;        // viterbi_ck: half width of the kept checkpoint band in wavefront steps, kCkBandOff = keep everything
     uint32_t long_pairs;     // decision-bit plan of a few long pairs (every strip 4 columns per lane): viterbi_lp fills it
 };
+// Before every launch of a persistent kernel: the ticket counter and the polled progress words start at zero.  The
+// planner lays the counter out right in front of the words (plan.hip), so this is ONE fill, not two.
+inline hipError_t zero_queue_and_progress(const BatchDeviceView& v, uint32_t n_words, hipStream_t stream) {
+    const size_t words = n_words < 4u ? 4u : n_words;
+    char* q = reinterpret_cast<char*>(v.queue);
+    char* p = reinterpret_cast<char*>(v.progress);
+    if(p > q && p - q <= 4096) return hipMemsetAsync(q, 0, static_cast<size_t>(p - q) + sizeof(uint32_t) * words, stream);
+    const hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
+    return e != hipSuccess ? e : hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * words, stream);
+}
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream);
 // viterbi_lp.hip: the same fill (same decision-bit layout, same strip pipeline) issued for wavefronts that are alone
 // on their SIMDs; 4-column strips only
@@ -516,7 +527,8 @@ double ck_stream_host_done_ms(void* host, int slot);  // (ms after the kernel st
 volatile uint32_t* ck_stream_host_done_flag(void* host, int slot);
 // wave_ck: ck_scratch_waves() checkpoint slots of wave_slot_dwords each; wave_scratch: as many traceback scratch areas
 hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared_tab, void* ctl, const void* host_words, uint32_t* wave_ck,
-                                    uint64_t wave_slot_dwords, uint32_t* wave_scratch, hipStream_t stream);
+                                    uint64_t wave_slot_dwords, uint32_t* wave_scratch, uint32_t band, hipStream_t stream);
+uint32_t ck_band_setting();  // the default half width of the kept checkpoint band (COATI_HIP_CK_BAND, else 96 steps)
 hipError_t launch_ck_all_flags(const BatchDeviceView& v, uint32_t pair, uint32_t* scratch, uint32_t n_waves, uint8_t* out,
                                hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);
@@ -548,6 +560,16 @@ hipError_t launch_spec_walk(const BatchDeviceView& v, const uint64_t* origin_sta
 hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, const uint8_t* tmp_ops,
                               const uint64_t* c_start, const uint32_t* c_len, const float* c_lw, uint8_t* ops,
                               uint64_t* ops_start, uint32_t* ops_len, float* log_weights, hipStream_t stream);
+
+// round 4: the step table of the exact-stream sampler (sampleback.hip): thresholds and log-weight increments per
+// (body cell, state), 24 bytes each, row-major per pair from entry tab_off[pair]; gap_len 1
+uint64_t step_entry_bytes();
+hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, hipStream_t stream);
+hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* origin_state, const uint64_t* mult_pow,
+                           const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream);
+hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* start_state, const uint64_t* mult_pow,
+                             const uint64_t* sample_offset, const uint64_t* sample_base, uint32_t n_samples, uint8_t* ops, uint64_t* ops_start,
+                             uint32_t* ops_len, float* log_weights, hipStream_t stream);
 
 }  // namespace coati_hip_detail
 #endif

@@ -199,7 +199,10 @@ namespace {
 constexpr int kCountWords = 3;  // per rank in the count exchange: pairs, op bytes, status (COATI_HIP_OK or the rank's error code)
 // which result arrays of a block a gather moves to the root
 enum : uint32_t { kScores = 1u, kOff = 2u, kLen = 4u, kOps = 8u, kAllArrays = 15u, kSummary = kScores | kLen };
-constexpr uint64_t kDefaultChunkCells = 12000ull * 1002 * 1002;
+// A rank's shard goes through the gather-all job in chunks of this many DP cells (48 000 pairs of 1 kb, ~17 ms of
+// kernel): the kernel of chunk k + 1 hides the planning and upload of chunk k + 2 and the gather of chunk k, and a
+// launch of this size loses little to its ragged end.  Two chunks are resident at a time (~2 x 14 GB).
+constexpr uint64_t kDefaultChunkCells = 48000ull * 1002 * 1002;
 
 struct Land {
     uint64_t scores, ops, off, len;  // byte offsets in the root's landing zone
@@ -600,7 +603,7 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
         uint64_t p0 = 0, n = 0, nb = 0;
         plan_block(plan, rank, k, p0, n, nb);
         const uint64_t lp = p0 - shard0, lo = plan.op_prefix[p0] - shard_ops0;  // this chunk in the rank's own arrays
-        if(out.local && my_status == COATI_HIP_OK && word[0] == n && word[1] == nb && n > 0) {
+        if(out.local && !Chunks::kDeliversLocal && my_status == COATI_HIP_OK && word[0] == n && word[1] == nb && n > 0) {
             // the rank's own download, on its own link, under the exchange of the summaries
             int lc = COATI_HIP_OK;
             if(out.scores != nullptr) lc = env.copy_out(out.scores + lp, own.scores, n * sizeof(float));
@@ -630,6 +633,7 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
 
 // chunks computed on the GPU: one resident batch per chunk (coati_hip_batch_create + coati_hip_viterbi_launch)
 struct GpuChunks {
+    static constexpr bool kDeliversLocal = false;
     coati_hip_model_t* model;
     int rank;
     const uint8_t *a_cat, *b_cat;
@@ -670,10 +674,68 @@ struct GpuChunks {
     void release(void* h) { coati_hip_batch_destroy(static_cast<coati_hip_batch_t*>(h)); }
 };
 
+// The local-results job on the GPU: a rank's whole shard is ONE chunk, computed by ONE coati_hip_viterbi_batch call --
+// the one-shot form that streams chunks through a persistent kernel and overlaps its own uploads and downloads
+// (0.98 of the resident kernel's rate on 1 000 000 pairs) -- straight into the rank's arrays; what is
+// left for the round's exchange is the summary, uploaded once (8 bytes per pair).
+struct GpuLocalChunks {
+    static constexpr bool kDeliversLocal = true;
+    coati_hip_model_t* model;
+    int rank;
+    const uint8_t *a_cat, *b_cat;
+    uint64_t a_first, b_first;
+    const uint64_t *a_off, *b_off;
+    uint64_t shard0, shard_ops0;  // the rank's first pair and its op prefix: where a chunk lies in the rank's arrays
+    const uint64_t* op_prefix;
+    const JobOut& out;
+    hipStream_t stream;
+    std::vector<uint64_t> loc_a, loc_b;
+    std::vector<float> tmp_scores;
+    std::vector<uint32_t> tmp_len;
+    void* d_summary = nullptr;
+    int check(uint64_t first_pair) {
+        if(a_off[first_pair] < a_first || b_off[first_pair] < b_first)
+            return fail(COATI_HIP_EINVAL, "dist_viterbi: the sequence arrays of rank %d start behind its shard", rank);
+        return COATI_HIP_OK;
+    }
+    int start(uint64_t p0, uint64_t n, void** h) {
+        loc_a.resize(n + 1), loc_b.resize(n + 1);
+        for(uint64_t i = 0; i <= n; ++i) loc_a[i] = a_off[p0 + i] - a_first, loc_b[i] = b_off[p0 + i] - b_first;
+        const uint64_t lp = p0 - shard0, lo = op_prefix[p0] - shard_ops0, nb = op_prefix[p0 + n] - op_prefix[p0];
+        float* scores = out.scores != nullptr ? out.scores + lp : nullptr;
+        uint32_t* len = out.ops_len != nullptr ? out.ops_len + lp : nullptr;
+        if(out.summary && scores == nullptr) tmp_scores.resize(n), scores = tmp_scores.data();
+        if(out.summary && len == nullptr) tmp_len.resize(n), len = tmp_len.data();
+        int rc = coati_hip_viterbi_batch(model, n, a_cat, loc_a.data(), b_cat, loc_b.data(), scores, out.ops != nullptr ? out.ops + lo : nullptr, nb,
+                                         out.ops_off != nullptr ? out.ops_off + lp : nullptr, len);
+        if(rc != COATI_HIP_OK) return fail(rc, "%s", coati_hip_last_error());
+        if(out.summary && n > 0) {
+            D_HIP(hipMalloc(&d_summary, n * (sizeof(float) + sizeof(uint32_t))));
+            D_HIP(hipMemcpyAsync(d_summary, scores, n * sizeof(float), hipMemcpyHostToDevice, stream));
+            D_HIP(hipMemcpyAsync(static_cast<char*>(d_summary) + n * sizeof(float), len, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            D_HIP(hipStreamSynchronize(stream));
+        }
+        n_now = n, nb_now = nb;
+        *h = this;
+        return COATI_HIP_OK;
+    }
+    uint64_t n_now = 0, nb_now = 0;
+    int finish(void*, Block& own, uint64_t& n, uint64_t& nb) {
+        n = n_now, nb = nb_now;
+        own = Block{d_summary, nullptr, nullptr, d_summary != nullptr ? static_cast<char*>(d_summary) + n_now * sizeof(float) : nullptr};
+        return COATI_HIP_OK;
+    }
+    void release(void*) {
+        if(d_summary != nullptr) (void)hipFree(d_summary);
+        d_summary = nullptr;
+    }
+};
+
 // chunks "computed" from given per-pair results (the host environments): a chunk as a resident batch leaves it --
 // scores[n], ops slots of la + lb bytes (the ops right-aligned in the slot: the walkers write right to left),
 // ops_start[n] = index of the first op in the chunk's ops array.  Only the rank's own pairs are read.
 struct HostChunks {
+    static constexpr bool kDeliversLocal = false;
     const JobPlan& plan;
     const float* pair_scores;
     const uint8_t* pair_ops;
@@ -818,9 +880,15 @@ static int shard_job_gpu(coati_hip_comm_t* c, int root, coati_hip_model_t* model
         // Chunk plan of EVERY rank (all ranks hold the same lengths, so all compute the same plan and the
         // collectives line up): a rank's shard in chunks of at most kDefaultChunkCells cells.
         JobPlan plan;
-        const int rc = make_job_plan(n_pairs, a_off, b_off, c->world, kDefaultChunkCells, plan);
+        const int rc = make_job_plan(n_pairs, a_off, b_off, c->world, out.local ? ~0ull : kDefaultChunkCells, plan);
         if(rc != COATI_HIP_OK) return rc;  // (bad offsets: the same verdict on every rank)
         RcclEnv env{c};
+        if(out.local) {
+            const uint64_t s0 = plan.bounds[static_cast<size_t>(c->rank)];
+            GpuLocalChunks chunks{model, c->rank, a_cat, b_cat, a_first, b_first, a_off, b_off, s0, plan.op_prefix[s0], plan.op_prefix.data(), out, c->stream,
+                                  {}, {}, {}, {}};
+            return run_shard_job(env, chunks, root, plan, n_pairs, out);
+        }
         GpuChunks chunks{model, c->rank, a_cat, b_cat, a_first, b_first, a_off, b_off, {}, {}};
         return run_shard_job(env, chunks, root, plan, n_pairs, out);
     } catch(const std::bad_alloc&) {

@@ -258,9 +258,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, kFast ? 3 : 2) void forward_k(
 
 hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream) {
     if(v.gap_len != 2 && v.gap_len != 3) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
-    if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_fwd_items, 4u), stream);
+    hipError_t e = zero_queue_and_progress(v, v.n_fwd_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
     // up to three workgroups (12 wavefronts) per CU, no more wavefronts than items
     const uint32_t blocks = std::min<uint32_t>(768u, std::max<uint32_t>(1u, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));

@@ -347,9 +347,7 @@ COATI_FWD_KERNEL(forward_l1_fast_narrow, true, true, __launch_bounds__(kFillWave
 }  // namespace
 
 hipError_t launch_forward_l1(const BatchDeviceView& v, bool one_table, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
-    if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_fwd_items, 4u), stream);
+    hipError_t e = zero_queue_and_progress(v, v.n_fwd_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
     // workgroups of 4 wavefronts (one per SIMD); per CU: 2 (fast, 16 columns per lane), 3 (exact, 16 columns), 4 (at most
     // 8 columns per lane: the narrow build); fewer when there are fewer items than wavefronts

@@ -127,12 +127,21 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     const uint64_t wave_slot_bytes = (std::min<uint64_t>(slot_dwords, 1ull << 20) * 4 + 255) / 256 * 256;
     const uint64_t scratch_bytes = ck_scratch_dwords_per_wave() * sizeof(uint32_t);
     const uint64_t waves_bytes = static_cast<uint64_t>(ck_scratch_waves()) * (wave_slot_bytes + scratch_bytes);
+    const bool alloc_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;
+    auto t_alloc = std::chrono::steady_clock::now();
+    auto alloc_stage = [&](const char* what, uint64_t bytes) {
+        if(!alloc_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "viterbi_batch[stream]: %s (%.1f MB) %.2f ms\n", what, bytes / 1048576.0, std::chrono::duration<double, std::milli>(t - t_alloc).count());
+        t_alloc = t;
+    };
     if(model->stream_waves_bytes < waves_bytes) {
         if(model->d_stream_waves != nullptr) (void)hipFree(model->d_stream_waves);
         model->d_stream_waves = nullptr;
         model->stream_waves_bytes = 0;
         if(!soft(hipMalloc(&model->d_stream_waves, waves_bytes))) return COATI_HIP_ESTATE;
         model->stream_waves_bytes = waves_bytes;
+        alloc_stage("wavefront slots + scratch allocated", waves_bytes);
     }
     // slots: fixed sizes (nothing can grow while the kernel runs; the chunks are cut to fit).  Workspace: room for
     // the largest pair this form accepts (kStreamPairCells) with its own checkpoints; staging block
@@ -174,6 +183,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             ss.pinned_bytes = kSlotStaging;
         }
     }
+    alloc_stage("stream slots ready", static_cast<uint64_t>(n_slots) * (kSlotArena + kSlotStaging));
     // the call's last chunks -- everything behind the first round of 4 096 wavefronts, up to ~7 500 pairs of 1 kb -- are
     // cut into row parts (finer items for the ragged end of the kernel, as a resident batch's later pairs are, abi.hip
     // "the ragged end"): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- six larger workspaces of ~1 250 pairs
@@ -222,7 +232,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     hipError_t e0 = hipMemsetAsync(model->d_stream_ctl, 0, ck_stream_ctl_bytes(), kernel_stream);
     if(e0 == hipSuccess)
         e0 = launch_viterbi_ck_stream(model->d_table, model->k, model->n_tables == 1, model->d_stream_ctl, hs_dev, wave_ck, wave_slot_bytes / 4,
-                                      wave_scratch, kernel_stream);
+                                      wave_scratch, model->ck_band, kernel_stream);
     if(e0 != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e0));
     struct Closer {  // whatever happens below, the kernel is told to finish
         void* host;

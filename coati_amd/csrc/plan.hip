@@ -225,7 +225,22 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             return items;
         };
         const uint64_t kSimds = 4ull * device_cu_count();
-        while(w_main > 4 && count_items(w_main) < kSimds) w_main /= 2;
+        // Narrow the strips until the batch has about TWO items per SIMD (round 4; before: one).  A wavefront that is alone
+        // on its SIMD issues at under half the SIMD's rate, so a plan that stops at one item per SIMD leaves
+        // half the chip's issue slots empty however the items are shaped; the sweep of {16 .. 1 024} pairs x {2 .. 32} kb
+        // under every kernel and strip width (tools/planner_sweep.py -> profiles/r04/planner_sweep.txt) puts the best
+        // forced choice at 1.9-2.0 items per SIMD everywhere between "a few long pairs" and "thousands of pairs":
+        // 64 x 8 kb 5.7 -> 4.6 ms, 256 x 2 kb 1.47 -> 1.10, 64 x 16 kb 15.3 -> 13.7, 256 x 4 kb 3.9 -> 3.5.
+        // Exception: a batch of SINGLE-strip pairs that already has an item per SIMD stays as it is (1 024 x 1 kb: whole
+        // pairs through viterbi_ck 1.02 ms, cut in two 8-column strips 1.24 -- a second strip adds its pipeline lag to a
+        // pair of only 1 000 rows, and multi-strip pairs lose the banded checkpoints); pairs of two or more strips gain.
+        uint64_t live = 0;
+        for(uint64_t p = 0; p < n_pairs; ++p) live += (b->desc[p].la > 0 && b->desc[p].lb > 0) ? 1 : 0;
+        auto narrow_more = [&](uint32_t w) {
+            const uint64_t items = count_items(w);
+            return items < kSimds || (items < kSimds * 7 / 4 && 2 * items >= 3 * live);
+        };
+        while(w_main > 4 && narrow_more(w_main)) w_main /= 2;
         // While every wavefront is alone on its SIMD it issues one instruction per ~4.5 cycles whatever it is, so the time is
         // (rows + strips x hand-off lag) x instructions per step -- and viterbi_lp's 2-column step is 52 instructions
         // against 90 for 4 columns while the lag per column only doubles: 2-column strips as long as there are no more
@@ -521,8 +536,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     };
     // [what goes up: descriptors, order, queue word, work items, progress words, sequences | what comes back: scores,
     // ops offsets and lengths, ops | scratch]: each group contiguous, so that a pipeline slot moves it with ONE copy
-    const uint64_t o_desc = carve(n_pairs * sizeof(PairDesc)), o_order = carve(n_pairs * sizeof(uint32_t)), o_queue = carve(sizeof(uint32_t)),
+    // (the ticket counter sits right in front of the progress words: one fill zeroes both before a launch, common.hpp)
+    const uint64_t o_desc = carve(n_pairs * sizeof(PairDesc)), o_order = carve(n_pairs * sizeof(uint32_t)),
                    o_items = carve(items.size() * sizeof(WorkItem)), o_fwd = carve(fwd_items.size() * sizeof(WorkItem)),
+                   o_queue = carve(sizeof(uint32_t)),
                    o_progress = carve(std::max<size_t>(std::max(items.size(), fwd_items.size()), 4) * sizeof(uint32_t)),
                    o_a = carve(a_total), o_b = carve(b_total), o_up_end = arena_need,
                    o_scores = carve(n_pairs * sizeof(float)), o_start = carve(n_pairs * sizeof(uint64_t)),
@@ -589,8 +606,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         const uint64_t b_alone = stage_b && !stage_a ? std::min<uint64_t>(std::max<uint64_t>(b_total, kMinDmaBytes + 256), arena_need - o_b) : 0;
         if(std::max(sent, o_a + b_alone) > opts->staging_bytes) B_TRY(hipErrorOutOfMemory);
         char* st = opts->staging;
-        std::memset(st + o_queue, 0, o_items - o_queue);
-        std::memset(st + o_progress, 0, o_a - o_progress);
+        std::memset(st + o_queue, 0, o_a - o_queue);  // (ticket counter + progress words)
         if(n_pairs > 0) {
             std::memcpy(st + o_desc, b->desc.data(), n_pairs * sizeof(PairDesc));
             std::memcpy(st + o_order, order.data(), n_pairs * sizeof(uint32_t));

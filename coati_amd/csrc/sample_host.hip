@@ -46,10 +46,28 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         std::lock_guard<std::mutex> hold(m->arena_lock);
         for(const auto& a : m->free_arenas) free_b += a.bytes;
     }
+    // Round 4: the step table (sampleback.hip) -- thresholds and log-weight increments per (body cell, state), built once
+    // per call -- when it fits 8 GB and a third of the free HBM (16 pairs of 1 kb: 1.15 GB); gap_len 1, the bit-exact
+    // build (the fast build's samplers keep the on-the-fly path: COATI_HIP_FORWARD_FAST is not a parity mode).  With it the
+    // candidates only count draws (no temporary ops) and ONE final launch writes every sample from its resolved offset.
+    uint64_t table_entries = 0;
+    std::vector<uint64_t> tab_off(n, 0);
+    uint64_t max_cells = 0;
+    for(uint64_t p = 0; p < n; ++p) {
+        tab_off[p] = table_entries;
+        const uint64_t cells = static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb;
+        table_entries += 3 * cells;
+        max_cells = std::max(max_cells, cells);
+    }
+    static const bool table_off = std::getenv("COATI_HIP_SAMPLE_TABLE") != nullptr && std::getenv("COATI_HIP_SAMPLE_TABLE")[0] == '0';
+    const uint64_t table_bytes = table_entries * step_entry_bytes();
+    const bool use_table = m->gap_len == 1 && !forward_fast_math() && !table_off && table_bytes <= (8ull << 30) && table_bytes <= free_b / 3 &&
+                           b->desc[0].f_compact == 0;
     // work arena for the candidates' ops: 2 GB, or a power of two below a quarter of the free HBM
     // (a stable size, so that repeated calls find their block in the cache)
     uint64_t tmp_budget = 2ull << 30;
     while(tmp_budget > (1ull << 20) && tmp_budget > free_b / 4) tmp_budget >>= 1;
+    if(use_table) tmp_budget = 0;  // (no temporary ops)
 
     uint64_t dbg_rounds = 0, dbg_cands = 0;  // reported with COATI_HIP_TIMING=1
     struct PairState {
@@ -77,6 +95,8 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     uint8_t* d_tmp = nullptr;
     uint32_t *d_clen = nullptr, *d_cdraws = nullptr;
     float* d_clw = nullptr;
+    uint64_t *d_tab_off = nullptr, *d_state0 = nullptr, *d_sample_off = nullptr, *d_base = nullptr;
+    char* d_steps = nullptr;
     void* block = nullptr;
     uint64_t block_bytes = 0;
     auto carve = [&](Carver& cv) {
@@ -88,7 +108,14 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         d_clen = cv.take<uint32_t>(kMaxCands);
         d_cdraws = cv.take<uint32_t>(kMaxCands);
         d_clw = cv.take<float>(kMaxCands);
-        d_tmp = cv.take<uint8_t>(tmp_budget);
+        d_tmp = cv.take<uint8_t>(std::max<uint64_t>(tmp_budget, 16));
+        if(use_table) {
+            d_tab_off = cv.take<uint64_t>(n);
+            d_state0 = cv.take<uint64_t>(2 * n);
+            d_sample_off = cv.take<uint64_t>(n * n_samples);
+            d_base = cv.take<uint64_t>(n);
+            d_steps = cv.take<char>(table_bytes);
+        }
     };
     auto release = [&]() {
         if(block == nullptr) return;
@@ -114,6 +141,16 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         carve(cv);
     }
     S_TRY(hipMemcpyAsync(d_pow, mult_pow, sizeof(mult_pow), hipMemcpyHostToDevice, m->stream));
+    const BatchDeviceView view = device_view(b);
+    std::vector<uint64_t> sample_off;  // table path: draws between a pair's original state and the start of each of its samples
+    if(use_table) {
+        sample_off.assign(n * n_samples, 0);
+        S_TRY(hipMemcpyAsync(d_tab_off, tab_off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(hipMemcpyAsync(d_state0, rng_state, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_step_table(view, d_tab_off, max_cells, d_steps, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));  // (tab_off / base are stack-lifetime vectors of the caller: uploaded before they can go)
+    }
 
     struct Window {  // candidates of one (pair, sample-in-chunk)
         uint32_t first_cand, lo, hi;
@@ -143,7 +180,6 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         origin_states.cap = origin_states.n = 2 * n;
         commits.cap = cap_m;
     }
-    const BatchDeviceView view = device_view(b);
     try {
     for(;;) {
         cands.clear();
@@ -161,7 +197,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             any = true;
             const uint64_t cand_begin = cands.size(), tmp_begin = tmp_used;
             if(cand_begin + 1 > kMaxCands ||
-               tmp_used + static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb > tmp_budget)
+               (!use_table && tmp_used + static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb > tmp_budget))
                 continue;  // more unfinished pairs than one round holds: this pair waits for the next round
             const uint64_t width = static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb;
             const uint32_t remaining = n_samples - s.done;
@@ -176,12 +212,12 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
                 const int64_t lo = std::max<int64_t>(center - half, j), hi = std::max<int64_t>(center + half, lo);
                 const uint64_t count = static_cast<uint64_t>(hi - lo + 1);
                 if(j > 0 && (cands.size() - cand_begin + count > cand_share ||
-                            tmp_used - tmp_begin + count * std::max<uint64_t>(width, 1) > tmp_share))
+                            (!use_table && tmp_used - tmp_begin + count * std::max<uint64_t>(width, 1) > tmp_share)))
                     break;
                 windows[p].push_back(Window{static_cast<uint32_t>(cands.size()), static_cast<uint32_t>(lo), static_cast<uint32_t>(hi)});
                 for(int64_t off = lo; off <= hi; ++off) {
                     cands.push_back(SpecCandidate{static_cast<uint32_t>(p), static_cast<uint32_t>(off), tmp_used});
-                    tmp_used += width;
+                    if(!use_table) tmp_used += width;
                 }
             }
             const u128 st = s.st0 * lehmer_pow(s.origin);
@@ -189,7 +225,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             origin_states[2 * p + 1] = static_cast<uint64_t>(st >> 64);
         }
         if(!any) break;
-        if(cands.size() > kMaxCands || tmp_used > tmp_budget) {  // a single sample does not fit the work arena
+        if(cands.size() > kMaxCands || (!use_table && tmp_used > tmp_budget)) {  // a single sample does not fit the work arena
             release();
             return hipErrorOutOfMemory;
         }
@@ -198,7 +234,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         dbg_cands += nc;
         S_TRY(hipMemcpyAsync(d_origin, origin_states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_cands, cands.data(), nc * sizeof(SpecCandidate), hipMemcpyHostToDevice, m->stream));
-        S_TRY(launch_spec_walk(view, d_origin, d_pow, d_cands, nc, d_tmp, d_cstart, d_clen, d_clw, d_cdraws, m->stream));
+        if(use_table)
+            S_TRY(launch_spec_len(view, d_tab_off, d_steps, d_origin, d_pow, d_cands, nc, d_cdraws, m->stream));
+        else
+            S_TRY(launch_spec_walk(view, d_origin, d_pow, d_cands, nc, d_tmp, d_cstart, d_clen, d_clw, d_cdraws, m->stream));
         draws.resize(nc);
         S_TRY(hipMemcpyAsync(draws.data(), d_cdraws, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));
@@ -212,7 +251,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
                 if(off < w.lo || off > w.hi) break;  // not speculated: first sample of the next chunk
                 const uint32_t cand = w.first_cand + static_cast<uint32_t>(off - w.lo);
                 const uint64_t out_index = p * n_samples + s.done;
-                commits.push_back(SpecCommit{cand, 0u, base[p] + (static_cast<uint64_t>(s.done) + 1) * width, out_index});
+                if(use_table)
+                    sample_off[out_index] = s.origin + off;
+                else
+                    commits.push_back(SpecCommit{cand, 0u, base[p] + (static_cast<uint64_t>(s.done) + 1) * width, out_index});
                 const double x = static_cast<double>(draws[cand]);
                 s.cnt += 1;  // Welford
                 const double d1 = x - s.mean;
@@ -223,10 +265,17 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             }
             s.origin += off;
         }
+        if(use_table) continue;  // (nothing to copy: the final launch below writes every sample)
         const uint32_t ncm = static_cast<uint32_t>(commits.size());
         S_TRY(hipMemcpyAsync(d_commits, commits.data(), ncm * sizeof(SpecCommit), hipMemcpyHostToDevice, m->stream));
         S_TRY(launch_spec_commit(d_commits, ncm, d_tmp, d_cstart, d_clen, d_clw, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));  // `commits`/`cands` are reused by the next round
+    }
+    if(use_table) {
+        // every sample's start in its pair's stream is known: one walker per (pair, sample), results in place
+        S_TRY(hipMemcpyAsync(d_sample_off, sample_off.data(), sample_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_final_walk(view, d_tab_off, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));
     }
     } catch(...) {  // host-side allocation failure: free the device work areas, report at the ABI
         release();

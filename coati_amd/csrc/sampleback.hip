@@ -19,6 +19,8 @@
 // Forward fill every draw, path and log-weight equals the CPU's.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace coati_hip_detail {
 namespace {
 
@@ -266,6 +268,196 @@ __global__ __launch_bounds__(64) void spec_walk_kernel(const float* __restrict__
     c_draws[idx] = draws;
 }
 
+// ---- exact stream, round 4: the step table -------------------------------------------------------
+// The speculation above walks ~100 candidates per committed sample, and every step of every candidate evaluated
+// three expf and one logf (the bit-exact restatements: ~250 instructions) on values that depend only on the CELL and
+// the STATE the walk is in -- not on the draw.  So they are computed once: per body cell and state
+//     scale = m + d + i,  m,  d + m            the thresholds of sample_mdi / sample_mi (align_pair.cc:336-385)
+//     l_M - logf(scale), l_D - ..., l_I - ...  what the picked state adds to the sample's log-weight
+// with exactly the operations of sample_walk / sample3 above (same order, same restatements: same bits).  A step is
+// then one 24-byte load, one multiply, two compares and an add; 16 pairs of 1 kb are 16 M cells -- the work of ~2 % of
+// the steps one sampleback call walks.  gap_len 1; margin cells (the last few steps of a walk) keep the formulas.
+// And the candidates no longer write their ops: the rounds only resolve the chain of stream offsets (how many draws
+// each sample takes), then ONE launch walks every (pair, sample) from its now known offset and writes the results.
+struct StepEntry {
+    float scale, m, dm, inc_m, inc_d, inc_i;
+};
+static_assert(sizeof(StepEntry) == 24, "one 24-byte entry per (cell, state)");
+
+__device__ __forceinline__ StepEntry step_entry(const Walker& w, uint32_t i, uint32_t j, int st) {
+    // (i, j): matrix coordinates of a BODY cell, gap_len 1; the lines of sample_walk's loop body, in its order
+    Triple cur;
+    w.cell(i, j, cur.m, cur.d, cur.in);
+    const bool is_m = st == COATI_HIP_OP_MATCH, is_d = st == COATI_HIP_OP_DEL;
+    const uint32_t pi = is_m ? i - 1 : (is_d ? i - 1 : i), pj = is_m ? j - 1 : (is_d ? j : j - 1);
+    Triple t{kLowest, kLowest, kLowest};
+    w.pred(pi, pj, t.m, t.d, t.in);
+    const float top = is_m ? cur.m : (is_d ? cur.d : cur.in);
+    const float s = w.subst(i, j);
+    const float m1 = t.m + (is_m || is_d ? w.k.ng : w.k.go);
+    const float e0 = is_m ? (m1 + w.k.ng) + s : (is_d ? (m1 + w.k.go) + w.ext_lm1 : m1 + w.ext_lm1);
+    const float e1 = is_m ? (t.d + w.k.gs) + s : t.d + w.ext_l;
+    const float i1 = t.in + w.k.gs;
+    const float e2 = is_m ? (i1 + w.k.ng) + s : (is_d ? (i1 + w.k.go) + w.ext_lm1 : t.in + w.ext_l);
+    const float l0 = e0 - top, l1 = (is_m || is_d) ? e1 - top : -__builtin_inff(), l2 = e2 - top;
+    const float m = libm::expf_nonpos(l0, w.exp_tab), d = libm::expf_nonpos(l1, w.exp_tab), in = libm::expf_nonpos(l2, w.exp_tab);
+    const float scale = m + d + in;
+    const float ls = libm::logf_pos(scale);
+    return StepEntry{scale, m, d + m, l0 - ls, l1 - ls, l2 - ls};
+}
+
+__global__ __launch_bounds__(256) void step_table_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+                                                         const uint64_t* __restrict__ tab_off, uint32_t n_pairs,
+                                                         const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
+                                                         const float* __restrict__ mdi, StepEntry* __restrict__ steps) {
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
+    const uint32_t pair = blockIdx.y;
+    if(pair >= n_pairs) return;
+    const PairDesc pd = pairs[pair];
+    const uint64_t cells = static_cast<uint64_t>(pd.la) * pd.lb;
+    const Walker w{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
+                   mdi, pd, exp_tab};
+    StepEntry* out = steps + tab_off[pair];
+    for(uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; c < cells; c += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t bi = static_cast<uint32_t>(c / pd.lb), bj = static_cast<uint32_t>(c - static_cast<uint64_t>(bi) * pd.lb);
+#pragma unroll
+        for(int st = 0; st < 3; ++st) out[c * 3 + st] = step_entry(w, bi + 1, bj + 1, st);
+    }
+}
+
+// sample_walk with the body steps read from the table.  kOps: write the ops (the final launch) or only count the
+// draws (the candidates of a round).  Identical decisions, log-weight and draw count as sample_walk.
+template <bool kOps>
+__device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ steps, Rng128& rng, uint8_t* __restrict__ ops, uint64_t slot,
+                               float& score, uint32_t& draws) {
+    draws = 1;
+    uint32_t i = w.la, j = w.lb;  // (gap_len 1: the last cell is (la, lb))
+    uint64_t pos = slot + w.la + w.lb;
+    score = 0.0f;
+    Triple cur;
+    w.cell(i, j, cur.m, cur.d, cur.in);
+    bool cur_valid = true;  // `cur` is M/D/I of the cell the walk is at (only kept up to date on the margins)
+    int st;
+    {
+        const float top = fmaxf(fmaxf(cur.m, cur.d), cur.in);
+        st = sample3(cur.m - top, cur.d - top, cur.in - top, rng_f24(rng), score, w.exp_tab);
+    }
+    const uint32_t lb = w.lb;
+    while(j > 0 || i > 0) {
+        ++draws;
+        const bool is_m = st == COATI_HIP_OP_MATCH, is_d = st == COATI_HIP_OP_DEL;
+        const uint32_t pi = is_m ? i - 1 : (is_d ? i - 1 : i), pj = is_m ? j - 1 : (is_d ? j : j - 1);
+        if(pi > i || pj > j || pos < slot + 1u) {  // (as in sample_walk: only with a table of -inf / NaN weights)
+            score = __builtin_nanf("");
+            break;
+        }
+        if(kOps) ops[--pos] = static_cast<uint8_t>(st);
+        else --pos;
+        if(i >= 1 && j >= 1) {
+            const StepEntry e = steps[(static_cast<uint64_t>(i - 1) * lb + (j - 1)) * 3 + static_cast<uint32_t>(st)];
+            float p = rng_f24(rng);
+            p *= e.scale;
+            int nst;
+            float inc;
+            if(p < e.m) {
+                nst = COATI_HIP_OP_MATCH;
+                inc = e.inc_m;
+            } else if(p < e.dm) {
+                nst = COATI_HIP_OP_DEL;
+                inc = e.inc_d;
+            } else {
+                nst = COATI_HIP_OP_INS;
+                inc = e.inc_i;
+            }
+            score += inc;
+            st = nst;
+            cur_valid = false;
+        } else {
+            // a margin cell: del_del / ins_ins are copies of the margin D / I (init_margins, align_pair.hpp:108-111)
+            if(!cur_valid) w.pred(i, j, cur.m, cur.d, cur.in);
+            Triple t{kLowest, kLowest, kLowest};
+            w.pred(pi, pj, t.m, t.d, t.in);
+            const float top = is_m ? cur.m : (is_d ? cur.d : cur.in);
+            float e0 = kLowest, e1 = kLowest, e2 = kLowest;
+            if(!is_m) {
+                float mm0, dm0, im0;
+                margin_mdi(w.k, 1u, i, j, mm0, dm0, im0);
+                if(is_d)
+                    e1 = dm0;
+                else
+                    e2 = im0;
+            }
+            const float l1 = (is_m || is_d) ? e1 - top : -__builtin_inff();
+            st = sample3(e0 - top, l1, e2 - top, rng_f24(rng), score, w.exp_tab);
+            cur = t;
+            cur_valid = true;
+        }
+        i = pi;
+        j = pj;
+    }
+    return pos;
+}
+
+__device__ __forceinline__ Rng128 rng_jump(const uint64_t* __restrict__ origin_state, const uint64_t* __restrict__ mult_pow, uint32_t pair, uint64_t offset) {
+    unsigned __int128 st = (static_cast<unsigned __int128>(origin_state[2 * pair + 1]) << 64) | origin_state[2 * pair];
+    for(uint32_t bit = 0; offset != 0; ++bit, offset >>= 1)
+        if(offset & 1u) st *= (static_cast<unsigned __int128>(mult_pow[2 * bit + 1]) << 64) | mult_pow[2 * bit];
+    return Rng128{static_cast<uint64_t>(st), static_cast<uint64_t>(st >> 64)};
+}
+
+// a round's candidates: how many draws does a sample that starts `offset` draws after the chunk origin take?
+__global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+                                                      const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
+                                                      const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
+                                                      const StepEntry* __restrict__ steps, const uint64_t* __restrict__ origin_state,
+                                                      const uint64_t* __restrict__ mult_pow, const SpecCandidate* __restrict__ cands,
+                                                      uint32_t n_cands, uint32_t* __restrict__ c_draws) {
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if(idx >= n_cands) return;
+    const SpecCandidate cd = cands[idx];
+    const PairDesc pd = pairs[cd.pair];
+    Rng128 rng = rng_jump(origin_state, mult_pow, cd.pair, cd.offset);
+    const Walker w{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
+                   mdi, pd, exp_tab};
+    float score;
+    uint32_t draws;
+    (void)table_walk<false>(w, steps + tab_off[cd.pair], rng, nullptr, 0, score, draws);
+    c_draws[idx] = draws;
+}
+
+// the chain is known: every (pair, sample) from its exact offset (draws after the pair's ORIGINAL state), results written
+__global__ __launch_bounds__(64) void final_walk_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+                                                        const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
+                                                        const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
+                                                        const StepEntry* __restrict__ steps, const uint64_t* __restrict__ start_state,
+                                                        const uint64_t* __restrict__ mult_pow, const uint64_t* __restrict__ sample_offset,
+                                                        const uint64_t* __restrict__ sample_base, uint32_t n_pairs, uint32_t n_samples,
+                                                        uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len,
+                                                        float* __restrict__ log_weights) {
+    __shared__ uint64_t exp_tab[32];
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
+    const uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if(idx >= static_cast<uint64_t>(n_pairs) * n_samples) return;
+    const uint32_t pair = static_cast<uint32_t>(idx / n_samples), n = static_cast<uint32_t>(idx % n_samples);
+    const PairDesc pd = pairs[pair];
+    Rng128 rng = rng_jump(start_state, mult_pow, pair, sample_offset[idx]);
+    const Walker w{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
+                   mdi, pd, exp_tab};
+    const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb, slot = sample_base[pair] + n * width;
+    float score;
+    uint32_t draws;
+    const uint64_t pos = table_walk<true>(w, steps + tab_off[pair], rng, ops, slot, score, draws);
+    ops_start[idx] = pos;
+    ops_len[idx] = static_cast<uint32_t>(slot + width - pos);
+    log_weights[idx] = score;
+}
+
 // Copy the candidates that turned out to be the true samples into the result arrays
 // (one workgroup per sample).
 __global__ __launch_bounds__(64) void spec_commit_kernel(const SpecCommit* __restrict__ commits, uint32_t n_commits,
@@ -312,6 +504,32 @@ hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, con
     if(n_commits == 0) return hipSuccess;
     hipLaunchKernelGGL(spec_commit_kernel, dim3(n_commits), dim3(64), 0, stream, commits, n_commits, tmp_ops, c_start,
                        c_len, c_lw, ops, ops_start, ops_len, log_weights);
+    return hipGetLastError();
+}
+
+uint64_t step_entry_bytes() { return sizeof(StepEntry); }
+hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, hipStream_t stream) {
+    if(v.n_pairs == 0 || max_cells == 0) return hipSuccess;
+    const uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((max_cells + 255) / 256, 4096));
+    hipLaunchKernelGGL(step_table_kernel, dim3(gx, v.n_pairs), dim3(256), 0, stream, v.table, v.k, v.pairs, tab_off, v.n_pairs, v.a_cat, v.b_cat, v.mdi,
+                       static_cast<StepEntry*>(steps));
+    return hipGetLastError();
+}
+hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* origin_state, const uint64_t* mult_pow,
+                           const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream) {
+    if(n_cands == 0) return hipSuccess;
+    hipLaunchKernelGGL(spec_len_kernel, dim3((n_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
+                       static_cast<const StepEntry*>(steps), origin_state, mult_pow, cands, n_cands, c_draws);
+    return hipGetLastError();
+}
+hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* start_state, const uint64_t* mult_pow,
+                             const uint64_t* sample_offset, const uint64_t* sample_base, uint32_t n_samples, uint8_t* ops, uint64_t* ops_start,
+                             uint32_t* ops_len, float* log_weights, hipStream_t stream) {
+    const uint64_t walkers = static_cast<uint64_t>(v.n_pairs) * n_samples;
+    if(walkers == 0) return hipSuccess;
+    hipLaunchKernelGGL(final_walk_kernel, dim3(static_cast<uint32_t>((walkers + 63) / 64)), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat,
+                       v.b_cat, v.mdi, static_cast<const StepEntry*>(steps), start_state, mult_pow, sample_offset, sample_base, v.n_pairs, n_samples, ops,
+                       ops_start, ops_len, log_weights);
     return hipGetLastError();
 }
 

@@ -118,26 +118,37 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffff0u, 0x00020000);
 }
 
-// BANDED CHECKPOINTS (round 3).  The checkpoints are 1.09 bytes per cell written to HBM of which the traceback reads
-// ~6 %: the tiles along the path.  And the stores are what holds the clock down (the fill's loop holds
-// 2.35 GHz without them, 1.9 GHz with them).  A pair of related sequences is aligned near the straight line from
-// (0, 0) to (la, lb), so a lane keeps the checkpoints of a band (kCkRows wavefront steps) only when the band's middle
-// lies within `band` steps of the step at which that line crosses the middle of the lane's columns:
-//     kept(lane t, band c)  <=>  | c * kCkRows + kCkRows/2 - centre(t) | <= band
+// BANDED CHECKPOINTS (round 3; the band's shape: round 4).  The checkpoints are 1.09 bytes per cell written to HBM of which
+// the traceback reads ~6 %: the tiles along the path.  And the stores are what holds the clock down (the
+// fill's loop holds 2.35 GHz without them, 1.9 GHz with them).  A lane therefore keeps the checkpoints of a band
+// (kCkRows wavefront steps) only when the band's middle lies within `half` steps of its centre step:
+//     kept(lane t, band c)  <=>  | c * kCkRows + kCkRows/2 - centre(t) | <= half
+// Where the path can be: every alignment column is a diagonal step or a gap, so with delta = la - lb the path needs at
+// least |delta| gap columns of one kind; a path whose gaps are (almost) all of that kind -- related sequences with a few
+// indels -- lies between the diagonal through (0, 0) and the one through (la, lb): at column j its row is between
+// j + min(0, delta) and j + max(0, delta).  So centre(t) = (middle column of the lane) + delta / 2 + t (the lane's
+// skew), and half = band + |delta| / 2: the band setting (COATI_HIP_OPT_CK_BAND, default 96) is the slack for gaps of the
+// OTHER kind, and a pair with one 300-base deletion keeps a wider band instead of being filled twice (round 3 centred
+// the band on the straight line (0, 0) -> (la, lb) with a fixed half width: a bag in which a quarter of the pairs
+// carry a 90-300 nt indel ran 26 % SLOWER than with everything kept; bench.py extra.band_sensitivity).
 // The FILL is unchanged -- every cell is computed, scores are the same bits; only which recompute hints exist changes.
 // A walk that asks for a tile that was not kept (it cannot know the decisions there) reports it, and the wavefront
 // fills the pair again with band = kCkBandOff (everything kept) and walks again: exact, at twice the cost for that
-// pair.  Single-strip pairs that are not cut into row parts only; COATI_HIP_CK_BAND=<steps> (0 = off) sets it.
-constexpr uint32_t kCkBandOff = 0xffffffffu;
-__device__ __forceinline__ uint32_t ck_lane_centre(uint32_t la, uint32_t lb, uint32_t w, uint32_t t) {
-    // body row of the line at the middle of the lane's columns, plus the lane's skew
-    const uint64_t col = static_cast<uint64_t>(t) * w + w / 2;
-    return static_cast<uint32_t>(col * la / max(lb, 1u)) + t;
+// pair.  Single-strip pairs only; 0 = off.
+__device__ __forceinline__ int32_t ck_lane_centre(uint32_t la, uint32_t lb, uint32_t w, uint32_t t) {
+    const int32_t delta = static_cast<int32_t>(la) - static_cast<int32_t>(lb);
+    return static_cast<int32_t>(t * w + w / 2) + delta / 2 + static_cast<int32_t>(t);
 }
-__device__ __forceinline__ bool ck_tile_kept(uint32_t band, uint32_t centre, int32_t c) {
-    if(band == kCkBandOff) return true;
+// half width of the kept band of a pair: the setting plus half the length difference (wave-uniform)
+__device__ __forceinline__ uint32_t ck_band_half(uint32_t band, uint32_t la, uint32_t lb) {
+    if(band == kCkBandOff) return band;
+    const uint32_t delta = la > lb ? la - lb : lb - la;
+    return band + (delta + 1u) / 2u;
+}
+__device__ __forceinline__ bool ck_tile_kept(uint32_t half, int32_t centre, int32_t c) {
+    if(half == kCkBandOff) return true;
     const int64_t d = static_cast<int64_t>(c) * kCkRows + kCkRows / 2 - static_cast<int64_t>(centre);
-    return (d < 0 ? -d : d) <= static_cast<int64_t>(band);
+    return (d < 0 ? -d : d) <= static_cast<int64_t>(half);
 }
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
 
@@ -149,7 +160,8 @@ struct CkCtx {
     int lane;
     bool last_strip;
     float *bnd_x, *bnd_z;  // (wave-uniform)
-    uint32_t band, centre;  // banded checkpoints: kCkBandOff or the half width in steps; this lane's centre step
+    uint32_t band;   // banded checkpoints: kCkBandOff or the half width in steps (ck_band_half)
+    int32_t centre;  // this lane's centre step
 };
 // HBM windows of one 64-step chunk (rebased per chunk so that offsets stay far below 2^32)
 struct CkChunkMem {
@@ -300,7 +312,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
     }
     const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z, band,
-                   band == kCkBandOff ? 0u : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane))};
+                   band == kCkBandOff ? 0 : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane))};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
     // ge*float(j-1)); a lane takes it again at its first step (ck_step)
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // banded checkpoints (above): whole single-strip pairs of the full-width shape only; the second time round
         // (redo: the walk left the kept band) everything is kept
         const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? band : kCkBandOff;
+        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? ck_band_half(band, pd.la, pd.lb) : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
@@ -861,7 +873,9 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[redo ? 4 : 3], 1ull);
         const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len);
         if(!walk_ok && band_now != kCkBandOff) {
-            // the walk asked for a tile outside the kept band: the same item once more, with everything kept
+            // the walk asked for a tile outside the kept band: the same item once more, with everything kept (counted:
+            // the word behind the ticket counter, zeroed with it; coati_hip_viterbi_band_stats)
+            if(lane == 0) atomicAdd(queue + 1, 1u);
             redo_ticket = ticket;
             continue;
         }
@@ -1113,7 +1127,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         }
         // (banded checkpoints: as in viterbi_ck)
         const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? band : kCkBandOff;
+        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? ck_band_half(band, pd.la, pd.lb) : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {
             if(cut)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
@@ -1286,9 +1300,7 @@ uint32_t ck_band_setting() {
 }
 
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
-    if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);  // polled words: zero every launch
+    hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
     const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
@@ -1297,7 +1309,7 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
         return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
     }();
     // (the debug export of every cell's decisions decodes every tile: that batch keeps every checkpoint)
-    const uint32_t band = v.ck_keep_all != 0 ? kCkBandOff : ck_band_setting();
+    const uint32_t band = v.ck_band;
     const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck<true>) : reinterpret_cast<const void*>(viterbi_ck<false>);
     if(shape.dynamic_lds > 0) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));
@@ -1359,7 +1371,7 @@ void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* aren
 }
 
 hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared_tab, void* ctl, const void* host_words, uint32_t* wave_ck,
-                                    uint64_t wave_slot_dwords, uint32_t* wave_scratch, hipStream_t stream) {
+                                    uint64_t wave_slot_dwords, uint32_t* wave_scratch, uint32_t band, hipStream_t stream) {
     const CkShape shape = ck_launch_shape(0xffffffffu, shared_tab);  // the whole chip: the kernel does not know how much is coming
     const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck_stream<true>) : reinterpret_cast<const void*>(viterbi_ck_stream<false>);
     if(shape.dynamic_lds > 0) {
@@ -1369,11 +1381,11 @@ hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared
     if(shared_tab)
         hipLaunchKernelGGL(viterbi_ck_stream<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
                            static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch,
-                           ck_band_setting());
+                           band);
     else
         hipLaunchKernelGGL(viterbi_ck_stream<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, table, k,
                            static_cast<CkStreamCtl*>(ctl), static_cast<const CkStreamHost*>(host_words), wave_ck, wave_slot_dwords, wave_scratch,
-                           ck_band_setting());
+                           band);
     return hipGetLastError();
 }
 

@@ -292,9 +292,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, kNarrowOnly ? 3 : 2) void viterb
 
 hipError_t launch_viterbi_k(const BatchDeviceView& v, bool narrow_only, hipStream_t stream) {
     if(v.gap_len != 2 && v.gap_len != 3) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
-    if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);
+    hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
     // two (three for the narrow-only kernel) workgroups per CU, no more wavefronts than items
     const uint32_t blocks = std::min<uint32_t>(narrow_only ? 768u : 512u, std::max<uint32_t>(1u, (v.n_items + kFillWaves - 1) / kFillWaves));

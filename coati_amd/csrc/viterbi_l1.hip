@@ -412,9 +412,7 @@ extern "C" int coati_hip_debug_trace_l1(unsigned long long* out) {
 #endif
 
 hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
-    if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);  // polled words: zero every launch
+    hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
     // strip boundaries: self-validating values (fill_strip) unless COATI_HIP_L1_PROGRESS=1 asks for the progress-word
     // protocol (A/B; 160 kb pair: 87.5 -> 85.2 ms with the 0.35 ms fill of the 800 MB of boundary arrays included)

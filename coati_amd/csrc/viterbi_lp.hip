@@ -475,9 +475,7 @@ extern "C" int coati_hip_debug_trace_lp(unsigned long long* out) {
 // The launch has one workgroup (one wavefront per SIMD) on every CU while the items fit, up to three after that,
 // enforced by LDS padding like viterbi_l1's.
 hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(v.queue, 0, sizeof(uint32_t), stream);
-    if(e != hipSuccess) return e;
-    e = hipMemsetAsync(v.progress, 0, sizeof(uint32_t) * std::max(v.n_items, 4u), stream);
+    hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
     if(v.bnd_bytes != 0) {  // the boundary values validate themselves: everything starts as the NaN pattern 0xffffffff
         e = hipMemsetAsync(v.bnd, 0xff, v.bnd_bytes, stream);

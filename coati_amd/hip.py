@@ -16,6 +16,7 @@ LIB_PATH = _ROOT / "_build" / "libcoati_hip.so"
 
 TABLE_ROWS, TABLE_COLS = 183, 15
 OP_MATCH, OP_DEL, OP_INS = 0, 1, 2
+OPT_PERSISTENT_CALL, OPT_CK_BAND = 1, 2  # coati_hip_model_set_option
 
 # every symbol include/coati_hip.h declares
 EXPORTS = (
@@ -38,6 +39,7 @@ EXPORTS = (
     "coati_hip_viterbi_wait",
     "coati_hip_viterbi_fetch",
     "coati_hip_viterbi_last_timing",
+    "coati_hip_viterbi_band_stats",
     "coati_hip_viterbi_timing",
     "coati_hip_batch_result_ptrs",
     "coati_hip_forward_launch",
@@ -103,6 +105,8 @@ def load() -> C.CDLL:
     lib.coati_hip_viterbi_fetch.argtypes = [vp, vp, vp, u64, vp, vp]
     lib.coati_hip_viterbi_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
     lib.coati_hip_viterbi_timing.argtypes = [vp, C.c_uint32, C.POINTER(f32), C.POINTER(f32)]
+    if hasattr(lib, "coati_hip_viterbi_band_stats"):
+        lib.coati_hip_viterbi_band_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.coati_hip_batch_result_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp),
                                                 C.POINTER(vp)]
     lib.coati_hip_forward_launch.argtypes = [vp]
@@ -336,6 +340,12 @@ class Batch:
         f, w = C.c_float(), C.c_float()
         _check(load().coati_hip_viterbi_timing(self._h, launches_back, C.byref(f), C.byref(w)))
         return f.value, w.value
+
+    def band_stats(self):
+        """(band half width in steps the last launch ran with -- 0: everything kept or not the banded kernel --, pairs filled twice)."""
+        band, twice = C.c_uint32(0), C.c_uint64(0)
+        _check(load().coati_hip_viterbi_band_stats(self._h, C.byref(band), C.byref(twice)))
+        return int(band.value), int(twice.value)
 
     def forward_launch(self):
         _check(load().coati_hip_forward_launch(self._h))

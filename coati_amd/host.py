@@ -251,3 +251,12 @@ def batch_reader_check(path) -> int:
     out = C.c_long(0)
     _check(load().coati_host_batch_reader_check(str(path).encode(), C.byref(out)))
     return int(out.value)
+
+
+def batch_shard_check(path, world: int, rank: int):
+    """One rank's host side of `coati-alignpair --batch --devices` without a device -> (s0, s1, first_difference): its shard
+    [s0, s1) from the file's index, parsed + encoded through the block pipeline and compared with the generic reader
+    (0 = identical, k + 1 = pair k differs)."""
+    s0, s1, out = C.c_ulonglong(0), C.c_ulonglong(0), C.c_long(0)
+    _check(load().coati_host_batch_shard_check(str(path).encode(), world, rank, C.byref(s0), C.byref(s1), C.byref(out)))
+    return int(s0.value), int(s1.value), int(out.value)

@@ -17,6 +17,9 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "coati_hip.h"
@@ -328,31 +331,50 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 constexpr std::size_t kBatchBlockPairs = 32768;
 
-// A FASTA file in memory and where its records start ('>' at the beginning of a line; io.cc:read_fasta).
+// A FASTA file in memory and where its records start ('>' at the beginning of a line; io.cc:read_fasta).  The file is
+// MAPPED, not read: every rank of a multi-GPU run indexes the whole file (the index is the shard plan) but touches the
+// sequence bytes of its own shard only, and the single-GPU driver saves the copy of a multi-GB input.
 struct fasta_index_t {
-    std::string buf;
-    std::vector<std::size_t> starts;  // offsets of the '>' of every record, then buf.size()
+    const char* data{nullptr};
+    std::size_t size{0};
+    std::vector<std::size_t> starts;  // offsets of the '>' of every record, then size
+    fasta_index_t() = default;
+    fasta_index_t(const fasta_index_t&) = delete;
+    fasta_index_t& operator=(const fasta_index_t&) = delete;
+    ~fasta_index_t() {
+        if(data != nullptr && size != 0) munmap(const_cast<char*>(data), size);
+    }
 };
 // false: not a plain FASTA file (stdin, "fmt:path" of another format, .phy, .json): the generic reader takes it
 bool load_fasta(const std::string& path, fasta_index_t& fi) {
     const file_type_t type = path.empty() ? file_type_t{"-", ".json"} : extract_file_type(path);
     if(type.path.empty() || type.path == "-" || !(type.type_ext == ".fa" || type.type_ext == ".fasta")) return false;
-    std::ifstream file(type.path, std::ios::binary);
-    if(!file) throw std::invalid_argument("Opening input file " + path + " failed.");
-    file.seekg(0, std::ios::end);
-    const std::streamoff size = file.tellg();
-    if(size < 0) return false;  // (not seekable: a pipe)
-    file.seekg(0);
-    fi.buf.resize(static_cast<std::size_t>(size));
-    file.read(fi.buf.data(), size);
-    if(file.gcount() != size) throw std::invalid_argument("Reading input file " + path + " failed.");
+    const int fd = open(type.path.c_str(), O_RDONLY | O_CLOEXEC);
+    if(fd < 0) throw std::invalid_argument("Opening input file " + path + " failed.");
+    struct stat st;
+    if(fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {  // (not a regular file: a pipe, a device)
+        close(fd);
+        return false;
+    }
+    fi.size = static_cast<std::size_t>(st.st_size);
+    if(fi.size != 0) {
+        void* m = mmap(nullptr, fi.size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if(m == MAP_FAILED) {
+            close(fd);
+            fi.size = 0;
+            throw std::invalid_argument("Reading input file " + path + " failed.");
+        }
+        fi.data = static_cast<const char*>(m);
+        (void)madvise(m, fi.size, MADV_WILLNEED);
+    }
+    close(fd);
     // record starts, found in parallel: every thread scans a slice for "\n>" (and the file's first byte)
-    const std::size_t n = fi.buf.size();
+    const std::size_t n = fi.size;
     const std::size_t slices = std::max<std::size_t>(1, std::min<std::size_t>(64, n >> 20));
     std::vector<std::vector<std::size_t>> found(slices);
     parallel_for(slices, 1, [&](std::size_t k) {
         const std::size_t lo = n * k / slices, hi = n * (k + 1) / slices;
-        const char* base = fi.buf.data();
+        const char* base = fi.data;
         for(const char* p = base + lo; p < base + hi;) {
             p = static_cast<const char*>(std::memchr(p, '>', static_cast<std::size_t>(base + hi - p)));
             if(p == nullptr) break;
@@ -367,8 +389,8 @@ bool load_fasta(const std::string& path, fasta_index_t& fi) {
 // record `rec` as read_fasta reads it: the name is the rest of the '>' line (a trailing '\r' dropped), the sequence
 // the following lines without white space; empty lines and lines starting with ';' are skipped
 void fasta_record(const fasta_index_t& fi, std::size_t rec, std::string& name, std::string& seq) {
-    const char* p = fi.buf.data() + fi.starts[rec] + 1;
-    const char* const end = fi.buf.data() + fi.starts[rec + 1];
+    const char* p = fi.data + fi.starts[rec] + 1;
+    const char* const end = fi.data + fi.starts[rec + 1];
     const char* eol = static_cast<const char*>(std::memchr(p, '\n', static_cast<std::size_t>(end - p)));
     if(eol == nullptr) eol = end;
     name.assign(p, eol);
@@ -404,13 +426,24 @@ struct batch_source_t {
     data_t all;
     std::size_t n_pairs{0};
 };
-batch_source_t open_batch_source(const alignment_t& aln) {
-    batch_source_t src;
-    src.fast = load_fasta(aln.data.path, src.fasta);
-    const std::size_t n_seqs = src.fast ? src.fasta.starts.size() - 1 : (src.all = read_input(aln.data.path)).size();
+std::unique_ptr<batch_source_t> open_batch_source(const alignment_t& aln) {
+    auto src = std::make_unique<batch_source_t>();
+    src->fast = load_fasta(aln.data.path, src->fasta);
+    const std::size_t n_seqs = src->fast ? src->fasta.starts.size() - 1 : (src->all = read_input(aln.data.path)).size();
     if(n_seqs == 0 || n_seqs % 2 != 0) throw std::invalid_argument("Batch input needs an even number of sequences.");
-    src.n_pairs = n_seqs / 2;
+    src->n_pairs = n_seqs / 2;
     return src;
+}
+// What decides the shards of a multi-GPU run: per pair the sizes of its two records (names and line breaks
+// included -- an estimate of len_a x len_b that needs no parsing; every rank derives the same bounds from the same
+// file).  Offsets as coati_hip_shard_bounds takes them.
+void batch_source_weights(const batch_source_t& src, std::vector<uint64_t>& a_off, std::vector<uint64_t>& b_off) {
+    a_off.assign(src.n_pairs + 1, 0), b_off.assign(src.n_pairs + 1, 0);
+    for(std::size_t p = 0; p < src.n_pairs; ++p) {
+        const uint64_t wa = src.fast ? src.fasta.starts[2 * p + 1] - src.fasta.starts[2 * p] : src.all.seqs[2 * p].size();
+        const uint64_t wb = src.fast ? src.fasta.starts[2 * p + 2] - src.fasta.starts[2 * p + 1] : src.all.seqs[2 * p + 1].size();
+        a_off[p + 1] = a_off[p] + wa, b_off[p + 1] = b_off[p] + wb;
+    }
 }
 // stage A, first half: the pairs [p0, p0 + n) parsed and processed; offsets filled in
 void batch_block_parse(const alignment_t& aln, const batch_source_t& src, std::size_t p0, std::size_t n, batch_block_t& blk) {
@@ -500,6 +533,101 @@ long batch_reader_first_difference(const std::string& path) {
     return 0;
 }
 
+namespace {
+// The block pipeline over the pairs [p_begin, p_end) of `src`: the JSON text of elements p_begin .. p_end of an array of
+// n_total leaves through `out`, blocks in order.  `model` is asked for when the first block is ready for the device
+// (the single-GPU driver brings the HIP runtime up on a helper thread meanwhile).
+template <typename GetModel>
+void run_batch_pipeline(const alignment_t& aln, const batch_source_t& src, std::size_t p_begin, std::size_t p_end, std::size_t n_total,
+                        GetModel&& model, std::ostream& out, host_timer& tm) {
+    const std::size_t n_mine = p_end - p_begin;
+    const std::size_t n_blocks = (n_mine + kBatchBlockPairs - 1) / kBatchBlockPairs;
+    if(n_blocks == 0) return;
+    auto stage_a = [&](std::size_t k) {
+        auto blk = std::make_unique<batch_block_t>();
+        const std::size_t p0 = p_begin + k * kBatchBlockPairs;
+        batch_block_parse(aln, src, p0, std::min(kBatchBlockPairs, p_end - p0), *blk);
+        batch_block_encode(*blk, 0, blk->n);
+        return blk;
+    };
+    std::future<std::unique_ptr<batch_block_t>> next = std::async(std::launch::async, stage_a, std::size_t{0});
+    std::future<void> writing;
+    coati_hip_model* m = nullptr;
+    try {
+        for(std::size_t k = 0; k < n_blocks; ++k) {
+            std::unique_ptr<batch_block_t> blk = next.get();
+            if(k + 1 < n_blocks) next = std::async(std::launch::async, stage_a, k + 1);
+            if(k == 0) {
+                tm.stage("parse + encode (first block)");
+                m = model();
+                tm.stage("model (overlapped with the input)");
+            }
+            batch_block_t& b = *blk;
+            b.scores.resize(b.n), b.off.resize(b.n), b.len.resize(b.n);
+            b.ops.resize(b.a_cat.size() + b.b_cat.size() + 1);
+            hip_check(coati_hip_viterbi_batch(m, b.n, b.a_cat.data(), b.a_off.data(), b.b_cat.data(), b.b_off.data(), b.scores.data(), b.ops.data(),
+                                              b.a_cat.size() + b.b_cat.size(), b.off.data(), b.len.data()));
+            check_block_scores(b);
+            if(k == 0) tm.stage("device (first block: workspaces, upload, kernels, download)");
+            if(writing.valid()) writing.get();  // (blocks leave in order; a failed write of the previous block stops the run here)
+            std::shared_ptr<batch_block_t> held = std::move(blk);
+            writing = std::async(std::launch::async, [&aln, held, n_total, &out]() {
+                batch_block_write(aln, *held, n_total, out);
+                if(!out) throw std::runtime_error("Writing output failed.");
+            });
+        }
+        if(writing.valid()) writing.get();
+    } catch(...) {
+        // (the helper threads hold references to this frame: let them finish before it unwinds)
+        if(next.valid()) next.wait();
+        if(writing.valid()) writing.wait();
+        throw;
+    }
+    out.flush();
+    if(!out) throw std::runtime_error("Writing output failed.");
+    tm.stage(n_blocks > 1 ? "remaining blocks (parse, device, output overlapped)" : "gapped strings + output");
+}
+}  // namespace
+
+// Test hook for the multi-GPU driver's host side (no device needed): rank `rank` of `world` plans its shard from the
+// index of `path` and parses + encodes ONLY that shard through the block pipeline's stage A; the result is compared,
+// pair by pair, with the generic path (read_input of the whole file -> process_marginal -> marginal_seq_encoding).
+// Returns 0 if names, processed sequences, stop codons and codes are identical, k + 1 if pair k of the input differs;
+// *s0 / *s1 = the shard.  Every rank derives the same bounds: the caller checks that the shards tile the input.
+long batch_shard_first_difference(const alignment_t& aln_in, int world, int rank, uint64_t* s0_out, uint64_t* s1_out) {
+    alignment_t aln = aln_in;
+    const std::unique_ptr<batch_source_t> src = open_batch_source(aln);
+    std::vector<uint64_t> wa, wb, bounds(static_cast<std::size_t>(world) + 1, 0);
+    batch_source_weights(*src, wa, wb);
+    hip_check(coati_hip_shard_bounds(src->n_pairs, wa.data(), wb.data(), world, bounds.data()));
+    const std::size_t s0 = bounds[static_cast<std::size_t>(rank)], s1 = bounds[static_cast<std::size_t>(rank) + 1];
+    if(s0_out != nullptr) *s0_out = s0;
+    if(s1_out != nullptr) *s1_out = s1;
+    const data_t all = read_input(aln.data.path);
+    // small blocks, so that a shard is several of them
+    constexpr std::size_t kBlock = 7;
+    for(std::size_t p0 = s0; p0 < s1; p0 += kBlock) {
+        batch_block_t blk;
+        batch_block_parse(aln, *src, p0, std::min(kBlock, s1 - p0), blk);
+        batch_block_encode(blk, 0, blk.n);
+        for(std::size_t i = 0; i < blk.n; ++i) {
+            const std::size_t p = p0 + i;
+            data_t d;
+            d.names = {all.names[2 * p], all.names[2 * p + 1]};
+            d.seqs = {all.seqs[2 * p], all.seqs[2 * p + 1]};
+            process_marginal(d, aln.gap, std::string(), aln.rev);
+            const auto enc = marginal_seq_encoding(d.seqs[0], d.seqs[1]);
+            const data_t& g = blk.pairs[i];
+            bool same = g.names == d.names && g.seqs == d.seqs && g.stops == d.stops;
+            same = same && blk.a_off[i + 1] - blk.a_off[i] == enc[0].size() && blk.b_off[i + 1] - blk.b_off[i] == enc[1].size();
+            same = same && std::equal(enc[0].begin(), enc[0].end(), blk.a_cat.begin() + static_cast<std::ptrdiff_t>(blk.a_off[i]));
+            same = same && std::equal(enc[1].begin(), enc[1].end(), blk.b_cat.begin() + static_cast<std::ptrdiff_t>(blk.b_off[i]));
+            if(!same) return static_cast<long>(p) + 1;
+        }
+    }
+    return 0;
+}
+
 bool marg_alignment_batch(alignment_t& aln) {
     host_timer tm("alignpair --batch");
     set_subst(aln);
@@ -520,8 +648,7 @@ bool marg_alignment_batch(alignment_t& aln) {
             if(m != nullptr && !g_fast_exit) coati_hip_model_destroy(m);
         }
     } guard{model_ready};
-    const batch_source_t src = open_batch_source(aln);
-    const std::size_t n_total = src.n_pairs;
+    const std::unique_ptr<batch_source_t> src = open_batch_source(aln);
     tm.stage("read + index");
     std::ofstream file;
     std::ostream* out = &std::cout;
@@ -530,38 +657,7 @@ bool marg_alignment_batch(alignment_t& aln) {
         if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
         out = &file;
     }
-    const std::size_t n_blocks = (n_total + kBatchBlockPairs - 1) / kBatchBlockPairs;
-    auto stage_a = [&](std::size_t k) {
-        auto blk = std::make_unique<batch_block_t>();
-        const std::size_t p0 = k * kBatchBlockPairs;
-        batch_block_parse(aln, src, p0, std::min(kBatchBlockPairs, n_total - p0), *blk);
-        batch_block_encode(*blk, 0, blk->n);
-        return blk;
-    };
-    std::future<std::unique_ptr<batch_block_t>> next = std::async(std::launch::async, stage_a, std::size_t{0});
-    std::future<void> writing;
-    for(std::size_t k = 0; k < n_blocks; ++k) {
-        std::unique_ptr<batch_block_t> blk = next.get();
-        if(k + 1 < n_blocks) next = std::async(std::launch::async, stage_a, k + 1);
-        if(k == 0) {
-            tm.stage("parse + encode (first block)");
-            guard.m = model_ready.get();
-            tm.stage("model (overlapped with the input)");
-        }
-        batch_block_t& b = *blk;
-        b.scores.resize(b.n), b.off.resize(b.n), b.len.resize(b.n);
-        b.ops.resize(b.a_cat.size() + b.b_cat.size() + 1);
-        hip_check(coati_hip_viterbi_batch(guard.m, b.n, b.a_cat.data(), b.a_off.data(), b.b_cat.data(), b.b_off.data(), b.scores.data(),
-                                          b.ops.data(), b.a_cat.size() + b.b_cat.size(), b.off.data(), b.len.data()));
-        check_block_scores(b);
-        if(k == 0) tm.stage("device (first block: workspaces, upload, kernels, download)");
-        if(writing.valid()) writing.get();  // (blocks leave in order)
-        std::shared_ptr<batch_block_t> held = std::move(blk);
-        writing = std::async(std::launch::async, [&aln, held, n_total, out]() { batch_block_write(aln, *held, n_total, *out); });
-    }
-    if(writing.valid()) writing.get();
-    out->flush();
-    tm.stage(n_blocks > 1 ? "remaining blocks (parse, device, output overlapped)" : "gapped strings + output");
+    run_batch_pipeline(aln, *src, 0, src->n_pairs, src->n_pairs, [&]() { return guard.m = model_ready.get(); }, *out, tm);
     return true;
 }
 
@@ -575,8 +671,7 @@ struct dist_api_t {
     int (*init)(const void*, int, int, int, void**){nullptr};
     void (*destroy)(void*){nullptr};
     int (*broadcast_model)(void*, int, float*, uint32_t, uint32_t*, float*, int*){nullptr};
-    int (*viterbi_shard)(void*, int, coati_hip_model*, uint64_t, const uint8_t*, uint64_t, const uint64_t*, const uint8_t*, uint64_t,
-                         const uint64_t*, float*, uint8_t*, uint64_t, uint64_t*, uint32_t*){nullptr};
+    int (*allreduce_f64)(void*, int, double*, uint32_t){nullptr};
 };
 dist_api_t load_dist_api() {
     dist_api_t api;
@@ -603,50 +698,80 @@ dist_api_t load_dist_api() {
     api.init = reinterpret_cast<decltype(api.init)>(sym("coati_hip_dist_init"));
     api.destroy = reinterpret_cast<decltype(api.destroy)>(sym("coati_hip_dist_destroy"));
     api.broadcast_model = reinterpret_cast<decltype(api.broadcast_model)>(sym("coati_hip_dist_broadcast_model"));
-    api.viterbi_shard = reinterpret_cast<decltype(api.viterbi_shard)>(sym("coati_hip_dist_viterbi_shard"));
+    api.allreduce_f64 = reinterpret_cast<decltype(api.allreduce_f64)>(sym("coati_hip_dist_allreduce_f64"));
     return api;
+}
+// `bytes` bytes of file `from` appended into `to_fd` at offset `at` (copy_file_range: the kernel moves the pages; plain
+// read / write where that is not available, e.g. across file systems)
+void copy_into(const std::string& from, int to_fd, uint64_t at, uint64_t bytes) {
+    const int in = open(from.c_str(), O_RDONLY | O_CLOEXEC);
+    if(in < 0) throw std::runtime_error("--devices: cannot reopen " + from);
+    struct closer {
+        int fd;
+        ~closer() { close(fd); }
+    } guard{in};
+    loff_t off_in = 0, off_out = static_cast<loff_t>(at);
+    uint64_t left = bytes;
+    while(left > 0) {
+        const ssize_t moved = copy_file_range(in, &off_in, to_fd, &off_out, static_cast<std::size_t>(std::min<uint64_t>(left, 1u << 30)), 0);
+        if(moved > 0) {
+            left -= static_cast<uint64_t>(moved);
+            continue;
+        }
+        // fall back: read + pwrite from where the kernel copy stopped
+        std::vector<char> buf(8u << 20);
+        while(left > 0) {
+            const ssize_t got = pread(in, buf.data(), static_cast<std::size_t>(std::min<uint64_t>(left, buf.size())), off_in);
+            if(got <= 0) throw std::runtime_error("--devices: reading " + from + " failed");
+            for(ssize_t done = 0; done < got;) {
+                const ssize_t put = pwrite(to_fd, buf.data() + done, static_cast<std::size_t>(got - done), off_out + done);
+                if(put <= 0) throw std::runtime_error("Writing output failed.");
+                done += put;
+            }
+            off_in += got, off_out += got, left -= static_cast<uint64_t>(got);
+        }
+    }
 }
 }  // namespace
 
+// One rank of `coati-alignpair --batch --devices ...` (one process per GPU).  Nothing of the data path crosses a link:
+//   * every rank maps and indexes the input (the record sizes are the shard plan: coati_hip_shard_bounds on them, the
+//     same bounds everywhere) but parses, encodes, aligns and FORMATS only its own shard, through the same three-stage
+//     block pipeline as the single-GPU driver;
+//   * the model is computed on rank 0 and broadcast over RCCL (every rank scores with the same bits);
+//   * rank 0 streams its slice of the JSON array straight into the output; the other ranks stream theirs into part
+//     files, the slice sizes are exchanged (one small all-reduce), and every rank moves its part to its place in the
+//     output (parallel kernel-side copies).  With the output on stdout rank 0 forwards the parts in order.
+// What the reference does for one pair per process: src/lib/align_marginal.cc:44-88, src/lib/utils.cc:809-812.
 bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std::string& id_file) {
-    if(world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("--devices: bad rank / world");
+    if(world < 1 || world > 64 || rank < 0 || rank >= world) throw std::invalid_argument("--devices: bad rank / world (at most 64 devices)");
     host_timer tm(rank == 0 ? "alignpair --batch --devices (rank 0)" : "alignpair --batch --devices");
     const dist_api_t api = load_dist_api();
     auto dist_check = [&](int rc) {
         if(rc != 0) throw std::runtime_error(api.last_error());
     };
-    // every rank reads and indexes the input (the LENGTHS of all pairs are the shard plan) but encodes only its shard;
-    // nothing but results crosses the links
-    const batch_source_t src = open_batch_source(aln);
-    batch_block_t in;
-    batch_block_parse(aln, src, 0, src.n_pairs, in);
-    std::vector<uint64_t> bounds(static_cast<std::size_t>(world) + 1, 0);
-    hip_check(coati_hip_shard_bounds(in.n, in.a_off.data(), in.b_off.data(), world, bounds.data()));
-    const std::size_t s0 = bounds[static_cast<std::size_t>(rank)], s1 = bounds[static_cast<std::size_t>(rank) + 1];
-    batch_block_encode(in, s0, s1);
-    tm.stage("read + encode (own shard)");
-    // ---- rendezvous: rank 0 leaves the id in a file (written under another name, then renamed)
-    unsigned char id[128];
-    if(rank == 0) {
-        dist_check(api.unique_id(id));
-        const std::string tmp = id_file + ".tmp";
-        std::ofstream f(tmp, std::ios::binary);
-        f.write(reinterpret_cast<const char*>(id), sizeof id);
-        f.close();
-        if(!f || std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("--devices: cannot write " + id_file);
-    } else {
-        bool got = false;
-        for(int tries = 0; tries < 6000 && !got; ++tries) {  // up to a minute
-            std::ifstream f(id_file, std::ios::binary);
-            if(f && f.read(reinterpret_cast<char*>(id), sizeof id) && f.gcount() == static_cast<std::streamsize>(sizeof id)) got = true;
-            if(!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    // ---- rendezvous + communicator on a helper thread (RCCL's bring-up takes longer than indexing the input)
+    auto comm_ready = std::async(std::launch::async, [&]() -> void* {
+        unsigned char id[128];
+        if(rank == 0) {  // rank 0 leaves the id in a file (written under another name, then renamed)
+            dist_check(api.unique_id(id));
+            const std::string tmp = id_file + ".tmp";
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(reinterpret_cast<const char*>(id), sizeof id);
+            f.close();
+            if(!f || std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("--devices: cannot write " + id_file);
+        } else {
+            bool got = false;
+            for(int tries = 0; tries < 6000 && !got; ++tries) {  // up to a minute
+                std::ifstream f(id_file, std::ios::binary);
+                if(f && f.read(reinterpret_cast<char*>(id), sizeof id) && f.gcount() == static_cast<std::streamsize>(sizeof id)) got = true;
+                if(!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            if(!got) throw std::runtime_error("--devices: rank 0 never published the rendezvous id (" + id_file + ")");
         }
-        if(!got) throw std::runtime_error("--devices: rank 0 never published the rendezvous id (" + id_file + ")");
-    }
-    void* comm = nullptr;
-    {
+        void* comm = nullptr;
         // RCCL prints its version banner on stdout when a communicator is created; rank 0's stdout is the JSON stream
-        // when no -o is given: send fd 1 to stderr for the duration
+        // when no -o is given: send fd 1 to stderr for the duration (nothing else writes to stdout before the pipeline)
         struct stdout_to_stderr {
             int saved;
             stdout_to_stderr() {
@@ -664,12 +789,31 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
             }
         } quiet;
         dist_check(api.init(id, world, rank, aln.device, &comm));
-    }
+        return comm;
+    });
     struct comm_guard {
         const dist_api_t& api;
-        void* c;
-        ~comm_guard() { api.destroy(c); }
-    } guard{api, comm};
+        std::future<void*>& f;
+        void* c{nullptr};
+        ~comm_guard() {
+            if(c == nullptr && f.valid()) {
+                try {
+                    c = f.get();
+                } catch(...) {
+                }
+            }
+            if(c != nullptr) api.destroy(c);
+        }
+    } guard{api, comm_ready};
+    // ---- the shard plan from the index alone
+    const std::unique_ptr<batch_source_t> src = open_batch_source(aln);
+    const std::size_t n_total = src->n_pairs;
+    std::vector<uint64_t> wa, wb, bounds(static_cast<std::size_t>(world) + 1, 0);
+    batch_source_weights(*src, wa, wb);
+    hip_check(coati_hip_shard_bounds(n_total, wa.data(), wb.data(), world, bounds.data()));
+    const std::size_t s0 = bounds[static_cast<std::size_t>(rank)], s1 = bounds[static_cast<std::size_t>(rank) + 1];
+    tm.stage("index + shard plan");
+    void* comm = guard.c = comm_ready.get();
     tm.stage("communicator");
     // ---- the model: computed on rank 0 only, broadcast, so every rank scores with the same bits
     std::vector<float> table(kTableRows * kTableCols, 0.f);
@@ -685,31 +829,71 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
     dist_check(api.broadcast_model(comm, 0, table.data(), 1, &n_tables, consts, &gap_len));
     coati_hip_model* model = nullptr;
     hip_check(coati_hip_model_create(table.data(), consts[0], consts[1], consts[2], consts[3], gap_len, aln.device, &model));
-    tm.stage("model broadcast");
-    const std::size_t n = in.n;
-    const uint64_t ops_total = in.a_off[n] + in.b_off[n];
-    in.scores.resize(rank == 0 ? n : 0), in.off.resize(rank == 0 ? n : 0), in.len.resize(rank == 0 ? n : 0);
-    in.ops.resize(rank == 0 ? ops_total + 1 : 1);
-    const int rc = api.viterbi_shard(comm, 0, model, n, in.a_cat.data(), in.a_off[s0], in.a_off.data(), in.b_cat.data(), in.b_off[s0],
-                                     in.b_off.data(), in.scores.data(), in.ops.data(), ops_total, in.off.data(), in.len.data());
-    coati_hip_model_destroy(model);
-    dist_check(rc);
-    // a pair whose strip hand-off timed out comes back with a NaN score (never a hang): an error here, as in the
-    // single-GPU driver -- not `"score": null` next to a garbage alignment
-    if(rank == 0) check_block_scores(in);
-    tm.stage("sharded Viterbi + gather");
-    if(rank == 0) {
-        std::ofstream file;
-        std::ostream* out = &std::cout;
-        if(!(aln.output.empty() || aln.output == "-")) {
-            file.open(extract_file_type(aln.output).path);
-            if(!file) throw std::invalid_argument("Opening output file " + aln.output + " failed.");
-            out = &file;
+    struct model_guard {
+        coati_hip_model* m;
+        ~model_guard() {
+            if(!g_fast_exit) coati_hip_model_destroy(m);
         }
-        batch_block_write(aln, in, n, *out);
-        out->flush();
-        tm.stage("gapped strings + output");
+    } mguard{model};
+    tm.stage("model broadcast");
+    // ---- this rank's slice of the output
+    const bool to_stdout = aln.output.empty() || aln.output == "-";
+    const std::string final_path = to_stdout ? std::string() : extract_file_type(aln.output).path;
+    const std::string part_path = (to_stdout ? id_file : final_path) + ".part" + std::to_string(rank);
+    std::ofstream file;
+    std::ostream* out = &std::cout;
+    if(rank != 0 || !to_stdout) {
+        const std::string& path = rank == 0 ? final_path : part_path;
+        file.open(path, std::ios::binary | std::ios::trunc);
+        if(!file) throw std::invalid_argument("Opening output file " + path + " failed.");
+        out = &file;
     }
+    run_batch_pipeline(aln, *src, s0, s1, n_total, [&]() { return model; }, *out, tm);
+    const uint64_t my_bytes = out == &std::cout ? 0 : static_cast<uint64_t>(file.tellp());
+    if(file.is_open()) {
+        file.close();
+        if(!file) throw std::runtime_error("Writing output failed.");
+    }
+    // ---- slice sizes of all ranks (exact in a double below 2^53), then every part to its place
+    std::vector<double> sizes(static_cast<std::size_t>(world), 0.0);
+    sizes[static_cast<std::size_t>(rank)] = static_cast<double>(my_bytes);
+    dist_check(api.allreduce_f64(comm, 0, sizes.data(), static_cast<uint32_t>(world)));
+    tm.stage("slice sizes exchanged");
+    if(to_stdout) {
+        if(rank == 0) {
+            std::vector<char> buf(8u << 20);
+            for(int r = 1; r < world; ++r) {
+                const std::string from = id_file + ".part" + std::to_string(r);
+                std::ifstream in(from, std::ios::binary);
+                if(!in) throw std::runtime_error("--devices: cannot read " + from);
+                while(in) {
+                    in.read(buf.data(), static_cast<std::streamsize>(buf.size()));
+                    std::cout.write(buf.data(), in.gcount());
+                }
+                std::remove(from.c_str());
+            }
+            std::cout.flush();
+            if(!std::cout) throw std::runtime_error("Writing output failed.");
+        }
+    } else if(rank != 0) {
+        uint64_t at = 0;
+        for(int r = 0; r < rank; ++r) at += static_cast<uint64_t>(sizes[static_cast<std::size_t>(r)]);
+        const int fd = open(final_path.c_str(), O_WRONLY | O_CLOEXEC);  // (rank 0 created it before its pipeline started)
+        if(fd < 0) throw std::runtime_error("Opening output file " + final_path + " failed.");
+        try {
+            copy_into(part_path, fd, at, my_bytes);
+        } catch(...) {
+            close(fd);
+            std::remove(part_path.c_str());
+            throw;
+        }
+        if(close(fd) != 0) throw std::runtime_error("Writing output failed.");
+        std::remove(part_path.c_str());
+    }
+    // (all parts are in place when every rank has left this collective)
+    double done = 1.0;
+    dist_check(api.allreduce_f64(comm, 0, &done, 1));
+    tm.stage("output assembled");
     return true;
 }
 

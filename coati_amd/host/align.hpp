@@ -93,6 +93,7 @@ bool marg_alignment_batch(alignment_t& aln);
 // left to the driver instead of being freed one by one (~65 ms of a 0.3 s run).  Off by default (libraries clean up).
 void set_process_exits_after_call(bool on);
 long batch_reader_first_difference(const std::string& path);  // (test hook, align.cc)
+long batch_shard_first_difference(const alignment_t& aln, int world, int rank, uint64_t* s0, uint64_t* s1);  // (test hook)
 // The same over several GPUs, ONE PROCESS PER GPU (this process is rank `rank` of `world` and drives
 // aln.device): every rank reads the input, rank 0 computes the model and broadcasts it (ncclBroadcast),
 // each rank aligns its shard of coati_hip_shard_bounds, the results are gathered to rank 0 over RCCL

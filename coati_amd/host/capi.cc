@@ -240,6 +240,18 @@ int coati_host_batch_reader_check(const char* path, long* first_difference) {
     return guarded([&] { *first_difference = coati_amd::batch_reader_first_difference(path); });
 }
 
+// The host side of one rank of `coati-alignpair --batch --devices` without a device: shard plan from the index, the
+// shard parsed + encoded by the block pipeline's stage A, compared with the generic reader (align.cc).
+int coati_host_batch_shard_check(const char* path, int world, int rank, unsigned long long* s0, unsigned long long* s1, long* first_difference) {
+    return guarded([&] {
+        coati_amd::alignment_t aln;
+        aln.data.path = path;
+        uint64_t a = 0, b = 0;
+        *first_difference = coati_amd::batch_shard_first_difference(aln, world, rank, &a, &b);
+        *s0 = a, *s1 = b;
+    });
+}
+
 int coati_host_synth_encoded(unsigned long long first, unsigned long long n, unsigned long long seed_base,
                              unsigned n_codons, unsigned char* a_cat, unsigned long long* a_off,
                              unsigned char* b_cat, unsigned long long* b_off) {

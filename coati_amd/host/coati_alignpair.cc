@@ -76,6 +76,7 @@ int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
     }
     std::remove(id_path);
     std::remove((id_path_s + ".tmp").c_str());
+    for(int r = 0; r < world; ++r) std::remove((id_path_s + ".part" + std::to_string(r)).c_str());  // (output on stdout: a failed run's slices)
     rmdir(id_dir);
     return status_all;
 }

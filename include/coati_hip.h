@@ -110,8 +110,15 @@ int coati_hip_model_trim(coati_hip_model_t* model);
  *     any other kernel of the process (and any copy the runtime does with a kernel) waits for it.  With 0 every
  *     call uses one launch per chunk (identical results, ~0.85 instead of ~0.95 of the resident kernel's rate)
  *     and other streams of the embedder interleave normally.
+ *   COATI_HIP_OPT_CK_BAND (default 96, or the environment's COATI_HIP_CK_BAND): half width, in wavefront steps, of the
+ *     band around a pair's straight line (0,0) -> (len_a, len_b) inside which the gap_len-1 kernel keeps the
+ *     checkpoints its traceback recomputes decisions from; 0 keeps all of them.  A narrower band writes fewer bytes
+ *     (the kernel is power-bound: bytes are clock); an alignment whose path leaves the band is detected by the walk and
+ *     the pair is filled a second time with everything kept -- same bits, twice the cost for that pair
+ *     (coati_hip_viterbi_band_stats counts them).  Related sequences stay inside 96 steps; for inputs with indels of
+ *     hundreds of bases in many pairs set a wider band or 0.  Takes effect for batches launched afterwards.
  * Returns COATI_HIP_EINVAL for an unknown option. */
-enum { COATI_HIP_OPT_PERSISTENT_CALL = 1 };
+enum { COATI_HIP_OPT_PERSISTENT_CALL = 1, COATI_HIP_OPT_CK_BAND = 2 };
 int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t value);
 
 /* ---- batch -------------------------------------------------------------- *
@@ -159,6 +166,11 @@ int coati_hip_viterbi_fetch(coati_hip_batch_t* batch, float* scores, uint8_t* op
 /* Device times (ms) of the last viterbi launch, from HIP events recorded on the
  * model's stream around each kernel (synchronises first). */
 int coati_hip_viterbi_last_timing(coati_hip_batch_t* batch, float* fill_ms, float* walk_ms);
+/* How the banded checkpoints (COATI_HIP_OPT_CK_BAND) fared in the batch's last launch (waits for it): *band_steps = the
+ * band's half width the launch ran with (0: everything was kept, or another kernel than the banded one ran),
+ * *pairs_refilled = pairs whose traceback left the band and that were therefore filled twice.  No reference
+ * counterpart (the reference keeps three fp32 matrices, align_pair.hpp:45-62). */
+int coati_hip_viterbi_band_stats(coati_hip_batch_t* batch, uint32_t* band_steps, uint64_t* pairs_refilled);
 /* Same for the launch issued `launches_back` launches before the last one (0 =
  * last; the most recent 64 launches are kept), so that a caller can enqueue many
  * launches back to back and read their kernel times afterwards. */

@@ -93,6 +93,7 @@ def test_bench_multi_gpu_path_with_one_rank():
     doc = json.loads(line)
     assert doc["n_gpus"] == 1 and doc["value"] > 100 and doc["scaling"] == "weak"
     st = doc["strong_1M"]
+    assert st["local_results"]["equal_to_gathered"] is True
     assert st["pairs"] == 3000 and st["model"] == "mar-ecm" and st["gcups"] > 10 and st["columns"] > 3000 * 990
     assert "gathered results of rank 0 identical to a direct fetch" in r.stderr
     # the strong job's scores are the single-GPU one-shot call's (same generator, same ECM model)
@@ -127,6 +128,18 @@ try:
     ok = False
 except hip.CoatiHipError:
     pass
+# the local-results form (coati_hip_dist_viterbi_shard_local): the rank keeps its shard's results (here: everything), the
+# root also gets the summary; with and without the summary, page-locked and pageable arrays
+for summary in (True, False):
+    for pinned in (True, False):
+        loc, (all_s, all_l) = comm.viterbi_shard_local(model, a_cat, a_first, a_off + np.uint64(a_first), b_cat, b_first, b_off + np.uint64(b_first),
+                                                       summary=summary, pinned=pinned)
+        ok = ok and all((np.asarray(g) == w).all() for g, w in zip((loc[0], loc[2], loc[3]), (want[0], want[2], want[3])))
+        ok = ok and (np.asarray(loc[1])[:len(want[1])] == want[1]).all()
+        if summary:
+            ok = ok and (all_s.view(np.uint32) == want[0].view(np.uint32)).all() and (all_l == want[3]).all()
+        else:
+            ok = ok and all_s is None
 comm.barrier()
 ok = ok and comm.allreduce([2.5, -1.0], "max").tolist() == [2.5, -1.0] and comm.allreduce([2.5], "sum").tolist() == [2.5]
 comm.close(); model.close()

@@ -229,3 +229,46 @@ def test_batch_driver_reader_equals_read_fasta(tmp_path):
     missing = tmp_path / "nope.fasta"
     with pytest.raises(Exception):
         host.batch_reader_check(missing)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_multi_gpu_driver_parses_only_its_shard(tmp_path, world):
+    """`coati-alignpair --batch --devices ...`, host side of every rank without a device (align.cc:
+    marg_alignment_batch_dist; what the reference does per pair: src/lib/align_marginal.cc:44-88): the shard plan
+    comes from the file's index alone, so every rank derives the same bounds; the shards tile the input, are balanced
+    by (record size a) x (record size b), and a rank's shard parsed + processed + encoded through the block pipeline
+    equals the generic reader's records (stop codons trimmed and remembered, codes)."""
+    import numpy as np
+
+    rng = np.random.default_rng(11)
+    stops = ["TAA", "TAG", "TGA"]
+    recs = []
+    weights = []
+    for p in range(173):
+        n_cod = int(rng.integers(1, 120)) * (4 if p % 17 == 0 else 1)  # a few heavy pairs
+        anc = "".join(rng.choice(list("ACGT"), 3 * n_cod))
+        for s in stops:  # no premature stop codons in the ancestor (process_marginal refuses them)
+            anc = "".join(c if c != s else "GCA" for c in (anc[i:i + 3] for i in range(0, len(anc), 3)))
+        des = list(anc)
+        for _ in range(int(rng.integers(0, 6))):
+            des[int(rng.integers(0, len(des)))] = str(rng.choice(list("ACGTN")))
+        des = "".join(des)
+        if rng.random() < 0.3:
+            anc += str(rng.choice(stops))
+            des += str(rng.choice(stops))
+        a_rec = f">anc{p}\n" + "\n".join(anc[i:i + 60] for i in range(0, len(anc), 60)) + "\n"
+        d_rec = f">des{p} x\n" + "\n".join(des[i:i + 71] for i in range(0, len(des), 71)) + "\n"
+        recs += [a_rec, d_rec]
+        weights.append(len(a_rec) * len(d_rec))
+    path = tmp_path / "pairs.fasta"
+    path.write_text("".join(recs))
+    bounds = []
+    for rank in range(world):
+        s0, s1, diff = host.batch_shard_check(path, world, rank)
+        assert diff == 0, (rank, diff)
+        bounds.append((s0, s1))
+    assert bounds[0][0] == 0 and bounds[-1][1] == 173
+    assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    w = np.array(weights, np.float64)
+    shares = np.array([w[s0:s1].sum() for s0, s1 in bounds])
+    assert shares.max() - w.sum() / world <= w.max() + 1
