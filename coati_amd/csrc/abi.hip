@@ -102,7 +102,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
-                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u, b->multi_strip ? 1u : 0u};
 }
 
 
@@ -131,7 +131,7 @@ hipError_t model_take_arena(coati_hip_model* m, uint64_t need, void** ptr, uint6
     // the driver has to find the pages (round 4: a 1 000 000-pair sharded job in 48 000-pair chunks took 12 s that way)
     uint64_t step = 32ull << 20;
     while(step * 16 <= need) step *= 2;  // (a sixteenth to an eighth of the need)
-    need = (need + step - 1) / step * step;
+    need = (need + need / 16 + step - 1) / step * step;  // (and a sixteenth of headroom: a need just above a class boundary must not start a new class)
     hipError_t e = hipMalloc(ptr, need);
     if(e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -296,8 +296,15 @@ void coati_hip_batch_destroy(coati_hip_batch_t* b) {
     if(m != nullptr) (void)hipSetDevice(m->device);
     if((b->arena != nullptr && b->arena_owned) || b->mdi_block != nullptr) {
         // the blocks go back to the model once nothing on the stream can still touch them
-        bool idle = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
-        if(idle && b->stream != nullptr && b->stream != m->stream) idle = hipStreamSynchronize(b->stream) == hipSuccess;
+        // (a batch that only ever ran Viterbi launches is idle when its LAST launch has ended -- its event; waiting for the
+        // whole stream would wait for the next batch's kernel too, which is how the sharded job's chunks used to serialise)
+        bool idle = false;
+        if(m != nullptr && b->launched && !b->forward_done && b->n_launches > 0 && b->ev[(b->n_launches - 1) % coati_hip_batch::kTimingRing][1] != nullptr)
+            idle = hipEventSynchronize(b->ev[(b->n_launches - 1) % coati_hip_batch::kTimingRing][1]) == hipSuccess;
+        if(!idle) {
+            idle = m != nullptr && hipStreamSynchronize(m->stream) == hipSuccess;
+            if(idle && b->stream != nullptr && b->stream != m->stream) idle = hipStreamSynchronize(b->stream) == hipSuccess;
+        }
         for(auto blk : {std::pair<void*, uint64_t>{b->arena_owned ? b->arena : nullptr, b->arena_bytes}, std::pair<void*, uint64_t>{b->mdi_block, b->mdi_block_bytes}}) {
             if(blk.first == nullptr) continue;
             if(idle)
@@ -632,9 +639,10 @@ int coati_hip_debug_viterbi_flags(coati_hip_batch_t* b, uint64_t pair, uint8_t* 
     uint8_t* d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n));
     hipError_t e = hipSuccess;
-    if(b->ck && b->desc[pair].flags_off == kCkWaveSlot) {
-        // the pair's checkpoints lived in a wavefront's slot and are gone: run the pair again, alone, in a
-        // batch that keeps them, and decode that
+    if(b->ck && !b->ck_keep_all) {
+        // the pair's checkpoints lived in a wavefront's slot and are gone, or -- own storage: multi-strip pairs, pairs cut
+        // into row parts -- only a band of them was kept: run the pair again, alone, in a batch that keeps them all, and
+        // decode that
         const PairDesc& d = b->desc[pair];
         std::vector<uint8_t> ha(std::max<uint32_t>(d.la, 1)), hb(std::max<uint32_t>(d.lb, 1));
         e = hipMemcpy(ha.data(), b->d_a + d.a_off, d.la, hipMemcpyDeviceToHost);

@@ -39,7 +39,7 @@ struct coati_hip_model {
         uint64_t bytes;
     };
     static constexpr size_t kCachedArenas = 4;
-    static constexpr uint64_t kMaxCachedBytes = 16ull << 30;  // larger blocks are freed, not cached
+    static constexpr uint64_t kMaxCachedBytes = 20ull << 30;  // larger blocks are freed, not cached (a 48 000-pair chunk of the sharded job: 14-16 GB)
     std::vector<Arena> free_arenas;
     std::mutex arena_lock;
     // the handle itself + one per live batch: coati_hip_model_destroy while batches are alive only
@@ -107,6 +107,7 @@ struct coati_hip_batch {
     WorkItem* d_fwd_items = nullptr;  // forward_l1 work list (1024-column strips)
     uint32_t n_fwd_items = 0;
     bool long_pairs = false;     // decision-bit plan with 4-column strips throughout (a few long pairs): viterbi_lp runs it
+    bool multi_strip = false;    // the Viterbi strip plan has a pair of more than one strip
     bool ck_keep_all = false;    // viterbi_ck keeps every checkpoint (no band): the debug export decodes every tile
     uint32_t fwd_wlog2_max = 4;  // widest Forward strip shape of the batch (forward_l1 has a leaner build for <= 8 columns per lane)
     uint32_t* d_progress = nullptr;

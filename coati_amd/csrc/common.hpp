@@ -416,7 +416,17 @@ __device__ __forceinline__ float log_plus_exact(float a, float b, const uint64_t
     const float hi = fmaxf(a, b);
     const float y = -fabsf(a - b);
     const float e = libm::expf_nonpos(y, exp_tab);
-    return hi + (y <= -16.0f ? e : libm::log1pf_mid(e));  // (e >= expf(-16) = 1.1e-7 on the log1pf side)
+    // (e >= expf(-16) = 1.1e-7 on the log1pf side.)  A wavefront whose lanes all either skip log1pf (y <= -16) or take its
+    // k = 0 route (e < 0.41422) runs that route alone -- the same operations on the same values, so the same bits; the
+    // reference's own early-out at y <= -16 (utils.hpp:141) is almost never wave-uniform (< 1 % of the instructions:
+    // profiles/r04/forward_y_histogram.txt), this one is in 25-40 %.
+    const bool small = y <= -16.0f || e < libm::u2f(0x3ed413d7u);
+    float l;
+    if(__builtin_amdgcn_ballot_w64(small) == __builtin_amdgcn_ballot_w64(true))
+        l = libm::log1pf_small(e);
+    else
+        l = libm::log1pf_mid(e);
+    return hi + (y <= -16.0f ? e : l);
 }
 __device__ __forceinline__ void load_exp_table(uint64_t* lds_tab, int tid) {
     constexpr uint64_t kTab[32] = {COATI_EXP2F_TABLE};
@@ -479,6 +489,7 @@ struct BatchDeviceView {
     uint32_t fwd_wlog2_max;  // forward_l1: the widest strip shape of the batch (log2 of the columns per lane)
     uint32_t ck_band;        // viterbi_ck: half width of the kept checkpoint band in wavefront steps, kCkBandOff = keep everything
     uint32_t long_pairs;     // decision-bit plan of a few long pairs (every strip 4 columns per lane): viterbi_lp fills it
+    uint32_t multi_strip;    // the Viterbi plan has pairs of several strips (their boundary arrays start every launch as NaN patterns)
 };
 // Before every launch of a persistent kernel: the ticket counter and the polled progress words start at zero.  The
 // planner lays the counter out right in front of the words (plan.hip), so this is ONE fill, not two.

@@ -189,6 +189,22 @@ COATI_MATH_FN float log1pf_mid(float x) {
     return res;
 }
 
+// The k = 0 route alone (x < 0.41422: 1 + x < sqrt(2), f = x): what log1pf_mid computes for such x, without the k = 1 side
+// (u = 1 + x, its mantissa test, the correction c / u, the second result) that log1pf_mid evaluates for every lane and then
+// discards.  For a wavefront whose lanes ALL take this route (or whose result is not used: y <= -16); round 4,
+// tools/forward_y_hist.py: a quarter to two fifths of the Forward's `plus` operations at 8 columns per lane.
+COATI_MATH_FN float log1pf_small(float x) {
+    constexpr float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f, Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f,
+                    Lp6 = 1.5313838422e-01f, Lp7 = 1.4798198640e-01f;
+    const float f = x;
+    const float hfsq = 0.5f * f * f;
+    const float s = div_rn(f, 2.0f + f);
+    const float z = s * s;
+    const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    const float t = s * (hfsq + R);
+    return f - (hfsq - t);
+}
+
 // logf for normal positive x (x = sum of up to three expf values in (0, 3]).
 COATI_MATH_FN float logf_pos(float x) {
     // {1/c, log(c)} for the 16 sub-intervals of [sqrt(2)/2, sqrt(2)) * 2^k

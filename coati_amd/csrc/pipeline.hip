@@ -94,24 +94,31 @@ bool stream_pair_fits(uint64_t la, uint64_t lb, uint32_t gap_len, bool in_pinned
 }  // namespace
 
 namespace {
-// The streamed form of coati_hip_viterbi_batch: viterbi_ck_stream runs for the whole call on the model's stream;
-// the host plans chunk after chunk into kCkStreamSlots small workspaces, uploads on ONE in-order stream, tells the
-// kernel how many work items exist through page-locked memory, and downloads a chunk (on a third stream) when the
-// kernel has flagged it complete.  Only copy-ENGINE copies may be issued while the kernel owns every wavefront
-// slot of the chip: no hipMemset, no copy of kMinDmaBytes or less (both are kernels), no hipMalloc / hipFree
-// (they may wait for the device).  Everything is allocated before the launch; COATI_HIP_ESTATE = nothing usable
-// happened (an allocation failed before the launch, or the kernel gave up waiting): the caller runs the chunk
-// pipeline instead.
-int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off, const uint8_t* b_cat,
-                         const uint64_t* b_off, float* scores, uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len, bool in_pinned,
-                         bool out_pinned, long double total_cells, uint64_t longest_single, std::chrono::steady_clock::time_point t_call) {
+// Everything a streamed call allocates -- streams, control blocks, events, the wavefronts' checkpoint slots (sized for
+// single-strip pairs of up to `longest_single` ancestor positions) and the stream slots a call of `total_cells` DP
+// cells can use -- so that it can be done AHEAD of the call (coati_hip_model_prepare: a fresh process pays ~100 ms for
+// these GBs, which an embedder can spend while it is still reading its input).  COATI_HIP_ESTATE: an allocation failed
+// (not an error of a call: the chunk pipeline serves it).
+// Page-locked staging a stream slot of this call should have: room for the largest chunk the cutter makes (3 units of
+// cells) in both directions, and for the call's longest pair, between 4 and 48 MB.  (Page-locking is the slow part of a
+// fresh process' bring-up -- ~0.25 ms per MB: nine 48 MB blocks cost coati-alignpair --batch 110 of its 360 ms on
+// 10 000 pairs of 1 kb, which need a third of that.)
+uint64_t stream_staging_need(uint64_t n_pairs, long double total_cells, uint64_t total_seq_bytes, uint64_t longest_pair_bytes, long double unit_cells) {
+    const long double mean_cells = total_cells / std::max<long double>(1, static_cast<long double>(n_pairs));
+    const long double chunk_pairs = std::min<long double>(static_cast<long double>(n_pairs), 3 * unit_cells / std::max<long double>(1, mean_cells) + 1);
+    const long double per_pair = 3.0L * static_cast<long double>(total_seq_bytes) / std::max<long double>(1, static_cast<long double>(n_pairs)) + 160;
+    const uint64_t est = static_cast<uint64_t>(1.5L * chunk_pairs * per_pair) + 3 * longest_pair_bytes + (2ull << 20);
+    const uint64_t step = 4ull << 20;
+    return std::min<uint64_t>(kStreamSlotStaging, std::max<uint64_t>(step, (est + step - 1) / step * step));
+}
+int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long double total_cells, uint64_t staging_need, uint64_t* wave_slot_bytes_out,
+                   int* n_slots_out, long double* unit_cells_out) {
     constexpr int kSlots = kCkStreamSlots;
     for(int q = 1; q <= 2; ++q)
         if(model->slots[q].stream == nullptr && hipStreamCreateWithFlags(&model->slots[q].stream, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
             return COATI_HIP_ESTATE;
         }
-    hipStream_t kernel_stream = model->stream, up_stream = model->slots[1].stream, down_stream = model->slots[2].stream;
     const uint64_t host_bytes = ck_stream_host_bytes();
     auto soft = [](hipError_t e) {  // an allocation that fails here is not an error of the call
         if(e != hipSuccess) (void)hipGetLastError();
@@ -146,9 +153,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // slots: fixed sizes (nothing can grow while the kernel runs; the chunks are cut to fit).  Workspace: room for
     // the largest pair this form accepts (kStreamPairCells) with its own checkpoints; staging block
     // [what goes up | short result arrays, and the ops when the caller's array is pageable]
-    constexpr uint64_t kSlotArena = kStreamSlotArena, kSlotStaging = kStreamSlotStaging;
-    auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) { return stream_out_bytes(n, ops_bytes, out_pinned); };
-    auto staging_of = [&](const ChunkNeed& nd, uint64_t n) { return stream_staging_bytes(nd, n, in_pinned, out_pinned); };
+    constexpr uint64_t kSlotArena = kStreamSlotArena;
+    const uint64_t kSlotStaging = std::min<uint64_t>(kStreamSlotStaging, std::max<uint64_t>(staging_need, 4ull << 20));
     // How many slots can this call use?  The chunk targets below in cells: 1/2, 1, 2, then 3 units, and 1 unit each
     // once four units are left.  A one-shot process (coati-alignpair --batch: ~0.1 ms per MB of fresh hipMalloc /
     // hipHostMalloc, 12 slots are 2.9 GB) allocates what its input needs; a second call on the model takes the rest.
@@ -184,6 +190,49 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         }
     }
     alloc_stage("stream slots ready", static_cast<uint64_t>(n_slots) * (kSlotArena + kSlotStaging));
+    if(model->stream_events[0] == nullptr) {
+        bool events_ok = true;
+        for(hipEvent_t& e : model->stream_events) events_ok = events_ok && soft(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if(!events_ok) {
+            for(hipEvent_t& e : model->stream_events) {
+                if(e != nullptr) (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+            return COATI_HIP_ESTATE;
+        }
+    }
+    *wave_slot_bytes_out = wave_slot_bytes;
+    *n_slots_out = n_slots;
+    *unit_cells_out = kUnitCells;
+    return COATI_HIP_OK;
+}
+
+// The streamed form of coati_hip_viterbi_batch: viterbi_ck_stream runs for the whole call on the model's stream;
+// the host plans chunk after chunk into kCkStreamSlots small workspaces, uploads on ONE in-order stream, tells the
+// kernel how many work items exist through page-locked memory, and downloads a chunk (on a third stream) when the
+// kernel has flagged it complete.  Only copy-ENGINE copies may be issued while the kernel owns every wavefront
+// slot of the chip: no hipMemset, no copy of kMinDmaBytes or less (both are kernels), no hipMalloc / hipFree
+// (they may wait for the device).  Everything is allocated before the launch; COATI_HIP_ESTATE = nothing usable
+// happened (an allocation failed before the launch, or the kernel gave up waiting): the caller runs the chunk
+// pipeline instead.
+int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off, const uint8_t* b_cat,
+                         const uint64_t* b_off, float* scores, uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len, bool in_pinned,
+                         bool out_pinned, long double total_cells, uint64_t longest_single, uint64_t staging_need, std::chrono::steady_clock::time_point t_call) {
+    constexpr int kSlots = kCkStreamSlots;
+    uint64_t wave_slot_bytes = 0;
+    int n_slots = 0;
+    long double kUnitCells = 0;
+    if(const int rc_res = stream_reserve(model, longest_single, total_cells, staging_need, &wave_slot_bytes, &n_slots, &kUnitCells); rc_res != COATI_HIP_OK)
+        return rc_res;
+    hipStream_t kernel_stream = model->stream, up_stream = model->slots[1].stream, down_stream = model->slots[2].stream;
+    const uint64_t host_bytes = ck_stream_host_bytes();
+    auto soft = [](hipError_t e) {  // an allocation that fails here is not an error of the call
+        if(e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    };
+    constexpr uint64_t kSlotArena = kStreamSlotArena;
+    auto out_bytes_of = [&](uint64_t n, uint64_t ops_bytes) { return stream_out_bytes(n, ops_bytes, out_pinned); };
+    auto staging_of = [&](const ChunkNeed& nd, uint64_t n) { return stream_staging_bytes(nd, n, in_pinned, out_pinned); };
     // the call's last chunks -- everything behind the first round of 4 096 wavefronts, up to ~7 500 pairs of 1 kb -- are
     // cut into row parts (finer items for the ragged end of the kernel, as a resident batch's later pairs are, abi.hip
     // "the ragged end"): their pairs keep their checkpoints, ~1.1 MB per 1 kb pair -- six larger workspaces of ~1 250 pairs
@@ -213,17 +262,6 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     ck_stream_host_set_slots(hs, static_cast<uint32_t>(n_slots));
     void* hs_dev = nullptr;
     if(!soft(hipHostGetDevicePointer(&hs_dev, hs, 0))) return COATI_HIP_ESTATE;
-    if(model->stream_events[0] == nullptr) {
-        bool events_ok = true;
-        for(hipEvent_t& e : model->stream_events) events_ok = events_ok && soft(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if(!events_ok) {
-            for(hipEvent_t& e : model->stream_events) {
-                if(e != nullptr) (void)hipEventDestroy(e);
-                e = nullptr;
-            }
-            return COATI_HIP_ESTATE;
-        }
-    }
     hipEvent_t up_done = model->stream_events[kSlots];
     hipEvent_t* copied = model->stream_events;
     // the control block starts zeroed (before the launch a fill kernel may run)
@@ -488,6 +526,33 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
 }
 }  // namespace
 
+/* Ahead of a coati_hip_viterbi_batch call of about n_pairs pairs of about len_a x len_b: allocate what that call
+ * would allocate first (include/coati_hip.h).  Nothing happens for inputs the persistent-kernel form does not serve. */
+int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t len_a, uint64_t len_b) {
+    if(model == nullptr) return fail(COATI_HIP_EINVAL, "model_prepare: model is NULL");
+    try {
+        std::lock_guard<std::mutex> one_call(model->pipeline_lock);
+        HIP_TRY(hipSetDevice(model->device));
+        const char* pipe_env = std::getenv("COATI_HIP_PIPE");
+        const bool forced = pipe_env != nullptr && std::strcmp(pipe_env, "stream") == 0;
+        bool streamed = model->gap_len == 1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr &&
+                        !(pipe_env != nullptr && std::strcmp(pipe_env, "chunks") == 0) && len_b <= 8ull * kStrip && len_a * len_b <= kStreamPairCells &&
+                        !model->stream_forbidden && !model->stream_unusable;
+        if(streamed && !forced) streamed = n_pairs >= 4096 && len_a * len_b >= 250ull * 250ull;
+        if(const char* sdma = std::getenv("HSA_ENABLE_SDMA"); sdma != nullptr && std::atoi(sdma) == 0) streamed = false;
+        if(!streamed) return COATI_HIP_OK;
+        uint64_t wave_slot_bytes = 0;
+        int n_slots = 0;
+        long double unit = 0;
+        const long double cells = static_cast<long double>(n_pairs) * static_cast<long double>(len_a) * static_cast<long double>(len_b);
+        const uint64_t staging = stream_staging_need(n_pairs, cells, n_pairs * (len_a + len_b), len_a + len_b, 1000.0L * 1002 * 1002);
+        (void)stream_reserve(model, len_b <= static_cast<uint64_t>(kStrip) ? len_a : 0, cells, staging, &wave_slot_bytes, &n_slots, &unit);  // (a failed allocation is the call's problem)
+        return COATI_HIP_OK;
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "model_prepare: host allocation failed");
+    }
+}
+
 /* One-shot Viterbi over any number of pairs, PIPELINED: the input is cut into chunks; chunk k's
  * upload and kernel run on one of three slots (stream + HBM workspace + page-locked staging, kept by
  * the model between calls) while chunk k-1's results travel back and the host plans chunk k+1; the
@@ -508,7 +573,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
     // ---- the input once: valid offsets, cells, what decides the form of the call
     long double total_cells = 0;
-    uint64_t widest = 0, max_pair_cells = 0, longest_single = 0, longest_a = 0;
+    uint64_t widest = 0, max_pair_cells = 0, longest_single = 0, longest_a = 0, longest_pair_bytes = 0;
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
             return fail(COATI_HIP_EINVAL, "viterbi_batch: offsets of pair %llu decrease", static_cast<unsigned long long>(p));
@@ -520,6 +585,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         widest = std::max(widest, lb);
         max_pair_cells = std::max(max_pair_cells, cells);
         longest_a = std::max(longest_a, la);
+        longest_pair_bytes = std::max(longest_pair_bytes, la + lb);
         if(lb > 0 && lb <= static_cast<uint64_t>(kStrip)) longest_single = std::max(longest_single, la);
     }
     const uint64_t ops_total = (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]);
@@ -554,8 +620,10 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
             }
         }
         if(streamed) {
+            const uint64_t staging_need = stream_staging_need(n_pairs, total_cells, (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]),
+                                                              longest_pair_bytes, 1000.0L * 1002 * 1002);
             const int rc_stream = viterbi_batch_stream(model, n_pairs, a_cat, a_off, b_cat, b_off, scores, ops, ops_off, ops_len, in_pinned,
-                                                       out_pinned, total_cells, longest_single, t_entry);
+                                                       out_pinned, total_cells, longest_single, staging_need, t_entry);
             if(rc_stream != COATI_HIP_ESTATE) return rc_stream;  // (ESTATE: nothing was started; the chunk pipeline takes the call)
         }
     }

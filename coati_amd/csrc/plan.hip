@@ -198,7 +198,9 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     const bool ck_shared = model->n_tables == 1;
     // longest-processing-time-first order for the dynamic queue
     std::vector<uint32_t> order(n_pairs);
-    lpt_order(b->desc, order, opts != nullptr && opts->device_validates);
+    // (the classes also for large resident batches: an exact sort of 48 000 pairs is 5.5 ms of a chunk's 12 ms of planning in
+    // the sharded job; up to 20 000 pairs -- the headline's 10 000 -- the order stays exact)
+    lpt_order(b->desc, order, (opts != nullptr && opts->device_validates) || n_pairs > 20000);
     stage("plan: longest-first order");
     // Ragged end of the queue.  The persistent kernel runs kFillSlots wavefronts, three per SIMD, and
     // the SIMD's issue arbitration favours the oldest: in the trace build one 1 kb item takes a
@@ -273,7 +275,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                     ++live;
                 }
             constexpr long double kShortPair = 250.0L * 250.0L;
-            if(w_main < kW || (live > 0 && cells / live < kShortPair)) b->ck = false;
+            // (round 4: 8-column strips stay with viterbi_ck -- its multi-strip pairs hand their boundaries over as
+            // self-validating values and keep banded checkpoints now: 256 x 4 kb 3.00 ms against viterbi_l1's 3.66,
+            // 64 x 16 kb 11.9 against 14.0; 4-column plans -- every wavefront nearly alone on its SIMD -- are viterbi_lp's)
+            if(w_main < 8 || (live > 0 && cells / live < kShortPair)) b->ck = false;
         }
         // a decision-bit plan of 4-column strips throughout is the "few long pairs" regime: viterbi_lp fills it (the same
         // layout, half the instructions per step; COATI_HIP_L1_LP=0 keeps viterbi_l1, the A/B partner)
@@ -348,6 +353,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             ns = std::max(1u, n_strips(d.lb));
         }
         d.v_strips = ns;
+        if(ns > 1) b->multi_strip = true;
         d.v_wmain = static_cast<uint8_t>(w_main_q);
         d.v_wlast = static_cast<uint8_t>(wl);
         if(plan_k && d.la > 0 && d.lb > 0 && (wl != k_narrow || (ns > 1 && w_main_q != k_narrow))) all_narrow = false;

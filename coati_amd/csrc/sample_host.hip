@@ -201,9 +201,14 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
                 continue;  // more unfinished pairs than one round holds: this pair waits for the next round
             const uint64_t width = static_cast<uint64_t>(b->desc[p].la) + b->desc[p].lb;
             const uint32_t remaining = n_samples - s.done;
-            const uint32_t want = s.cnt == 0 ? 1u : (s.cnt < 4 ? 4u : (s.cnt < 16 ? 16u : kChunkMax));
+            // Before anything is known about a pair a sample is expected to take 1 + max(la, lb) draws plus a few gap
+            // columns, give or take 2 % of la + lb: the first round walks 8 samples under that prior (a round costs its ~1 000
+            // dependent steps whatever it holds, so the rounds of 1 and 4 samples that used to learn the mean were two
+            // rounds' time for five samples); from 8 observations on the running estimate decides and the chunk is what the
+            // candidate budget allows.  A window that is too narrow only ends the chunk early.
+            const uint32_t want = s.cnt == 0 ? 8u : (s.cnt < 8 ? 16u : kChunkMax);
             const uint32_t chunk = std::min(remaining, want);
-            // (few observations: widen, a window that is too narrow only ends the chunk early)
+            if(s.cnt == 0) s.mean = 1.0 + static_cast<double>(std::max(b->desc[p].la, b->desc[p].lb)) + 0.005 * static_cast<double>(width);
             const double sigma = s.cnt >= 2 ? std::sqrt(s.m2 / (s.cnt - 1)) * (1.0 + 4.0 / s.cnt) + 1.0
                                             : 0.02 * static_cast<double>(width) + 2.0;
             for(uint32_t j = 0; j < chunk; ++j) {
@@ -256,6 +261,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
                 else
                     commits.push_back(SpecCommit{cand, 0u, base[p] + (static_cast<uint64_t>(s.done) + 1) * width, out_index});
                 const double x = static_cast<double>(draws[cand]);
+                if(s.cnt == 0) s.mean = 0.0;  // (the prior has served: the estimate starts from the observations)
                 s.cnt += 1;  // Welford
                 const double d1 = x - s.mean;
                 s.mean += d1 / s.cnt;

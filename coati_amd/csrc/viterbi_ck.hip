@@ -135,15 +135,22 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
 // A walk that asks for a tile that was not kept (it cannot know the decisions there) reports it, and the wavefront
 // fills the pair again with band = kCkBandOff (everything kept) and walks again: exact, at twice the cost for that
 // pair.  Single-strip pairs only; 0 = off.
-__device__ __forceinline__ int32_t ck_lane_centre(uint32_t la, uint32_t lb, uint32_t w, uint32_t t) {
+__device__ __forceinline__ int32_t ck_lane_centre(uint32_t la, uint32_t lb, uint32_t w, uint32_t t, uint32_t col0 = 0) {
+    // (col0: first column of the lane's strip -- strips after the first of a multi-strip pair)
     const int32_t delta = static_cast<int32_t>(la) - static_cast<int32_t>(lb);
-    return static_cast<int32_t>(t * w + w / 2) + delta / 2 + static_cast<int32_t>(t);
+    return static_cast<int32_t>(col0 + t * w + w / 2) + delta / 2 + static_cast<int32_t>(t);
 }
 // half width of the kept band of a pair: the setting plus half the length difference (wave-uniform)
 __device__ __forceinline__ uint32_t ck_band_half(uint32_t band, uint32_t la, uint32_t lb) {
     if(band == kCkBandOff) return band;
     const uint32_t delta = la > lb ? la - lb : lb - la;
     return band + (delta + 1u) / 2u;
+}
+// the same for the strips of a MULTI-strip pair (round 4): a long pair's path wanders further from its diagonal than a 1 kb
+// pair's, so the slack grows with the length (8 kb: 96 + 61 steps, 32 kb: 96 + 230)
+__device__ __forceinline__ uint32_t ck_band_half_long(uint32_t band, uint32_t la, uint32_t lb) {
+    if(band == kCkBandOff) return band;
+    return ck_band_half(band, la, lb) + la / 128u;
 }
 __device__ __forceinline__ bool ck_tile_kept(uint32_t half, int32_t centre, int32_t c) {
     if(half == kCkBandOff) return true;
@@ -160,6 +167,8 @@ struct CkCtx {
     int lane;
     bool last_strip;
     float *bnd_x, *bnd_z;  // (wave-uniform)
+    const uint32_t *in_x, *in_z;  // the left neighbour's boundary column as bit patterns (strip > 0; kSub: loaded 16 rows at a time)
+    bool first_strip;
     uint32_t band;   // banded checkpoints: kCkBandOff or the half width in steps (ck_band_half)
     int32_t centre;  // this lane's centre step
 };
@@ -189,7 +198,7 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
 // whatever it holds (never looked at), and at step l it takes the state of the margin row.  ONE
 // instantiation serves every chunk: a separate start-up copy of the loop (as viterbi_l1.hip has)
 // cost ~50 VGPRs here and with them the fourth wavefront per SIMD.
-template <int W>
+template <int W, bool kSub>
 __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
                                         uint32_t a_chunk, float bx, float bz, uint32_t colin_voff) {
@@ -210,8 +219,9 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
         }
     }
     // ---- hand-off from the left neighbour (full exec)
-    const float diag = shift_in(st.xlast_old, read_lane(bx, kk));
-    const float zl = shift_in(st.zlast, read_lane(bz, kk));
+    // (kSub: bx / bz hold the 16 rows of the current sub-block in lanes 0-15, else the chunk's 64 rows)
+    const float diag = shift_in(st.xlast_old, read_lane(bx, kSub ? static_cast<int>(kk & 15u) : static_cast<int>(kk)));
+    const float zl = shift_in(st.zlast, read_lane(bz, kSub ? static_cast<int>(kk & 15u) : static_cast<int>(kk)));
     const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
     // ---- checkpoint: what this lane received (one coalesced 512-byte row per wavefront step)
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, kk * (kWave * 8u), 0);
@@ -227,11 +237,18 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
 }
 
 // Up to 64 wavefront steps in sub-blocks of kCkRows, each preceded by its row checkpoint.
-template <int W>
-__device__ __forceinline__ void ck_chunk(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
+// kSub (the strips of multi-strip pairs in the resident kernel, round 4): the strip's LEFT boundary arrives 16 rows at a
+// time, as self-validating values -- the boundary arrays are filled with the NaN pattern 0xffffffff before the launch, the
+// left neighbour stores its values write-through as it produces them (no per-chunk drain, no progress word), and this
+// strip loads the 16 rows of its next sub-block past the L2 until none is the pattern.  A strip then follows its
+// neighbour at 63 (the skew of the 64 lanes) + 16 + a round trip steps instead of 63 + 64 + a drain + a poll + an
+// L2 invalidate (viterbi_l1 / viterbi_lp do the same).  Returns false if values never arrived.
+template <int W, bool kSub>
+__device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                          float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk,
                                          float bx, float bz) {
     const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+    bool ok = true;
     for(uint32_t kb = 0; kb < kend; kb += kCkRows) {
         // (banded checkpoints: one comparison per lane and kCkRows steps; a lane outside the band stores nothing)
         const bool keep = ck_tile_kept(cx.band, cx.centre, static_cast<int32_t>((kbase + kb) / kCkRows));
@@ -239,17 +256,48 @@ __device__ __forceinline__ void ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         asm volatile("" : "+v"(colin_voff));
         colin_voff = keep ? colin_voff * 8u : kCkDropOffset;
         store_rowck<W>(mem, cx.lane, st, kb, keep);
+        if constexpr(kSub) {
+            static_assert(kCkRows == 16, "the boundary sub-blocks are the checkpoint bands");
+            uint32_t row = kbase + kb + (static_cast<uint32_t>(cx.lane) & 15u);  // (lanes 16-63 repeat lanes 0-15)
+            asm volatile("" : "+v"(row));
+            bx = bz = kLowest;
+            if(cx.first_strip) {
+                // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
+                if(row < cx.la) bx = row == 0 ? (0.0f + cx.k.ng) + cx.k.ng : ((cx.k.ng + cx.k.go) + cx.k.ge * static_cast<float>(row - 1)) + cx.k.gs;
+            } else {
+                uint32_t xb = 0, zb = 0;
+                for(uint32_t spins = 0;; ++spins) {
+                    if(row < cx.la) {
+                        xb = __hip_atomic_load(cx.in_x + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        zb = __hip_atomic_load(cx.in_z + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const bool valid = row >= cx.la || (xb != 0xffffffffu && zb != 0xffffffffu);
+                    if(__builtin_amdgcn_ballot_w64(valid) == ~0ull) break;
+                    if(spins > (1u << 24)) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if(row < cx.la) {
+                    bx = __builtin_bit_cast(float, xb);
+                    bz = __builtin_bit_cast(float, zb);
+                }
+            }
+            asm volatile("" : "+v"(bx), "+v"(bz));
+        }
         const uint32_t ke = min(kb + kCkRows, kend);
         // two steps per iteration: the new X of a column must not overwrite the old one before the
         // next column has taken it as its diagonal input; with two copies of the body the register
         // allocator ping-pongs X between two register sets instead of copying W values per step
         uint32_t kk = kb;
         for(; kk + 1 < ke; kk += 2) {
-            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
-            ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
         }
-        if(kk < ke) ck_step<W>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+        if(kk < ke) ck_step<W, kSub>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
     }
+    return ok;
 }
 
 // Checkpoints of strip `strip` of a pair (dwords from the start of the PAIR's checkpoint area, which is
@@ -271,7 +319,7 @@ __device__ __forceinline__ void ck_report_bad(unsigned long long* bad, uint32_t 
 
 // One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
 // the left neighbour's boundary column did not arrive within the spin bound.
-template <int W>
+template <int W, bool kSub = false>
 __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip,
                                               uint32_t ticket, int lane, uint32_t lds_tab, const char* tab_bytes,
                                               const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
@@ -311,8 +359,9 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         if(bad != nullptr && worst >= static_cast<uint32_t>(kTabCols)) ck_report_bad(bad, pair, worst, true);
         if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
     }
-    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z, band,
-                   band == kCkBandOff ? 0 : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane))};
+    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z, reinterpret_cast<const uint32_t*>(in_x),
+                   reinterpret_cast<const uint32_t*>(in_z), strip == 0, band,
+                   band == kCkBandOff ? 0 : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane), col0)};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
     // ge*float(j-1)); a lane takes it again at its first step (ck_step)
@@ -364,7 +413,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             if(bad != nullptr && code >= static_cast<uint32_t>(kTabRows)) ck_report_bad(bad, pair, code, false);  // (streamed chunks)
             a_chunk = code * (kTabStride * 4u);
         }
-        if(crow < la && strip == 0) {
+        if(!kSub && crow < la && strip == 0) {
             // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
             if(crow == 0) {
                 bx = (0.0f + k.ng) + k.ng;
@@ -373,7 +422,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                 bx = dm + k.gs;
             }
         }
-        if(strip > 0) {
+        if(!kSub && strip > 0) {
             // rows kbase .. kbase+63 of the left neighbour's last column must be published
             handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
             if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
@@ -386,8 +435,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
         const CkChunkMem mem{make_rsrc(ck_strip + static_cast<uint64_t>(kbase) * (2 * kWave)),
                              make_rsrc(rowck_strip + static_cast<uint64_t>(kbase / kCkRows) * (2 * W * kWave))};
-        ck_chunk<W>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz);
-        if(!last_strip) {
+        handoff_ok = ck_chunk<W, kSub>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz) && handoff_ok;
+        if(!kSub && !last_strip) {  // (kSub: the boundary values validate themselves: no per-chunk drain, no progress word)
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
         }
@@ -410,6 +459,12 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
 #pragma unroll
         for(int c = 1; c < W; ++c) sc = (c == last_c) ? st.X[c] : sc;
         scores[pair] = sc;
+    }
+    if(kSub && strip > 0) {
+        // (the chain "every earlier strip has released its checkpoints" still runs through the progress words: this strip
+        // says "complete" only after its left neighbour has)
+        handoff_ok = wait_progress(progress + ticket - 1, la) && handoff_ok;
+        if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
     }
     if(!last_strip) {
         // The pair's traceback runs on the wavefront of the LAST strip: release this strip's
@@ -526,7 +581,7 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
     // rows this tile covers: k0 - t + [0, kCkRows)
     valid = valid && t >= 0 && t < static_cast<int32_t>(sp.nlanes) && k0 - t + static_cast<int32_t>(kCkRows) > 0 && k0 - t < la;
     // (banded checkpoints: a tile the fill kept no checkpoints for cannot be recomputed)
-    if(band != kCkBandOff) valid = valid && ck_tile_kept(band, ck_lane_centre(pd.la, pd.lb, W, static_cast<uint32_t>(max(t, 0))), c);
+    if(band != kCkBandOff) valid = valid && ck_tile_kept(band, ck_lane_centre(pd.la, pd.lb, W, static_cast<uint32_t>(max(t, 0)), sp.col0), c);
     const bool computed = valid;
     if(!valid) {
         t = 0;
@@ -647,6 +702,12 @@ struct CkWalkArgs {
     uint32_t* wbits;  // this wavefront's scratch
     bool stats;
     uint32_t band;    // banded checkpoints: what the fill of this pair kept (kCkBandOff: everything)
+    unsigned long long kept_all = 0;  // multi-strip pairs: strips (bit s, s < 64) that were filled again with everything kept
+    // what the fill of strip `strip` kept (strips from 64 on of a very long pair are never banded)
+    __device__ __forceinline__ uint32_t band_of(uint32_t strip, uint32_t n_strips) const {
+        if(n_strips == 1) return band;
+        return (strip >= 64u || ((kept_all >> strip) & 1ull)) ? kCkBandOff : band;
+    }
 };
 
 // traceback<tropical> (align_pair.cc:249-303) of one pair by one WAVEFRONT, in rounds (above).
@@ -665,7 +726,7 @@ __device__ __forceinline__ void put_result(V* p, V v) {
 template <bool kThrough = false>
 __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, const PairDesc& pd, uint32_t pair,
                                              uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
-                                             uint32_t* __restrict__ ops_len) {
+                                             uint32_t* __restrict__ ops_len, uint32_t* failed_strip = nullptr) {
     const uint32_t la = pd.la, lb = pd.lb;
     uint32_t i = la, j = lb;  // matrix coordinates of the cell whose decision is pending
     int moved = COATI_HIP_OP_MATCH;  // max_mdi of the terminal-adjusted last cell == its "after match" decision
@@ -694,11 +755,11 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             // this round's bits are written and then read by the same wavefront through L2
             bool done;
             if(sp.w == 16)
-                done = ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band);
+                done = ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips));
             else if(sp.w == 8)
-                done = ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band);
+                done = ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips));
             else
-                done = ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band);
+                done = ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips));
             ts.computed = __builtin_amdgcn_ballot_w64(done);
             // the wavefront reads back what it stored itself: once the stores are acknowledged its
             // loads see them (same L1, write-through)
@@ -709,6 +770,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             // the pending cell's own tile was not recomputed: with banded checkpoints the walk has left the kept band
             // (the caller fills the pair again with everything kept); otherwise it cannot happen.  Never spin.
             ok = false;
+            if(failed_strip != nullptr && j >= 1) *failed_strip = ck_strip_of(pd, wa.ck, j - 1).strip;
             break;
         }
         while(st != kWalkEnd && st != kWalkUnknown) {
@@ -791,6 +853,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     }
 #endif
     uint32_t redo_ticket = 0xffffffffu;
+    uint32_t redo_strip = 0;                 // multi-strip pairs: the strip to fill again (everything kept) before the walk is repeated
+    unsigned long long redo_kept_all = 0ull;  // ... and the strips of the pair that have been (this one included)
     for(;;) {
         // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
         // loop-invariant condition and may peel/unswitch this loop per lane, after which the
@@ -804,8 +868,14 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         redo_ticket = 0xffffffffu;
         if(ticket >= n_items) break;
         const WorkItem item = items[ticket];
-        const uint32_t pair = item.pair, strip = item.strip & 0xffffu, part = item.strip >> 16;
+        const uint32_t pair = item.pair, part = item.strip >> 16;
         const PairDesc pd = pairs[pair];
+        const bool multi = pd.v_strips > 1;
+        // (a multi-strip pair is walked by the wavefront of its LAST strip; when that walk leaves the band of strip s, this
+        // wavefront fills strip s again -- its left boundary column is complete in memory -- and walks again)
+        const uint32_t strip = (redo && multi) ? redo_strip : (item.strip & 0xffffu);
+        const uint32_t fill_ticket = ticket - ((item.strip & 0xffffu) - strip);  // (the strips of a pair are consecutive items)
+        if(!redo) redo_kept_all = 0ull;
         // the pair's checkpoint area: its own, or (single-strip pair of a large batch) this wavefront's slot
         uint32_t* __restrict__ ckp = ck + (pd.flags_off == kCkWaveSlot ? static_cast<uint64_t>(wave_id) * ck_slot_dwords : pd.flags_off);
         bool handoff_ok = true;
@@ -837,10 +907,19 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // banded checkpoints (above): whole single-strip pairs of the full-width shape only; the second time round
         // (redo: the walk left the kept band) everything is kept
         const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? ck_band_half(band, pd.la, pd.lb) : kCkBandOff;
+        // what the item keeps: single-strip pairs of the full-width shape a band around their diagonal; the strips of a
+        // multi-strip pair (round 4) a wider one, strips from 64 on everything; a redo everything
+        const uint32_t band_pair = multi ? ck_band_half_long(band, pd.la, pd.lb) : ck_band_half(band, pd.la, pd.lb);
+        const uint32_t band_now = (!redo && pd.la > 0 && pd.lb > 0 && (multi ? strip < 64u : w_item == 16)) ? band_pair : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
+            else if(multi && w_item == 16)
+                handoff_ok = ck_fill_strip<16, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+            else if(multi && w_item == 8)
+                handoff_ok = ck_fill_strip<8, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+            else if(multi)
+                handoff_ok = ck_fill_strip<4, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(w_item == 16)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(w_item == 8)
@@ -857,7 +936,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             publish_progress(progress + ticket, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
             continue;
         }
-        if(strip + 1 < pd.v_strips || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
+        if((!redo && strip + 1 < pd.v_strips) || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
         // ---- traceback of this pair by the wavefront of its last strip.  What the wave wrote
         // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
         // strips): they released before publishing "complete", which this wave polled; acquire.
@@ -869,14 +948,25 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             (void)terminal_state(k, m, d, in, score);
             if(lane == 0) scores[pair] = score;
         }
-        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u, band_now};
+        // (multi-strip: the band the pair's strips were filled with, minus the strips filled again since)
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u, multi ? band_pair : band_now, redo_kept_all};
         if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[redo ? 4 : 3], 1ull);
-        const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len);
-        if(!walk_ok && band_now != kCkBandOff) {
+        uint32_t failed_strip = 0;
+        const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len, &failed_strip);
+        if(!walk_ok && !multi && band_now != kCkBandOff) {
             // the walk asked for a tile outside the kept band: the same item once more, with everything kept (counted:
             // the word behind the ticket counter, zeroed with it; coati_hip_viterbi_band_stats)
             if(lane == 0) atomicAdd(queue + 1, 1u);
             redo_ticket = ticket;
+            continue;
+        }
+        failed_strip = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(failed_strip)));
+        if(!walk_ok && multi && band_pair != kCkBandOff && failed_strip < 64u && !((redo_kept_all >> failed_strip) & 1ull)) {
+            // a multi-strip pair: fill THAT strip again with everything kept, then walk again (each strip at most once)
+            if(lane == 0) atomicAdd(queue + 1, 1u);
+            redo_ticket = ticket;
+            redo_strip = failed_strip;
+            redo_kept_all |= 1ull << failed_strip;
             continue;
         }
         // NaN = "this pair failed": a producer strip never arrived (spin bound), or the walk lost its way
@@ -1302,6 +1392,12 @@ uint32_t ck_band_setting() {
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
     hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch
     if(e != hipSuccess) return e;
+    // strip boundaries of multi-strip pairs are self-validating values (ck_chunk<W, true>): every launch starts from the
+    // NaN pattern (64 pairs of 8 kb: 60 MB, ~15 us)
+    if(v.multi_strip != 0 && v.bnd_bytes != 0) {
+        e = hipMemsetAsync(v.bnd, 0xff, v.bnd_bytes, stream);
+        if(e != hipSuccess) return e;
+    }
     const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
     static const uint32_t dbg = [] {

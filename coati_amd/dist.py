@@ -110,10 +110,12 @@ class Comm:
         _check(load().coati_hip_dist_gather(self._h, root, h, hip._ptr(counts), None, None, 0, None, None))
         return counts.reshape(-1, 2)
 
-    def viterbi_shard(self, model, a_cat, a_first, a_off, b_cat, b_first, b_off, root: int = 0, reuse=None):
+    def viterbi_shard(self, model, a_cat, a_first, a_off, b_cat, b_first, b_off, root: int = 0, reuse=None, pinned: bool = True):
         """coati_hip_dist_viterbi_shard: a_off / b_off describe ALL pairs, a_cat / b_cat hold this rank's part of the
-        concatenations starting at byte a_first / b_first.  Results on root (None elsewhere); `reuse` may pass an
-        earlier call's result arrays back in."""
+        concatenations starting at byte a_first / b_first.  Results on root (None elsewhere) -- in page-locked arrays by
+        default: everything every rank computed comes down the root's one PCIe link, 57 GB/s into page-locked memory
+        against 14-22 GB/s into pages that have to be faulted in first; `reuse` may pass an earlier call's result
+        arrays back in."""
         a_cat, b_cat = np.ascontiguousarray(a_cat, np.uint8), np.ascontiguousarray(b_cat, np.uint8)
         a_off, b_off = np.ascontiguousarray(a_off, np.uint64), np.ascontiguousarray(b_off, np.uint64)
         n = len(a_off) - 1
@@ -122,8 +124,9 @@ class Comm:
             if reuse is not None and len(reuse[0]) == n and len(reuse[1]) >= max(total, 1):
                 scores, ops, off, ln = reuse
             else:
-                scores, ops = np.zeros(n, np.float32), np.zeros(max(total, 1), np.uint8)
-                off, ln = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+                make = hip.pinned_empty if pinned else (lambda shape, dt: np.zeros(shape, dt))
+                scores, ops = make(max(n, 1), np.float32)[:n], make(max(total, 1), np.uint8)
+                off, ln = make(max(n, 1), np.uint64)[:n], make(max(n, 1), np.uint32)[:n]
             args = (hip._ptr(scores), hip._ptr(ops), total, hip._ptr(off), hip._ptr(ln))
         else:
             scores = ops = off = ln = None

@@ -28,6 +28,7 @@ EXPORTS = (
     "coati_hip_model_destroy",
     "coati_hip_model_trim",
     "coati_hip_model_set_option",
+    "coati_hip_model_prepare",
     "coati_hip_batch_create",
     "coati_hip_batch_create_tables",
     "coati_hip_batch_destroy",
@@ -91,6 +92,8 @@ def load() -> C.CDLL:
         lib.coati_hip_model_trim.argtypes = [vp]
     if hasattr(lib, "coati_hip_model_set_option"):
         lib.coati_hip_model_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    if hasattr(lib, "coati_hip_model_prepare"):
+        lib.coati_hip_model_prepare.argtypes = [vp, u64, u64, u64]
     lib.coati_hip_batch_create.argtypes = [vp, u64, vp, vp, vp, vp, C.POINTER(vp)]
     lib.coati_hip_batch_destroy.argtypes = [vp]
     lib.coati_hip_batch_destroy.restype = None
@@ -227,6 +230,10 @@ class Model:
     def set_option(self, option: int, value: int):
         """coati_hip_model_set_option (OPT_PERSISTENT_CALL = 1: 0 forbids the device-owning one-shot form)."""
         _check(load().coati_hip_model_set_option(self._h, int(option), int(value)))
+
+    def prepare(self, n_pairs: int, len_a: int, len_b: int):
+        """coati_hip_model_prepare: allocate now what a one-shot call of about this size would allocate first."""
+        _check(load().coati_hip_model_prepare(self._h, int(n_pairs), int(len_a), int(len_b)))
 
     def close(self):
         if self._h:

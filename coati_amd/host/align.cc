@@ -1,6 +1,7 @@
 #include "align.hpp"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -631,8 +632,26 @@ long batch_shard_first_difference(const alignment_t& aln_in, int world, int rank
 bool marg_alignment_batch(alignment_t& aln) {
     host_timer tm("alignpair --batch");
     set_subst(aln);
-    // the HIP runtime, the model and (inside the first call) the pipeline's workspaces come up while the input is read
-    auto model_ready = std::async(std::launch::async, [&aln]() { return make_model(aln); });
+    // the HIP runtime, the model and the pipeline's workspaces (coati_hip_model_prepare, sized from the input's index:
+    // pairs and the mean record size) come up on a helper thread while the input is read, parsed and encoded
+    std::promise<std::array<uint64_t, 3>> hint_promise;
+    std::shared_future<std::array<uint64_t, 3>> hint = hint_promise.get_future().share();
+    auto model_ready = std::async(std::launch::async, [&aln, hint]() {
+        coati_hip_model* m = make_model(aln);
+        try {
+            const std::array<uint64_t, 3> h = hint.get();  // (pairs, len_a, len_b; an exception here = the input failed: nothing to prepare)
+            (void)coati_hip_model_prepare(m, h[0], h[1], h[2]);
+        } catch(...) {
+        }
+        return m;
+    });
+    struct hint_guard {  // (whatever happens below, the helper thread is not left waiting)
+        std::promise<std::array<uint64_t, 3>>& p;
+        bool set{false};
+        ~hint_guard() {
+            if(!set) p.set_exception(std::make_exception_ptr(std::runtime_error("no input")));
+        }
+    } hguard{hint_promise};
     struct model_guard {
         std::future<coati_hip_model*>& f;
         coati_hip_model* m{nullptr};
@@ -649,6 +668,17 @@ bool marg_alignment_batch(alignment_t& aln) {
         }
     } guard{model_ready};
     const std::unique_ptr<batch_source_t> src = open_batch_source(aln);
+    {
+        // mean sequence length from the record sizes (names and line breaks make it a slight overestimate: sizes things only)
+        std::vector<uint64_t> wa, wb;
+        batch_source_weights(*src, wa, wb);
+        const uint64_t n = std::max<uint64_t>(src->n_pairs, 1);
+        uint64_t la = 0;  // the LONGEST ancestor record sizes the wavefronts' checkpoint slots (a slot too small is re-allocated by the call)
+        for(std::size_t p = 0; p < src->n_pairs; ++p) la = std::max(la, wa[p + 1] - wa[p]);
+        const uint64_t lb = wb[src->n_pairs] / n;
+        hint_promise.set_value({static_cast<uint64_t>(src->n_pairs), la - la % 3, lb});
+        hguard.set = true;
+    }
     tm.stage("read + index");
     std::ofstream file;
     std::ostream* out = &std::cout;

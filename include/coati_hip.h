@@ -121,6 +121,13 @@ int coati_hip_model_trim(coati_hip_model_t* model);
 enum { COATI_HIP_OPT_PERSISTENT_CALL = 1, COATI_HIP_OPT_CK_BAND = 2 };
 int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t value);
 
+/* Warm-up for a coming coati_hip_viterbi_batch call of about n_pairs pairs of about len_a x len_b positions: the
+ * device workspaces and page-locked staging blocks that call would allocate first (several GB: ~50-100 ms in a fresh
+ * process) are allocated now -- e.g. on a helper thread while the caller is still reading its input
+ * (coati-alignpair --batch does).  The hints only size things: a call that needs more allocates more.  No reference
+ * counterpart (the reference allocates its three matrices per pair, align_pair.hpp:45-62). */
+int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t len_a, uint64_t len_b);
+
 /* ---- batch -------------------------------------------------------------- *
  * Validates and uploads n_pairs encoded pairs (host pointers) and reserves the
  * HBM workspace for the Viterbi path.  a_off/b_off have n_pairs+1 entries.

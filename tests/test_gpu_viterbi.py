@@ -454,6 +454,7 @@ def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, 
         pytest.skip("viterbi_l1 forced: row parts are viterbi_ck's")
     monkeypatch.setenv("COATI_HIP_CK_SPLIT", plan)
     monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")  # (a batch this small would go to viterbi_l1's planner rule otherwise)
+    monkeypatch.setenv("COATI_HIP_STRIP_W", "16")    # (... and be narrowed to 4-column strips: only 16-column single-strip pairs are cut)
     rng = np.random.default_rng(5)
     table, consts = util.random_table(rng), oracle.gap_consts()
     pairs = util.make_pairs(rng, 50, 100, 420, L=1, amb=0.03)  # 300 .. 1 260 nt
