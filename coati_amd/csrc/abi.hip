@@ -61,14 +61,87 @@ __global__ void decode_mdi(const PairDesc* __restrict__ pairs, uint32_t pair, co
 }  // namespace
 
 namespace coati_hip_detail {
-bool forward_fast_math() {
-    static const bool fast = [] {
-        const char* e = std::getenv("COATI_HIP_FORWARD_FAST");
-        return e != nullptr && e[0] != '\0' && e[0] != '0';
-    }();
-    return fast;
+namespace {
+std::atomic<const EnvOptions*> g_env{nullptr};
+std::mutex g_env_lock;
+const EnvOptions* read_env() {
+    auto* o = new EnvOptions;  // (never freed: a reader may still hold the old one; a reload is a test-only event)
+    auto set = [](const char* name) { return std::getenv(name) != nullptr; };
+    auto zero = [](const char* name) {
+        const char* e = std::getenv(name);
+        return e != nullptr && e[0] == '0';
+    };
+    auto num = [](const char* name, long long dflt) {
+        const char* e = std::getenv(name);
+        return e != nullptr ? std::atoll(e) : dflt;
+    };
+    o->force_generic = set("COATI_HIP_FORCE_GENERIC");
+    o->viterbi_bits = set("COATI_HIP_VITERBI_BITS");
+    o->viterbi_ck = set("COATI_HIP_VITERBI_CK");
+    o->l1_lp_off = zero("COATI_HIP_L1_LP");
+    o->l1_progress = set("COATI_HIP_L1_PROGRESS");
+    o->ck_per_pair = set("COATI_HIP_CK_PER_PAIR");
+    o->stream_parts = set("COATI_HIP_STREAM_PARTS");
+    o->pipe_no_d2h = set("COATI_HIP_PIPE_NO_D2H");
+    o->sample_sequential = set("COATI_HIP_SAMPLE_SEQUENTIAL");
+    o->sample_table_off = zero("COATI_HIP_SAMPLE_TABLE");
+    o->fwd_wide_build = set("COATI_HIP_FWD_WIDE_BUILD");
+    o->lp_pairtab_off = zero("COATI_HIP_LP_PAIRTAB");
+    if(const char* e = std::getenv("COATI_HIP_FORWARD_FAST")) o->forward_fast = e[0] != '\0' && e[0] != '0';
+    o->timing = set("COATI_HIP_TIMING");
+    o->pipe_timing = set("COATI_HIP_PIPE_TIMING");
+    if(const char* e = std::getenv("HSA_ENABLE_SDMA")) o->sdma_off = std::atoi(e) == 0;
+    if(const char* e = std::getenv("COATI_HIP_PIPE")) o->pipe = std::strcmp(e, "chunks") == 0 ? 1 : (std::strcmp(e, "stream") == 0 ? 2 : 0);
+    o->strip_w = static_cast<int>(num("COATI_HIP_STRIP_W", 0));
+    o->fwd_w = static_cast<int>(num("COATI_HIP_FWD_W", 0));
+    o->fill_blocks_per_cu = static_cast<int>(num("COATI_HIP_FILL_BLOCKS_PER_CU", 0));
+    o->lp_blocks_per_cu = static_cast<int>(num("COATI_HIP_LP_BLOCKS_PER_CU", 0));
+    o->tail_pairs = num("COATI_HIP_TAIL_PAIRS", -1);
+    if(const char* e = std::getenv("COATI_HIP_CK_BAND")) {
+        const long x = std::atol(e);
+        o->ck_band = x <= 0 ? kCkBandOff : static_cast<uint32_t>(x);
+    }
+    o->ck_debug = static_cast<uint32_t>(num("COATI_HIP_CK_DEBUG", 0));
+    if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {  // "pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
+        char* rest = nullptr;
+        o->ck_split_set = true;
+        o->ck_split_pairs = std::strtoull(e, &rest, 10);
+        if(rest != nullptr && *rest == ',') o->ck_split_parts = std::strtoull(rest + 1, &rest, 10);
+        o->ck_split_taper = rest != nullptr && rest[0] == ',' && rest[1] == 't';
+    }
+    if(const long long v = num("COATI_HIP_SPEC_CANDS", 0); v >= 1024 && v <= (1 << 22)) o->spec_cands = static_cast<uint32_t>(v);
+    if(const char* e = std::getenv("COATI_HIP_SPEC_Z")) {
+        const double v = std::atof(e);
+        if(v >= 0.25 && v <= 10.0) o->spec_z = v;
+    }
+    if(const char* e = std::getenv("COATI_HIP_STREAM_UNIT")) {
+        const long double v = std::strtold(e, nullptr);
+        if(v >= 1.0L) o->stream_unit = v;
+    }
+    if(const char* e = std::getenv("COATI_HIP_MEM_BUDGET")) o->mem_budget = std::strtoull(e, nullptr, 10);
+    return o;
 }
+}  // namespace
+const EnvOptions& env_options() {
+    const EnvOptions* o = g_env.load(std::memory_order_acquire);
+    if(o == nullptr) {
+        std::lock_guard<std::mutex> hold(g_env_lock);
+        o = g_env.load(std::memory_order_acquire);
+        if(o == nullptr) {
+            o = read_env();
+            g_env.store(o, std::memory_order_release);
+        }
+    }
+    return *o;
+}
+bool forward_fast_math() { return env_options().forward_fast; }
+uint32_t ck_band_setting() { return env_options().ck_band; }
 }  // namespace coati_hip_detail
+
+extern "C" void coati_hip_debug_reload_env(void) {
+    std::lock_guard<std::mutex> hold(coati_hip_detail::g_env_lock);
+    coati_hip_detail::g_env.store(coati_hip_detail::read_env(), std::memory_order_release);
+}
 
 namespace {
 thread_local std::string g_error;
@@ -390,7 +463,7 @@ int coati_hip_viterbi_launch(coati_hip_batch_t* b) {
     HIP_TRY(hipEventRecord(ev[0], b->stream));
     if(n > 0) {
         const BatchDeviceView v = device_view(b);
-        static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+        const bool force_generic = env_options().force_generic;
         if(b->ck)
             HIP_TRY(launch_viterbi_ck(v, m->n_tables == 1, b->stream));
         else if(m->gap_len == 1 && !force_generic)
@@ -509,7 +582,7 @@ int coati_hip_forward_launch(coati_hip_batch_t* b) {
         b->device_bytes += sizing.used;
     }
     if(b->n_pairs > 0) {
-        static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+        const bool force_generic = env_options().force_generic;
         if(m->gap_len == 1 && !force_generic)
             HIP_TRY(launch_forward_l1(device_view(b), m->n_tables == 1, m->stream));
         else if((m->gap_len == 2 || m->gap_len == 3) && !force_generic)

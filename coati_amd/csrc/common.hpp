@@ -452,6 +452,46 @@ __device__ __forceinline__ float log_plus(float a, float b) {
 }
 
 // ---------------------------------------------------------------------------
+// The COATI_HIP_* environment, read ONCE per process (first use) into one struct -- not on every batch_create or launch:
+// the one-pair call path is 0.27 ms.  These are A/B, test and experiment switches; what an embedder needs is a model
+// option (coati_hip_model_set_option: persistent-call form, checkpoint band).  coati_hip_debug_reload_env() reads the
+// environment again (the Python test plumbing calls it before every entry, so tests can switch kernels in one process).
+struct EnvOptions {
+    bool force_generic = false;      // COATI_HIP_FORCE_GENERIC: dp_generic for every gap_len (second implementation)
+    bool viterbi_bits = false;       // COATI_HIP_VITERBI_BITS: viterbi_l1 / viterbi_lp instead of viterbi_ck
+    bool viterbi_ck = false;         // COATI_HIP_VITERBI_CK: viterbi_ck whatever the planner would choose
+    bool l1_lp_off = false;          // COATI_HIP_L1_LP=0: viterbi_l1 where viterbi_lp would run
+    bool l1_progress = false;        // COATI_HIP_L1_PROGRESS: progress-word boundary protocol in viterbi_l1
+    bool ck_per_pair = false;        // COATI_HIP_CK_PER_PAIR: no per-wavefront checkpoint slots
+    bool stream_parts = false;       // COATI_HIP_STREAM_PARTS: row parts in the last chunks of a streamed call
+    bool pipe_no_d2h = false;        // COATI_HIP_PIPE_NO_D2H: chunk pipeline without downloads (timing experiment)
+    bool sample_sequential = false;  // COATI_HIP_SAMPLE_SEQUENTIAL: one serial walker per pair
+    bool sample_table_off = false;   // COATI_HIP_SAMPLE_TABLE=0: exact-stream sampler without the step table
+    bool fwd_wide_build = false;     // COATI_HIP_FWD_WIDE_BUILD: forward_l1's 16-column build for narrow strips too
+    bool lp_pairtab_off = false;     // COATI_HIP_LP_PAIRTAB=0
+    bool forward_fast = false;       // COATI_HIP_FORWARD_FAST: hardware exp / log in the log-semiring plus (not a parity mode)
+    bool timing = false;             // COATI_HIP_TIMING: host stage times on stderr
+    bool pipe_timing = false;        // COATI_HIP_PIPE_TIMING: timeline of a one-shot call on stderr
+    bool sdma_off = false;           // HSA_ENABLE_SDMA=0: copies are kernels -- no persistent-kernel call form
+    int pipe = 0;                    // COATI_HIP_PIPE: 0 = by the input, 1 = "chunks", 2 = "stream"
+    int strip_w = 0;                 // COATI_HIP_STRIP_W: 2 / 4 / 8 / 16 columns per lane in every strip but the last
+    int fwd_w = 0;                   // COATI_HIP_FWD_W: 1 / 2 / 4 / 8 / 16
+    int fill_blocks_per_cu = 0;      // COATI_HIP_FILL_BLOCKS_PER_CU
+    int lp_blocks_per_cu = 0;        // COATI_HIP_LP_BLOCKS_PER_CU
+    long long tail_pairs = -1;       // COATI_HIP_TAIL_PAIRS (-1: the planner's rule)
+    uint32_t ck_band = 96;           // COATI_HIP_CK_BAND: default of COATI_HIP_OPT_CK_BAND (0 -> kCkBandOff)
+    uint32_t ck_debug = 0;           // COATI_HIP_CK_DEBUG: bit 0 fill only, bit 1 traceback statistics
+    bool ck_split_set = false;       // COATI_HIP_CK_SPLIT="pairs,parts[,t]"
+    uint64_t ck_split_pairs = 0, ck_split_parts = 3;
+    bool ck_split_taper = false;
+    uint32_t spec_cands = 1u << 17;  // COATI_HIP_SPEC_CANDS
+    double spec_z = 2.0;             // COATI_HIP_SPEC_Z
+    long double stream_unit = 0;     // COATI_HIP_STREAM_UNIT (cells; 0: the default)
+    uint64_t mem_budget = 0;         // COATI_HIP_MEM_BUDGET (bytes; 0: none)
+};
+const EnvOptions& env_options();
+
+// ---------------------------------------------------------------------------
 // launchers implemented in the kernel translation units
 // ---------------------------------------------------------------------------
 // One unit of work of the persistent kernels: one strip of one pair.  The strips of a pair are

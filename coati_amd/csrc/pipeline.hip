@@ -134,7 +134,7 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
     const uint64_t wave_slot_bytes = (std::min<uint64_t>(slot_dwords, 1ull << 20) * 4 + 255) / 256 * 256;
     const uint64_t scratch_bytes = ck_scratch_dwords_per_wave() * sizeof(uint32_t);
     const uint64_t waves_bytes = static_cast<uint64_t>(ck_scratch_waves()) * (wave_slot_bytes + scratch_bytes);
-    const bool alloc_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;
+    const bool alloc_timing = env_options().pipe_timing;
     auto t_alloc = std::chrono::steady_clock::now();
     auto alloc_stage = [&](const char* what, uint64_t bytes) {
         if(!alloc_timing) return;
@@ -159,10 +159,7 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
     // once four units are left.  A one-shot process (coati-alignpair --batch: ~0.1 ms per MB of fresh hipMalloc /
     // hipHostMalloc, 12 slots are 2.9 GB) allocates what its input needs; a second call on the model takes the rest.
     long double kUnitCells = 1000.0L * 1002 * 1002;
-    if(const char* e = std::getenv("COATI_HIP_STREAM_UNIT")) {
-        const long double forced = std::strtold(e, nullptr);
-        if(forced >= 1.0L) kUnitCells = forced;
-    }
+    if(env_options().stream_unit >= 1.0L) kUnitCells = env_options().stream_unit;  // (COATI_HIP_STREAM_UNIT)
     int n_slots = kSlots;
     if(model->stream_calls == 0) {
         int est = 0;
@@ -243,7 +240,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // page-locked arrays: 10 000 pairs 5.15 -> 4.92 ms, 40 000 pairs 16.55 -> 15.93 ms without them).  A resident batch
     // keeps its row parts: there a part's predecessor is >= 4 096 tickets back.  COATI_HIP_STREAM_PARTS=1 turns them on
     // (tests, A/B).
-    const bool tail_parts_on = std::getenv("COATI_HIP_STREAM_PARTS") != nullptr;  // (read per call: the tests switch it)
+    const bool tail_parts_on = env_options().stream_parts;
     // (a model's FIRST call on a small input runs without them: 2 x 1.4 GB of fresh allocation cost a one-shot process
     // ~30 ms)
     const bool want_tails = tail_parts_on && (model->stream_calls > 0 || total_cells >= 30 * kUnitCells);
@@ -288,7 +285,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     };
     InFlight fl[kSlots];
     int rc = COATI_HIP_OK;
-    const bool pipe_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;
+    const bool pipe_timing = env_options().pipe_timing;
     auto t_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: schedule made, kernel launched at %.2f ms\n", t_ms());
     constexpr int kGaveUp = -1000, kRedo = -1001;  // (private to this function)
@@ -533,13 +530,10 @@ int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t
     try {
         std::lock_guard<std::mutex> one_call(model->pipeline_lock);
         HIP_TRY(hipSetDevice(model->device));
-        const char* pipe_env = std::getenv("COATI_HIP_PIPE");
-        const bool forced = pipe_env != nullptr && std::strcmp(pipe_env, "stream") == 0;
-        bool streamed = model->gap_len == 1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr &&
-                        !(pipe_env != nullptr && std::strcmp(pipe_env, "chunks") == 0) && len_b <= 8ull * kStrip && len_a * len_b <= kStreamPairCells &&
-                        !model->stream_forbidden && !model->stream_unusable;
-        if(streamed && !forced) streamed = n_pairs >= 4096 && len_a * len_b >= 250ull * 250ull;
-        if(const char* sdma = std::getenv("HSA_ENABLE_SDMA"); sdma != nullptr && std::atoi(sdma) == 0) streamed = false;
+        const EnvOptions& env = env_options();
+        bool streamed = model->gap_len == 1 && !env.viterbi_bits && !env.force_generic && env.pipe != 1 && len_b <= 8ull * kStrip &&
+                        len_a * len_b <= kStreamPairCells && !model->stream_forbidden && !model->stream_unusable && !env.sdma_off;
+        if(streamed && env.pipe != 2) streamed = n_pairs >= 4096 && len_a * len_b >= 250ull * 250ull;
         if(!streamed) return COATI_HIP_OK;
         uint64_t wave_slot_bytes = 0;
         int n_slots = 0;
@@ -599,18 +593,13 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     // kind (the planner's rule: not short pairs, not lone long ones; and no pair whose own checkpoints would not fit
     // a stream slot's workspace); else a launch per chunk (below).  COATI_HIP_PIPE=chunks|stream forces one.
     {
-        const char* pipe_env = std::getenv("COATI_HIP_PIPE");
-        bool streamed = gap_len == 1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr &&
-                        !(pipe_env != nullptr && std::strcmp(pipe_env, "chunks") == 0) && widest <= 8 * kStrip && max_pair_cells <= kStreamPairCells;
-        if(streamed && !(pipe_env != nullptr && std::strcmp(pipe_env, "stream") == 0))
-            streamed = n_pairs >= 4096 && total_cells / n_pairs >= 250.0L * 250.0L;
+        const EnvOptions& env = env_options();
+        bool streamed = gap_len == 1 && !env.viterbi_bits && !env.force_generic && env.pipe != 1 && widest <= 8 * kStrip && max_pair_cells <= kStreamPairCells;
+        if(streamed && env.pipe != 2) streamed = n_pairs >= 4096 && total_cells / n_pairs >= 250.0L * 250.0L;
         // the persistent kernel owns the GPU for the length of the call: not when the embedder said no
         // (coati_hip_model_set_option), not where it failed before, and not where copies are done by kernels
         if(streamed && (model->stream_forbidden || model->stream_unusable)) streamed = false;
-        if(streamed) {
-            const char* sdma = std::getenv("HSA_ENABLE_SDMA");
-            if(sdma != nullptr && std::atoi(sdma) == 0) streamed = false;
-        }
+        if(streamed && env.sdma_off) streamed = false;
         // every pair must fit a stream slot on its own (the chunk cutter takes the first pair of a chunk unseen).
         // Ordinary pairs pass by two comparisons; the few long or wide ones are priced exactly.
         if(streamed && (longest_a > 32768 || widest > static_cast<uint64_t>(kStrip))) {
@@ -638,10 +627,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     // per-slot workspace budget: a third of 80 % of the free HBM, at most 16 GB (~14 000 pairs of 1 kb:
     // larger chunks gain nothing, the kernel is at its steady rate from ~10 000 pairs)
     uint64_t budget = std::min<uint64_t>(static_cast<uint64_t>(free_b * 0.8) / kSlots, 16ull << 30);
-    if(const char* e = std::getenv("COATI_HIP_MEM_BUDGET")) {  // tests: force chunking with a small budget (bytes)
-        const uint64_t forced = std::strtoull(e, nullptr, 10);
-        if(forced > 0) budget = std::min(budget, forced);
-    }
+    if(env_options().mem_budget > 0) budget = std::min<uint64_t>(budget, env_options().mem_budget);  // (COATI_HIP_MEM_BUDGET, tests: force chunking)
     // ---- chunk schedule.  Full chunks hold ~1.6e10 cells (16 000 pairs of 1 kb) or what the budget
     // allows; the first one is a sixth of that (planning it takes ~0.4 ms, then the GPU has work while the next is planned).
     constexpr uint64_t kFullCells = 16000ull * 1002 * 1002;
@@ -756,8 +742,8 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     };
     InFlight fl[kSlots];
     int rc = COATI_HIP_OK;
-    const bool pipe_timing = std::getenv("COATI_HIP_PIPE_TIMING") != nullptr;  // timeline of the call on stderr
-    static const bool no_d2h = std::getenv("COATI_HIP_PIPE_NO_D2H") != nullptr;   // (timing experiment: results stay on the device)
+    const bool pipe_timing = env_options().pipe_timing;  // timeline of the call on stderr
+    const bool no_d2h = env_options().pipe_no_d2h;   // (timing experiment: results stay on the device)
     const auto t_call = std::chrono::steady_clock::now();
     auto t_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     hipEvent_t ev_base = nullptr;

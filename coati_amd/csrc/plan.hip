@@ -88,7 +88,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     } owner{b};
     auto cleanup = [&](int rc) { return rc; };
     // COATI_HIP_TIMING=1: host-side stage times of this call on stderr
-    static const bool timing = std::getenv("COATI_HIP_TIMING") != nullptr;
+    const EnvOptions& env = env_options();  // (the COATI_HIP_* switches: read once per process, common.hpp)
+    const bool timing = env.timing;
     auto t_prev = std::chrono::steady_clock::now();
     auto stage = [&](const char* what) {
         if(!timing) return;
@@ -98,7 +99,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     };
     b->desc.resize(n_pairs);
     const uint64_t L = static_cast<uint64_t>(model->gap_len);
-    static const bool force_generic = std::getenv("COATI_HIP_FORCE_GENERIC") != nullptr;
+    const bool force_generic = env.force_generic;
     // Forward strip shape (forward_l1): 16 columns per lane, narrowed to 8 and 4 while the batch has
     // fewer strips than 1.5 rounds of the kernel's wavefront slots (3 per SIMD) -- a wavefront per
     // 1 024 columns leaves a small batch on a handful of SIMDs (16 pairs of 1 kb: 17.8 ms at W = 16,
@@ -126,10 +127,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // 256 pairs 7.1 / 6.0 / 7.1, 1 024 pairs 15 / 16 / 19.6 -- i.e. while the strips still fit ~2 per SIMD.
         if(fwd_wlog2 == 2 && count_strips(2) <= 2304) fwd_wlog2 = 1;
         if(fwd_wlog2 == 1 && count_strips(1) <= 1536) fwd_wlog2 = 0;
-        if(const char* e = std::getenv("COATI_HIP_FWD_W")) {
-            const int w = std::atoi(e);
-            if(w == 1 || w == 2 || w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 1 ? 0u : w == 2 ? 1u : w == 4 ? 2u : (w == 8 ? 3u : 4u);
-        }
+        if(const int w = env.fwd_w; w == 1 || w == 2 || w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 1 ? 0u : w == 2 ? 1u : w == 4 ? 2u : (w == 8 ? 3u : 4u);
     }
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
@@ -191,10 +189,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // has fewer strips than the GPU has SIMDs (a few long pairs), narrower strips everywhere put
     // more wavefronts to work on each pair.  dp_generic (gap_len > 1) writes 16-column strips only.
     uint32_t w_main = kW;
-    const bool plan_l1 = L == 1 && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;  // viterbi_ck / viterbi_l1 will run
+    const bool plan_l1 = L == 1 && !force_generic;  // viterbi_ck / viterbi_l1 will run
     // COATI_HIP_VITERBI_BITS=1: the round-1 kernel (five decision bits per cell written by the fill), kept
     // as the A/B partner and second implementation of viterbi_ck
-    b->ck = plan_l1 && std::getenv("COATI_HIP_VITERBI_BITS") == nullptr;
+    b->ck = plan_l1 && !env.viterbi_bits;
     const bool ck_shared = model->n_tables == 1;
     // longest-processing-time-first order for the dynamic queue
     std::vector<uint32_t> order(n_pairs);
@@ -250,14 +248,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // wavefronts, which then run at half speed each (the packed adds, maxima and bit deposits are limited by the
         // SIMD, not by the wavefront: tools/ubench, "cell19 lp" 4.06 cycles per instruction alone, 4.03 per SIMD with two)
         // and hold the whole pipeline back: 66 ms against 44.  viterbi_lp only (COATI_HIP_L1_LP=0 keeps viterbi_l1).
-        const char* lp_env = std::getenv("COATI_HIP_L1_LP");
-        const bool lp_allowed = !(lp_env != nullptr && lp_env[0] == '0') && std::getenv("COATI_HIP_L1_PROGRESS") == nullptr;
-        const bool ck_forced = std::getenv("COATI_HIP_VITERBI_CK") != nullptr || (opts != nullptr && (opts->force_w_main != 0 || opts->force_ck));
+        const bool lp_allowed = !env.l1_lp_off && !env.l1_progress;
+        const bool ck_forced = env.viterbi_ck || (opts != nullptr && (opts->force_w_main != 0 || opts->force_ck));
         if(lp_allowed && !ck_forced && w_main == 4 && count_items(2) <= kSimds) w_main = 2;
-        if(const char* e = std::getenv("COATI_HIP_STRIP_W")) {
-            const int w = std::atoi(e);
-            if(w == 4 || w == 8 || w == 16 || (w == 2 && lp_allowed && !ck_forced)) w_main = static_cast<uint32_t>(w);
-        }
+        if(const int w = env.strip_w; w == 4 || w == 8 || w == 16 || (w == 2 && lp_allowed && !ck_forced)) w_main = static_cast<uint32_t>(w);
         if(opts != nullptr && opts->force_w_main != 0) w_main = opts->force_w_main;
         // Which gap_len-1 kernel.  viterbi_ck (lean fill + checkpoint traceback) wins where the fill
         // dominates; viterbi_l1 (decision bits written by the fill) keeps two regimes, both measured
@@ -266,7 +260,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // at 750 nt viterbi_ck leads by 16 %), and a few LONG pairs cut into narrow strips, where every
         // wavefront is alone on its SIMD and the 4x larger checkpoint stream of 4-column strips costs more
         // than the shorter cell saves (160 kb pair: 86 vs 104 ms).  COATI_HIP_VITERBI_CK=1 / _BITS=1 force one.
-        if(b->ck && std::getenv("COATI_HIP_VITERBI_CK") == nullptr && !(opts != nullptr && (opts->force_w_main != 0 || opts->force_ck))) {
+        if(b->ck && !env.viterbi_ck && !(opts != nullptr && (opts->force_w_main != 0 || opts->force_ck))) {
             long double cells = 0;
             uint64_t live = 0;
             for(uint64_t p = 0; p < n_pairs; ++p)
@@ -285,8 +279,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         b->long_pairs = !b->ck && w_main <= 4 && lp_allowed;
         const uint64_t kFillSlots = (b->ck && ck_shared ? 4 : 3) * kSimds;  // resident wavefronts of the persistent kernel
         uint64_t tail_pairs = 0;
-        if(const char* tp = std::getenv("COATI_HIP_TAIL_PAIRS")) {
-            tail_pairs = std::min<uint64_t>(n_pairs, std::strtoull(tp, nullptr, 10));
+        if(env.tail_pairs >= 0) {
+            tail_pairs = std::min<uint64_t>(n_pairs, static_cast<uint64_t>(env.tail_pairs));
         } else if(w_main == kW && n_pairs > 0) {
             // "equal pairs": the smallest has at least half the cells of the largest (LPT order);
             // and the batch must be clearly longer than one round (3 500 pairs: -1 %, 6 644: +6 %)
@@ -300,7 +294,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     }
     // the same remedy for forward_l1 (3 slots per SIMD as well): a batch of equal pairs that runs
     // full-width strips ends with its last quarter round in 8-column strips
-    if(L == 1 && !force_generic && fwd_wlog2 == 4 && n_pairs > 3 * 1024 * 3 / 2 && std::getenv("COATI_HIP_FWD_W") == nullptr) {
+    if(L == 1 && !force_generic && fwd_wlog2 == 4 && n_pairs > 3 * 1024 * 3 / 2 && env.fwd_w == 0) {
         auto cells_of = [&](uint64_t p) { return static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb; };
         if(cells_of(order[n_pairs - 1]) > 0 && cells_of(order[n_pairs - 1]) * 2 >= cells_of(order[0]))
             for(uint64_t q = n_pairs - 3 * 1024 / 4; q < n_pairs; ++q) b->desc[order[q]].f_wlog2 = 3;
@@ -319,7 +313,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     }
     // gap_len 2 and 3: viterbi_k works on the live cells only, in block columns (lb / L), strips of
     // 16 block columns per lane and a narrow shape (6 for L = 3, 8 for L = 2) for the last strip
-    const bool plan_k = (L == 2 || L == 3) && std::getenv("COATI_HIP_FORCE_GENERIC") == nullptr;
+    const bool plan_k = (L == 2 || L == 3) && !force_generic;
     b->compact = plan_k;
     uint32_t k_main = L == 3 ? 12u : 16u;  // (viterbi_k.hip: kWMain / kWNarrow)
     const uint32_t k_narrow = L == 3 ? 6u : 8u;
@@ -419,7 +413,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         b->ck_slot_dwords = opts->wave_slot_dwords;
     } else if(b->ck && opts != nullptr && opts->ck_per_pair) {
         b->ck_keep_all = true;  // (the debug export: per-pair storage, every tile kept)
-    } else if(b->ck && std::getenv("COATI_HIP_CK_PER_PAIR") == nullptr) {
+    } else if(b->ck && !env.ck_per_pair) {
         constexpr uint64_t kSlotCap = 1ull << 20;  // dwords (4 MB)
         uint64_t slot = 0, per_pair_total = 0;
         auto need_of = [&](const PairDesc& d) { return d.la > 0 && d.lb > 0 ? ck_strip_dwords(d.la, d.v_wlast) : 0; };
@@ -451,11 +445,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             if(split_pairs < 256) split_pairs = 0;
         }
         bool taper = false;
-        if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {  // "pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
-            char* rest = nullptr;
-            split_pairs = std::strtoull(e, &rest, 10);
-            if(rest != nullptr && *rest == ',') parts = std::strtoull(rest + 1, &rest, 10);
-            taper = rest != nullptr && rest[0] == ',' && rest[1] == 't';
+        if(env.ck_split_set) {  // COATI_HIP_CK_SPLIT="pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
+            split_pairs = env.ck_split_pairs;
+            parts = env.ck_split_parts;
+            taper = env.ck_split_taper;
             if(parts < 2 || parts > 8) split_pairs = 0;
         }
         split_pairs = std::min<uint64_t>(split_pairs, n_pairs);

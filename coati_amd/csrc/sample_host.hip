@@ -27,18 +27,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     coati_hip_model* m = b->model;
     const uint64_t n = b->n_pairs;
     constexpr uint32_t kChunkMax = 512;
-    static const uint32_t kMaxCands = [] {
-        const char* e = std::getenv("COATI_HIP_SPEC_CANDS");
-        const long v = e != nullptr ? std::atol(e) : 0;
-        return v >= 1024 && v <= (1 << 22) ? static_cast<uint32_t>(v) : (1u << 17);  // measured best (tools/sample_bench.py)
-    }();
+    const uint32_t kMaxCands = env_options().spec_cands;  // (COATI_HIP_SPEC_CANDS; default 2^17: measured best, tools/sample_bench.py)
     // half-width of a candidate window in standard deviations of the offset; too narrow only ends
     // a chunk early (COATI_HIP_SPEC_Z overrides, for tuning)
-    static const double kZ = [] {
-        const char* e = std::getenv("COATI_HIP_SPEC_Z");
-        const double v = e != nullptr ? std::atof(e) : 0.0;
-        return v >= 0.25 && v <= 10.0 ? v : 2.0;  // measured (16 x 1 000 samples of 1 kb pairs): z = 5: 38.8 ms, 3: 30.9, 2: 25.9, 1.5: 26.0, 1: 35.9
-    }();
+    const double kZ = env_options().spec_z;  // (default 2; measured, 16 x 1 000 samples of 1 kb pairs: z = 5: 38.8 ms, 3: 30.9, 2: 25.9, 1.5: 26.0, 1: 35.9)
     size_t free_b = 0, total_b = 0;
     hipError_t e = hipMemGetInfo(&free_b, &total_b);
     if(e != hipSuccess) return e;
@@ -59,7 +51,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         table_entries += 3 * cells;
         max_cells = std::max(max_cells, cells);
     }
-    static const bool table_off = std::getenv("COATI_HIP_SAMPLE_TABLE") != nullptr && std::getenv("COATI_HIP_SAMPLE_TABLE")[0] == '0';
+    const bool table_off = env_options().sample_table_off;
     const uint64_t table_bytes = table_entries * step_entry_bytes();
     const bool use_table = m->gap_len == 1 && !forward_fast_math() && !table_off && table_bytes <= (8ull << 30) && table_bytes <= free_b / 3 &&
                            b->desc[0].f_compact == 0;
@@ -288,7 +280,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         throw;
     }
 #undef S_TRY
-    if(std::getenv("COATI_HIP_TIMING") != nullptr)
+    if(env_options().timing)
         std::fprintf(stderr, "sampleback_speculative: %llu rounds, %llu candidate walks for %llu samples\n",
                      static_cast<unsigned long long>(dbg_rounds), static_cast<unsigned long long>(dbg_cands),
                      static_cast<unsigned long long>(n * n_samples));
@@ -393,7 +385,7 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
         }
         // exact stream with several samples per pair: walked in parallel by speculating the stream
         // offsets (identical results); COATI_HIP_SAMPLE_SEQUENTIAL=1 keeps the one-walker-per-pair loop
-        static const bool sequential = std::getenv("COATI_HIP_SAMPLE_SEQUENTIAL") != nullptr;
+        const bool sequential = env_options().sample_sequential;
         if(!independent_streams && n_samples >= 4 && !sequential) {
             if((e = sampleback_speculative(b, n_samples, rng_state, base, d_ops, d_start, d_len, d_lw, states.data())) != hipSuccess) return e;
             if((e = hipMemcpy(d_states, states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) return e;

@@ -1342,10 +1342,7 @@ struct CkShape {
 CkShape ck_launch_shape(uint32_t n_items, bool shared_tab) {
     const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
     const int max_blocks = shared_tab ? 4 : 3;  // wavefronts per SIMD: <= 128 VGPRs -> 4; per-wavefront tables (12.4 KB each): 12 per CU
-    static const int forced = [] {
-        const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
-        return e != nullptr ? std::atoi(e) : 0;
-    }();
+    const int forced = env_options().fill_blocks_per_cu;
     int best = static_cast<int>(std::min<uint64_t>(max_blocks, (static_cast<uint64_t>(n_items) + kSimds - 1) / kSimds));
     best = std::max(best, 1);
     if(forced >= 1 && forced <= max_blocks) best = forced;
@@ -1376,18 +1373,8 @@ extern "C" int coati_hip_debug_trace(unsigned long long* out) {
 uint32_t ck_scratch_waves() { return 256u * 4u * 4u; }  // 4 wavefronts on each of the 1 024 SIMDs
 uint64_t ck_scratch_dwords_per_wave() { return kCkScratchDwords; }
 
-// Half width of the kept checkpoint band in wavefront steps (COATI_HIP_CK_BAND; 0 = keep everything).  Default 96:
-// a lane keeps 13 of a 1 kb pair's 67 bands, the path may stray ~70 rows from the straight line before a pair is
-// filled twice.
-uint32_t ck_band_setting() {
-    static const uint32_t v = [] {
-        const char* e = std::getenv("COATI_HIP_CK_BAND");
-        if(e == nullptr) return 96u;
-        const long x = std::atol(e);
-        return x <= 0 ? kCkBandOff : static_cast<uint32_t>(x);
-    }();
-    return v;
-}
+// (the default half width of the kept checkpoint band -- COATI_HIP_CK_BAND, else 96 steps: a lane keeps 13 of a 1 kb pair's 67
+// bands -- is ck_band_setting() in abi.hip, from the process' options)
 
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
     hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch
@@ -1400,10 +1387,7 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     }
     const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
-    static const uint32_t dbg = [] {
-        const char* e = std::getenv("COATI_HIP_CK_DEBUG");
-        return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
-    }();
+    const uint32_t dbg = env_options().ck_debug;
     // (the debug export of every cell's decisions decodes every tile: that batch keeps every checkpoint)
     const uint32_t band = v.ck_band;
     const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck<true>) : reinterpret_cast<const void*>(viterbi_ck<false>);

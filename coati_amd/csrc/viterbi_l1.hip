@@ -381,10 +381,7 @@ struct FillShape {
 FillShape fill_launch_shape(uint32_t n_items) {
     const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
     constexpr int kMaxBlocks = 3;  // <= 168 VGPRs -> 3 waves per SIMD
-    static const int forced = [] {
-        const char* e = std::getenv("COATI_HIP_FILL_BLOCKS_PER_CU");
-        return e != nullptr ? std::atoi(e) : 0;
-    }();
+    const int forced = env_options().fill_blocks_per_cu;
     int best = static_cast<int>(std::min<uint64_t>(kMaxBlocks, (static_cast<uint64_t>(n_items) + kSimds - 1) / kSimds));
     best = std::max(best, 1);
     if(forced >= 1 && forced <= kMaxBlocks) best = forced;
@@ -416,7 +413,7 @@ hipError_t launch_viterbi_l1(const BatchDeviceView& v, hipStream_t stream) {
     if(e != hipSuccess) return e;
     // strip boundaries: self-validating values (fill_strip) unless COATI_HIP_L1_PROGRESS=1 asks for the progress-word
     // protocol (A/B; 160 kb pair: 87.5 -> 85.2 ms with the 0.35 ms fill of the 800 MB of boundary arrays included)
-    static const bool sentinel = std::getenv("COATI_HIP_L1_PROGRESS") == nullptr;
+    const bool sentinel = !env_options().l1_progress;
     if(sentinel && v.bnd_bytes != 0) {
         e = hipMemsetAsync(v.bnd, 0xff, v.bnd_bytes, stream);
         if(e != hipSuccess) return e;

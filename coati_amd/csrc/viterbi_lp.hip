@@ -483,15 +483,12 @@ hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
     }
     const uint32_t kCUs = device_cu_count(), kSimds = kCUs * 4;
     int best = static_cast<int>(std::clamp<uint64_t>((static_cast<uint64_t>(v.n_items) + kSimds - 1) / kSimds, 1, 3));
-    if(const char* e = std::getenv("COATI_HIP_LP_BLOCKS_PER_CU")) best = std::clamp(std::atoi(e), 1, 3);  // (experiment)
+    if(env_options().lp_blocks_per_cu != 0) best = std::clamp(env_options().lp_blocks_per_cu, 1, 3);  // (COATI_HIP_LP_BLOCKS_PER_CU: experiment)
     constexpr size_t kStatic = kFillWaves * kTabRows * kTabStride * sizeof(float);
     constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 52 * 1024};
     // one workgroup per CU: the dynamic LDS holds a pair table per wavefront (99.6 KB, which also keeps a second workgroup
     // off the CU); more: padding only, single-column gathers.  COATI_HIP_LP_PAIRTAB=0: never (A/B)
-    static const bool pair_ok = [] {
-        const char* e = std::getenv("COATI_HIP_LP_PAIRTAB");
-        return !(e != nullptr && e[0] == '0');
-    }();
+    const bool pair_ok = !env_options().lp_pairtab_off;
     const bool pair_tables = best == 1 && pair_ok;
     const size_t dyn = pair_tables ? static_cast<size_t>(kFillWaves) * kTabRows * kLpPairStride : kPerBlock[best] - ((kStatic + 255) / 256) * 256;
     if(dyn > 48 * 1024) {

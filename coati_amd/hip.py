@@ -54,6 +54,7 @@ EXPORTS = (
     "coati_hip_host_alloc",
     "coati_hip_host_free",
     "coati_hip_debug_viterbi_flags",
+    "coati_hip_debug_reload_env",
 )
 
 
@@ -129,6 +130,14 @@ def load() -> C.CDLL:
         lib.coati_hip_host_free.restype = None
     _lib = lib
     return lib
+
+
+def reload_env() -> None:
+    """The library reads its COATI_HIP_* switches once per process; this plumbing (tests, tools that flip a switch between two
+    batches of one process) has it read them again before every entry that consults them."""
+    lib = load()
+    if hasattr(lib, "coati_hip_debug_reload_env"):
+        lib.coati_hip_debug_reload_env()
 
 
 def _check(rc: int) -> None:
@@ -211,6 +220,7 @@ class Model:
             table = table[None]
         if table.ndim != 3 or table.shape[1:] != (TABLE_ROWS, TABLE_COLS):
             raise ValueError("table must be 183x15 or n x 183 x 15")
+        reload_env()
         self._h = C.c_void_p()
         self.gap_len = gap_len
         self.device = device
@@ -263,6 +273,7 @@ class Model:
         """One-shot coati_hip_viterbi_batch.  Returns (scores, ops, ops_off, ops_len); `out` may pass
         the four arrays of an earlier call back in (a loop over batches then writes into memory whose
         pages exist already -- first-touch page faults are half the cost of downloading the ops)."""
+        reload_env()
         n = len(a_off) - 1
         total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
         if out is not None and len(out[0]) == n and len(out[1]) >= max(total, 1):
@@ -284,6 +295,7 @@ class Batch:
     """coati_hip_batch_t: encoded pairs + workspace resident in HBM."""
 
     def __init__(self, model: Model, a_cat, a_off, b_cat, b_off, table_index=None):
+        reload_env()
         self.model = model
         self.n = len(a_off) - 1
         self.ops_total = int(a_off[-1] - a_off[0] + b_off[-1] - b_off[0])
@@ -324,6 +336,7 @@ class Batch:
         return int(load().coati_hip_batch_device_bytes(self._h))
 
     def viterbi_launch(self):
+        reload_env()
         _check(load().coati_hip_viterbi_launch(self._h))
 
     def sync(self):
@@ -355,6 +368,7 @@ class Batch:
         return int(band.value), int(twice.value)
 
     def forward_launch(self):
+        reload_env()
         _check(load().coati_hip_forward_launch(self._h))
 
     def forward_final(self):
@@ -375,6 +389,7 @@ class Batch:
     def sampleback(self, n_samples: int, rng_states, independent: bool = False):
         """rng_states: (n, 2) uint64 (lo, hi).  Returns (log_weights (n, S), ops, ops_off (n, S), ops_len (n, S),
         rng_states_out)."""
+        reload_env()
         st = np.ascontiguousarray(rng_states, np.uint64).reshape(self.n, 2)
         total = int(n_samples * self.lens.sum())
         lw = np.zeros((self.n, n_samples), np.float32)
@@ -395,6 +410,7 @@ class Batch:
         return sc.value, ops.value, int(nbytes.value), off.value, ln.value
 
     def debug_flags(self, pair: int):
+        reload_env()
         la, lb = self.lens[pair]
         out = np.zeros((int(la), int(lb)), np.uint8)
         if out.size:

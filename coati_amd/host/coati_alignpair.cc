@@ -9,10 +9,12 @@
 #include <stdexcept>
 #include <string>
 #include <sys/wait.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
 #include "cli.hpp"
+#include "coati_hip.h"
 
 extern char** environ;
 
@@ -84,6 +86,18 @@ int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
 
 int main(int argc, char* argv[]) {
     using namespace coati_amd;
+    // The HIP runtime takes 0.06-0.3 s to come up in a fresh process (it is most of a 10 000-pair run): for a batch run on
+    // one device start it NOW, on a thread of its own, before the arguments are parsed and the model's matrix exponentials
+    // are computed.  (Not in the --devices launcher, which must never touch HIP, see launch_ranks.)
+    {
+        bool batch = false, launcher = false;
+        for(int i = 1; i < argc; ++i) {
+            const std::string a = argv[i];
+            batch = batch || a == "--batch";
+            launcher = launcher || a == "--devices";
+        }
+        if(batch && !launcher) std::thread([] { (void)coati_hip_device_count(); }).detach();
+    }
     args_t args;
     try {
         args = parse_arguments(verb_t::alignpair, argc, argv);

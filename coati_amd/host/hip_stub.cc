@@ -29,6 +29,7 @@ int coati_hip_viterbi_fetch(coati_hip_batch_t*, float*, uint8_t*, uint64_t, uint
 int coati_hip_viterbi_last_timing(coati_hip_batch_t*, float*, float*) { return kNo; }
 int coati_hip_viterbi_band_stats(coati_hip_batch_t*, uint32_t*, uint64_t*) { return kNo; }
 int coati_hip_model_prepare(coati_hip_model_t*, uint64_t, uint64_t, uint64_t) { return kNo; }
+void coati_hip_debug_reload_env(void) {}
 int coati_hip_viterbi_timing(coati_hip_batch_t*, uint32_t, float*, float*) { return kNo; }
 int coati_hip_batch_result_ptrs(coati_hip_batch_t*, void**, void**, uint64_t*, void**, void**) { return kNo; }
 int coati_hip_forward_launch(coati_hip_batch_t*) { return kNo; }

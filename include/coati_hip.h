@@ -269,6 +269,10 @@ int coati_hip_shard_bounds(uint64_t n_pairs, const uint64_t* a_off, const uint64
 int coati_hip_host_alloc(uint64_t bytes, void** out);
 void coati_hip_host_free(void* p);
 
+/* The library reads its COATI_HIP_* environment switches (A/B, test and experiment knobs; csrc/common.hpp: EnvOptions)
+ * ONCE per process, on first use.  This reads them again: for test harnesses that switch kernels within one process. */
+void coati_hip_debug_reload_env(void);
+
 /* Parity/debug export: the per-cell traceback decision byte of pair `pair`
  * (bits 0-1 state after a match move arrives at the cell, bits 2-3 after a
  * deletion move, bit 4 after an insertion move) for the len_a x len_b BODY

@@ -35,6 +35,8 @@ while time.time() < t_end:
         w = str(rng.choice(["", "", "2", "4"]))
         if w:
             os.environ["COATI_HIP_STRIP_W"] = w
+        if rng.random() < 0.5:  # ... the single-column gathers (the library re-reads its switches per entry of this plumbing)
+            os.environ["COATI_HIP_LP_PAIRTAB"] = "0"
     if forced == "l1":  # the decision-bit kernel it replaced there
         os.environ["COATI_HIP_VITERBI_BITS"] = "1"
         os.environ["COATI_HIP_L1_LP"] = "0"
