@@ -661,7 +661,7 @@ constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
 
 // COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
 // pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
-__device__ unsigned long long g_ck_stats[5];  // rounds, valid tiles, walker iterations, pairs, pairs filled twice (left the kept band)
+__device__ unsigned long long g_ck_stats[8];  // rounds, valid tiles, walker iterations, pairs, pairs filled twice (left the kept band), hand-overs of row parts, their waits in 10 ns, waits longer than 10 us
 
 // State the walk is in after a move of kind `moved` arrives at body cell (bi, bj): from the
 // round's recomputed bits, or kWalkUnknown.
@@ -900,8 +900,15 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
             ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
             if(part > 0) {
+                const unsigned long long t_wait = (dbg & 2u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 handoff_ok = wait_progress(progress + ticket - split_items, kbegin);  // (acquires)
                 if(__hip_atomic_load(progress + ticket - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+                if((dbg & 2u) && lane == 0) {  // (statistics: how long did this part wait for its predecessor? 100 MHz clock)
+                    const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t_wait;
+                    atomicAdd(&g_ck_stats[5], 1ull);
+                    atomicAdd(&g_ck_stats[6], waited);
+                    if(waited > 1000ull) atomicAdd(&g_ck_stats[7], 1ull);
+                }
             }
         }
         // banded checkpoints (above): whole single-strip pairs of the full-width shape only; the second time round
@@ -1404,13 +1411,15 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
                            v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg, band);
     if(dbg & 2u) {
-        unsigned long long st[5] = {0, 0, 0, 0, 0}, zero[5] = {0, 0, 0, 0, 0};
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         e = hipStreamSynchronize(stream);
         if(e == hipSuccess) e = hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ck_stats), sizeof st);
         if(e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ck_stats), zero, sizeof zero);
         if(e != hipSuccess) return e;
-        std::fprintf(stderr, "viterbi_ck: %llu pairs, %.2f rounds/pair, %.1f valid tiles/round, %.1f walker iterations/pair, %llu pairs filled twice (band %u)\n", st[3],
-                     st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0, st[4], band);
+        std::fprintf(stderr, "viterbi_ck: %llu pairs, %.2f rounds/pair, %.1f valid tiles/round, %.1f walker iterations/pair, %llu pairs filled twice (band %u); "
+                     "%llu row-part hand-overs waited %.1f us on average, %llu of them more than 10 us (%.1f wavefront-ms in all)\n", st[3],
+                     st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0, st[4], band, st[5],
+                     st[5] ? double(st[6]) / st[5] / 100.0 : 0.0, st[7], double(st[6]) / 1e5);
     }
     return hipGetLastError();
 }
