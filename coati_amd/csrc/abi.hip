@@ -82,6 +82,7 @@ const EnvOptions* read_env() {
     o->l1_progress = set("COATI_HIP_L1_PROGRESS");
     o->ck_per_pair = set("COATI_HIP_CK_PER_PAIR");
     o->stream_parts = set("COATI_HIP_STREAM_PARTS");
+    o->stream_helpers = static_cast<int>(num("COATI_HIP_STREAM_HELPERS", 7));
     o->pipe_no_d2h = set("COATI_HIP_PIPE_NO_D2H");
     o->sample_sequential = set("COATI_HIP_SAMPLE_SEQUENTIAL");
     o->sample_table_off = zero("COATI_HIP_SAMPLE_TABLE");
@@ -333,6 +334,7 @@ int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float n
 namespace {
 void model_release(coati_hip_model* m) {
     if(m->refs.fetch_sub(1) != 1) return;  // batches (or the handle) still hold it
+    m->helpers.reset();
     (void)hipSetDevice(m->device);
     for(const auto& a : m->free_arenas) (void)hipFree(a.ptr);
     for(auto& sl : m->slots) {

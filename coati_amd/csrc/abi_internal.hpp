@@ -15,7 +15,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <future>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <sched.h>
 #include <new>
 #include <string>
@@ -23,6 +29,57 @@
 #include <vector>
 
 using namespace coati_hip_detail;
+
+/* A few helper threads that live as long as their model (started by the first call that wants them): the streamed call
+ * plans its first chunks on them.  Creating a thread per task (std::async) cost ~40 us each on the calling thread --
+ * as much as planning the chunk -- waking a sleeping one ~5 us. */
+class HelperPool {
+  public:
+    explicit HelperPool(int n) {
+        for(int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); });
+    }
+    ~HelperPool() {
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for(std::thread& t : threads_) t.join();
+    }
+    HelperPool(const HelperPool&) = delete;
+    HelperPool& operator=(const HelperPool&) = delete;
+    template<class F>
+    auto submit(F f) -> std::future<decltype(f())> {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::move(f));
+        auto fut = task->get_future();
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            tasks_.emplace_back([task] { (*task)(); });
+        }
+        wake_.notify_one();
+        return fut;
+    }
+
+  private:
+    void run() {
+        for(;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(lock_);
+                wake_.wait(g, [this] { return stop_ || !tasks_.empty(); });
+                if(tasks_.empty()) return;  // (stop_)
+                job = std::move(tasks_.front());
+                tasks_.pop_front();
+            }
+            job();
+        }
+    }
+    std::mutex lock_;
+    std::condition_variable wake_;
+    std::deque<std::function<void()>> tasks_;
+    std::vector<std::thread> threads_;
+    bool stop_ = false;
+};
 
 struct coati_hip_model {
     int device = 0;
@@ -77,12 +134,13 @@ struct coati_hip_model {
     size_t stream_tail_bytes = 0;
     void* d_stream_waves = nullptr;  // per-wavefront checkpoint slots + traceback scratch, shared by all chunks of a call
     size_t stream_waves_bytes = 0;
-    hipEvent_t stream_events[kCkStreamSlots + 1] = {};  // [slot]: its download is done; [last]: an upload is done
+    hipEvent_t stream_events[2 * kCkStreamSlots] = {};  // [slot]: its download is done; [kCkStreamSlots + slot]: its upload is done
     std::mutex pipeline_lock;  // one pipelined call at a time per model
     uint32_t stream_calls = 0;     // streamed calls this model has served (the first one allocates lazily: a one-shot process pays for what it uses)
     bool stream_unusable = false;  // the persistent kernel's first upload did not arrive in time once (copies not on the copy engine): never again on this model
     uint32_t ck_band = 96;  // viterbi_ck: half width of the kept checkpoint band, kCkBandOff = keep everything (COATI_HIP_OPT_CK_BAND; default: ck_band_setting())
     bool stream_forbidden = false;  // coati_hip_model_set_option(COATI_HIP_OPT_PERSISTENT_CALL, 0): the embedder shares the GPU
+    std::unique_ptr<HelperPool> helpers;  // the streamed call's planning helpers (pipeline.hip), made by its first use or by coati_hip_model_prepare
 };
 
 struct coati_hip_batch {

@@ -4,6 +4,10 @@
 // (viterbi_batch_stream) and one launch per chunk over three slots.
 #include "abi_internal.hpp"
 
+#include <future>
+#include <string>
+#include <utility>
+
 using namespace coati_hip_abi;
 
 namespace {
@@ -169,21 +173,40 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
         for(int q = 0; q < kSlots; ++q)
             if(model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= kSlotStaging) n_slots = std::max(n_slots, q + 1);
     }
-    for(int q = 0; q < n_slots; ++q) {
+    // (a fresh process page-locks at ~4 GB/s and maps fresh HBM at ~10 GB/s: the slots are made side by side on the
+    // model's helper threads -- the first call of a model is mostly this)
+    if(!model->helpers) model->helpers = std::make_unique<HelperPool>(3);
+    auto make_slot = [model, kSlotStaging](int q) -> bool {
         auto& ss = model->sslots[q];
+        if(hipSetDevice(model->device) != hipSuccess) return false;
         if(ss.arena_bytes < kSlotArena) {
             if(ss.arena != nullptr) (void)hipFree(ss.arena);
             ss.arena = nullptr;
             ss.arena_bytes = 0;
-            if(!soft(hipMalloc(&ss.arena, kSlotArena))) return COATI_HIP_ESTATE;
+            if(hipMalloc(&ss.arena, kSlotArena) != hipSuccess) return false;
             ss.arena_bytes = kSlotArena;
         }
         if(ss.pinned_bytes < kSlotStaging) {
             if(ss.pinned != nullptr) (void)hipHostFree(ss.pinned);
             ss.pinned = nullptr;
             ss.pinned_bytes = 0;
-            if(!soft(hipHostMalloc(&ss.pinned, kSlotStaging, hipHostMallocDefault))) return COATI_HIP_ESTATE;
+            if(hipHostMalloc(&ss.pinned, kSlotStaging, hipHostMallocDefault) != hipSuccess) return false;
             ss.pinned_bytes = kSlotStaging;
+        }
+        return true;
+    };
+    {
+        std::vector<std::future<bool>> made;
+        bool all = true;
+        auto ready = [&](int q) { return model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= kSlotStaging; };
+        for(int q = 0; q < n_slots; ++q)
+            if(q % 4 != 3 && !ready(q) && (env_options().stream_helpers & 4) != 0) made.push_back(model->helpers->submit([make_slot, q] { return make_slot(q); }));
+        for(int q = 0; q < n_slots; ++q)  // (this thread takes its share)
+            if((q % 4 == 3 || (env_options().stream_helpers & 4) == 0) && !ready(q)) all = make_slot(q) && all;
+        for(auto& m : made) all = m.get() && all;
+        if(!all) {
+            (void)hipGetLastError();
+            return COATI_HIP_ESTATE;
         }
     }
     alloc_stage("stream slots ready", static_cast<uint64_t>(n_slots) * (kSlotArena + kSlotStaging));
@@ -254,12 +277,21 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         for(void*& t : model->stream_tail_arena) ok = ok && soft(hipMalloc(&t, tail_bytes));
         if(ok) model->stream_tail_bytes = tail_bytes;  // (else: no row parts in this call)
     }
+    if((env_options().stream_helpers & 8) != 0) {
+        std::fprintf(stderr, "viterbi_batch[stream]: begin (%llu pairs, %d slots) host words %p ctl %p waves %p + %zx table %p; inputs %p %p outputs %p %p %p %p\n",
+                     static_cast<unsigned long long>(n_pairs), n_slots, model->h_stream, model->d_stream_ctl, model->d_stream_waves, model->stream_waves_bytes,
+                     static_cast<void*>(model->d_table), static_cast<const void*>(a_cat), static_cast<const void*>(b_cat), static_cast<void*>(scores),
+                     static_cast<void*>(ops), static_cast<void*>(ops_off), static_cast<void*>(ops_len));
+        for(int q = 0; q < n_slots; ++q)
+            std::fprintf(stderr, "viterbi_batch[stream]:   slot %d arena %p + %zx staging %p + %zx\n", q, model->sslots[q].arena, model->sslots[q].arena_bytes,
+                         model->sslots[q].pinned, model->sslots[q].pinned_bytes);
+    }
     void* hs = model->h_stream;
     std::memset(hs, 0, host_bytes);
     ck_stream_host_set_slots(hs, static_cast<uint32_t>(n_slots));
     void* hs_dev = nullptr;
     if(!soft(hipHostGetDevicePointer(&hs_dev, hs, 0))) return COATI_HIP_ESTATE;
-    hipEvent_t up_done = model->stream_events[kSlots];
+    hipEvent_t* uploaded = model->stream_events + kSlots;  // (recorded by whichever thread planned the chunk, right behind its copies)
     hipEvent_t* copied = model->stream_events;
     // the control block starts zeroed (before the launch a fill kernel may run)
     uint32_t* wave_ck = static_cast<uint32_t*>(model->d_stream_waves);
@@ -282,8 +314,17 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         char* out_stage = nullptr;
         uint64_t out_off = 0;
         bool ops_staged = false;
+        std::future<void> unstage;  // the chunk's results are being copied out of the staging block by a helper thread
     };
     InFlight fl[kSlots];
+    struct JoinUnstage {  // (no helper may still write the caller's arrays, or read this frame, when the call returns)
+        InFlight (&fl)[kSlots];
+        ~JoinUnstage() {
+            for(InFlight& f : fl)
+                if(f.unstage.valid()) f.unstage.wait();
+        }
+    } join_unstage{fl};
+    if(!model->helpers) model->helpers = std::make_unique<HelperPool>(3);
     int rc = COATI_HIP_OK;
     const bool pipe_timing = env_options().pipe_timing;
     auto t_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
@@ -331,23 +372,37 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
                 const hipError_t e = submit_d2h(f, q);
                 if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
             }
-            const hipError_t qd = hipEventQuery(copied[q]);
-            if(qd == hipErrorNotReady) continue;
-            if(qd != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(qd));
+            if(!f.unstage.valid()) {
+                const hipError_t qd = hipEventQuery(copied[q]);
+                if(qd == hipErrorNotReady) continue;
+                if(qd != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(qd));
+            }
             const PipeChunk& c = f.chunk;
             const uint64_t n = c.p1 - c.p0;
-            {
-                char* at = f.out_stage;
+            // out of the staging block into the caller's arrays: megabytes when the ops array is pageable (a chunk of 2 000
+            // pairs: 4 MB, 0.15-0.2 ms on one thread, and the chunks of a call's end complete together) -- on the helpers
+            auto unstage = [scores, ops, ops_off, ops_len, c, n, at0 = f.out_stage, staged = f.ops_staged]() {
+                char* at = at0;
                 if(scores != nullptr) std::memcpy(scores + c.p0, at, n * sizeof(float));
                 at += (n * sizeof(float) + 255) / 256 * 256;
-                if(ops_off != nullptr) std::memcpy(ops_off + c.p0, at, n * sizeof(uint64_t));
+                if(ops_off != nullptr) {
+                    const uint64_t* src = reinterpret_cast<const uint64_t*>(at);
+                    for(uint64_t p = 0; p < n; ++p) ops_off[c.p0 + p] = src[p] + c.ops_base;
+                }
                 at += (n * sizeof(uint64_t) + 255) / 256 * 256;
                 if(ops_len != nullptr) std::memcpy(ops_len + c.p0, at, n * sizeof(uint32_t));
                 at += (n * sizeof(uint32_t) + 255) / 256 * 256;
-                if(f.ops_staged) std::memcpy(ops + c.ops_base, at, c.ops_bytes);
+                if(staged) std::memcpy(ops + c.ops_base, at, c.ops_bytes);
+            };
+            if(f.unstage.valid()) {
+                if(f.unstage.wait_for(std::chrono::seconds(0)) != std::future_status::ready) continue;
+                f.unstage.get();
+            } else if(f.ops_staged && c.ops_bytes > (256u << 10) && (env_options().stream_helpers & 2) != 0) {
+                f.unstage = model->helpers->submit(unstage);
+                continue;
+            } else {
+                unstage();
             }
-            if(ops_off != nullptr)
-                for(uint64_t p = c.p0; p < c.p1; ++p) ops_off[p] += c.ops_base;
             if(pipe_timing)
                 std::fprintf(stderr, "viterbi_batch[stream]: chunk %u (%llu pairs) complete %.2f ms after the kernel started, on the host at %.2f ms\n",
                              f.chunk_no, static_cast<unsigned long long>(n), ck_stream_host_done_ms(hs, q), t_ms());
@@ -381,13 +436,24 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     uint64_t p0 = 0, ops_base = 0;
     long double cells_done = 0;
     int tails_used = 0;
-    for(size_t ci = 0; p0 < n_pairs && rc == COATI_HIP_OK; ++ci) {
-        const int q = static_cast<int>(ci % static_cast<size_t>(n_slots));
+    // A chunk, cut and ready to be planned.  The cutter runs AHEAD of the loop below: while this thread plans and uploads
+    // chunk ci, the model's three helper threads plan chunks ci + 1 .. ci + 3 into their (free: first lap over the slots) slots --
+    // one thread plans ~10 pairs per microsecond, so that the chip, which wants 4 096 pairs before every wavefront has one,
+    // was full only ~0.6-1.0 ms after a 10 000-pair call had started (round 4; profiles/r04/stream_timeline_10000.txt).
+    struct Ahead {
+        bool valid = false, fits = true, tail = false, planned = false;
+        int slot = 0;
+        PipeChunk c;
+        ChunkNeed nd;
+        uint64_t out_off = 0;
+        BatchOpts bo;
+        coati_hip_batch_t* batch = nullptr;
+        double t_plan0 = 0, t_plan1 = 0;  // (COATI_HIP_PIPE_TIMING)
+        std::future<std::pair<int, std::string>> task;
+    };
+    Ahead ahead[kSlots];
+    auto cut_chunk = [&](size_t ci, int q, Ahead& a) {
         coati_hip_model::StreamSlot& sl = model->sslots[q];
-        InFlight& f = fl[q];
-        const double t_begin = t_ms();
-        rc = wait_free(q);
-        if(rc != COATI_HIP_OK) break;
         const long double target = ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
         // row parts, in the large workspaces: the chunks behind the first 4 100 pairs' worth of cells, while at most
         // 8 300 pairs' worth are left
@@ -407,36 +473,100 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             nd = with;
             ++p1;
         }
-        const PipeChunk c{p0, p1, ops_base, nd.ops};
+        a.valid = true;
+        a.planned = false;
+        a.slot = q;
+        a.tail = tail;
+        a.batch = nullptr;
+        a.c = PipeChunk{p0, p1, ops_base, nd.ops};
+        a.nd = nd;
         p0 = p1;
         ops_base += nd.ops;
         cells_done += static_cast<long double>(nd.cells);
-        const uint64_t n = c.p1 - c.p0;
+        const uint64_t n = a.c.p1 - a.c.p0;
         // (the cutter takes the first pair of a chunk unseen: one that does not fit a slot ends the streamed form --
         // the kernel is closed below and the chunk pipeline, whose workspaces grow, does the call; never compute the
         // staging split from an unchecked subtraction)
-        if(staging_of(nd, n) > sl.pinned_bytes || out_bytes_of(n, c.ops_bytes) > sl.pinned_bytes ||
-           nd.arena_streamed(tail) + nd.arena_streamed(tail) / 8 + (1u << 20) > arena_bytes) {
+        a.fits = !(staging_of(nd, n) > sl.pinned_bytes || out_bytes_of(n, a.c.ops_bytes) > sl.pinned_bytes ||
+                   nd.arena_streamed(tail) + nd.arena_streamed(tail) / 8 + (1u << 20) > arena_bytes);
+        if(!a.fits) return;
+        a.out_off = (sl.pinned_bytes - out_bytes_of(n, a.c.ops_bytes)) / 256 * 256;
+        a.bo = BatchOpts{};
+        a.bo.stream = up_stream;
+        a.bo.arena = arena;
+        a.bo.arena_bytes = arena_bytes;
+        a.bo.staging = static_cast<char*>(sl.pinned);
+        a.bo.staging_bytes = a.out_off;
+        a.bo.seqs_pinned = in_pinned;
+        a.bo.force_ck = true;
+        a.bo.force_w_main = kW;  // (a small chunk is not a small batch: no narrowed strips)
+        a.bo.device_validates = true;
+        if(tail) {
+            a.bo.tail_parts = 3;
+            ++tails_used;
+        }
+        a.bo.wave_slot_dwords = wave_slot_bytes / 4;
+    };
+    auto plan_chunk = [&](Ahead& a) -> std::pair<int, std::string> {  // (this thread or a helper: the error text is thread-local)
+        if(pipe_timing) a.t_plan0 = t_ms();
+        int r = batch_create_impl(model, a.c.p1 - a.c.p0, a_cat, a_off + a.c.p0, b_cat, b_off + a.c.p0, nullptr, &a.bo, &a.batch);
+        if(r == COATI_HIP_OK) {  // the chunk's data (with its zeroed progress words) is on its way; once it is in HBM the kernel may know
+            if(const hipError_t e = hipEventRecord(uploaded[a.slot], up_stream); e != hipSuccess) r = fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+        }
+        if(pipe_timing) a.t_plan1 = t_ms();
+        return {r, r == COATI_HIP_OK ? std::string() : std::string(coati_hip_last_error())};
+    };
+    struct JoinAhead {  // whatever ends the loop: no helper thread is left running on this frame, no planned chunk is leaked
+        Ahead (&ahead)[kSlots];
+        ~JoinAhead() {
+            for(Ahead& a : ahead) {
+                if(a.task.valid()) (void)a.task.get();
+                if(a.valid && a.batch != nullptr) coati_hip_batch_destroy(a.batch);
+            }
+        }
+    } join_ahead{ahead};
+    for(size_t ci = 0; rc == COATI_HIP_OK; ++ci) {
+        const int q = static_cast<int>(ci % static_cast<size_t>(n_slots));
+        InFlight& f = fl[q];
+        const double t_begin = t_ms();
+        rc = wait_free(q);
+        if(rc != COATI_HIP_OK) break;
+        Ahead& a = ahead[q];
+        if(!a.valid) {
+            if(p0 >= n_pairs) break;
+            cut_chunk(ci, q, a);
+        }
+        if(!a.fits) {
+            a.valid = false;
             rc = kRedo;
             break;
         }
-        const uint64_t out_off = (sl.pinned_bytes - out_bytes_of(n, c.ops_bytes)) / 256 * 256;
-        BatchOpts bo;
-        bo.stream = up_stream;
-        bo.arena = arena;
-        bo.arena_bytes = arena_bytes;
-        bo.staging = static_cast<char*>(sl.pinned);
-        bo.staging_bytes = out_off;
-        bo.seqs_pinned = in_pinned;
-        bo.force_ck = true;
-        bo.force_w_main = kW;  // (a small chunk is not a small batch: no narrowed strips)
-        bo.device_validates = true;
-        if(tail) {
-            bo.tail_parts = 3;
-            ++tails_used;
+        const PipeChunk c = a.c;
+        const ChunkNeed nd = a.nd;
+        const uint64_t n = c.p1 - c.p0, out_off = a.out_off;
+        const double t_cut = t_ms();
+        // this chunk first (its copies enter the upload stream ahead of the helpers': the kernel is waiting for THIS one),
+        // then the look-ahead, then -- if a helper had this chunk -- its result
+        std::pair<int, std::string> planned{COATI_HIP_OK, std::string()};
+        const bool was_ahead = a.task.valid();
+        if(!was_ahead) planned = plan_chunk(a);
+        if(!tail_parts_on && planned.first == COATI_HIP_OK && (env_options().stream_helpers & 1) != 0) {
+            for(size_t k = 1; k <= 3 && ci + k < static_cast<size_t>(n_slots) && p0 < n_pairs; ++k) {
+                const int q2 = static_cast<int>((ci + k) % static_cast<size_t>(n_slots));
+                Ahead& a2 = ahead[q2];
+                if(a2.valid || fl[q2].batch != nullptr) continue;
+                cut_chunk(ci + k, q2, a2);
+                if(a2.fits) a2.task = model->helpers->submit([&plan_chunk, &a2]() { return plan_chunk(a2); });
+            }
         }
-        bo.wave_slot_dwords = wave_slot_bytes / 4;
-        rc = batch_create_impl(model, n, a_cat, a_off + c.p0, b_cat, b_off + c.p0, nullptr, &bo, &f.batch);
+        if(was_ahead) planned = a.task.get();
+        {
+            rc = planned.first;
+            f.batch = a.batch;
+            a.batch = nullptr;
+            a.valid = false;
+            if(rc != COATI_HIP_OK) (void)fail(rc, "%s", planned.second.c_str());
+        }
         if(rc != COATI_HIP_OK) {  // (ENOMEM: the slot's workspace cannot grow while the kernel runs)
             if(pipe_timing)
                 std::fprintf(stderr, "viterbi_batch[stream]: chunk %zu of %llu pairs: estimate %llu bytes (fixed %llu, own checkpoints %llu)\n", ci,
@@ -453,8 +583,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         f.chunk_no = static_cast<uint32_t>(ci);
         f.d2h_submitted = false;
         f.out_off = out_off;
-        // the chunk's data (with its zeroed progress words) is on its way; once it is in HBM the kernel may know
-        hipError_t e = hipEventRecord(up_done, up_stream);
+        hipError_t e = hipSuccess;
         ck_stream_fill_chunk(hs, hs_dev, q, b->arena, device_view(b), static_cast<uint32_t>(n), published, static_cast<uint32_t>(ci));
         // Every copy under the persistent kernel must be done by the copy ENGINE: a copy the runtime does with a blit
         // kernel (HSA_ENABLE_SDMA=0, or its own choice) cannot start while viterbi_ck_stream holds every wavefront
@@ -465,7 +594,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             const auto t_up = std::chrono::steady_clock::now();
             const double bound_ms = ci == 0 ? 100.0 : 5000.0;
             for(uint64_t spins = 0;; ++spins) {
-                e = hipEventQuery(up_done);
+                e = hipEventQuery(uploaded[q]);
                 if(e != hipErrorNotReady) break;
                 if(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count() > bound_ms) break;
                 if(spins > 256) sched_yield();
@@ -485,8 +614,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         published += b->n_items;
         ck_stream_host_announce(hs, static_cast<uint32_t>(ci) + 1u, published);
         if(pipe_timing)
-            std::fprintf(stderr, "viterbi_batch[stream]: chunk %zu (%llu pairs, %u items, slot %d) planned + uploaded %.2f .. %.2f ms\n", ci,
-                         static_cast<unsigned long long>(n), b->n_items, q, t_begin, t_ms());
+            std::fprintf(stderr, "viterbi_batch[stream]: chunk %zu (%llu pairs, %u items, slot %d) planned + uploaded %.2f .. %.2f ms (cut by %.2f, planned %.2f .. %.2f)\n", ci,
+                         static_cast<unsigned long long>(n), b->n_items, q, t_begin, t_ms(), t_cut, a.t_plan0, a.t_plan1);
         rc = progress();
     }
     ck_stream_host_close(hs);
@@ -504,7 +633,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             f.batch = nullptr;
         }
     }
-    if(pipe_timing) std::fprintf(stderr, "viterbi_batch[stream]: done at %.2f ms\n", t_ms());
+    if(pipe_timing || (env_options().stream_helpers & 8) != 0) std::fprintf(stderr, "viterbi_batch[stream]: done at %.2f ms (rc %d, %llu pairs)\n", t_ms(), rc, static_cast<unsigned long long>(n_pairs));
     if(rc == kRedo) {
         // a pair or an upload the streamed form cannot serve: the chunk pipeline does the call -- unless the stream itself
         // failed on top of it (a GPU fault is the likeliest reason for an upload to miss its bound): that is the error
@@ -541,6 +670,7 @@ int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t
         const long double cells = static_cast<long double>(n_pairs) * static_cast<long double>(len_a) * static_cast<long double>(len_b);
         const uint64_t staging = stream_staging_need(n_pairs, cells, n_pairs * (len_a + len_b), len_a + len_b, 1000.0L * 1002 * 1002);
         (void)stream_reserve(model, len_b <= static_cast<uint64_t>(kStrip) ? len_a : 0, cells, staging, &wave_slot_bytes, &n_slots, &unit);  // (a failed allocation is the call's problem)
+        if(!model->helpers) model->helpers = std::make_unique<HelperPool>(3);
         return COATI_HIP_OK;
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "model_prepare: host allocation failed");

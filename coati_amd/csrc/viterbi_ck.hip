@@ -1078,11 +1078,24 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
                 chunks = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(fin >> 32))));
             }
             for(; mirrored != chunks; ++mirrored) {  // entries first ...
+                // An entry changes under the eyes of workers that are looking for THEIR chunk (their own entry is complete:
+                // `published` covers a ticket only after its entry is in memory -- but the lookup reads every entry).  A
+                // worker that read the old first_ticket and the new n_items of a slot took it for its own (first lap: old
+                // = 0, so every ticket below n_items matched), indexed the slot's work items with ticket - first_ticket =
+                // -1 ... and the GPU faulted (seen once the host announced chunks 50 us apart, round 4).  So n_items is 0
+                // while the rest of the entry changes, and is written last; the lookup reads n_items first and reads twice.
                 const uint32_t q = mirrored % n_slots;
+                constexpr int kCountWord = static_cast<int>(offsetof(CkStreamChunk, n_items) / 4);
+                uint32_t* const entry = reinterpret_cast<uint32_t*>(&ctl->chunk[q]);
+                if(lane_id == kCountWord) __hip_atomic_store(entry + lane_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t v = 0;
                 if(lane_id < static_cast<int>(sizeof(CkStreamChunk) / 4)) {
-                    const uint32_t v = sys_load(reinterpret_cast<const uint32_t*>(&host->chunk[q]) + lane_id);
-                    __hip_atomic_store(reinterpret_cast<uint32_t*>(&ctl->chunk[q]) + lane_id, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = sys_load(reinterpret_cast<const uint32_t*>(&host->chunk[q]) + lane_id);
+                    if(lane_id != kCountWord) __hip_atomic_store(entry + lane_id, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if(lane_id == kCountWord) __hip_atomic_store(entry + lane_id, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if(items != last) {  // ... then the count that makes their tickets valid
@@ -1147,9 +1160,22 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         __builtin_amdgcn_s_dcache_inv();
         // ---- which chunk: the slots hold disjoint ticket ranges
         int slot = -1;
+        uint32_t candidates = 0;
 #pragma unroll
         for(int q = 0; q < kCkStreamSlots; ++q) {
             const uint32_t first = dev_load(&ctl->chunk[q].first_ticket), n = dev_load(&ctl->chunk[q].n_items);
+            if(ticket - first < n) candidates |= 1u << q;
+        }
+        // (another slot's entry may have been changing while it was read -- the pilot above: a candidate counts when a
+        // second look, its count FIRST, says the same)
+        candidates = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(candidates)));
+        while(candidates != 0u) {
+            const int q = __builtin_ctz(candidates);
+            candidates &= candidates - 1u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t n = dev_load(&ctl->chunk[q].n_items);
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(n) : "memory");
+            const uint32_t first = dev_load(&ctl->chunk[q].first_ticket);
             if(ticket - first < n) slot = q;
         }
         slot = __builtin_amdgcn_readfirstlane(slot);
