@@ -463,7 +463,8 @@ struct EnvOptions {
     bool l1_lp_off = false;          // COATI_HIP_L1_LP=0: viterbi_l1 where viterbi_lp would run
     bool l1_progress = false;        // COATI_HIP_L1_PROGRESS: progress-word boundary protocol in viterbi_l1
     bool ck_per_pair = false;        // COATI_HIP_CK_PER_PAIR: no per-wavefront checkpoint slots
-    bool stream_parts = false;       // COATI_HIP_STREAM_PARTS: row parts in the last chunks of a streamed call
+    int stream_parts = -1;           // COATI_HIP_STREAM_PARTS: -1 (default) = ONE large last chunk of a streamed call cut into 3 row parts, 22 .. 28 = into 2 .. 8,
+                                     // 0 = no row parts, 1 = row parts in the last ~1 000-pair chunks (round 3's form)
     int stream_helpers = 7;          // COATI_HIP_STREAM_HELPERS (A/B): 1 = chunks planned ahead, 2 = results unstaged, 4 = slots allocated on the model's helper threads
     bool pipe_no_d2h = false;        // COATI_HIP_PIPE_NO_D2H: chunk pipeline without downloads (timing experiment)
     bool sample_sequential = false;  // COATI_HIP_SAMPLE_SEQUENTIAL: one serial walker per pair

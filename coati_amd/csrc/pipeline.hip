@@ -115,6 +115,29 @@ uint64_t stream_staging_need(uint64_t n_pairs, long double total_cells, uint64_t
     const uint64_t step = 4ull << 20;
     return std::min<uint64_t>(kStreamSlotStaging, std::max<uint64_t>(step, (est + step - 1) / step * step));
 }
+// The streamed call's last chunk (viterbi_batch_stream: "ONE last chunk"): at most kBigTailUnits units of cells, its pairs cut
+// into row parts that keep their own checkpoints (1.09 MB per 1 kb pair) -- one workspace of ~3 GB, kept on the model.
+constexpr long double kBigTailUnits = 2.6L;
+int stream_big_tail_parts() {  // 0 = off
+    const int v = env_options().stream_parts;
+    return v < 0 ? 3 : (v >= 22 && v <= 28) ? v - 20 : 0;
+}
+uint64_t stream_big_tail_bytes(uint64_t wave_slot_bytes) {
+    return std::min<uint64_t>(8ull << 30, static_cast<uint64_t>(kBigTailUnits * 1040) * (wave_slot_bytes + 4096) + (64ull << 20));
+}
+void stream_reserve_big_tail(coati_hip_model_t* model, uint64_t wave_slot_bytes) {  // (a failed allocation: the call runs without row parts)
+    const uint64_t big = stream_big_tail_bytes(wave_slot_bytes);
+    if(model->stream_tail_bytes >= big && model->stream_tail_arena[0] != nullptr) return;
+    for(void*& t : model->stream_tail_arena) {
+        if(t != nullptr) (void)hipFree(t);
+        t = nullptr;
+    }
+    model->stream_tail_bytes = 0;
+    if(hipMalloc(&model->stream_tail_arena[0], big) == hipSuccess)
+        model->stream_tail_bytes = big;
+    else
+        (void)hipGetLastError();
+}
 int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long double total_cells, uint64_t staging_need, uint64_t* wave_slot_bytes_out,
                    int* n_slots_out, long double* unit_cells_out) {
     constexpr int kSlots = kCkStreamSlots;
@@ -263,11 +286,20 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // page-locked arrays: 10 000 pairs 5.15 -> 4.92 ms, 40 000 pairs 16.55 -> 15.93 ms without them).  A resident batch
     // keeps its row parts: there a part's predecessor is >= 4 096 tickets back.  COATI_HIP_STREAM_PARTS=1 turns them on
     // (tests, A/B).
-    const bool tail_parts_on = env_options().stream_parts;
-    // (a model's FIRST call on a small input runs without them: 2 x 1.4 GB of fresh allocation cost a one-shot process
-    // ~30 ms)
+    const bool tail_parts_on = env_options().stream_parts == 1;
+    // Round 4: ONE last chunk instead -- everything behind the first ~7 400 pairs' worth of a call, at most kBigTailUnits
+    // units (2 600 pairs of 1 kb), cut into three row parts in part-major order: a part's predecessor is then ~2 500 tickets
+    // back, which the 4 096 wavefronts take ~1 ms to draw while a part takes ~0.6 ms.  Page-locked arrays, same process:
+    // 10 000 pairs 4.93 -> 4.65 ms, 12 000 6.57 -> 5.95, 20 000 9.60 -> 9.42, 40 000 15.77 -> 15.72; a tail of 3 600 or
+    // 4 600 pairs loses again (tools/stream_tail_ab.py, profiles/r04/stream_tail_ab.txt).  Default; COATI_HIP_STREAM_PARTS=0
+    // = no row parts, 22 .. 28 = 2 .. 8 parts.
+    const int big_tail_parts = stream_big_tail_parts();
+    const bool big_tail_on = big_tail_parts != 0;
+    // (a model's FIRST call runs without either unless coati_hip_model_prepare made the workspace: ~3 GB of fresh hipMalloc
+    // cost a one-shot process ~30 ms, ten times what the row parts save)
     const bool want_tails = tail_parts_on && (model->stream_calls > 0 || total_cells >= 30 * kUnitCells);
-    if(want_tails && model->stream_tail_bytes < tail_bytes) {
+    if(big_tail_on && total_cells >= 6 * kUnitCells && model->stream_calls > 0) stream_reserve_big_tail(model, wave_slot_bytes);
+    if(want_tails && (model->stream_tail_bytes < tail_bytes || model->stream_tail_arena[coati_hip_model::kStreamTails - 1] == nullptr)) {
         for(void*& t : model->stream_tail_arena) {
             if(t != nullptr) (void)hipFree(t);
             t = nullptr;
@@ -454,11 +486,13 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     Ahead ahead[kSlots];
     auto cut_chunk = [&](size_t ci, int q, Ahead& a) {
         coati_hip_model::StreamSlot& sl = model->sslots[q];
-        const long double target = ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
+        const bool big_tail = big_tail_on && ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= kBigTailUnits * kUnit && tails_used == 0 &&
+                              model->stream_tail_bytes >= stream_big_tail_bytes(wave_slot_bytes) && model->stream_tail_arena[0] != nullptr;
+        const long double target = big_tail ? total_cells : ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
         // row parts, in the large workspaces: the chunks behind the first 4 100 pairs' worth of cells, while at most
         // 8 300 pairs' worth are left
-        const bool tail = ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= 8.3L * kUnit &&
-                          tails_used < coati_hip_model::kStreamTails && model->stream_tail_bytes != 0 && tail_parts_on;
+        const bool tail = big_tail || (ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= 8.3L * kUnit &&
+                                       tails_used < coati_hip_model::kStreamTails && model->stream_tail_bytes != 0 && tail_parts_on);
         void* const arena = tail ? model->stream_tail_arena[tails_used] : sl.arena;
         const uint64_t arena_bytes = tail ? model->stream_tail_bytes : sl.arena_bytes;
         ChunkNeed nd;
@@ -502,7 +536,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         a.bo.force_w_main = kW;  // (a small chunk is not a small batch: no narrowed strips)
         a.bo.device_validates = true;
         if(tail) {
-            a.bo.tail_parts = 3;
+            a.bo.tail_parts = big_tail_on ? static_cast<uint32_t>(big_tail_parts) : 3;
             ++tails_used;
         }
         a.bo.wave_slot_dwords = wave_slot_bytes / 4;
@@ -671,6 +705,7 @@ int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t
         const uint64_t staging = stream_staging_need(n_pairs, cells, n_pairs * (len_a + len_b), len_a + len_b, 1000.0L * 1002 * 1002);
         (void)stream_reserve(model, len_b <= static_cast<uint64_t>(kStrip) ? len_a : 0, cells, staging, &wave_slot_bytes, &n_slots, &unit);  // (a failed allocation is the call's problem)
         if(!model->helpers) model->helpers = std::make_unique<HelperPool>(3);
+        if(stream_big_tail_parts() != 0 && cells >= 6 * unit) stream_reserve_big_tail(model, wave_slot_bytes);
         return COATI_HIP_OK;
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "model_prepare: host allocation failed");

@@ -476,6 +476,33 @@ def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, 
     model.close()
 
 
+def test_streamed_call_many_small_chunks_in_quick_succession(hip, kernel_choice, monkeypatch):
+    """Thirty streamed calls whose chunks are a few dozen pairs each, so that the host announces chunk after chunk
+    within microseconds while the first chunks' wavefronts are still looking up their chunk-table entries.  (Round 4: a
+    wavefront could read another slot's entry half-rewritten, take it for its own and index that chunk's work items
+    with ticket - first_ticket = -1 -- a GPU memory fault in one run of eight once chunks were planned ahead on helper
+    threads; viterbi_ck.hip, the pilot.)  Every call: the resident batch's scores, lengths and ops."""
+    from coati_amd import host
+
+    if kernel_choice == "bits":
+        pytest.skip("viterbi_l1 forced: the streamed form is viterbi_ck only")
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(3, 700)
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    want = batch.viterbi_fetch()
+    batch.close()
+    monkeypatch.setenv("COATI_HIP_PIPE", "stream")
+    for call in range(30):
+        monkeypatch.setenv("COATI_HIP_STREAM_UNIT", str(20000000 + 3000000 * (call % 7)))  # 20 .. 38 pairs in the first chunk
+        got = model.viterbi(a_cat, a_off, b_cat, b_off)
+        assert (bits(got[0]) == bits(want[0])).all() and (got[3] == want[3]).all(), call
+        for p in range(0, 700, 53):
+            assert (got[1][int(got[2][p]):int(got[2][p]) + int(got[3][p])] == want[1][int(want[2][p]):int(want[2][p]) + int(want[3][p])]).all()
+    model.close()
+
+
 def test_streamed_call_reports_bad_input_and_recovers(hip, kernel_choice, monkeypatch):
     """An invalid pair deep inside a streamed call (the persistent kernel is already running when its chunk is
     planned): the call returns the reference's error (process_marginal, src/lib/utils.cc:822-835), the kernel is
