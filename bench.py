@@ -606,7 +606,9 @@ def main():
         band_rec = None
         try:
             band_steps, refilled = batch.band_stats()
-            if band_steps:
+            if band_steps and args.no_extras:  # (the profiled command: headline launches only, so that rocprofv3's averages are the headline's)
+                band_rec = {"steps": band_steps, "pairs_filled_twice": refilled, "pairs": n_mine}
+            elif band_steps:
                 model.set_option(hip.OPT_CK_BAND, 0)
                 off_ms = []
                 for i in range(8):

@@ -347,6 +347,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         uint64_t out_off = 0;
         bool ops_staged = false;
         std::future<void> unstage;  // the chunk's results are being copied out of the staging block by a helper thread
+        double t_d2h = 0, t_copied = 0;  // (COATI_HIP_PIPE_TIMING)
     };
     InFlight fl[kSlots];
     struct JoinUnstage {  // (no helper may still write the caller's arrays, or read this frame, when the call returns)
@@ -403,11 +404,13 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
                 }
                 const hipError_t e = submit_d2h(f, q);
                 if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+                if(pipe_timing) f.t_d2h = t_ms();
             }
             if(!f.unstage.valid()) {
                 const hipError_t qd = hipEventQuery(copied[q]);
                 if(qd == hipErrorNotReady) continue;
                 if(qd != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(qd));
+                if(pipe_timing) f.t_copied = t_ms();
             }
             const PipeChunk& c = f.chunk;
             const uint64_t n = c.p1 - c.p0;
@@ -436,8 +439,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
                 unstage();
             }
             if(pipe_timing)
-                std::fprintf(stderr, "viterbi_batch[stream]: chunk %u (%llu pairs) complete %.2f ms after the kernel started, on the host at %.2f ms\n",
-                             f.chunk_no, static_cast<unsigned long long>(n), ck_stream_host_done_ms(hs, q), t_ms());
+                std::fprintf(stderr, "viterbi_batch[stream]: chunk %u (%llu pairs) complete %.2f ms after the kernel started, on the host at %.2f ms (download %.2f .. %.2f)\n",
+                             f.chunk_no, static_cast<unsigned long long>(n), ck_stream_host_done_ms(hs, q), t_ms(), f.t_d2h, f.t_copied);
             coati_hip_batch_destroy(f.batch);
             f.batch = nullptr;
         }
