@@ -82,6 +82,7 @@ const EnvOptions* read_env() {
     o->l1_progress = set("COATI_HIP_L1_PROGRESS");
     o->ck_per_pair = set("COATI_HIP_CK_PER_PAIR");
     o->stream_parts = static_cast<int>(num("COATI_HIP_STREAM_PARTS", -1));
+    o->spec_host_rounds = set("COATI_HIP_SPEC_HOST_ROUNDS");
     o->stream_helpers = static_cast<int>(num("COATI_HIP_STREAM_HELPERS", 7));
     o->pipe_no_d2h = set("COATI_HIP_PIPE_NO_D2H");
     o->sample_sequential = set("COATI_HIP_SAMPLE_SEQUENTIAL");

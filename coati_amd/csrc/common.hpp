@@ -488,6 +488,7 @@ struct EnvOptions {
     bool ck_split_taper = false;
     uint32_t spec_cands = 1u << 17;  // COATI_HIP_SPEC_CANDS
     double spec_z = 2.0;             // COATI_HIP_SPEC_Z
+    bool spec_host_rounds = false;   // COATI_HIP_SPEC_HOST_ROUNDS: the sampler's speculation rounds planned and resolved on the host (round 3's loop; A/B, tests)
     long double stream_unit = 0;     // COATI_HIP_STREAM_UNIT (cells; 0: the default)
     uint64_t mem_budget = 0;         // COATI_HIP_MEM_BUDGET (bytes; 0: none)
 };
@@ -613,6 +614,25 @@ hipError_t launch_spec_walk(const BatchDeviceView& v, const uint64_t* origin_sta
 hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, const uint8_t* tmp_ops,
                               const uint64_t* c_start, const uint32_t* c_len, const float* c_lw, uint8_t* ops,
                               uint64_t* ops_start, uint32_t* ops_len, float* log_weights, hipStream_t stream);
+
+// round 4: the speculation loop of the table path on the DEVICE (sampleback.hip "device rounds"): per pair what the host
+// loop keeps (sample_host.hip), a round's windows, and three launches per round with no host round trip in between
+struct SpecPairState {
+    uint64_t origin;     // draws consumed by the samples resolved so far
+    uint32_t done, cnt;  // samples resolved; observations in the running estimate
+    double mean, m2;     // draws per sample: Welford
+    uint32_t n_cands, n_windows, rank, pad_;  // this round: candidates, windows, which share of the candidate array
+};
+struct SpecWindow {  // the candidates of one (pair, sample-in-chunk): offsets lo .. hi from the pair's origin
+    uint32_t first, lo, hi;
+};
+struct SpecRound {  // written by the plan launch: [0] unfinished pairs before the round, [1] candidates per share
+    uint32_t active, share, ranked, pad_;
+};
+constexpr uint32_t kSpecChunkMax = 512;  // samples speculated per pair and round, at most
+hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
+                             uint32_t n_samples, uint32_t max_cands, double z, SpecPairState* states, SpecWindow* windows, uint32_t* rank_pair,
+                             SpecRound* round, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream);
 
 // round 4: the step table of the exact-stream sampler (sampleback.hip): thresholds and log-weight increments per
 // (body cell, state), 24 bytes each, row-major per pair from entry tab_off[pair]; gap_len 1

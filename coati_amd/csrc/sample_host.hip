@@ -89,6 +89,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     float* d_clw = nullptr;
     uint64_t *d_tab_off = nullptr, *d_state0 = nullptr, *d_sample_off = nullptr, *d_base = nullptr;
     char* d_steps = nullptr;
+    SpecPairState* d_states = nullptr;  // (table path: the speculation loop runs on the device, sampleback.hip "device rounds")
+    SpecWindow* d_windows = nullptr;
+    uint32_t* d_rank_pair = nullptr;
+    SpecRound* d_round = nullptr;
     void* block = nullptr;
     uint64_t block_bytes = 0;
     auto carve = [&](Carver& cv) {
@@ -106,6 +110,10 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             d_state0 = cv.take<uint64_t>(2 * n);
             d_sample_off = cv.take<uint64_t>(n * n_samples);
             d_base = cv.take<uint64_t>(n);
+            d_states = cv.take<SpecPairState>(n);
+            d_windows = cv.take<SpecWindow>(n * kSpecChunkMax);
+            d_rank_pair = cv.take<uint32_t>(n);
+            d_round = cv.take<SpecRound>(1);
             d_steps = cv.take<char>(table_bytes);
         }
     };
@@ -144,6 +152,41 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(hipStreamSynchronize(m->stream));  // (tab_off / base are stack-lifetime vectors of the caller: uploaded before they can go)
     }
 
+    const bool device_rounds = use_table && !env_options().spec_host_rounds;  // (COATI_HIP_SPEC_HOST_ROUNDS=1: the host loop below, the A/B partner)
+    if(device_rounds) {
+        // ---- device rounds: plan + walks + chain per round, enqueued several rounds at a time; the host reads the number
+        // of unfinished pairs each round started with (a round that starts with none is three empty launches)
+        constexpr uint32_t kBatch = 6;
+        void* host_block = nullptr;
+        S_TRY(model_pinned(m, kBatch * sizeof(SpecRound) + n * sizeof(SpecPairState) + 64, &host_block));
+        SpecRound* h_round = static_cast<SpecRound*>(host_block);
+        SpecPairState* h_states = reinterpret_cast<SpecPairState*>(h_round + kBatch);
+        for(uint64_t p = 0; p < n; ++p) h_states[p] = SpecPairState{0, 0, 0, 0.0, 0.0, 0, 0, 0, 0};
+        S_TRY(hipMemcpyAsync(d_states, h_states, n * sizeof(SpecPairState), hipMemcpyHostToDevice, m->stream));
+        const bool timing = env_options().timing;
+        for(bool finished = n_samples == 0 || n == 0; !finished;) {
+            for(uint32_t r = 0; r < kBatch; ++r) {
+                S_TRY(launch_spec_round(view, d_tab_off, d_steps, d_state0, d_pow, n_samples, kMaxCands, kZ, d_states, d_windows, d_rank_pair, d_round,
+                                        d_cdraws, d_sample_off, m->stream));
+                S_TRY(hipMemcpyAsync(h_round + r, d_round, sizeof(SpecRound), hipMemcpyDeviceToHost, m->stream));
+            }
+            S_TRY(hipStreamSynchronize(m->stream));
+            for(uint32_t r = 0; r < kBatch; ++r) {
+                if(h_round[r].active == 0) {
+                    finished = true;
+                    break;
+                }
+                ++dbg_rounds;
+            }
+        }
+        // every sample's start in its pair's stream is known (on the device): one walker per (pair, sample), results in place
+        S_TRY(launch_final_walk(view, d_tab_off, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
+        S_TRY(hipMemcpyAsync(h_states, d_states, n * sizeof(SpecPairState), hipMemcpyDeviceToHost, m->stream));
+        S_TRY(hipStreamSynchronize(m->stream));
+        for(uint64_t p = 0; p < n; ++p) ps[p].origin = h_states[p].origin;
+        if(timing) std::fprintf(stderr, "sampleback_speculative: %llu device rounds for %llu samples\n", static_cast<unsigned long long>(dbg_rounds),
+                                static_cast<unsigned long long>(n * n_samples));
+    } else {
     struct Window {  // candidates of one (pair, sample-in-chunk)
         uint32_t first_cand, lo, hi;
     };
@@ -172,8 +215,12 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         origin_states.cap = origin_states.n = 2 * n;
         commits.cap = cap_m;
     }
+    const bool timing = env_options().timing;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_build = 0, t_gpu = 0, t_chain = 0;
     try {
     for(;;) {
+        const double t_round0 = timing ? now_ms() : 0;
         cands.clear();
         uint64_t tmp_used = 0;
         bool any = false;
@@ -229,6 +276,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         const uint32_t nc = static_cast<uint32_t>(cands.size());
         ++dbg_rounds;
         dbg_cands += nc;
+        const double t_round1 = timing ? now_ms() : 0;
         S_TRY(hipMemcpyAsync(d_origin, origin_states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_cands, cands.data(), nc * sizeof(SpecCandidate), hipMemcpyHostToDevice, m->stream));
         if(use_table)
@@ -238,6 +286,11 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         draws.resize(nc);
         S_TRY(hipMemcpyAsync(draws.data(), d_cdraws, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));
+        const double t_round2 = timing ? now_ms() : 0;
+        if(timing) std::fprintf(stderr, "sampleback_speculative: round %llu: %u candidates, lists %.3f ms, upload + walks + download %.3f ms\n",
+                                static_cast<unsigned long long>(dbg_rounds), nc, t_round1 - t_round0, t_round2 - t_round1);
+        t_build += t_round1 - t_round0;
+        t_gpu += t_round2 - t_round1;
         // follow the chain of true offsets
         commits.clear();
         for(uint64_t p = 0; p < n; ++p) {
@@ -263,6 +316,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             }
             s.origin += off;
         }
+        if(timing) t_chain += now_ms() - t_round2;
         if(use_table) continue;  // (nothing to copy: the final launch below writes every sample)
         const uint32_t ncm = static_cast<uint32_t>(commits.size());
         S_TRY(hipMemcpyAsync(d_commits, commits.data(), ncm * sizeof(SpecCommit), hipMemcpyHostToDevice, m->stream));
@@ -279,11 +333,12 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         release();
         throw;
     }
-#undef S_TRY
-    if(env_options().timing)
-        std::fprintf(stderr, "sampleback_speculative: %llu rounds, %llu candidate walks for %llu samples\n",
+    if(timing)
+        std::fprintf(stderr, "sampleback_speculative: %llu rounds, %llu candidate walks for %llu samples; host lists %.2f ms, device rounds %.2f ms, chains %.2f ms\n",
                      static_cast<unsigned long long>(dbg_rounds), static_cast<unsigned long long>(dbg_cands),
-                     static_cast<unsigned long long>(n * n_samples));
+                     static_cast<unsigned long long>(n * n_samples), t_build, t_gpu, t_chain);
+    }  // (!device_rounds)
+#undef S_TRY
     for(uint64_t p = 0; p < n; ++p) {
         const u128 st = ps[p].st0 * lehmer_pow(ps[p].origin);  // where n serial sampleback calls leave the stream
         states_out[2 * p] = static_cast<uint64_t>(st);
@@ -374,6 +429,7 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
             (void)hipFree(block);
         block = nullptr;
     };
+    bool states_final_on_host = false;
     auto attempt = [&]() -> hipError_t {
         hipError_t e;
         {
@@ -388,7 +444,7 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
         const bool sequential = env_options().sample_sequential;
         if(!independent_streams && n_samples >= 4 && !sequential) {
             if((e = sampleback_speculative(b, n_samples, rng_state, base, d_ops, d_start, d_len, d_lw, states.data())) != hipSuccess) return e;
-            if((e = hipMemcpy(d_states, states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
+            states_final_on_host = true;  // (the streams' final states were computed here: no trip through the device)
         } else {
             if((e = hipMemcpyAsync(d_states, states.data(), states.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
             if((e = hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream)) != hipSuccess) return e;
@@ -400,8 +456,12 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
         if(ops != nullptr && total > 0 && (e = hipMemcpy(ops, d_ops, total, hipMemcpyDeviceToHost)) != hipSuccess) return e;
         if(ops_off != nullptr && (e = hipMemcpy(ops_off, d_start, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
         if(ops_len != nullptr && (e = hipMemcpy(ops_len, d_len, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
-        if(rng_state_out != nullptr && !independent_streams &&
-           (e = hipMemcpy(rng_state_out, d_states, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        if(rng_state_out != nullptr && !independent_streams) {
+            if(states_final_on_host)
+                std::memcpy(rng_state_out, states.data(), 2 * n * sizeof(uint64_t));
+            else if((e = hipMemcpy(rng_state_out, d_states, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess)
+                return e;
+        }
         return hipSuccess;
     };
     const hipError_t e = attempt();

@@ -345,7 +345,69 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
         st = sample3(cur.m - top, cur.d - top, cur.in - top, rng_f24(rng), score, w.exp_tab);
     }
     const uint32_t lb = w.lb;
-    while(j > 0 || i > 0) {
+    // Body steps go in BATCHES.  A walk is a chain of ~la dependent loads (~0.35 us each: a round of candidates took the
+    // same 0.37-0.47 ms whether it held 20 000 or 130 000 of them); but 97 % of a sample's steps are matches, which move
+    // down the diagonal, so the entries of the next kAhead - 1 diagonal cells for state M are loaded TOGETHER with the
+    // entry the walk needs now, and consumed for as long as the draws keep choosing M (a lane whose draw chose a gap
+    // state starts its next batch from there).  Same entries, same draws, same order: same decisions.
+    constexpr int kAhead = 8;
+    bool failed = false;
+    while((j > 0 || i > 0) && !failed) {
+        if(i >= 1 && j >= 1) {
+            StepEntry e[kAhead];
+            const StepEntry* const here = steps + (static_cast<uint64_t>(i - 1) * lb + (j - 1)) * 3;  // this cell's three entries
+            e[0] = here[static_cast<uint32_t>(st)];
+            {
+                const bool m0 = st == COATI_HIP_OP_MATCH, d0 = st == COATI_HIP_OP_DEL;
+                const uint32_t i1 = (m0 || d0) ? i - 1 : i, j1 = d0 ? j : j - 1;  // where this step leads
+                // (entry of cell (i1, j1) for M, then one diagonal step = lb + 1 cells back per entry: no multiply per address)
+                const StepEntry* at = here - (m0 ? static_cast<uint64_t>(lb) + 1 : (d0 ? static_cast<uint64_t>(lb) : 1ull)) * 3 + COATI_HIP_OP_MATCH;
+                const uint64_t diag = (static_cast<uint64_t>(lb) + 1) * 3;
+                const uint32_t room = min(i1, j1);  // cells (i1 - q + 1, j1 - q + 1), q = 1 .. room, are body cells
+#pragma unroll
+                for(int q = 1; q < kAhead; ++q) {
+                    e[q] = *(static_cast<uint32_t>(q) <= room ? at : steps);
+                    at -= diag;
+                }
+            }
+            bool go = true;
+#pragma unroll
+            for(int q = 0; q < kAhead; ++q) {
+                if(go) {
+                    ++draws;
+                    if(pos < slot + 1u) {  // (as in sample_walk: only with a table of -inf / NaN weights)
+                        score = __builtin_nanf("");
+                        failed = true;
+                        go = false;
+                    } else {
+                        if(kOps) ops[--pos] = static_cast<uint8_t>(st);
+                        else --pos;
+                        float p = rng_f24(rng);
+                        p *= e[q].scale;
+                        int nst;
+                        float inc;
+                        if(p < e[q].m) {
+                            nst = COATI_HIP_OP_MATCH;
+                            inc = e[q].inc_m;
+                        } else if(p < e[q].dm) {
+                            nst = COATI_HIP_OP_DEL;
+                            inc = e[q].inc_d;
+                        } else {
+                            nst = COATI_HIP_OP_INS;
+                            inc = e[q].inc_i;
+                        }
+                        score += inc;
+                        const bool is_m = st == COATI_HIP_OP_MATCH, is_d = st == COATI_HIP_OP_DEL;
+                        i = (is_m || is_d) ? i - 1 : i;
+                        j = is_d ? j : j - 1;
+                        st = nst;
+                        go = nst == COATI_HIP_OP_MATCH && i >= 1 && j >= 1;  // (the next prefetched entry is this cell's, for M)
+                    }
+                }
+            }
+            cur_valid = false;
+            continue;
+        }
         ++draws;
         const bool is_m = st == COATI_HIP_OP_MATCH, is_d = st == COATI_HIP_OP_DEL;
         const uint32_t pi = is_m ? i - 1 : (is_d ? i - 1 : i), pj = is_m ? j - 1 : (is_d ? j : j - 1);
@@ -355,26 +417,7 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
         }
         if(kOps) ops[--pos] = static_cast<uint8_t>(st);
         else --pos;
-        if(i >= 1 && j >= 1) {
-            const StepEntry e = steps[(static_cast<uint64_t>(i - 1) * lb + (j - 1)) * 3 + static_cast<uint32_t>(st)];
-            float p = rng_f24(rng);
-            p *= e.scale;
-            int nst;
-            float inc;
-            if(p < e.m) {
-                nst = COATI_HIP_OP_MATCH;
-                inc = e.inc_m;
-            } else if(p < e.dm) {
-                nst = COATI_HIP_OP_DEL;
-                inc = e.inc_d;
-            } else {
-                nst = COATI_HIP_OP_INS;
-                inc = e.inc_i;
-            }
-            score += inc;
-            st = nst;
-            cur_valid = false;
-        } else {
+        {
             // a margin cell: del_del / ins_ins are copies of the margin D / I (init_margins, align_pair.hpp:108-111)
             if(!cur_valid) w.pred(i, j, cur.m, cur.d, cur.in);
             Triple t{kLowest, kLowest, kLowest};
@@ -428,6 +471,227 @@ __global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ 
     uint32_t draws;
     (void)table_walk<false>(w, steps + tab_off[cd.pair], rng, nullptr, 0, score, draws);
     c_draws[idx] = draws;
+}
+
+// ---- device rounds (round 4).  The host loop of sample_host.hip, on the device: per round ONE plan launch (windows of
+// every unfinished pair, under the same rules), ONE walk launch over the whole candidate array (a pair's candidates sit in
+// its share: index = rank * share + local), ONE chain launch (a workgroup per pair follows the true offsets through the
+// draw counts, staged through LDS, writes every resolved sample's stream offset and updates the pair's estimate).  The
+// host only enqueues rounds and looks at the number of unfinished pairs every few rounds: a round cost ~0.27 ms of
+// host work and copies beside ~0.45 ms of walks.
+__global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restrict__ pairs, uint32_t n_pairs, uint32_t n_samples, uint32_t max_cands,
+                                                       double z, SpecPairState* __restrict__ states, SpecWindow* __restrict__ windows,
+                                                       uint32_t* __restrict__ rank_pair, SpecRound* __restrict__ round) {
+    // one wavefront per pair: how many pairs are unfinished, how many of them come before this one (its rank = its share of
+    // the candidate array), then the pair's windows, eight per lane, with a prefix sum over their sizes
+    __shared__ uint32_t s_count[kSpecChunkMax];
+    const uint32_t p = blockIdx.x, lane = threadIdx.x;
+    uint32_t active = 0, before = 0;
+    for(uint32_t q = lane; q < n_pairs; q += kWave) {
+        const uint32_t unfinished = states[q].done < n_samples ? 1u : 0u;
+        active += unfinished;
+        before += q < p ? unfinished : 0u;
+    }
+    for(int sh = 1; sh < kWave; sh <<= 1) {
+        active += __shfl_xor(active, sh);
+        before += __shfl_xor(before, sh);
+    }
+    const uint32_t share = max(max_cands / max(active, 1u), 1u), ranked = min(active, max_cands / share);
+    if(p == 0 && lane == 0) round->active = active, round->share = share, round->ranked = ranked;
+    SpecPairState& s = states[p];
+    const bool mine = s.done < n_samples && before < ranked;  // (more unfinished pairs than a round holds: the others wait)
+    if(!mine) {
+        if(lane == 0) s.n_cands = 0, s.n_windows = 0;
+        return;
+    }
+    const double width = static_cast<double>(pairs[p].la) + static_cast<double>(pairs[p].lb);
+    const uint32_t remaining = n_samples - s.done;
+    const uint32_t want = s.cnt == 0 ? 8u : (s.cnt < 8 ? 16u : kSpecChunkMax);
+    const uint32_t chunk = min(remaining, want);
+    double mean = s.mean;
+    if(s.cnt == 0) mean = 1.0 + static_cast<double>(max(pairs[p].la, pairs[p].lb)) + 0.005 * width;  // (the prior: sample_host.hip)
+    const double sigma = s.cnt >= 2 ? sqrt(s.m2 / (s.cnt - 1)) * (1.0 + 4.0 / s.cnt) + 1.0 : 0.02 * width + 2.0;
+    constexpr uint32_t kPer = kSpecChunkMax / kWave;  // windows lane * kPer .. lane * kPer + kPer - 1
+    uint32_t lo_w[kPer], hi_w[kPer];
+    unsigned long long mine_sum = 0;
+    constexpr uint32_t kUnusable = 0x80000000u;  // (an unusable window is "larger than any share": it ends the chunk)
+#pragma unroll
+    for(uint32_t t = 0; t < kPer; ++t) {
+        const uint32_t j = lane * kPer + t;
+        const long long center = llrint(j * mean);
+        const long long half = j == 0 ? 0 : static_cast<long long>(ceil(z * sigma * sqrt(static_cast<double>(j)))) + 2;
+        const long long lo = max(center - half, static_cast<long long>(j)), hi = max(center + half, lo);
+        const bool usable = j < chunk && hi <= 0x7ffffff0ll;
+        lo_w[t] = static_cast<uint32_t>(lo), hi_w[t] = static_cast<uint32_t>(hi);
+        const uint32_t count = usable ? static_cast<uint32_t>(hi - lo + 1) : kUnusable;
+        s_count[j] = count;
+        mine_sum += count;
+    }
+    unsigned long long incl = mine_sum;  // inclusive prefix over the lanes
+    for(int sh = 1; sh < kWave; sh <<= 1) {
+        const unsigned long long up = __shfl_up(incl, sh);
+        if(lane >= static_cast<uint32_t>(sh)) incl += up;
+    }
+    unsigned long long first = incl - mine_sum;
+    SpecWindow* w = windows + static_cast<uint64_t>(p) * kSpecChunkMax;
+    uint32_t last_in = 0, used = 0;  // the windows that fit the share are a prefix (sizes are positive; window 0 is one candidate: always in)
+#pragma unroll
+    for(uint32_t t = 0; t < kPer; ++t) {
+        const uint32_t j = lane * kPer + t, count = s_count[j];
+        const bool fits = count != kUnusable && (j == 0 || first + count <= share);
+        if(fits) {
+            w[j] = SpecWindow{static_cast<uint32_t>(first), lo_w[t], hi_w[t]};
+            last_in = j + 1;
+            used = static_cast<uint32_t>(first) + count;
+        }
+        first += count;
+    }
+    for(int sh = 1; sh < kWave; sh <<= 1) {
+        last_in = max(last_in, __shfl_xor(last_in, sh));
+        used = max(used, __shfl_xor(used, sh));
+    }
+    if(lane == 0) {
+        s.rank = before;
+        rank_pair[before] = p;
+        s.n_cands = min(used, share);
+        s.n_windows = last_in;
+    }
+}
+
+__global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
+                                                            const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
+                                                            const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
+                                                            const StepEntry* __restrict__ steps, const uint64_t* __restrict__ state0,
+                                                            const uint64_t* __restrict__ mult_pow, const SpecPairState* __restrict__ states,
+                                                            const SpecWindow* __restrict__ windows, const uint32_t* __restrict__ rank_pair,
+                                                            const SpecRound* __restrict__ round, uint32_t* __restrict__ c_draws) {
+    __shared__ uint64_t exp_tab[32];
+    const uint32_t share = round->share, ranked = round->ranked;
+    const uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+    if(static_cast<uint64_t>(blockIdx.x) * blockDim.x >= static_cast<uint64_t>(ranked) * share) return;  // (the whole workgroup: before the barrier)
+    load_exp_table(exp_tab, threadIdx.x);
+    __syncthreads();
+    const uint32_t r = static_cast<uint32_t>(idx / share), local = static_cast<uint32_t>(idx % share);
+    if(r >= ranked) return;
+    const uint32_t pair = rank_pair[r];
+    const SpecPairState& s = states[pair];
+    if(local >= s.n_cands) return;
+    const SpecWindow* w = windows + static_cast<uint64_t>(pair) * kSpecChunkMax;
+    uint32_t lo_w = 0, hi_w = s.n_windows;  // the last window whose first candidate is <= local
+    while(hi_w - lo_w > 1) {
+        const uint32_t mid = (lo_w + hi_w) / 2;
+        if(w[mid].first <= local)
+            lo_w = mid;
+        else
+            hi_w = mid;
+    }
+    const uint64_t offset = s.origin + w[lo_w].lo + (local - w[lo_w].first);
+    const PairDesc pd = pairs[pair];
+    Rng128 rng = rng_jump(state0, mult_pow, pair, offset);
+    const Walker wk{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
+                    mdi, pd, exp_tab};
+    float score;
+    uint32_t draws;
+    (void)table_walk<false>(wk, steps + tab_off[pair], rng, nullptr, 0, score, draws);
+    c_draws[idx] = draws;
+}
+
+constexpr uint32_t kChainLds = 12288;  // draw counts staged per batch of windows (48 KB)
+__global__ __launch_bounds__(256) void spec_chain_kernel(uint32_t n_samples, SpecPairState* __restrict__ states, const SpecWindow* __restrict__ windows,
+                                                         const SpecRound* __restrict__ round, const uint32_t* __restrict__ c_draws,
+                                                         uint64_t* __restrict__ sample_off) {
+    __shared__ uint32_t lds[kChainLds];
+    __shared__ SpecWindow w[kSpecChunkMax];  // (the chain reads a window per sample: from LDS, not from memory)
+    __shared__ uint32_t s_next, s_alive, s_off;
+    const uint32_t pair = blockIdx.x;
+    SpecPairState& s = states[pair];
+    const uint32_t nw = s.n_windows, n_cands = s.n_cands;
+    if(nw == 0 || n_cands == 0) return;
+    for(uint32_t q = threadIdx.x; q < nw; q += blockDim.x) w[q] = windows[static_cast<uint64_t>(pair) * kSpecChunkMax + q];
+    const uint32_t* draws = c_draws + static_cast<uint64_t>(s.rank) * round->share;
+    // the pair's state, advanced by thread 0 only; the running estimate of draws per sample takes this round's
+    // observations as integer sums (one double division per round, not per sample: a lone lane pays ~5 cycles per instruction)
+    const uint64_t origin = s.origin;
+    uint32_t done = s.done;
+    unsigned long long sum_x = 0, sum_xx = 0;
+    uint32_t seen = 0;
+    if(threadIdx.x == 0) s_next = 0, s_alive = 1, s_off = 0;
+    __syncthreads();
+    for(;;) {
+        const uint32_t j0 = s_next;
+        if(j0 >= nw || s_alive == 0) break;
+        // windows j0 .. j1-1 fit the staging area together (binary search on `first`: monotone); a window wider than the
+        // area goes alone and is read from memory
+        const uint32_t first0 = w[j0].first;
+        uint32_t lo_w = j0, hi_w = nw;  // the last window that still ends inside first0 + kChainLds
+        while(hi_w - lo_w > 1) {
+            const uint32_t mid = (lo_w + hi_w) / 2;
+            if(w[mid].first + (w[mid].hi - w[mid].lo + 1) - first0 <= kChainLds)
+                lo_w = mid;
+            else
+                hi_w = mid;
+        }
+        const uint32_t j1 = lo_w + 1;
+        const uint32_t end = min(w[j1 - 1].first + (w[j1 - 1].hi - w[j1 - 1].lo + 1), n_cands);
+        const bool staged = end - first0 <= kChainLds;
+        if(staged) {  // (eight loads in flight per thread: one load per trip of a plain loop was 32 memory round trips, most of the kernel's 48 us)
+            const uint32_t n_stage = end - first0;
+            for(uint32_t q0 = 0; q0 < n_stage; q0 += 8 * blockDim.x) {
+                uint32_t v[8];
+#pragma unroll
+                for(uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t q = q0 + u * blockDim.x + threadIdx.x;
+                    v[u] = q < n_stage ? draws[first0 + q] : 0u;
+                }
+#pragma unroll
+                for(uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t q = q0 + u * blockDim.x + threadIdx.x;
+                    if(q < n_stage) lds[q] = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        if(threadIdx.x == 0) {
+            uint32_t off = s_off, j = j0;
+            bool alive = true;
+            for(; j < j1; ++j) {
+                const SpecWindow wj = w[j];
+                if(off < wj.lo || off > wj.hi || wj.first + (off - wj.lo) >= n_cands) {  // not speculated: first sample of the next round
+                    alive = false;
+                    break;
+                }
+                const uint32_t c = wj.first + (off - wj.lo);
+                uint32_t x;
+                if(staged) {
+                    x = lds[c - first0];
+                } else {  // (a window wider than the staging area: alone in its batch.  A branch, not a select: as a select the
+                    // compiler issued the memory load for every sample, ~0.6 us each, most of this kernel's time)
+                    x = __hip_atomic_load(draws + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                sample_off[static_cast<uint64_t>(pair) * n_samples + done] = origin + off;
+                sum_x += x;
+                sum_xx += static_cast<unsigned long long>(x) * x;
+                seen += 1;
+                off += x;
+                done += 1;
+            }
+            s_off = off, s_next = j, s_alive = alive ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if(threadIdx.x == 0) {
+        s.origin = origin + s_off;
+        s.done = done;
+        if(seen > 0) {  // Welford's update for a batch (Chan et al.): the round's mean and sum of squared deviations joined to the estimate
+            const double nb = static_cast<double>(seen), mean_b = static_cast<double>(sum_x) / nb;
+            const double m2_b = fmax(static_cast<double>(sum_xx) - nb * mean_b * mean_b, 0.0);
+            const double na = static_cast<double>(s.cnt);  // (0: the prior has served, the estimate starts from the observations)
+            const double delta = mean_b - (s.cnt == 0 ? 0.0 : s.mean), nab = na + nb;
+            s.mean = s.cnt == 0 ? mean_b : s.mean + delta * nb / nab;
+            s.m2 = s.cnt == 0 ? m2_b : s.m2 + m2_b + delta * delta * na * nb / nab;
+            s.cnt = s.cnt + seen;
+        }
+    }
 }
 
 // the chain is known: every (pair, sample) from its exact offset (draws after the pair's ORIGINAL state), results written
@@ -520,6 +784,16 @@ hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, co
     if(n_cands == 0) return hipSuccess;
     hipLaunchKernelGGL(spec_len_kernel, dim3((n_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
                        static_cast<const StepEntry*>(steps), origin_state, mult_pow, cands, n_cands, c_draws);
+    return hipGetLastError();
+}
+hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
+                             uint32_t n_samples, uint32_t max_cands, double z, SpecPairState* states, SpecWindow* windows, uint32_t* rank_pair,
+                             SpecRound* round, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream) {
+    if(v.n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(spec_plan_kernel, dim3(v.n_pairs), dim3(kWave), 0, stream, v.pairs, v.n_pairs, n_samples, max_cands, z, states, windows, rank_pair, round);
+    hipLaunchKernelGGL(spec_len_round_kernel, dim3((max_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
+                       static_cast<const StepEntry*>(steps), state0, mult_pow, states, windows, rank_pair, round, c_draws);
+    hipLaunchKernelGGL(spec_chain_kernel, dim3(v.n_pairs), dim3(256), 0, stream, n_samples, states, windows, round, c_draws, sample_off);
     return hipGetLastError();
 }
 hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* start_state, const uint64_t* mult_pow,

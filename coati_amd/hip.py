@@ -386,17 +386,21 @@ class Batch:
             _check(load().coati_hip_debug_forward_matrices(self._h, pair, _ptr(M), _ptr(D), _ptr(I), M.size))
         return M, D, I
 
-    def sampleback(self, n_samples: int, rng_states, independent: bool = False):
+    def sampleback(self, n_samples: int, rng_states, independent: bool = False, out=None):
         """rng_states: (n, 2) uint64 (lo, hi).  Returns (log_weights (n, S), ops, ops_off (n, S), ops_len (n, S),
-        rng_states_out)."""
+        rng_states_out).  out: the tuple a previous call of the same shape returned, to be written again (an embedder
+        keeps its result arrays: fresh ones are first touched page by page under the download)."""
         reload_env()
         st = np.ascontiguousarray(rng_states, np.uint64).reshape(self.n, 2)
         total = int(n_samples * self.lens.sum())
-        lw = np.zeros((self.n, n_samples), np.float32)
-        ops = np.zeros(max(total, 1), np.uint8)
-        off = np.zeros((self.n, n_samples), np.uint64)
-        ln = np.zeros((self.n, n_samples), np.uint32)
-        st_out = np.zeros_like(st)
+        if out is not None and out[0].shape == (self.n, n_samples) and out[1].size == max(total, 1):
+            lw, ops, off, ln, st_out = out
+        else:
+            lw = np.zeros((self.n, n_samples), np.float32)
+            ops = np.zeros(max(total, 1), np.uint8)
+            off = np.zeros((self.n, n_samples), np.uint64)
+            ln = np.zeros((self.n, n_samples), np.uint32)
+            st_out = np.zeros_like(st)
         _check(load().coati_hip_sampleback(self._h, n_samples, _ptr(st), int(independent), _ptr(lw), _ptr(ops), total,
                                            _ptr(off), _ptr(ln), _ptr(st_out)))
         return lw, ops, off, ln, st_out

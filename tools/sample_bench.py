@@ -49,12 +49,13 @@ batch = hip.Batch(model, *host.synth_encoded(0, args.sample_pairs))
 t_fwd = timed(batch.forward_launch, batch.sync)
 states = np.array([host.rng_seed(["42"]) for _ in range(args.sample_pairs)], np.uint64)
 for mode, indep in (("exact_stream", False), ("independent_streams", True)):
-    ts = []
-    for r in range(3):
+    ts, res = [], None
+    for r in range(4):  # (the caller's result arrays are written again from the second call on)
         t0 = time.perf_counter()
-        lw, ops, off, ln, _ = batch.sampleback(args.samples, states, independent=indep)
+        res = batch.sampleback(args.samples, states, independent=indep, out=res)
         ts.append(time.perf_counter() - t0)
-    out[f"sampleback_{mode}"] = {"pairs": args.sample_pairs, "samples_per_pair": args.samples, "ms": float(np.min(ts)) * 1e3,
+    lw, ops, off, ln, _ = res
+    out[f"sampleback_{mode}"] = {"pairs": args.sample_pairs, "samples_per_pair": args.samples, "ms": float(np.min(ts)) * 1e3, "first_call_ms": ts[0] * 1e3,
                                  "samples_per_s": args.sample_pairs * args.samples / float(np.min(ts)),
                                  "mean_columns": float(ln.mean()), "finite": bool(np.isfinite(lw).all())}
 out["forward_fill_16_pairs_ms"] = t_fwd * 1e3
