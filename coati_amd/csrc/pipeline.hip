@@ -107,13 +107,35 @@ namespace {
 // cells) in both directions, and for the call's longest pair, between 4 and 48 MB.  (Page-locking is the slow part of a
 // fresh process' bring-up -- ~0.25 ms per MB: nine 48 MB blocks cost coati-alignpair --batch 110 of its 360 ms on
 // 10 000 pairs of 1 kb, which need a third of that.)
-uint64_t stream_staging_need(uint64_t n_pairs, long double total_cells, uint64_t total_seq_bytes, uint64_t longest_pair_bytes, long double unit_cells) {
+uint64_t stream_staging_need(uint64_t n_pairs, long double total_cells, uint64_t total_seq_bytes, uint64_t longest_pair_bytes, long double unit_cells,
+                             bool in_pinned = false, bool out_pinned = false) {
+    // (page-locked caller arrays are read and written by the copy engine directly: only descriptors, work items and the
+    // three short result arrays go through the block -- ~160 bytes per pair; a model's first call on page-locked arrays
+    // spent 15 of its 23 ms page-locking staging it never used)
     const long double mean_cells = total_cells / std::max<long double>(1, static_cast<long double>(n_pairs));
     const long double chunk_pairs = std::min<long double>(static_cast<long double>(n_pairs), 3 * unit_cells / std::max<long double>(1, mean_cells) + 1);
-    const long double per_pair = 3.0L * static_cast<long double>(total_seq_bytes) / std::max<long double>(1, static_cast<long double>(n_pairs)) + 160;
-    const uint64_t est = static_cast<uint64_t>(1.5L * chunk_pairs * per_pair) + 3 * longest_pair_bytes + (2ull << 20);
+    const long double seq_per_pair = static_cast<long double>(total_seq_bytes) / std::max<long double>(1, static_cast<long double>(n_pairs));
+    const long double per_pair = (in_pinned ? 0.0L : 1.5L) * seq_per_pair + (out_pinned ? 0.0L : 1.5L) * seq_per_pair + 160;
+    const uint64_t est = static_cast<uint64_t>(1.5L * chunk_pairs * per_pair) + (in_pinned && out_pinned ? 0 : 3 * longest_pair_bytes) + (2ull << 20);
     const uint64_t step = 4ull << 20;
     return std::min<uint64_t>(kStreamSlotStaging, std::max<uint64_t>(step, (est + step - 1) / step * step));
+}
+// ... and the first three slots hold the call's first three chunks (1/2, 1 and 2 units of cells against 3 later on):
+// a sixth, a third and two thirds of the block, in whole 4 MB (a later lap only cuts smaller chunks for them)
+struct StagingNeed {
+    uint64_t full = 0;   // a slot that takes 3-unit chunks
+    uint64_t floor = 0;  // no slot below this: the call's longest pair must fit every slot (a chunk's first pair is taken unseen)
+};
+uint64_t stream_slot_staging(const StagingNeed& need, int q) {
+    const uint64_t step = 4ull << 20;
+    const uint64_t part = std::max(need.floor, q == 0 ? need.full / 6 : q == 1 ? need.full / 3 : q == 2 ? 2 * need.full / 3 : need.full);
+    return std::min(need.full, std::max<uint64_t>(step, (part + step - 1) / step * step));
+}
+StagingNeed stream_staging(uint64_t n_pairs, long double total_cells, uint64_t total_seq_bytes, uint64_t longest_pair_bytes, bool in_pinned, bool out_pinned) {
+    StagingNeed need;
+    need.full = stream_staging_need(n_pairs, total_cells, total_seq_bytes, longest_pair_bytes, 1000.0L * 1002 * 1002, in_pinned, out_pinned);
+    need.floor = std::min<uint64_t>(need.full, 4 * longest_pair_bytes + (2ull << 20));
+    return need;
 }
 // The streamed call's last chunk (viterbi_batch_stream: "ONE last chunk"): at most kBigTailUnits units of cells, its pairs cut
 // into row parts that keep their own checkpoints (1.09 MB per 1 kb pair) -- one workspace of ~3 GB, kept on the model.
@@ -138,7 +160,7 @@ void stream_reserve_big_tail(coati_hip_model_t* model, uint64_t wave_slot_bytes)
     else
         (void)hipGetLastError();
 }
-int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long double total_cells, uint64_t staging_need, uint64_t* wave_slot_bytes_out,
+int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long double total_cells, const StagingNeed& staging_need, uint64_t* wave_slot_bytes_out,
                    int* n_slots_out, long double* unit_cells_out) {
     constexpr int kSlots = kCkStreamSlots;
     for(int q = 1; q <= 2; ++q)
@@ -181,7 +203,7 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
     // the largest pair this form accepts (kStreamPairCells) with its own checkpoints; staging block
     // [what goes up | short result arrays, and the ops when the caller's array is pageable]
     constexpr uint64_t kSlotArena = kStreamSlotArena;
-    const uint64_t kSlotStaging = std::min<uint64_t>(kStreamSlotStaging, std::max<uint64_t>(staging_need, 4ull << 20));
+    const StagingNeed kSlotStaging{std::min<uint64_t>(kStreamSlotStaging, std::max<uint64_t>(staging_need.full, 4ull << 20)), staging_need.floor};
     // How many slots can this call use?  The chunk targets below in cells: 1/2, 1, 2, then 3 units, and 1 unit each
     // once four units are left.  A one-shot process (coati-alignpair --batch: ~0.1 ms per MB of fresh hipMalloc /
     // hipHostMalloc, 12 slots are 2.9 GB) allocates what its input needs; a second call on the model takes the rest.
@@ -194,7 +216,7 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
             done += est == 0 ? kUnitCells / 2 : (est == 1 || total_cells - done <= 4 * kUnitCells) ? kUnitCells : est == 2 ? 2 * kUnitCells : 3 * kUnitCells;
         n_slots = std::min(kSlots, std::max(3, est + 1));  // (+1: a memory-bound cut may add a chunk; fewer slots than chunks only means reuse)
         for(int q = 0; q < kSlots; ++q)
-            if(model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= kSlotStaging) n_slots = std::max(n_slots, q + 1);
+            if(model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= stream_slot_staging(kSlotStaging, q)) n_slots = std::max(n_slots, q + 1);
     }
     // (a fresh process page-locks at ~4 GB/s and maps fresh HBM at ~10 GB/s: the slots are made side by side on the
     // model's helper threads -- the first call of a model is mostly this)
@@ -209,19 +231,19 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
             if(hipMalloc(&ss.arena, kSlotArena) != hipSuccess) return false;
             ss.arena_bytes = kSlotArena;
         }
-        if(ss.pinned_bytes < kSlotStaging) {
+        if(const uint64_t want = stream_slot_staging(kSlotStaging, q); ss.pinned_bytes < want) {
             if(ss.pinned != nullptr) (void)hipHostFree(ss.pinned);
             ss.pinned = nullptr;
             ss.pinned_bytes = 0;
-            if(hipHostMalloc(&ss.pinned, kSlotStaging, hipHostMallocDefault) != hipSuccess) return false;
-            ss.pinned_bytes = kSlotStaging;
+            if(hipHostMalloc(&ss.pinned, want, hipHostMallocDefault) != hipSuccess) return false;
+            ss.pinned_bytes = want;
         }
         return true;
     };
     {
         std::vector<std::future<bool>> made;
         bool all = true;
-        auto ready = [&](int q) { return model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= kSlotStaging; };
+        auto ready = [&](int q) { return model->sslots[q].arena_bytes >= kSlotArena && model->sslots[q].pinned_bytes >= stream_slot_staging(kSlotStaging, q); };
         for(int q = 0; q < n_slots; ++q)
             if(q % 4 != 3 && !ready(q) && (env_options().stream_helpers & 4) != 0) made.push_back(model->helpers->submit([make_slot, q] { return make_slot(q); }));
         for(int q = 0; q < n_slots; ++q)  // (this thread takes its share)
@@ -232,7 +254,11 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
             return COATI_HIP_ESTATE;
         }
     }
-    alloc_stage("stream slots ready", static_cast<uint64_t>(n_slots) * (kSlotArena + kSlotStaging));
+    {
+        uint64_t made_bytes = 0;
+        for(int q = 0; q < n_slots; ++q) made_bytes += model->sslots[q].arena_bytes + model->sslots[q].pinned_bytes;
+        alloc_stage("stream slots ready", made_bytes);
+    }
     if(model->stream_events[0] == nullptr) {
         bool events_ok = true;
         for(hipEvent_t& e : model->stream_events) events_ok = events_ok && soft(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -260,7 +286,7 @@ int stream_reserve(coati_hip_model_t* model, uint64_t longest_single, long doubl
 // pipeline instead.
 int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat, const uint64_t* a_off, const uint8_t* b_cat,
                          const uint64_t* b_off, float* scores, uint8_t* ops, uint64_t* ops_off, uint32_t* ops_len, bool in_pinned,
-                         bool out_pinned, long double total_cells, uint64_t longest_single, uint64_t staging_need, std::chrono::steady_clock::time_point t_call) {
+                         bool out_pinned, long double total_cells, uint64_t longest_single, const StagingNeed& staging_need, std::chrono::steady_clock::time_point t_call) {
     constexpr int kSlots = kCkStreamSlots;
     uint64_t wave_slot_bytes = 0;
     int n_slots = 0;
@@ -705,7 +731,7 @@ int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t
         int n_slots = 0;
         long double unit = 0;
         const long double cells = static_cast<long double>(n_pairs) * static_cast<long double>(len_a) * static_cast<long double>(len_b);
-        const uint64_t staging = stream_staging_need(n_pairs, cells, n_pairs * (len_a + len_b), len_a + len_b, 1000.0L * 1002 * 1002);
+        const StagingNeed staging = stream_staging(n_pairs, cells, n_pairs * (len_a + len_b), len_a + len_b, false, false);
         (void)stream_reserve(model, len_b <= static_cast<uint64_t>(kStrip) ? len_a : 0, cells, staging, &wave_slot_bytes, &n_slots, &unit);  // (a failed allocation is the call's problem)
         if(!model->helpers) model->helpers = std::make_unique<HelperPool>(3);
         if(stream_big_tail_parts() != 0 && cells >= 6 * unit) stream_reserve_big_tail(model, wave_slot_bytes);
@@ -777,8 +803,8 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
             }
         }
         if(streamed) {
-            const uint64_t staging_need = stream_staging_need(n_pairs, total_cells, (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]),
-                                                              longest_pair_bytes, 1000.0L * 1002 * 1002);
+            const StagingNeed staging_need = stream_staging(n_pairs, total_cells, (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]), longest_pair_bytes,
+                                                            in_pinned, out_pinned);
             const int rc_stream = viterbi_batch_stream(model, n_pairs, a_cat, a_off, b_cat, b_off, scores, ops, ops_off, ops_len, in_pinned,
                                                        out_pinned, total_cells, longest_single, staging_need, t_entry);
             if(rc_stream != COATI_HIP_ESTATE) return rc_stream;  // (ESTATE: nothing was started; the chunk pipeline takes the call)

@@ -181,8 +181,9 @@ def test_independent_streams(oracle):
 
 def test_speculative_exact_stream_equals_sequential():
     """The parallel exact-stream sampler (speculated stream offsets) returns exactly what the
-    one-walker-per-pair loop returns: same ops, same log-weight bits, same final RNG state.
-    The sequential loop is selected with COATI_HIP_SAMPLE_SEQUENTIAL=1 in a child process."""
+    one-walker-per-pair loop returns: same ops, same log-weight bits, same final RNG state -- with its rounds on the
+    device (default) and on the host, and with a candidate budget small enough to need dozens of rounds.
+    Each variant runs in a child process (the switches are COATI_HIP_* environment variables)."""
     import os
     import subprocess
     import sys
@@ -208,13 +209,19 @@ for p in range(len(enc)):
         crc = zlib.crc32(ops[int(off[p, s]):int(off[p, s]) + int(ln[p, s])].tobytes(), crc)
 print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum()), "st": zlib.crc32(st.tobytes())}))
 ''' % str(root)
+    # the same call: device rounds (default), the one-walker-per-pair loop, the rounds planned and resolved on the host
+    # (round 3's loop), and device rounds with so few candidates that a round resolves a handful of samples per pair and
+    # most of a share is one window (many rounds, windows cut by the share, pairs that finish rounds apart)
+    variants = [{}, {"COATI_HIP_SAMPLE_SEQUENTIAL": "1"}, {"COATI_HIP_SPEC_HOST_ROUNDS": "1"}, {"COATI_HIP_SPEC_CANDS": "1024"},
+                {"COATI_HIP_SPEC_CANDS": "1024", "COATI_HIP_SPEC_Z": "0.5"}]
     outs = []
-    for seq in (False, True):
+    for extra in variants:
         env = dict(os.environ)
-        env.pop("COATI_HIP_SAMPLE_SEQUENTIAL", None)
-        if seq:
-            env["COATI_HIP_SAMPLE_SEQUENTIAL"] = "1"
+        for k in ("COATI_HIP_SAMPLE_SEQUENTIAL", "COATI_HIP_SPEC_HOST_ROUNDS", "COATI_HIP_SPEC_CANDS", "COATI_HIP_SPEC_Z"):
+            env.pop(k, None)
+        env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1], outs
+    for extra, out in zip(variants[1:], outs[1:]):
+        assert out == outs[0], (extra, out, outs[0])

@@ -9,6 +9,7 @@ depends on glibc's and the GPU's log1p(exp()) agreeing in the last bit.  In the 
 build every exact-stream sample is also compared with the oracle's own sample: same ops, same
 log-weight bits.
 usage: fuzz_sample.py [seconds] [seed]"""
+import os
 import sys, time
 from pathlib import Path
 import numpy as np
@@ -45,6 +46,17 @@ while time.time() < t_end:
     batch.forward_launch()
     st = np.stack([host.rng_seed([str(seed), str(rounds), str(p)]) for p in range(len(enc))])
     indep = bool(rng.random() < 0.3)
+    # the exact-stream sampler's own switches: candidate budget (1 024: dozens of rounds, windows cut by the share) and where
+    # the rounds are planned and resolved (device: default; host: round 3's loop)
+    for k in ("COATI_HIP_SPEC_CANDS", "COATI_HIP_SPEC_HOST_ROUNDS", "COATI_HIP_SPEC_Z"):
+        os.environ.pop(k, None)
+    pick = rng.random()
+    if pick < 0.3:
+        os.environ["COATI_HIP_SPEC_CANDS"] = str(int(rng.choice([1024, 4096])))
+        if rng.random() < 0.5:
+            os.environ["COATI_HIP_SPEC_Z"] = str(float(rng.choice([0.5, 1.0, 4.0])))
+    elif pick < 0.45:
+        os.environ["COATI_HIP_SPEC_HOST_ROUNDS"] = "1"
     lw, ops, off, ln, so = batch.sampleback(n_s, st, independent=indep)
     for p, (a, b) in enumerate(enc):
         M, D, I = orc.fill(orc.LOG, tables[tix[p]], consts, L, a, b)
