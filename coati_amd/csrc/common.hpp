@@ -621,18 +621,19 @@ struct SpecPairState {
     uint64_t origin;     // draws consumed by the samples resolved so far
     uint32_t done, cnt;  // samples resolved; observations in the running estimate
     double mean, m2;     // draws per sample: Welford
-    uint32_t n_cands, n_windows, rank, pad_;  // this round: candidates, windows, which share of the candidate array
+    uint32_t n_cands, n_windows, rank, n_draws;  // this round: candidates, windows, which share of the candidate array, draws of the stream its walks may take
 };
 struct SpecWindow {  // the candidates of one (pair, sample-in-chunk): offsets lo .. hi from the pair's origin
     uint32_t first, lo, hi;
 };
-struct SpecRound {  // written by the plan launch: [0] unfinished pairs before the round, [1] candidates per share
-    uint32_t active, share, ranked, pad_;
+struct SpecRound {  // written by the plan launch: unfinished pairs before the round, candidates per share, pairs in the round, draws per slice
+    uint32_t active, share, ranked, slice;
 };
+constexpr uint32_t kSpecDrawFloats = 16u << 20;  // the round's table of stream draws (64 MB), cut into one slice per pair of the round
 constexpr uint32_t kSpecChunkMax = 512;  // samples speculated per pair and round, at most
 hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
-                             uint32_t n_samples, uint32_t max_cands, double z, SpecPairState* states, SpecWindow* windows, uint32_t* rank_pair,
-                             SpecRound* round, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream);
+                             uint32_t n_samples, uint32_t max_cands, uint32_t max_width, double z, SpecPairState* states, SpecWindow* windows,
+                             uint32_t* rank_pair, SpecRound* round, float* draw_table, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream);
 
 // round 4: the step table of the exact-stream sampler (sampleback.hip): thresholds and log-weight increments per
 // (body cell, state), 24 bytes each, row-major per pair from entry tab_off[pair]; gap_len 1

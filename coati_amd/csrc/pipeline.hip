@@ -321,8 +321,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // = no row parts, 22 .. 28 = 2 .. 8 parts.
     const int big_tail_parts = stream_big_tail_parts();
     const bool big_tail_on = big_tail_parts != 0;
-    // (a model's FIRST call runs without either unless coati_hip_model_prepare made the workspace: ~3 GB of fresh hipMalloc
-    // cost a one-shot process ~30 ms, ten times what the row parts save)
+    // (a model's FIRST call runs without either: ~3 GB of fresh hipMalloc cost a one-shot process 15-30 ms, a hundred times what
+    // the row parts save it)
     const bool want_tails = tail_parts_on && (model->stream_calls > 0 || total_cells >= 30 * kUnitCells);
     if(big_tail_on && total_cells >= 6 * kUnitCells && model->stream_calls > 0) stream_reserve_big_tail(model, wave_slot_bytes);
     if(want_tails && (model->stream_tail_bytes < tail_bytes || model->stream_tail_arena[coati_hip_model::kStreamTails - 1] == nullptr)) {
@@ -734,7 +734,7 @@ int coati_hip_model_prepare(coati_hip_model_t* model, uint64_t n_pairs, uint64_t
         const StagingNeed staging = stream_staging(n_pairs, cells, n_pairs * (len_a + len_b), len_a + len_b, false, false);
         (void)stream_reserve(model, len_b <= static_cast<uint64_t>(kStrip) ? len_a : 0, cells, staging, &wave_slot_bytes, &n_slots, &unit);  // (a failed allocation is the call's problem)
         if(!model->helpers) model->helpers = std::make_unique<HelperPool>(3);
-        if(stream_big_tail_parts() != 0 && cells >= 6 * unit) stream_reserve_big_tail(model, wave_slot_bytes);
+        // (not the last chunk's ~3 GB workspace: ~15 ms of fresh hipMalloc against 0.25 ms per call -- a model's second call makes it)
         return COATI_HIP_OK;
     } catch(const std::bad_alloc&) {
         return fail(COATI_HIP_ENOMEM, "model_prepare: host allocation failed");

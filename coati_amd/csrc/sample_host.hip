@@ -93,6 +93,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     SpecWindow* d_windows = nullptr;
     uint32_t* d_rank_pair = nullptr;
     SpecRound* d_round = nullptr;
+    float* d_draw_table = nullptr;  // the round's stream draws, a slice per pair (spec_draws_kernel)
     void* block = nullptr;
     uint64_t block_bytes = 0;
     auto carve = [&](Carver& cv) {
@@ -114,6 +115,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             d_windows = cv.take<SpecWindow>(n * kSpecChunkMax);
             d_rank_pair = cv.take<uint32_t>(n);
             d_round = cv.take<SpecRound>(1);
+            d_draw_table = cv.take<float>(kSpecDrawFloats + 64);
             d_steps = cv.take<char>(table_bytes);
         }
     };
@@ -152,11 +154,15 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(hipStreamSynchronize(m->stream));  // (tab_off / base are stack-lifetime vectors of the caller: uploaded before they can go)
     }
 
-    const bool device_rounds = use_table && !env_options().spec_host_rounds;  // (COATI_HIP_SPEC_HOST_ROUNDS=1: the host loop below, the A/B partner)
+    uint32_t widest = 0;
+    for(uint64_t p = 0; p < n; ++p) widest = std::max(widest, b->desc[p].la + b->desc[p].lb);
+    // (device rounds read the streams' draws from a 64 MB table, a slice per pair: one whole walk must fit a slice)
+    const bool device_rounds = use_table && !env_options().spec_host_rounds && static_cast<uint64_t>(widest) + 128 <= kSpecDrawFloats;  // (COATI_HIP_SPEC_HOST_ROUNDS=1: the host loop below, the A/B partner)
     if(device_rounds) {
         // ---- device rounds: plan + walks + chain per round, enqueued several rounds at a time; the host reads the number
         // of unfinished pairs each round started with (a round that starts with none is three empty launches)
         constexpr uint32_t kBatch = 6;
+        const uint32_t max_width = widest;
         void* host_block = nullptr;
         S_TRY(model_pinned(m, kBatch * sizeof(SpecRound) + n * sizeof(SpecPairState) + 64, &host_block));
         SpecRound* h_round = static_cast<SpecRound*>(host_block);
@@ -166,8 +172,8 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         const bool timing = env_options().timing;
         for(bool finished = n_samples == 0 || n == 0; !finished;) {
             for(uint32_t r = 0; r < kBatch; ++r) {
-                S_TRY(launch_spec_round(view, d_tab_off, d_steps, d_state0, d_pow, n_samples, kMaxCands, kZ, d_states, d_windows, d_rank_pair, d_round,
-                                        d_cdraws, d_sample_off, m->stream));
+                S_TRY(launch_spec_round(view, d_tab_off, d_steps, d_state0, d_pow, n_samples, kMaxCands, max_width, kZ, d_states, d_windows, d_rank_pair, d_round,
+                                        d_draw_table, d_cdraws, d_sample_off, m->stream));
                 S_TRY(hipMemcpyAsync(h_round + r, d_round, sizeof(SpecRound), hipMemcpyDeviceToHost, m->stream));
             }
             S_TRY(hipStreamSynchronize(m->stream));

@@ -327,10 +327,33 @@ __global__ __launch_bounds__(256) void step_table_kernel(const float* __restrict
     }
 }
 
+// Where a table walk takes its draws from.  The final launch draws from the generator (one 128-bit multiply and a
+// conversion per draw: ~27 of a step's ~50 vector instructions); a round's candidates read the pair's stream from a table
+// that one launch per round fills (spec_draws_kernel): candidate `offset` takes table[offset], table[offset + 1], ... --
+// the same floats, and eight of them arrive with the batch's step-table entries.
+struct DrawsFromRng {
+    Rng128& rng;
+    __device__ __forceinline__ void prefetch(float (&)[8]) const {}
+    __device__ __forceinline__ float take(const float (&)[8], int) { return rng_f24(rng); }
+    __device__ __forceinline__ float next() { return rng_f24(rng); }
+};
+struct DrawsFromTable {
+    const float* __restrict__ at;
+    __device__ __forceinline__ void prefetch(float (&d)[8]) const {
+#pragma unroll
+        for(int q = 0; q < 8; ++q) d[q] = at[q];  // (the table has 8 floats of slack behind every slice)
+    }
+    __device__ __forceinline__ float take(const float (&d)[8], int q) {
+        ++at;
+        return d[q];
+    }
+    __device__ __forceinline__ float next() { return *at++; }
+};
+
 // sample_walk with the body steps read from the table.  kOps: write the ops (the final launch) or only count the
 // draws (the candidates of a round).  Identical decisions, log-weight and draw count as sample_walk.
-template <bool kOps>
-__device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ steps, Rng128& rng, uint8_t* __restrict__ ops, uint64_t slot,
+template <bool kOps, class Draws>
+__device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ steps, Draws src, uint8_t* __restrict__ ops, uint64_t slot,
                                float& score, uint32_t& draws) {
     draws = 1;
     uint32_t i = w.la, j = w.lb;  // (gap_len 1: the last cell is (la, lb))
@@ -342,7 +365,7 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
     int st;
     {
         const float top = fmaxf(fmaxf(cur.m, cur.d), cur.in);
-        st = sample3(cur.m - top, cur.d - top, cur.in - top, rng_f24(rng), score, w.exp_tab);
+        st = sample3(cur.m - top, cur.d - top, cur.in - top, src.next(), score, w.exp_tab);
     }
     const uint32_t lb = w.lb;
     // Body steps go in BATCHES.  A walk is a chain of ~la dependent loads (~0.35 us each: a round of candidates took the
@@ -370,6 +393,9 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
                     at -= diag;
                 }
             }
+            static_assert(kAhead == 8, "the draw sources hand out eight draws per batch");
+            float dr[8];
+            src.prefetch(dr);
             bool go = true;
 #pragma unroll
             for(int q = 0; q < kAhead; ++q) {
@@ -382,7 +408,7 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
                     } else {
                         if(kOps) ops[--pos] = static_cast<uint8_t>(st);
                         else --pos;
-                        float p = rng_f24(rng);
+                        float p = src.take(dr, q);
                         p *= e[q].scale;
                         int nst;
                         float inc;
@@ -433,7 +459,7 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
                     e2 = im0;
             }
             const float l1 = (is_m || is_d) ? e1 - top : -__builtin_inff();
-            st = sample3(e0 - top, l1, e2 - top, rng_f24(rng), score, w.exp_tab);
+            st = sample3(e0 - top, l1, e2 - top, src.next(), score, w.exp_tab);
             cur = t;
             cur_valid = true;
         }
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ 
                    mdi, pd, exp_tab};
     float score;
     uint32_t draws;
-    (void)table_walk<false>(w, steps + tab_off[cd.pair], rng, nullptr, 0, score, draws);
+    (void)table_walk<false>(w, steps + tab_off[cd.pair], DrawsFromRng{rng}, nullptr, 0, score, draws);
     c_draws[idx] = draws;
 }
 
@@ -480,7 +506,7 @@ __global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ 
 // host only enqueues rounds and looks at the number of unfinished pairs every few rounds: a round cost ~0.27 ms of
 // host work and copies beside ~0.45 ms of walks.
 __global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restrict__ pairs, uint32_t n_pairs, uint32_t n_samples, uint32_t max_cands,
-                                                       double z, SpecPairState* __restrict__ states, SpecWindow* __restrict__ windows,
+                                                       uint32_t max_width, double z, SpecPairState* __restrict__ states, SpecWindow* __restrict__ windows,
                                                        uint32_t* __restrict__ rank_pair, SpecRound* __restrict__ round) {
     // one wavefront per pair: how many pairs are unfinished, how many of them come before this one (its rank = its share of
     // the candidate array), then the pair's windows, eight per lane, with a prefix sum over their sizes
@@ -496,12 +522,15 @@ __global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restric
         active += __shfl_xor(active, sh);
         before += __shfl_xor(before, sh);
     }
-    const uint32_t share = max(max_cands / max(active, 1u), 1u), ranked = min(active, max_cands / share);
-    if(p == 0 && lane == 0) round->active = active, round->share = share, round->ranked = ranked;
+    // (pairs of a round: as many as have a share of the candidates AND a slice of the draw table that holds one whole walk)
+    const uint32_t share = max(max_cands / max(active, 1u), 1u);
+    const uint32_t ranked = min(min(active, max_cands / share), max(kSpecDrawFloats / ((max_width + 2u + 8u + 63u) / 64u * 64u), 1u));
+    const uint32_t slice = kSpecDrawFloats / max(ranked, 1u) / 64u * 64u;  // floats of the draw table per pair of the round
+    if(p == 0 && lane == 0) round->active = active, round->share = share, round->ranked = ranked, round->slice = slice;
     SpecPairState& s = states[p];
     const bool mine = s.done < n_samples && before < ranked;  // (more unfinished pairs than a round holds: the others wait)
     if(!mine) {
-        if(lane == 0) s.n_cands = 0, s.n_windows = 0;
+        if(lane == 0) s.n_cands = 0, s.n_windows = 0, s.n_draws = 0;
         return;
     }
     const double width = static_cast<double>(pairs[p].la) + static_cast<double>(pairs[p].lb);
@@ -521,7 +550,8 @@ __global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restric
         const long long center = llrint(j * mean);
         const long long half = j == 0 ? 0 : static_cast<long long>(ceil(z * sigma * sqrt(static_cast<double>(j)))) + 2;
         const long long lo = max(center - half, static_cast<long long>(j)), hi = max(center + half, lo);
-        const bool usable = j < chunk && hi <= 0x7ffffff0ll;
+        // (a walk from offset hi takes at most la + lb + 1 draws: they must lie in the pair's slice of the draw table)
+        const bool usable = j < chunk && hi <= 0x7ffffff0ll && hi + static_cast<long long>(width) + 2 <= static_cast<long long>(slice);
         lo_w[t] = static_cast<uint32_t>(lo), hi_w[t] = static_cast<uint32_t>(hi);
         const uint32_t count = usable ? static_cast<uint32_t>(hi - lo + 1) : kUnusable;
         s_count[j] = count;
@@ -534,7 +564,7 @@ __global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restric
     }
     unsigned long long first = incl - mine_sum;
     SpecWindow* w = windows + static_cast<uint64_t>(p) * kSpecChunkMax;
-    uint32_t last_in = 0, used = 0;  // the windows that fit the share are a prefix (sizes are positive; window 0 is one candidate: always in)
+    uint32_t last_in = 0, used = 0, last_hi = 0;  // the windows that fit the share are a prefix (sizes are positive; window 0 is one candidate: always in)
 #pragma unroll
     for(uint32_t t = 0; t < kPer; ++t) {
         const uint32_t j = lane * kPer + t, count = s_count[j];
@@ -543,19 +573,41 @@ __global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restric
             w[j] = SpecWindow{static_cast<uint32_t>(first), lo_w[t], hi_w[t]};
             last_in = j + 1;
             used = static_cast<uint32_t>(first) + count;
+            last_hi = hi_w[t];
         }
         first += count;
     }
     for(int sh = 1; sh < kWave; sh <<= 1) {
         last_in = max(last_in, __shfl_xor(last_in, sh));
         used = max(used, __shfl_xor(used, sh));
+        last_hi = max(last_hi, __shfl_xor(last_hi, sh));
     }
     if(lane == 0) {
         s.rank = before;
         rank_pair[before] = p;
         s.n_cands = min(used, share);
         s.n_windows = last_in;
+        s.n_draws = min(slice, last_hi + static_cast<uint32_t>(width) + 2u);
     }
+}
+
+// the round's draws: slice r of the table = the stream of pair rank_pair[r] from its origin on, as far as the round's walks
+// can read (n_draws); a thread jumps to its 64 draws and steps through them
+__global__ __launch_bounds__(64) void spec_draws_kernel(const uint64_t* __restrict__ state0, const uint64_t* __restrict__ mult_pow,
+                                                        const SpecPairState* __restrict__ states, const uint32_t* __restrict__ rank_pair,
+                                                        const SpecRound* __restrict__ round, float* __restrict__ draw_table) {
+    const uint32_t slice = round->slice, ranked = round->ranked;
+    if(slice == 0) return;
+    const uint64_t pos = (blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x) * 64u;
+    const uint32_t r = static_cast<uint32_t>(pos / slice), at = static_cast<uint32_t>(pos % slice);
+    if(r >= ranked) return;
+    const uint32_t pair = rank_pair[r];
+    const SpecPairState& s = states[pair];
+    if(at >= s.n_draws) return;
+    Rng128 rng = rng_jump(state0, mult_pow, pair, s.origin + at);
+    float* out = draw_table + static_cast<uint64_t>(r) * slice + at;
+    const uint32_t n = min(64u, s.n_draws - at);
+    for(uint32_t q = 0; q < n; ++q) out[q] = rng_f24(rng);
 }
 
 __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
@@ -564,7 +616,8 @@ __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restr
                                                             const StepEntry* __restrict__ steps, const uint64_t* __restrict__ state0,
                                                             const uint64_t* __restrict__ mult_pow, const SpecPairState* __restrict__ states,
                                                             const SpecWindow* __restrict__ windows, const uint32_t* __restrict__ rank_pair,
-                                                            const SpecRound* __restrict__ round, uint32_t* __restrict__ c_draws) {
+                                                            const SpecRound* __restrict__ round, const float* __restrict__ draw_table,
+                                                            uint32_t* __restrict__ c_draws) {
     __shared__ uint64_t exp_tab[32];
     const uint32_t share = round->share, ranked = round->ranked;
     const uint64_t idx = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -585,14 +638,13 @@ __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restr
         else
             hi_w = mid;
     }
-    const uint64_t offset = s.origin + w[lo_w].lo + (local - w[lo_w].first);
+    const uint32_t offset = w[lo_w].lo + (local - w[lo_w].first);  // draws after the pair's origin: where this walk starts in its slice
     const PairDesc pd = pairs[pair];
-    Rng128 rng = rng_jump(state0, mult_pow, pair, offset);
     const Walker wk{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
                     mdi, pd, exp_tab};
     float score;
     uint32_t draws;
-    (void)table_walk<false>(wk, steps + tab_off[pair], rng, nullptr, 0, score, draws);
+    (void)table_walk<false>(wk, steps + tab_off[pair], DrawsFromTable{draw_table + static_cast<uint64_t>(r) * round->slice + offset}, nullptr, 0, score, draws);
     c_draws[idx] = draws;
 }
 
@@ -716,7 +768,7 @@ __global__ __launch_bounds__(64) void final_walk_kernel(const float* __restrict_
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb, slot = sample_base[pair] + n * width;
     float score;
     uint32_t draws;
-    const uint64_t pos = table_walk<true>(w, steps + tab_off[pair], rng, ops, slot, score, draws);
+    const uint64_t pos = table_walk<true>(w, steps + tab_off[pair], DrawsFromRng{rng}, ops, slot, score, draws);
     ops_start[idx] = pos;
     ops_len[idx] = static_cast<uint32_t>(slot + width - pos);
     log_weights[idx] = score;
@@ -787,12 +839,13 @@ hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, co
     return hipGetLastError();
 }
 hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
-                             uint32_t n_samples, uint32_t max_cands, double z, SpecPairState* states, SpecWindow* windows, uint32_t* rank_pair,
-                             SpecRound* round, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream) {
+                             uint32_t n_samples, uint32_t max_cands, uint32_t max_width, double z, SpecPairState* states, SpecWindow* windows,
+                             uint32_t* rank_pair, SpecRound* round, float* draw_table, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream) {
     if(v.n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(spec_plan_kernel, dim3(v.n_pairs), dim3(kWave), 0, stream, v.pairs, v.n_pairs, n_samples, max_cands, z, states, windows, rank_pair, round);
+    hipLaunchKernelGGL(spec_plan_kernel, dim3(v.n_pairs), dim3(kWave), 0, stream, v.pairs, v.n_pairs, n_samples, max_cands, max_width, z, states, windows, rank_pair, round);
+    hipLaunchKernelGGL(spec_draws_kernel, dim3(kSpecDrawFloats / 64 / 64), dim3(64), 0, stream, state0, mult_pow, states, rank_pair, round, draw_table);
     hipLaunchKernelGGL(spec_len_round_kernel, dim3((max_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
-                       static_cast<const StepEntry*>(steps), state0, mult_pow, states, windows, rank_pair, round, c_draws);
+                       static_cast<const StepEntry*>(steps), state0, mult_pow, states, windows, rank_pair, round, draw_table, c_draws);
     hipLaunchKernelGGL(spec_chain_kernel, dim3(v.n_pairs), dim3(256), 0, stream, n_samples, states, windows, round, c_draws, sample_off);
     return hipGetLastError();
 }
