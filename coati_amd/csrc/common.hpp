@@ -486,7 +486,7 @@ struct EnvOptions {
     bool ck_split_set = false;       // COATI_HIP_CK_SPLIT="pairs,parts[,t]"
     uint64_t ck_split_pairs = 0, ck_split_parts = 3;
     bool ck_split_taper = false;
-    uint32_t spec_cands = 1u << 17;  // COATI_HIP_SPEC_CANDS
+    uint32_t spec_cands = 3u << 16;  // COATI_HIP_SPEC_CANDS (196 608: 16 x 1 000 samples 6.1 ms; 2^17: 6.4, 2^18: 6.4, 2^16: 7.8 -- tools/sample_bench.py, round 4)
     double spec_z = 2.0;             // COATI_HIP_SPEC_Z
     bool spec_host_rounds = false;   // COATI_HIP_SPEC_HOST_ROUNDS: the sampler's speculation rounds planned and resolved on the host (round 3's loop; A/B, tests)
     long double stream_unit = 0;     // COATI_HIP_STREAM_UNIT (cells; 0: the default)

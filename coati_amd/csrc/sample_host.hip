@@ -27,7 +27,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     coati_hip_model* m = b->model;
     const uint64_t n = b->n_pairs;
     constexpr uint32_t kChunkMax = 512;
-    const uint32_t kMaxCands = env_options().spec_cands;  // (COATI_HIP_SPEC_CANDS; default 2^17: measured best, tools/sample_bench.py)
+    const uint32_t kMaxCands = env_options().spec_cands;  // (COATI_HIP_SPEC_CANDS; default 3 * 2^16: measured best, tools/sample_bench.py)
     // half-width of a candidate window in standard deviations of the offset; too narrow only ends
     // a chunk early (COATI_HIP_SPEC_Z overrides, for tuning)
     const double kZ = env_options().spec_z;  // (default 2; measured, 16 x 1 000 samples of 1 kb pairs: z = 5: 38.8 ms, 3: 30.9, 2: 25.9, 1.5: 26.0, 1: 35.9)
