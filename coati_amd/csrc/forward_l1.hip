@@ -154,21 +154,21 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint3
 }
 
 template <int W, bool kFirst, bool kFast>
-__device__ __forceinline__ void fwd_chunk(const FwdCtx& cx, FwdLane<W>& st, uint32_t& arow, float (&s)[W],
-                                          const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk, float chDM,
-                                          float chDD, float chDI, float chLM, float chLI, const char* tab_bytes) {
-    const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
+__device__ __forceinline__ void fwd_steps(const FwdCtx& cx, FwdLane<W>& st, uint32_t& arow, float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase,
+                                          uint32_t k0, uint32_t k1, uint32_t a_chunk, float chDM, float chDD, float chDI, float chLM, float chLI,
+                                          const char* tab_bytes) {
+    // steps kbase + k0 .. kbase + k1 - 1 of a chunk
     if constexpr(!kFirst && kFast) {
         // two steps per iteration: M/D/I of the row above ping-pong between two register sets
         // instead of being copied (see viterbi_l1.hip: run_chunk)
-        uint32_t kk = 0;
-        for(; kk + 1 < kend; kk += 2) {
+        uint32_t kk = k0;
+        for(; kk + 1 < k1; kk += 2) {
             fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
             fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk + 1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
         }
-        if(kk < kend) fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+        if(kk < k1) fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     } else {
-        for(uint32_t kk = 0; kk < kend; ++kk)
+        for(uint32_t kk = k0; kk < k1; ++kk)
             fwd_step<W, kFirst, kFast>(cx, st, arow, s, boff, kbase, kk, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
     }
 }
@@ -225,6 +225,12 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
 #pragma unroll
     for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
 
+    // Hand-over between the strips of a pair.  Wide strips: once per 64-step chunk (the consumer waits for the 64 rows its
+    // next chunk needs, the producer publishes its progress at the end of a chunk: a strip follows its neighbour at ~130-190
+    // steps).  Strips of <= 4 columns per lane -- few pairs: `coati sample` works on one, and a 1 kb pair is 16 such strips in
+    // a row -- hand over every kSubRows = 16 steps instead (the cost is a drain of the M/D/I stores per publish, nothing
+    // when a step is ~1 us of arithmetic): the pipeline of 16 strips fills in 16 x ~85 steps instead of 16 x ~160.
+    constexpr uint32_t kSubRows = W <= 4 ? 16u : static_cast<uint32_t>(kWave);
     bool ok = true;
     for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
         const uint32_t crow = kbase + lane;  // the body row lane 0 processes at step kbase + lane
@@ -235,26 +241,32 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
             // matrix column 0 (align_pair.cc:82-86): diagonal of body row r is matrix cell (r, 0)
             if(crow == 0) chDM = 0.0f;
             else if(crow < la) chDD = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
-        } else {
-            ok = ok && wait_rows(progress + ticket - 1, min(la, kbase + kWave));
-            if(crow < la) {
-                const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
-                const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
-                chDM = dgp[0];
-                chDD = dgp[1];
-                chDI = dgp[2];
-                chLM = lfp[0];
-                chLI = lfp[2];
-            }
         }
-        asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
-        if(kbase == 0)
-            fwd_chunk<W, true, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
-        else
-            fwd_chunk<W, false, kFast>(cx, st, arow, s, boff, kbase, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
-        if(!last_strip) {
-            const uint32_t done = min(kbase + kWave, nsteps);
-            if(done > kWave - 1) publish(progress + ticket, min(la, done - (kWave - 1)), lane == kWave - 1);
+        const uint32_t kend = min(static_cast<uint32_t>(kWave), nsteps - kbase);
+        for(uint32_t k0 = 0; k0 < kend; k0 += kSubRows) {
+            const uint32_t k1 = min(k0 + kSubRows, kend);
+            if(strip > 0) {
+                // rows kbase + k0 .. kbase + k1 - 1 of the left neighbour's last column: lanes k0 .. k1 - 1 take theirs
+                ok = ok && wait_rows(progress + ticket - 1, min(la, kbase + k1));
+                if(crow < la && static_cast<uint32_t>(lane) >= k0 && static_cast<uint32_t>(lane) < k1) {
+                    const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
+                    const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
+                    chDM = dgp[0];
+                    chDD = dgp[1];
+                    chDI = dgp[2];
+                    chLM = lfp[0];
+                    chLI = lfp[2];
+                }
+            }
+            asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
+            if(kbase == 0)
+                fwd_steps<W, true, kFast>(cx, st, arow, s, boff, kbase, k0, k1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            else
+                fwd_steps<W, false, kFast>(cx, st, arow, s, boff, kbase, k0, k1, a_chunk, chDM, chDD, chDI, chLM, chLI, tab_bytes);
+            if(!last_strip) {
+                const uint32_t done = kbase + k1;  // steps completed: lane 63 has finished body row done - 64
+                if(done > kWave - 1) publish(progress + ticket, min(la, done - (kWave - 1)), lane == kWave - 1);
+            }
         }
     }
     if(!last_strip) publish(progress + ticket, la, lane == kWave - 1);

@@ -583,7 +583,12 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         Ahead (&ahead)[kSlots];
         ~JoinAhead() {
             for(Ahead& a : ahead) {
-                if(a.task.valid()) (void)a.task.get();
+                if(a.task.valid()) {
+                    try {
+                        (void)a.task.get();
+                    } catch(...) {  // (a helper's std::bad_alloc: the call is already on its way out)
+                    }
+                }
                 if(a.valid && a.batch != nullptr) coati_hip_batch_destroy(a.batch);
             }
         }
