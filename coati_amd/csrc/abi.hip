@@ -3,6 +3,7 @@
 // (shared declarations: abi_internal.hpp); the kernels live in viterbi_ck.hip, viterbi_l1.hip, viterbi_k.hip,
 // forward_l1.hip, forward_k.hip, dp_generic.hip and sampleback.hip.
 #include "abi_internal.hpp"
+#include <map>
 
 using namespace coati_hip_abi;
 
@@ -693,14 +694,43 @@ int coati_hip_shard_bounds(uint64_t n_pairs, const uint64_t* a_off, const uint64
 /* Page-locked host memory for the arrays of coati_hip_viterbi_batch (inputs and outputs): copies to
  * and from such memory are asynchronous DMA transfers that overlap the kernels; pageable memory goes
  * through a staging copy. */
+extern "C++" {
+namespace {
+// blocks handed out by coati_hip_host_alloc: asking the runtime whether a pointer is page-locked costs 5-10 us per array
+// (hipPointerGetAttributes), six arrays per one-shot call; these are known without asking
+std::mutex g_host_blocks_lock;
+std::map<uintptr_t, uint64_t> g_host_blocks;  // start -> bytes
+}  // namespace
+namespace coati_hip_abi {
+bool host_block_contains(const void* p) {
+    const uintptr_t at = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> hold(g_host_blocks_lock);
+    auto it = g_host_blocks.upper_bound(at);
+    if(it == g_host_blocks.begin()) return false;
+    --it;
+    return at - it->first < it->second;
+}
+}  // namespace coati_hip_abi
+}  // extern "C++"
+
 int coati_hip_host_alloc(uint64_t bytes, void** out) {
     if(out == nullptr) return fail(COATI_HIP_EINVAL, "host_alloc: out is NULL");
     *out = nullptr;
     HIP_TRY(hipHostMalloc(out, std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+    try {
+        std::lock_guard<std::mutex> hold(g_host_blocks_lock);
+        g_host_blocks[reinterpret_cast<uintptr_t>(*out)] = std::max<uint64_t>(bytes, 1);
+    } catch(const std::bad_alloc&) {  // (not recorded: the runtime is asked about it instead)
+    }
     return COATI_HIP_OK;
 }
 void coati_hip_host_free(void* p) {
-    if(p != nullptr) (void)hipHostFree(p);
+    if(p == nullptr) return;
+    {
+        std::lock_guard<std::mutex> hold(g_host_blocks_lock);
+        g_host_blocks.erase(reinterpret_cast<uintptr_t>(p));
+    }
+    (void)hipHostFree(p);
 }
 
 int coati_hip_debug_viterbi_flags(coati_hip_batch_t* b, uint64_t pair, uint8_t* out, uint64_t capacity) {

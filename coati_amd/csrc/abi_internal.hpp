@@ -195,6 +195,8 @@ namespace coati_hip_abi {
 
 // the error channel of the C ABI: formats into the calling thread's message, returns `code`
 int fail(int code, const char* fmt, ...);
+// is p inside a block coati_hip_host_alloc handed out (and coati_hip_host_free has not taken back)?
+bool host_block_contains(const void* p);
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \

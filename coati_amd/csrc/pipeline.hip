@@ -14,6 +14,7 @@ namespace {
 // Is `p` page-locked host memory HIP knows about (hipHostMalloc / hipHostRegister / coati_hip_host_alloc)?
 bool is_pinned_host(const void* p) {
     if(p == nullptr) return false;
+    if(host_block_contains(p)) return true;  // (coati_hip_host_alloc's own blocks: no question to the runtime)
     hipPointerAttribute_t attr;
     if(hipPointerGetAttributes(&attr, p) != hipSuccess) {
         (void)hipGetLastError();
@@ -765,7 +766,7 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
     HIP_TRY(hipSetDevice(model->device));
     const uint32_t gap_len = static_cast<uint32_t>(model->gap_len);
     // ---- the input once: valid offsets, cells, what decides the form of the call
-    long double total_cells = 0;
+    double cells_sum = 0;  // (x87 long double adds made this loop 3x slower; 53 bits are plenty for the thresholds the sum meets)
     uint64_t widest = 0, max_pair_cells = 0, longest_single = 0, longest_a = 0, longest_pair_bytes = 0;
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
@@ -774,13 +775,14 @@ int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const ui
         if(la > 0xffffffffull || lb > 0xffffffffull)
             return fail(COATI_HIP_EINVAL, "viterbi_batch: pair %llu is longer than 2^32", static_cast<unsigned long long>(p));
         const uint64_t cells = la * lb;
-        total_cells += static_cast<long double>(cells);
+        cells_sum += static_cast<double>(cells);
         widest = std::max(widest, lb);
         max_pair_cells = std::max(max_pair_cells, cells);
         longest_a = std::max(longest_a, la);
         longest_pair_bytes = std::max(longest_pair_bytes, la + lb);
         if(lb > 0 && lb <= static_cast<uint64_t>(kStrip)) longest_single = std::max(longest_single, la);
     }
+    const long double total_cells = cells_sum;
     const uint64_t ops_total = (a_off[n_pairs] - a_off[0]) + (b_off[n_pairs] - b_off[0]);
     if(ops != nullptr && ops_capacity < ops_total)
         return fail(COATI_HIP_EINVAL, "viterbi_batch: ops_capacity %llu < %llu", static_cast<unsigned long long>(ops_capacity),
