@@ -448,7 +448,10 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
         // exact stream with several samples per pair: walked in parallel by speculating the stream
         // offsets (identical results); COATI_HIP_SAMPLE_SEQUENTIAL=1 keeps the one-walker-per-pair loop
         const bool sequential = env_options().sample_sequential;
-        if(!independent_streams && n_samples >= 4 && !sequential) {
+        // (speculation buys parallelism for FEW pairs with many samples; thousands of pairs are parallel as they are -- one walker
+        // per pair, sample after sample -- and a round's per-pair work would only add to it: 3 000 short pairs x 12 samples
+        // 6.4 ms sequentially, 9.4-14.5 ms speculated; tools/sample_many_pairs_check.py)
+        if(!independent_streams && n_samples >= 4 && !sequential && n <= 1024) {
             if((e = sampleback_speculative(b, n_samples, rng_state, base, d_ops, d_start, d_len, d_lw, states.data())) != hipSuccess) return e;
             states_final_on_host = true;  // (the streams' final states were computed here: no trip through the device)
         } else {

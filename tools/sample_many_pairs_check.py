@@ -7,7 +7,7 @@ import numpy as np
 from coati_amd import hip, host
 from tests import util
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000  # (above 1 024 pairs the library walks sequentially whatever the switches say)
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 rng = np.random.default_rng(11)
 pairs = util.make_pairs(rng, n, 10, 60, L=1)  # 30 .. 180 nt
