@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the persistent fill kernel from the trace build (make trace): per wavefront the
 100 MHz wall-clock stamps start / fill-done / walk-done of each item it processed.
-usage: COATI_HIP_LIB=coati_amd/_build/libcoati_hip_trace.so python tools/trace_fill.py [pairs]"""
+usage: COATI_HIP_LIB=coati_amd/_build/libcoati_hip_trace.so python tools/trace_fill.py [pairs] [codons per pair]"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -13,8 +13,9 @@ sys.path.insert(0, str(ROOT))
 from coati_amd import hip, host  # noqa: E402
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+codons = int(sys.argv[2]) if len(sys.argv) > 2 else None
 model = hip.Model(host.set_subst("mar-mg"), host.gap_consts(), 1)
-batch = hip.Batch(model, *host.synth_encoded(0, pairs))
+batch = hip.Batch(model, *(host.synth_encoded(0, pairs) if codons is None else host.synth_encoded(0, pairs, n_codons=codons)))
 tr = np.zeros(4096 * 16, np.uint64)
 for _ in range(3):
     hip.load().coati_hip_debug_trace(tr.ctypes.data_as(C.c_void_p))  # read + clear
