@@ -760,7 +760,7 @@ def strong_job(comm, hip, host, torch, world, rank, local_rank, args):
     # to rank 0 over RCCL) -- what `coati-alignpair --batch --devices` builds on: every rank formats its own slice
     times_local = []
     loc = None
-    for _ in range(2):
+    for _ in range(3):  # (the model's first streamed call allocates its slots, the second the last chunk's workspace)
         comm.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -785,7 +785,7 @@ def strong_job(comm, hip, host, torch, world, rank, local_rank, args):
             "pairs": total, "model": "mar-ecm", "n_gpus": world, "seconds": times[-1], "first_job_seconds": times[0],
             "gcups": cells / times[-1] / 1e9, "pairs_per_s": total / times[-1], "scaling": "strong",
             "shard_generation_seconds": t_gen, "scores_crc32": "%08x" % zlib.crc32(sc.tobytes()), "columns": int(ln.sum()),
-            "local_results": {"what": "the same job through coati_hip_dist_viterbi_shard_local: ops stay with the rank that computed them "
+            "local_results": {"what": "the same job (third of three) through coati_hip_dist_viterbi_shard_local: ops stay with the rank that computed them "
                                       "(own PCIe link, page-locked arrays), scores + op lengths of all pairs gathered to rank 0 over RCCL",
                               "seconds": times_local[-1], "first_job_seconds": times_local[0], "gcups": cells / times_local[-1] / 1e9,
                               "pairs_per_s": total / times_local[-1], "equal_to_gathered": same}}

@@ -35,6 +35,12 @@ for w in [int(x) for x in sys.argv[1:]] or [8, 4, 16]:
         fill = (raw[used, 1] - t0) / 100.0
         walk = (raw[used, 2] - raw[used, 1]) / 100.0
         rows.append((strips, total, fill.mean(), walk.mean()))
+        if strips == 15:  # every strip's fill end: the 64 pairs are alike, so the sorted times fall into one group per strip
+            ends = np.sort((raw[raw[:, 1] > 0, 1] - t0) / 100.0)
+            print("   items traced:", len(ends))
+            groups = np.array([g.mean() for g in np.array_split(ends, strips)])
+            print("   fill ends by strip (us):", " ".join(f"{g:.0f}" for g in groups))
+            print("   strip-to-strip (us):    ", " ".join(f"{d:.0f}" for d in np.diff(groups)))
         batch.close(); model.close()
     step_us = rows[0][2] / (7998 + 63)
     print(f"W {w}: step {step_us:.3f} us (one strip: fill {rows[0][2]:.0f} us, traceback {rows[0][3]:.0f} us)")
