@@ -503,7 +503,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     // one thread plans ~10 pairs per microsecond, so that the chip, which wants 4 096 pairs before every wavefront has one,
     // was full only ~0.6-1.0 ms after a 10 000-pair call had started (round 4; profiles/r04/stream_timeline_10000.txt).
     struct Ahead {
-        bool valid = false, fits = true, tail = false, planned = false;
+        bool valid = false, fits = true, tail = false;
         int slot = 0;
         PipeChunk c;
         ChunkNeed nd;
@@ -538,7 +538,6 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             ++p1;
         }
         a.valid = true;
-        a.planned = false;
         a.slot = q;
         a.tail = tail;
         a.batch = nullptr;
