@@ -341,7 +341,7 @@ struct DrawsFromTable {
     const float* __restrict__ at;
     __device__ __forceinline__ void prefetch(float (&d)[8]) const {
 #pragma unroll
-        for(int q = 0; q < 8; ++q) d[q] = at[q];  // (the table has 8 floats of slack behind every slice)
+        for(int q = 0; q < 8; ++q) d[q] = at[q];  // (the table has slack behind every slice)
     }
     __device__ __forceinline__ float take(const float (&d)[8], int q) {
         ++at;
@@ -476,6 +476,98 @@ __device__ __forceinline__ Rng128 rng_jump(const uint64_t* __restrict__ origin_s
     return Rng128{static_cast<uint64_t>(st), static_cast<uint64_t>(st >> 64)};
 }
 
+// What a round's candidate needs from its walk is only HOW MANY draws it takes.  Counting does not have to go step by step:
+// a batch loads the thresholds of the cell the walk is at (for its state) and of the next K - 1 cells down the diagonal
+// (for M), with the K draws; the K products and comparisons are independent of each other (a lone wavefront overlaps
+// them: the step-by-step loop was ~55 dependent instructions per step); the number of leading "match" decisions says how
+// many of the steps happened, and one more comparison of the first other decision says which gap state the walk is in
+// then.  Same thresholds, same draws, same comparisons as table_walk: the same count.  ~60 instructions per batch of up
+// to 16 steps instead of ~55 per step.
+struct StepThresholds {  // the first 12 bytes of a StepEntry
+    float scale, m, dm;
+};
+template <int K>
+__device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restrict__ steps, const float* __restrict__ at) {
+    static_assert(K >= 2 && K <= 31, "decisions of a batch are bits of a word");
+    uint32_t draws = 1;
+    uint32_t i = w.la, j = w.lb;
+    float score = 0.0f;  // (sample3 accumulates it; not a result here)
+    Triple cur;
+    w.cell(i, j, cur.m, cur.d, cur.in);
+    bool cur_valid = true;
+    int st;
+    {
+        const float top = fmaxf(fmaxf(cur.m, cur.d), cur.in);
+        st = sample3(cur.m - top, cur.d - top, cur.in - top, *at++, score, w.exp_tab);
+    }
+    const uint32_t lb = w.lb;
+    const uint64_t diag = (static_cast<uint64_t>(lb) + 1) * 3;
+    while(j > 0 || i > 0) {
+        if(i >= 1 && j >= 1) {
+            const StepEntry* const here = steps + (static_cast<uint64_t>(i - 1) * lb + (j - 1)) * 3;
+            const bool m0 = st == COATI_HIP_OP_MATCH, d0 = st == COATI_HIP_OP_DEL;
+            const uint32_t i1 = (m0 || d0) ? i - 1 : i, j1 = d0 ? j : j - 1;  // where this step leads
+            const uint32_t room = min(i1, j1);  // steps 1 .. room of the batch are at body cells (i1 - q + 1, j1 - q + 1)
+            const StepEntry* dg = here - (m0 ? static_cast<uint64_t>(lb) + 1 : (d0 ? static_cast<uint64_t>(lb) : 1ull)) * 3 + COATI_HIP_OP_MATCH;
+            StepThresholds e[K];
+            float dr[K];
+            e[0] = *reinterpret_cast<const StepThresholds*>(here + static_cast<uint32_t>(st));
+#pragma unroll
+            for(int q = 1; q < K; ++q) {
+                e[q] = *reinterpret_cast<const StepThresholds*>(static_cast<uint32_t>(q) <= room ? dg : steps);
+                dg -= diag;
+            }
+#pragma unroll
+            for(int q = 0; q < K; ++q) dr[q] = at[q];  // (the table has slack behind every slice)
+            uint32_t is_m = 0, is_d = 0;  // bit q: the draw of step q falls under the M threshold / under the D threshold
+#pragma unroll
+            for(int q = 0; q < K; ++q) {
+                const float p = dr[q] * e[q].scale;
+                is_m |= (p < e[q].m ? 1u : 0u) << q;
+                is_d |= (p < e[q].dm ? 1u : 0u) << q;
+            }
+            // steps 0 .. lead - 1 chose M; step q >= 1 happens if every step before it chose M and its cell is a body cell
+            const uint32_t lead = static_cast<uint32_t>(__builtin_ctz(~is_m | (1u << K)));
+            const uint32_t c = min(min(lead + 1u, static_cast<uint32_t>(K)), room + 1u);  // steps of this batch that happen
+            const uint32_t last = c - 1u;
+            st = last < lead ? COATI_HIP_OP_MATCH : (((is_d >> last) & 1u) != 0 ? COATI_HIP_OP_DEL : COATI_HIP_OP_INS);
+            i = i1 - last;
+            j = j1 - last;
+            draws += c;
+            at += c;
+            cur_valid = false;
+            continue;
+        }
+        ++draws;
+        const bool is_m = st == COATI_HIP_OP_MATCH, is_d = st == COATI_HIP_OP_DEL;
+        const uint32_t pi = is_m ? i - 1 : (is_d ? i - 1 : i), pj = is_m ? j - 1 : (is_d ? j : j - 1);
+        if(pi > i || pj > j) break;  // (as in sample_walk: only with a table of -inf / NaN weights)
+        {
+            // a margin cell: del_del / ins_ins are copies of the margin D / I (init_margins, align_pair.hpp:108-111)
+            if(!cur_valid) w.pred(i, j, cur.m, cur.d, cur.in);
+            Triple t{kLowest, kLowest, kLowest};
+            w.pred(pi, pj, t.m, t.d, t.in);
+            const float top = is_m ? cur.m : (is_d ? cur.d : cur.in);
+            float e0 = kLowest, e1 = kLowest, e2 = kLowest;
+            if(!is_m) {
+                float mm0, dm0, im0;
+                margin_mdi(w.k, 1u, i, j, mm0, dm0, im0);
+                if(is_d)
+                    e1 = dm0;
+                else
+                    e2 = im0;
+            }
+            const float l1 = (is_m || is_d) ? e1 - top : -__builtin_inff();
+            st = sample3(e0 - top, l1, e2 - top, *at++, score, w.exp_tab);
+            cur = t;
+            cur_valid = true;
+        }
+        i = pi;
+        j = pj;
+    }
+    return draws;
+}
+
 // a round's candidates: how many draws does a sample that starts `offset` draws after the chunk origin take?
 __global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
                                                       const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
@@ -524,7 +616,7 @@ __global__ __launch_bounds__(64) void spec_plan_kernel(const PairDesc* __restric
     }
     // (pairs of a round: as many as have a share of the candidates AND a slice of the draw table that holds one whole walk)
     const uint32_t share = max(max_cands / max(active, 1u), 1u);
-    const uint32_t ranked = min(min(active, max_cands / share), max(kSpecDrawFloats / ((max_width + 2u + 8u + 63u) / 64u * 64u), 1u));
+    const uint32_t ranked = min(min(active, max_cands / share), max(kSpecDrawFloats / ((max_width + 2u + 16u + 63u) / 64u * 64u), 1u));
     const uint32_t slice = kSpecDrawFloats / max(ranked, 1u) / 64u * 64u;  // floats of the draw table per pair of the round
     if(p == 0 && lane == 0) round->active = active, round->share = share, round->ranked = ranked, round->slice = slice;
     SpecPairState& s = states[p];
@@ -642,9 +734,7 @@ __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restr
     const PairDesc pd = pairs[pair];
     const Walker wk{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
                     mdi, pd, exp_tab};
-    float score;
-    uint32_t draws;
-    (void)table_walk<false>(wk, steps + tab_off[pair], DrawsFromTable{draw_table + static_cast<uint64_t>(r) * round->slice + offset}, nullptr, 0, score, draws);
+    const uint32_t draws = table_walk_count<16>(wk, steps + tab_off[pair], draw_table + static_cast<uint64_t>(r) * round->slice + offset);
     c_draws[idx] = draws;
 }
 
