@@ -633,12 +633,15 @@ constexpr uint32_t kSpecDrawFloats = 16u << 20;  // the round's table of stream 
 constexpr uint32_t kSpecChunkMax = 512;  // samples speculated per pair and round, at most
 hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
                              uint32_t n_samples, uint32_t max_cands, uint32_t max_width, double z, SpecPairState* states, SpecWindow* windows,
-                             uint32_t* rank_pair, SpecRound* round, float* draw_table, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream);
+                             uint32_t* rank_pair, SpecRound* round, float* draw_table, const uint64_t* thr_off, const void* thr_m, uint32_t* c_draws,
+                             uint64_t* sample_off, hipStream_t stream);
 
 // round 4: the step table of the exact-stream sampler (sampleback.hip): thresholds and log-weight increments per
 // (body cell, state), 24 bytes each, row-major per pair from entry tab_off[pair]; gap_len 1
 uint64_t step_entry_bytes();
-hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, hipStream_t stream);
+hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, const uint64_t* thr_off, void* thr_m,
+                             hipStream_t stream);  // thr_m (may be null): the M-state thresholds again, 12 bytes per body cell, diagonal-major (sampleback.hip)
+uint64_t step_thr_entries(uint32_t la, uint32_t lb);  // entries of a pair in thr_m
 hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* origin_state, const uint64_t* mult_pow,
                            const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream);
 hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* start_state, const uint64_t* mult_pow,

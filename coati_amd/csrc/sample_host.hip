@@ -52,7 +52,14 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         max_cells = std::max(max_cells, cells);
     }
     const bool table_off = env_options().sample_table_off;
-    const uint64_t table_bytes = table_entries * step_entry_bytes();
+    // (+ the M-state thresholds once more, diagonal-major, 12 bytes per entry: what a round's candidates read -- sampleback.hip)
+    std::vector<uint64_t> thr_off(n, 0);
+    uint64_t thr_entries = 0;
+    for(uint64_t p = 0; p < n; ++p) {
+        thr_off[p] = thr_entries;
+        thr_entries += step_thr_entries(b->desc[p].la, b->desc[p].lb);
+    }
+    const uint64_t table_bytes = table_entries * step_entry_bytes() + thr_entries * 12 + 256;
     const bool use_table = m->gap_len == 1 && !forward_fast_math() && !table_off && table_bytes <= (8ull << 30) && table_bytes <= free_b / 3 &&
                            b->desc[0].f_compact == 0;
     // work arena for the candidates' ops: 2 GB, or a power of two below a quarter of the free HBM
@@ -94,6 +101,8 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     uint32_t* d_rank_pair = nullptr;
     SpecRound* d_round = nullptr;
     float* d_draw_table = nullptr;  // the round's stream draws, a slice per pair (spec_draws_kernel)
+    uint64_t* d_thr_off = nullptr;
+    char* d_thr = nullptr;
     void* block = nullptr;
     uint64_t block_bytes = 0;
     auto carve = [&](Carver& cv) {
@@ -116,7 +125,9 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             d_rank_pair = cv.take<uint32_t>(n);
             d_round = cv.take<SpecRound>(1);
             d_draw_table = cv.take<float>(kSpecDrawFloats + 64);
-            d_steps = cv.take<char>(table_bytes);
+            d_thr_off = cv.take<uint64_t>(n);
+            d_thr = cv.take<char>(thr_entries * 12 + 256);
+            d_steps = cv.take<char>(table_entries * step_entry_bytes());
         }
     };
     auto release = [&]() {
@@ -150,7 +161,8 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(hipMemcpyAsync(d_tab_off, tab_off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_state0, rng_state, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
-        S_TRY(launch_step_table(view, d_tab_off, max_cells, d_steps, m->stream));
+        S_TRY(hipMemcpyAsync(d_thr_off, thr_off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
+        S_TRY(launch_step_table(view, d_tab_off, max_cells, d_steps, d_thr_off, d_thr, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));  // (tab_off / base are stack-lifetime vectors of the caller: uploaded before they can go)
     }
 
@@ -173,7 +185,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         for(bool finished = n_samples == 0 || n == 0; !finished;) {
             for(uint32_t r = 0; r < kBatch; ++r) {
                 S_TRY(launch_spec_round(view, d_tab_off, d_steps, d_state0, d_pow, n_samples, kMaxCands, max_width, kZ, d_states, d_windows, d_rank_pair, d_round,
-                                        d_draw_table, d_cdraws, d_sample_off, m->stream));
+                                        d_draw_table, d_thr_off, d_thr, d_cdraws, d_sample_off, m->stream));
                 S_TRY(hipMemcpyAsync(h_round + r, d_round, sizeof(SpecRound), hipMemcpyDeviceToHost, m->stream));
             }
             S_TRY(hipStreamSynchronize(m->stream));

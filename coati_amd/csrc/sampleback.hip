@@ -306,10 +306,22 @@ __device__ __forceinline__ StepEntry step_entry(const Walker& w, uint32_t i, uin
     return StepEntry{scale, m, d + m, l0 - ls, l1 - ls, l2 - ls};
 }
 
+struct StepThresholds {  // the first 12 bytes of a StepEntry
+    float scale, m, dm;
+};
+// The M-state thresholds once more, DIAGONAL-major: entry (d, t) with d = i - j + lb - 1 and t = min(i, j) - 1 at d * L + t,
+// L = min(la, lb).  A run of matches walks down a diagonal: the batch of table_walk_count reads 16 consecutive entries
+// (192 bytes) instead of 16 entries 72 * (lb + 1) bytes apart, and the candidates of a pair, which are all near the same
+// diagonals, share cache lines within a load instruction.
+__device__ __forceinline__ uint64_t thr_index(uint32_t i, uint32_t j, uint32_t la, uint32_t lb) {
+    return static_cast<uint64_t>(i + (lb - 1u) - j) * min(la, lb) + (min(i, j) - 1u);
+}
+
 __global__ __launch_bounds__(256) void step_table_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
                                                          const uint64_t* __restrict__ tab_off, uint32_t n_pairs,
                                                          const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
-                                                         const float* __restrict__ mdi, StepEntry* __restrict__ steps) {
+                                                         const float* __restrict__ mdi, StepEntry* __restrict__ steps,
+                                                         const uint64_t* __restrict__ thr_off, StepThresholds* __restrict__ thr_m) {
     __shared__ uint64_t exp_tab[32];
     load_exp_table(exp_tab, threadIdx.x);
     __syncthreads();
@@ -323,7 +335,11 @@ __global__ __launch_bounds__(256) void step_table_kernel(const float* __restrict
     for(uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; c < cells; c += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
         const uint32_t bi = static_cast<uint32_t>(c / pd.lb), bj = static_cast<uint32_t>(c - static_cast<uint64_t>(bi) * pd.lb);
 #pragma unroll
-        for(int st = 0; st < 3; ++st) out[c * 3 + st] = step_entry(w, bi + 1, bj + 1, st);
+        for(int st = 0; st < 3; ++st) {
+            const StepEntry e = step_entry(w, bi + 1, bj + 1, st);
+            out[c * 3 + st] = e;
+            if(st == COATI_HIP_OP_MATCH && thr_m != nullptr) thr_m[thr_off[pair] + thr_index(bi + 1, bj + 1, pd.la, pd.lb)] = StepThresholds{e.scale, e.m, e.dm};
+        }
     }
 }
 
@@ -483,11 +499,8 @@ __device__ __forceinline__ Rng128 rng_jump(const uint64_t* __restrict__ origin_s
 // many of the steps happened, and one more comparison of the first other decision says which gap state the walk is in
 // then.  Same thresholds, same draws, same comparisons as table_walk: the same count.  ~60 instructions per batch of up
 // to 16 steps instead of ~55 per step.
-struct StepThresholds {  // the first 12 bytes of a StepEntry
-    float scale, m, dm;
-};
 template <int K>
-__device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restrict__ steps, const float* __restrict__ at) {
+__device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restrict__ steps, const StepThresholds* __restrict__ thr, const float* __restrict__ at) {
     static_assert(K >= 2 && K <= 31, "decisions of a batch are bits of a word");
     uint32_t draws = 1;
     uint32_t i = w.la, j = w.lb;
@@ -508,14 +521,22 @@ __device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restric
             const bool m0 = st == COATI_HIP_OP_MATCH, d0 = st == COATI_HIP_OP_DEL;
             const uint32_t i1 = (m0 || d0) ? i - 1 : i, j1 = d0 ? j : j - 1;  // where this step leads
             const uint32_t room = min(i1, j1);  // steps 1 .. room of the batch are at body cells (i1 - q + 1, j1 - q + 1)
-            const StepEntry* dg = here - (m0 ? static_cast<uint64_t>(lb) + 1 : (d0 ? static_cast<uint64_t>(lb) : 1ull)) * 3 + COATI_HIP_OP_MATCH;
             StepThresholds e[K];
             float dr[K];
-            e[0] = *reinterpret_cast<const StepThresholds*>(here + static_cast<uint32_t>(st));
+            // (two batches in three end because all K steps were matches: the next one starts in state M, on the diagonal the
+            // neighbouring candidates are reading too)
+            e[0] = thr != nullptr && m0 ? thr[thr_index(i, j, w.la, lb)] : *reinterpret_cast<const StepThresholds*>(here + static_cast<uint32_t>(st));
+            if(thr != nullptr) {  // the next K - 1 diagonal cells' M thresholds: consecutive, descending (thr_index)
+                const StepThresholds* dg = room > 0 ? thr + thr_index(i1, j1, w.la, lb) : thr;
 #pragma unroll
-            for(int q = 1; q < K; ++q) {
-                e[q] = *reinterpret_cast<const StepThresholds*>(static_cast<uint32_t>(q) <= room ? dg : steps);
-                dg -= diag;
+                for(int q = 1; q < K; ++q) e[q] = *(static_cast<uint32_t>(q) <= room ? dg - (q - 1) : thr);
+            } else {
+                const StepEntry* dg = here - (m0 ? static_cast<uint64_t>(lb) + 1 : (d0 ? static_cast<uint64_t>(lb) : 1ull)) * 3 + COATI_HIP_OP_MATCH;
+#pragma unroll
+                for(int q = 1; q < K; ++q) {
+                    e[q] = *reinterpret_cast<const StepThresholds*>(static_cast<uint32_t>(q) <= room ? dg : steps);
+                    dg -= diag;
+                }
             }
 #pragma unroll
             for(int q = 0; q < K; ++q) dr[q] = at[q];  // (the table has slack behind every slice)
@@ -709,6 +730,7 @@ __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restr
                                                             const uint64_t* __restrict__ mult_pow, const SpecPairState* __restrict__ states,
                                                             const SpecWindow* __restrict__ windows, const uint32_t* __restrict__ rank_pair,
                                                             const SpecRound* __restrict__ round, const float* __restrict__ draw_table,
+                                                            const uint64_t* __restrict__ thr_off, const StepThresholds* __restrict__ thr_m,
                                                             uint32_t* __restrict__ c_draws) {
     __shared__ uint64_t exp_tab[32];
     const uint32_t share = round->share, ranked = round->ranked;
@@ -734,7 +756,8 @@ __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restr
     const PairDesc pd = pairs[pair];
     const Walker wk{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
                     mdi, pd, exp_tab};
-    const uint32_t draws = table_walk_count<16>(wk, steps + tab_off[pair], draw_table + static_cast<uint64_t>(r) * round->slice + offset);
+    const uint32_t draws = table_walk_count<16>(wk, steps + tab_off[pair], thr_m != nullptr ? thr_m + thr_off[pair] : nullptr,
+                                                draw_table + static_cast<uint64_t>(r) * round->slice + offset);
     c_draws[idx] = draws;
 }
 
@@ -914,11 +937,15 @@ hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, con
 }
 
 uint64_t step_entry_bytes() { return sizeof(StepEntry); }
-hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, hipStream_t stream) {
+uint64_t step_thr_entries(uint32_t la, uint32_t lb) {
+    return la == 0 || lb == 0 ? 0 : (static_cast<uint64_t>(la) + lb - 1) * std::min(la, lb);
+}
+hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, const uint64_t* thr_off, void* thr_m,
+                             hipStream_t stream) {
     if(v.n_pairs == 0 || max_cells == 0) return hipSuccess;
     const uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((max_cells + 255) / 256, 4096));
     hipLaunchKernelGGL(step_table_kernel, dim3(gx, v.n_pairs), dim3(256), 0, stream, v.table, v.k, v.pairs, tab_off, v.n_pairs, v.a_cat, v.b_cat, v.mdi,
-                       static_cast<StepEntry*>(steps));
+                       static_cast<StepEntry*>(steps), thr_off, static_cast<StepThresholds*>(thr_m));
     return hipGetLastError();
 }
 hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* origin_state, const uint64_t* mult_pow,
@@ -930,12 +957,14 @@ hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, co
 }
 hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
                              uint32_t n_samples, uint32_t max_cands, uint32_t max_width, double z, SpecPairState* states, SpecWindow* windows,
-                             uint32_t* rank_pair, SpecRound* round, float* draw_table, uint32_t* c_draws, uint64_t* sample_off, hipStream_t stream) {
+                             uint32_t* rank_pair, SpecRound* round, float* draw_table, const uint64_t* thr_off, const void* thr_m, uint32_t* c_draws,
+                             uint64_t* sample_off, hipStream_t stream) {
     if(v.n_pairs == 0) return hipSuccess;
     hipLaunchKernelGGL(spec_plan_kernel, dim3(v.n_pairs), dim3(kWave), 0, stream, v.pairs, v.n_pairs, n_samples, max_cands, max_width, z, states, windows, rank_pair, round);
     hipLaunchKernelGGL(spec_draws_kernel, dim3(kSpecDrawFloats / 64 / 64), dim3(64), 0, stream, state0, mult_pow, states, rank_pair, round, draw_table);
     hipLaunchKernelGGL(spec_len_round_kernel, dim3((max_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
-                       static_cast<const StepEntry*>(steps), state0, mult_pow, states, windows, rank_pair, round, draw_table, c_draws);
+                       static_cast<const StepEntry*>(steps), state0, mult_pow, states, windows, rank_pair, round, draw_table, thr_off,
+                       static_cast<const StepThresholds*>(thr_m), c_draws);
     hipLaunchKernelGGL(spec_chain_kernel, dim3(v.n_pairs), dim3(256), 0, stream, n_samples, states, windows, round, c_draws, sample_off);
     return hipGetLastError();
 }
