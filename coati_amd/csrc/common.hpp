@@ -488,6 +488,7 @@ struct EnvOptions {
     bool ck_split_taper = false;
     uint32_t spec_cands = 3u << 16;  // COATI_HIP_SPEC_CANDS (196 608: 16 x 1 000 samples 6.1 ms; 2^17: 6.4, 2^18: 6.4, 2^16: 7.8 -- tools/sample_bench.py, round 4)
     double spec_z = 2.0;             // COATI_HIP_SPEC_Z
+    uint32_t sample_band = 64;       // COATI_HIP_SAMPLE_BAND: half width, in diagonals, of the sampler's step table (tests: 1 or 2 force the walkers' own entries)
     bool spec_host_rounds = false;   // COATI_HIP_SPEC_HOST_ROUNDS: the sampler's speculation rounds planned and resolved on the host (round 3's loop; A/B, tests)
     long double stream_unit = 0;     // COATI_HIP_STREAM_UNIT (cells; 0: the default)
     uint64_t mem_budget = 0;         // COATI_HIP_MEM_BUDGET (bytes; 0: none)
@@ -631,21 +632,39 @@ struct SpecRound {  // written by the plan launch: unfinished pairs before the r
 };
 constexpr uint32_t kSpecDrawFloats = 16u << 20;  // the round's table of stream draws (64 MB), cut into one slice per pair of the round
 constexpr uint32_t kSpecChunkMax = 512;  // samples speculated per pair and round, at most
-hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
+hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, uint32_t band, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
                              uint32_t n_samples, uint32_t max_cands, uint32_t max_width, double z, SpecPairState* states, SpecWindow* windows,
                              uint32_t* rank_pair, SpecRound* round, float* draw_table, const uint64_t* thr_off, const void* thr_m, uint32_t* c_draws,
                              uint64_t* sample_off, hipStream_t stream);
 
+// The step table covers a BAND of diagonals around the straight line of a pair: d = i - j from min(0, la - lb) - B to
+// max(0, la - lb) + B (clipped to the matrix).  A sampled path leaves it only by an excess of > B gap columns of one kind;
+// the walkers compute the entries of cells outside it as they go (sampleback.hip: step_entry).  16 pairs of 1 kb at B = 64:
+// 150 MB and 0.15 ms to build instead of 1.15 GB and 0.8 ms.
+struct StepBand {
+    int64_t dhi;      // the largest d = i - j in the band: column j of row i is entry k = j - i + dhi of the row
+    uint32_t width;   // diagonals in the band = entries per row
+    uint32_t diag_len;  // min(la, lb): entries per diagonal of the diagonal-major threshold array
+};
+__host__ __device__ inline StepBand step_band(uint32_t la, uint32_t lb, uint32_t half) {
+    if(la == 0 || lb == 0) return StepBand{0, 0, 0};
+    const int64_t delta = static_cast<int64_t>(la) - static_cast<int64_t>(lb);
+    int64_t dlo = (delta < 0 ? delta : 0) - static_cast<int64_t>(half), dhi = (delta > 0 ? delta : 0) + static_cast<int64_t>(half);
+    if(dlo < 1 - static_cast<int64_t>(lb)) dlo = 1 - static_cast<int64_t>(lb);
+    if(dhi > static_cast<int64_t>(la) - 1) dhi = static_cast<int64_t>(la) - 1;
+    return StepBand{dhi, static_cast<uint32_t>(dhi - dlo + 1), la < lb ? la : lb};
+}
+
 // round 4: the step table of the exact-stream sampler (sampleback.hip): thresholds and log-weight increments per
 // (body cell, state), 24 bytes each, row-major per pair from entry tab_off[pair]; gap_len 1
 uint64_t step_entry_bytes();
-hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, const uint64_t* thr_off, void* thr_m,
-                             hipStream_t stream);  // thr_m (may be null): the M-state thresholds again, 12 bytes per body cell, diagonal-major (sampleback.hip)
-uint64_t step_thr_entries(uint32_t la, uint32_t lb);  // entries of a pair in thr_m
-hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* origin_state, const uint64_t* mult_pow,
-                           const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream);
-hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* start_state, const uint64_t* mult_pow,
-                             const uint64_t* sample_offset, const uint64_t* sample_base, uint32_t n_samples, uint8_t* ops, uint64_t* ops_start,
+hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, uint32_t band, void* steps, const uint64_t* thr_off,
+                             void* thr_m, hipStream_t stream);  // thr_m (may be null): the M-state thresholds again, 12 bytes per body cell, diagonal-major (sampleback.hip)
+
+hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, uint32_t band, const void* steps, const uint64_t* origin_state,
+                           const uint64_t* mult_pow, const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream);
+hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, uint32_t band, const void* steps, const uint64_t* start_state,
+                             const uint64_t* mult_pow, const uint64_t* sample_offset, const uint64_t* sample_base, uint32_t n_samples, uint8_t* ops, uint64_t* ops_start,
                              uint32_t* ops_len, float* log_weights, hipStream_t stream);
 
 }  // namespace coati_hip_detail

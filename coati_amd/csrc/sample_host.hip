@@ -42,23 +42,21 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     // per call -- when it fits 8 GB and a third of the free HBM (16 pairs of 1 kb: 1.15 GB); gap_len 1, the bit-exact
     // build (the fast build's samplers keep the on-the-fly path: COATI_HIP_FORWARD_FAST is not a parity mode).  With it the
     // candidates only count draws (no temporary ops) and ONE final launch writes every sample from its resolved offset.
-    uint64_t table_entries = 0;
-    std::vector<uint64_t> tab_off(n, 0);
+    // (a band of diagonals around each pair's straight line: common.hpp step_band; cells outside it are computed by the walkers)
+    const uint32_t band_half = env_options().sample_band;
+    uint64_t table_entries = 0, thr_entries = 0;
+    std::vector<uint64_t> tab_off(n, 0), thr_off(n, 0);
     uint64_t max_cells = 0;
     for(uint64_t p = 0; p < n; ++p) {
+        const StepBand band = step_band(b->desc[p].la, b->desc[p].lb, band_half);
         tab_off[p] = table_entries;
-        const uint64_t cells = static_cast<uint64_t>(b->desc[p].la) * b->desc[p].lb;
+        thr_off[p] = thr_entries;
+        const uint64_t cells = static_cast<uint64_t>(b->desc[p].la) * band.width;
         table_entries += 3 * cells;
+        thr_entries += static_cast<uint64_t>(band.width) * band.diag_len;  // the M-state thresholds once more, diagonal-major (sampleback.hip)
         max_cells = std::max(max_cells, cells);
     }
     const bool table_off = env_options().sample_table_off;
-    // (+ the M-state thresholds once more, diagonal-major, 12 bytes per entry: what a round's candidates read -- sampleback.hip)
-    std::vector<uint64_t> thr_off(n, 0);
-    uint64_t thr_entries = 0;
-    for(uint64_t p = 0; p < n; ++p) {
-        thr_off[p] = thr_entries;
-        thr_entries += step_thr_entries(b->desc[p].la, b->desc[p].lb);
-    }
     const uint64_t table_bytes = table_entries * step_entry_bytes() + thr_entries * 12 + 256;
     const bool use_table = m->gap_len == 1 && !forward_fast_math() && !table_off && table_bytes <= (8ull << 30) && table_bytes <= free_b / 3 &&
                            b->desc[0].f_compact == 0;
@@ -162,7 +160,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(hipMemcpyAsync(d_state0, rng_state, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_base, base.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_thr_off, thr_off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
-        S_TRY(launch_step_table(view, d_tab_off, max_cells, d_steps, d_thr_off, d_thr, m->stream));
+        S_TRY(launch_step_table(view, d_tab_off, max_cells, band_half, d_steps, d_thr_off, d_thr, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));  // (tab_off / base are stack-lifetime vectors of the caller: uploaded before they can go)
     }
 
@@ -184,7 +182,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         const bool timing = env_options().timing;
         for(bool finished = n_samples == 0 || n == 0; !finished;) {
             for(uint32_t r = 0; r < kBatch; ++r) {
-                S_TRY(launch_spec_round(view, d_tab_off, d_steps, d_state0, d_pow, n_samples, kMaxCands, max_width, kZ, d_states, d_windows, d_rank_pair, d_round,
+                S_TRY(launch_spec_round(view, d_tab_off, band_half, d_steps, d_state0, d_pow, n_samples, kMaxCands, max_width, kZ, d_states, d_windows, d_rank_pair, d_round,
                                         d_draw_table, d_thr_off, d_thr, d_cdraws, d_sample_off, m->stream));
                 S_TRY(hipMemcpyAsync(h_round + r, d_round, sizeof(SpecRound), hipMemcpyDeviceToHost, m->stream));
             }
@@ -198,7 +196,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             }
         }
         // every sample's start in its pair's stream is known (on the device): one walker per (pair, sample), results in place
-        S_TRY(launch_final_walk(view, d_tab_off, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
+        S_TRY(launch_final_walk(view, d_tab_off, band_half, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipMemcpyAsync(h_states, d_states, n * sizeof(SpecPairState), hipMemcpyDeviceToHost, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));
         for(uint64_t p = 0; p < n; ++p) ps[p].origin = h_states[p].origin;
@@ -298,7 +296,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(hipMemcpyAsync(d_origin, origin_states.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
         S_TRY(hipMemcpyAsync(d_cands, cands.data(), nc * sizeof(SpecCandidate), hipMemcpyHostToDevice, m->stream));
         if(use_table)
-            S_TRY(launch_spec_len(view, d_tab_off, d_steps, d_origin, d_pow, d_cands, nc, d_cdraws, m->stream));
+            S_TRY(launch_spec_len(view, d_tab_off, band_half, d_steps, d_origin, d_pow, d_cands, nc, d_cdraws, m->stream));
         else
             S_TRY(launch_spec_walk(view, d_origin, d_pow, d_cands, nc, d_tmp, d_cstart, d_clen, d_clw, d_cdraws, m->stream));
         draws.resize(nc);
@@ -344,7 +342,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     if(use_table) {
         // every sample's start in its pair's stream is known: one walker per (pair, sample), results in place
         S_TRY(hipMemcpyAsync(d_sample_off, sample_off.data(), sample_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, m->stream));
-        S_TRY(launch_final_walk(view, d_tab_off, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
+        S_TRY(launch_final_walk(view, d_tab_off, band_half, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipStreamSynchronize(m->stream));
     }
     } catch(...) {  // host-side allocation failure: free the device work areas, report at the ABI

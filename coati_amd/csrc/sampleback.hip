@@ -309,16 +309,27 @@ __device__ __forceinline__ StepEntry step_entry(const Walker& w, uint32_t i, uin
 struct StepThresholds {  // the first 12 bytes of a StepEntry
     float scale, m, dm;
 };
-// The M-state thresholds once more, DIAGONAL-major: entry (d, t) with d = i - j + lb - 1 and t = min(i, j) - 1 at d * L + t,
-// L = min(la, lb).  A run of matches walks down a diagonal: the batch of table_walk_count reads 16 consecutive entries
-// (192 bytes) instead of 16 entries 72 * (lb + 1) bytes apart, and the candidates of a pair, which are all near the same
-// diagonals, share cache lines within a load instruction.
-__device__ __forceinline__ uint64_t thr_index(uint32_t i, uint32_t j, uint32_t la, uint32_t lb) {
-    return static_cast<uint64_t>(i + (lb - 1u) - j) * min(la, lb) + (min(i, j) - 1u);
-}
+// The table a walk reads: the pair's entries (a band of diagonals, common.hpp: step_band), row-major -- column j of row i is
+// entry k = j - i + dhi of the row, so a diagonal move is a constant stride of `width` cells -- and the M-state thresholds
+// once more, DIAGONAL-major: diagonal k, position t = min(i, j) - 1 at k * diag_len + t.  A run of matches walks down a
+// diagonal: the batch of table_walk_count reads 16 consecutive threshold entries (192 bytes), and the candidates of a pair,
+// which are all near the same diagonals, share cache lines within a load instruction.
+struct StepTable {
+    const StepEntry* __restrict__ steps;      // the pair's entries
+    const StepThresholds* __restrict__ thr;   // the pair's M thresholds (may be null: the host-rounds path)
+    StepBand band;
+    __device__ __forceinline__ int64_t diag(uint32_t i, uint32_t j) const { return static_cast<int64_t>(j) - static_cast<int64_t>(i) + band.dhi; }
+    __device__ __forceinline__ bool holds(int64_t k) const { return k >= 0 && k < static_cast<int64_t>(band.width); }
+    __device__ __forceinline__ const StepEntry* cell(uint32_t i, int64_t k) const {  // the three entries of (i, j), holds(k)
+        return steps + (static_cast<uint64_t>(i - 1) * band.width + static_cast<uint64_t>(k)) * 3;
+    }
+    __device__ __forceinline__ const StepThresholds* thr_at(uint32_t i, uint32_t j, int64_t k) const {
+        return thr + static_cast<uint64_t>(k) * band.diag_len + (min(i, j) - 1u);
+    }
+};
 
 __global__ __launch_bounds__(256) void step_table_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
-                                                         const uint64_t* __restrict__ tab_off, uint32_t n_pairs,
+                                                         const uint64_t* __restrict__ tab_off, uint32_t n_pairs, uint32_t band_half,
                                                          const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
                                                          const float* __restrict__ mdi, StepEntry* __restrict__ steps,
                                                          const uint64_t* __restrict__ thr_off, StepThresholds* __restrict__ thr_m) {
@@ -328,17 +339,22 @@ __global__ __launch_bounds__(256) void step_table_kernel(const float* __restrict
     const uint32_t pair = blockIdx.y;
     if(pair >= n_pairs) return;
     const PairDesc pd = pairs[pair];
-    const uint64_t cells = static_cast<uint64_t>(pd.la) * pd.lb;
+    const StepBand band = step_band(pd.la, pd.lb, band_half);
+    const uint64_t cells = static_cast<uint64_t>(pd.la) * band.width;  // (row, k) of the band; columns outside the matrix are skipped
     const Walker w{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
                    mdi, pd, exp_tab};
     StepEntry* out = steps + tab_off[pair];
     for(uint64_t c = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; c < cells; c += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-        const uint32_t bi = static_cast<uint32_t>(c / pd.lb), bj = static_cast<uint32_t>(c - static_cast<uint64_t>(bi) * pd.lb);
+        const uint32_t row = static_cast<uint32_t>(c / band.width), kk = static_cast<uint32_t>(c - static_cast<uint64_t>(row) * band.width);
+        const int64_t jj = static_cast<int64_t>(row + 1) - band.dhi + kk;
+        if(jj < 1 || jj > static_cast<int64_t>(pd.lb)) continue;
+        const uint32_t i = row + 1, j = static_cast<uint32_t>(jj);
 #pragma unroll
         for(int st = 0; st < 3; ++st) {
-            const StepEntry e = step_entry(w, bi + 1, bj + 1, st);
+            const StepEntry e = step_entry(w, i, j, st);
             out[c * 3 + st] = e;
-            if(st == COATI_HIP_OP_MATCH && thr_m != nullptr) thr_m[thr_off[pair] + thr_index(bi + 1, bj + 1, pd.la, pd.lb)] = StepThresholds{e.scale, e.m, e.dm};
+            if(st == COATI_HIP_OP_MATCH && thr_m != nullptr)
+                thr_m[thr_off[pair] + static_cast<uint64_t>(kk) * band.diag_len + (min(i, j) - 1u)] = StepThresholds{e.scale, e.m, e.dm};
         }
     }
 }
@@ -369,7 +385,7 @@ struct DrawsFromTable {
 // sample_walk with the body steps read from the table.  kOps: write the ops (the final launch) or only count the
 // draws (the candidates of a round).  Identical decisions, log-weight and draw count as sample_walk.
 template <bool kOps, class Draws>
-__device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ steps, Draws src, uint8_t* __restrict__ ops, uint64_t slot,
+__device__ uint64_t table_walk(const Walker& w, const StepTable& tb, Draws src, uint8_t* __restrict__ ops, uint64_t slot,
                                float& score, uint32_t& draws) {
     draws = 1;
     uint32_t i = w.la, j = w.lb;  // (gap_len 1: the last cell is (la, lb))
@@ -383,7 +399,6 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
         const float top = fmaxf(fmaxf(cur.m, cur.d), cur.in);
         st = sample3(cur.m - top, cur.d - top, cur.in - top, src.next(), score, w.exp_tab);
     }
-    const uint32_t lb = w.lb;
     // Body steps go in BATCHES.  A walk is a chain of ~la dependent loads (~0.35 us each: a round of candidates took the
     // same 0.37-0.47 ms whether it held 20 000 or 130 000 of them); but 97 % of a sample's steps are matches, which move
     // down the diagonal, so the entries of the next kAhead - 1 diagonal cells for state M are loaded TOGETHER with the
@@ -394,18 +409,22 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
     while((j > 0 || i > 0) && !failed) {
         if(i >= 1 && j >= 1) {
             StepEntry e[kAhead];
-            const StepEntry* const here = steps + (static_cast<uint64_t>(i - 1) * lb + (j - 1)) * 3;  // this cell's three entries
-            e[0] = here[static_cast<uint32_t>(st)];
+            const int64_t k0 = tb.diag(i, j);
+            // (a cell outside the band of the table: its entry the way the table's were made -- rare: a sampled path that
+            // drifted more than the band's half width off the pair's straight line)
+            e[0] = tb.holds(k0) ? tb.cell(i, k0)[static_cast<uint32_t>(st)] : step_entry(w, i, j, st);
+            uint32_t room;  // steps 1 .. room of the batch are at body cells (i1 - q + 1, j1 - q + 1) the table holds
             {
                 const bool m0 = st == COATI_HIP_OP_MATCH, d0 = st == COATI_HIP_OP_DEL;
                 const uint32_t i1 = (m0 || d0) ? i - 1 : i, j1 = d0 ? j : j - 1;  // where this step leads
-                // (entry of cell (i1, j1) for M, then one diagonal step = lb + 1 cells back per entry: no multiply per address)
-                const StepEntry* at = here - (m0 ? static_cast<uint64_t>(lb) + 1 : (d0 ? static_cast<uint64_t>(lb) : 1ull)) * 3 + COATI_HIP_OP_MATCH;
-                const uint64_t diag = (static_cast<uint64_t>(lb) + 1) * 3;
-                const uint32_t room = min(i1, j1);  // cells (i1 - q + 1, j1 - q + 1), q = 1 .. room, are body cells
+                const int64_t k1 = tb.diag(i1, j1);
+                room = tb.holds(k1) ? min(i1, j1) : 0u;
+                // (entry of cell (i1, j1) for M, then one diagonal step = `width` cells back per entry: no multiply per address)
+                const StepEntry* at = room > 0 ? tb.cell(i1, k1) + COATI_HIP_OP_MATCH : tb.steps;
+                const uint64_t diag = static_cast<uint64_t>(tb.band.width) * 3;
 #pragma unroll
                 for(int q = 1; q < kAhead; ++q) {
-                    e[q] = *(static_cast<uint32_t>(q) <= room ? at : steps);
+                    e[q] = *(static_cast<uint32_t>(q) <= room ? at : tb.steps);
                     at -= diag;
                 }
             }
@@ -443,7 +462,7 @@ __device__ uint64_t table_walk(const Walker& w, const StepEntry* __restrict__ st
                         i = (is_m || is_d) ? i - 1 : i;
                         j = is_d ? j : j - 1;
                         st = nst;
-                        go = nst == COATI_HIP_OP_MATCH && i >= 1 && j >= 1;  // (the next prefetched entry is this cell's, for M)
+                        go = nst == COATI_HIP_OP_MATCH && static_cast<uint32_t>(q) < room;  // (the next prefetched entry is this cell's, for M)
                     }
                 }
             }
@@ -500,7 +519,7 @@ __device__ __forceinline__ Rng128 rng_jump(const uint64_t* __restrict__ origin_s
 // then.  Same thresholds, same draws, same comparisons as table_walk: the same count.  ~60 instructions per batch of up
 // to 16 steps instead of ~55 per step.
 template <int K>
-__device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restrict__ steps, const StepThresholds* __restrict__ thr, const float* __restrict__ at) {
+__device__ uint32_t table_walk_count(const Walker& w, const StepTable& tb, const float* __restrict__ at) {
     static_assert(K >= 2 && K <= 31, "decisions of a batch are bits of a word");
     uint32_t draws = 1;
     uint32_t i = w.la, j = w.lb;
@@ -513,28 +532,32 @@ __device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restric
         const float top = fmaxf(fmaxf(cur.m, cur.d), cur.in);
         st = sample3(cur.m - top, cur.d - top, cur.in - top, *at++, score, w.exp_tab);
     }
-    const uint32_t lb = w.lb;
-    const uint64_t diag = (static_cast<uint64_t>(lb) + 1) * 3;
     while(j > 0 || i > 0) {
         if(i >= 1 && j >= 1) {
-            const StepEntry* const here = steps + (static_cast<uint64_t>(i - 1) * lb + (j - 1)) * 3;
             const bool m0 = st == COATI_HIP_OP_MATCH, d0 = st == COATI_HIP_OP_DEL;
             const uint32_t i1 = (m0 || d0) ? i - 1 : i, j1 = d0 ? j : j - 1;  // where this step leads
-            const uint32_t room = min(i1, j1);  // steps 1 .. room of the batch are at body cells (i1 - q + 1, j1 - q + 1)
+            const int64_t k0 = tb.diag(i, j), k1 = tb.diag(i1, j1);
+            const uint32_t room = tb.holds(k1) ? min(i1, j1) : 0u;  // steps 1 .. room of the batch are at body cells (i1 - q + 1, j1 - q + 1) the table holds
             StepThresholds e[K];
             float dr[K];
             // (two batches in three end because all K steps were matches: the next one starts in state M, on the diagonal the
-            // neighbouring candidates are reading too)
-            e[0] = thr != nullptr && m0 ? thr[thr_index(i, j, w.la, lb)] : *reinterpret_cast<const StepThresholds*>(here + static_cast<uint32_t>(st));
-            if(thr != nullptr) {  // the next K - 1 diagonal cells' M thresholds: consecutive, descending (thr_index)
-                const StepThresholds* dg = room > 0 ? thr + thr_index(i1, j1, w.la, lb) : thr;
-#pragma unroll
-                for(int q = 1; q < K; ++q) e[q] = *(static_cast<uint32_t>(q) <= room ? dg - (q - 1) : thr);
+            // neighbouring candidates are reading too; a cell outside the table's band: its entry the way the table's were made)
+            if(tb.holds(k0)) {
+                e[0] = tb.thr != nullptr && m0 ? *tb.thr_at(i, j, k0) : *reinterpret_cast<const StepThresholds*>(tb.cell(i, k0) + static_cast<uint32_t>(st));
             } else {
-                const StepEntry* dg = here - (m0 ? static_cast<uint64_t>(lb) + 1 : (d0 ? static_cast<uint64_t>(lb) : 1ull)) * 3 + COATI_HIP_OP_MATCH;
+                const StepEntry full = step_entry(w, i, j, st);
+                e[0] = StepThresholds{full.scale, full.m, full.dm};
+            }
+            if(tb.thr != nullptr) {  // the next K - 1 diagonal cells' M thresholds: consecutive, descending
+                const StepThresholds* dg = room > 0 ? tb.thr_at(i1, j1, k1) : tb.thr;
+#pragma unroll
+                for(int q = 1; q < K; ++q) e[q] = *(static_cast<uint32_t>(q) <= room ? dg - (q - 1) : tb.thr);
+            } else {
+                const StepEntry* dg = room > 0 ? tb.cell(i1, k1) + COATI_HIP_OP_MATCH : tb.steps;
+                const uint64_t diag = static_cast<uint64_t>(tb.band.width) * 3;
 #pragma unroll
                 for(int q = 1; q < K; ++q) {
-                    e[q] = *reinterpret_cast<const StepThresholds*>(static_cast<uint32_t>(q) <= room ? dg : steps);
+                    e[q] = *reinterpret_cast<const StepThresholds*>(static_cast<uint32_t>(q) <= room ? dg : tb.steps);
                     dg -= diag;
                 }
             }
@@ -593,7 +616,7 @@ __device__ uint32_t table_walk_count(const Walker& w, const StepEntry* __restric
 __global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
                                                       const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
                                                       const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
-                                                      const StepEntry* __restrict__ steps, const uint64_t* __restrict__ origin_state,
+                                                      const StepEntry* __restrict__ steps, uint32_t band_half, const uint64_t* __restrict__ origin_state,
                                                       const uint64_t* __restrict__ mult_pow, const SpecCandidate* __restrict__ cands,
                                                       uint32_t n_cands, uint32_t* __restrict__ c_draws) {
     __shared__ uint64_t exp_tab[32];
@@ -608,7 +631,7 @@ __global__ __launch_bounds__(64) void spec_len_kernel(const float* __restrict__ 
                    mdi, pd, exp_tab};
     float score;
     uint32_t draws;
-    (void)table_walk<false>(w, steps + tab_off[cd.pair], DrawsFromRng{rng}, nullptr, 0, score, draws);
+    (void)table_walk<false>(w, StepTable{steps + tab_off[cd.pair], nullptr, step_band(pd.la, pd.lb, band_half)}, DrawsFromRng{rng}, nullptr, 0, score, draws);
     c_draws[idx] = draws;
 }
 
@@ -726,7 +749,7 @@ __global__ __launch_bounds__(64) void spec_draws_kernel(const uint64_t* __restri
 __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
                                                             const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
                                                             const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
-                                                            const StepEntry* __restrict__ steps, const uint64_t* __restrict__ state0,
+                                                            const StepEntry* __restrict__ steps, uint32_t band_half, const uint64_t* __restrict__ state0,
                                                             const uint64_t* __restrict__ mult_pow, const SpecPairState* __restrict__ states,
                                                             const SpecWindow* __restrict__ windows, const uint32_t* __restrict__ rank_pair,
                                                             const SpecRound* __restrict__ round, const float* __restrict__ draw_table,
@@ -756,8 +779,8 @@ __global__ __launch_bounds__(64) void spec_len_round_kernel(const float* __restr
     const PairDesc pd = pairs[pair];
     const Walker wk{k, 1u, pd.la, pd.lb, k.ge * 0.0f, k.ge * 1.0f, table + static_cast<size_t>(pd.table) * kTabFloats, a_cat + pd.a_off, b_cat + pd.b_off,
                     mdi, pd, exp_tab};
-    const uint32_t draws = table_walk_count<16>(wk, steps + tab_off[pair], thr_m != nullptr ? thr_m + thr_off[pair] : nullptr,
-                                                draw_table + static_cast<uint64_t>(r) * round->slice + offset);
+    const StepTable tb{steps + tab_off[pair], thr_m != nullptr ? thr_m + thr_off[pair] : nullptr, step_band(pd.la, pd.lb, band_half)};
+    const uint32_t draws = table_walk_count<16>(wk, tb, draw_table + static_cast<uint64_t>(r) * round->slice + offset);
     c_draws[idx] = draws;
 }
 
@@ -863,7 +886,7 @@ __global__ __launch_bounds__(256) void spec_chain_kernel(uint32_t n_samples, Spe
 __global__ __launch_bounds__(64) void final_walk_kernel(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
                                                         const uint64_t* __restrict__ tab_off, const uint8_t* __restrict__ a_cat,
                                                         const uint8_t* __restrict__ b_cat, const float* __restrict__ mdi,
-                                                        const StepEntry* __restrict__ steps, const uint64_t* __restrict__ start_state,
+                                                        const StepEntry* __restrict__ steps, uint32_t band_half, const uint64_t* __restrict__ start_state,
                                                         const uint64_t* __restrict__ mult_pow, const uint64_t* __restrict__ sample_offset,
                                                         const uint64_t* __restrict__ sample_base, uint32_t n_pairs, uint32_t n_samples,
                                                         uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len,
@@ -881,7 +904,7 @@ __global__ __launch_bounds__(64) void final_walk_kernel(const float* __restrict_
     const uint64_t width = static_cast<uint64_t>(pd.la) + pd.lb, slot = sample_base[pair] + n * width;
     float score;
     uint32_t draws;
-    const uint64_t pos = table_walk<true>(w, steps + tab_off[pair], DrawsFromRng{rng}, ops, slot, score, draws);
+    const uint64_t pos = table_walk<true>(w, StepTable{steps + tab_off[pair], nullptr, step_band(pd.la, pd.lb, band_half)}, DrawsFromRng{rng}, ops, slot, score, draws);
     ops_start[idx] = pos;
     ops_len[idx] = static_cast<uint32_t>(slot + width - pos);
     log_weights[idx] = score;
@@ -937,25 +960,22 @@ hipError_t launch_spec_commit(const SpecCommit* commits, uint32_t n_commits, con
 }
 
 uint64_t step_entry_bytes() { return sizeof(StepEntry); }
-uint64_t step_thr_entries(uint32_t la, uint32_t lb) {
-    return la == 0 || lb == 0 ? 0 : (static_cast<uint64_t>(la) + lb - 1) * std::min(la, lb);
-}
-hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, void* steps, const uint64_t* thr_off, void* thr_m,
-                             hipStream_t stream) {
+hipError_t launch_step_table(const BatchDeviceView& v, const uint64_t* tab_off, uint64_t max_cells, uint32_t band, void* steps, const uint64_t* thr_off,
+                             void* thr_m, hipStream_t stream) {
     if(v.n_pairs == 0 || max_cells == 0) return hipSuccess;
     const uint32_t gx = static_cast<uint32_t>(std::min<uint64_t>((max_cells + 255) / 256, 4096));
-    hipLaunchKernelGGL(step_table_kernel, dim3(gx, v.n_pairs), dim3(256), 0, stream, v.table, v.k, v.pairs, tab_off, v.n_pairs, v.a_cat, v.b_cat, v.mdi,
+    hipLaunchKernelGGL(step_table_kernel, dim3(gx, v.n_pairs), dim3(256), 0, stream, v.table, v.k, v.pairs, tab_off, v.n_pairs, band, v.a_cat, v.b_cat, v.mdi,
                        static_cast<StepEntry*>(steps), thr_off, static_cast<StepThresholds*>(thr_m));
     return hipGetLastError();
 }
-hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* origin_state, const uint64_t* mult_pow,
-                           const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream) {
+hipError_t launch_spec_len(const BatchDeviceView& v, const uint64_t* tab_off, uint32_t band, const void* steps, const uint64_t* origin_state,
+                           const uint64_t* mult_pow, const SpecCandidate* cands, uint32_t n_cands, uint32_t* c_draws, hipStream_t stream) {
     if(n_cands == 0) return hipSuccess;
     hipLaunchKernelGGL(spec_len_kernel, dim3((n_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
-                       static_cast<const StepEntry*>(steps), origin_state, mult_pow, cands, n_cands, c_draws);
+                       static_cast<const StepEntry*>(steps), band, origin_state, mult_pow, cands, n_cands, c_draws);
     return hipGetLastError();
 }
-hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
+hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, uint32_t band, const void* steps, const uint64_t* state0, const uint64_t* mult_pow,
                              uint32_t n_samples, uint32_t max_cands, uint32_t max_width, double z, SpecPairState* states, SpecWindow* windows,
                              uint32_t* rank_pair, SpecRound* round, float* draw_table, const uint64_t* thr_off, const void* thr_m, uint32_t* c_draws,
                              uint64_t* sample_off, hipStream_t stream) {
@@ -963,18 +983,18 @@ hipError_t launch_spec_round(const BatchDeviceView& v, const uint64_t* tab_off, 
     hipLaunchKernelGGL(spec_plan_kernel, dim3(v.n_pairs), dim3(kWave), 0, stream, v.pairs, v.n_pairs, n_samples, max_cands, max_width, z, states, windows, rank_pair, round);
     hipLaunchKernelGGL(spec_draws_kernel, dim3(kSpecDrawFloats / 64 / 64), dim3(64), 0, stream, state0, mult_pow, states, rank_pair, round, draw_table);
     hipLaunchKernelGGL(spec_len_round_kernel, dim3((max_cands + 63) / 64), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat, v.b_cat, v.mdi,
-                       static_cast<const StepEntry*>(steps), state0, mult_pow, states, windows, rank_pair, round, draw_table, thr_off,
+                       static_cast<const StepEntry*>(steps), band, state0, mult_pow, states, windows, rank_pair, round, draw_table, thr_off,
                        static_cast<const StepThresholds*>(thr_m), c_draws);
     hipLaunchKernelGGL(spec_chain_kernel, dim3(v.n_pairs), dim3(256), 0, stream, n_samples, states, windows, round, c_draws, sample_off);
     return hipGetLastError();
 }
-hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, const void* steps, const uint64_t* start_state, const uint64_t* mult_pow,
-                             const uint64_t* sample_offset, const uint64_t* sample_base, uint32_t n_samples, uint8_t* ops, uint64_t* ops_start,
+hipError_t launch_final_walk(const BatchDeviceView& v, const uint64_t* tab_off, uint32_t band, const void* steps, const uint64_t* start_state,
+                             const uint64_t* mult_pow, const uint64_t* sample_offset, const uint64_t* sample_base, uint32_t n_samples, uint8_t* ops, uint64_t* ops_start,
                              uint32_t* ops_len, float* log_weights, hipStream_t stream) {
     const uint64_t walkers = static_cast<uint64_t>(v.n_pairs) * n_samples;
     if(walkers == 0) return hipSuccess;
     hipLaunchKernelGGL(final_walk_kernel, dim3(static_cast<uint32_t>((walkers + 63) / 64)), dim3(64), 0, stream, v.table, v.k, v.pairs, tab_off, v.a_cat,
-                       v.b_cat, v.mdi, static_cast<const StepEntry*>(steps), start_state, mult_pow, sample_offset, sample_base, v.n_pairs, n_samples, ops,
+                       v.b_cat, v.mdi, static_cast<const StepEntry*>(steps), band, start_state, mult_pow, sample_offset, sample_base, v.n_pairs, n_samples, ops,
                        ops_start, ops_len, log_weights);
     return hipGetLastError();
 }

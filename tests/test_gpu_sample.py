@@ -212,12 +212,14 @@ print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum(
     # the same call: device rounds (default), the one-walker-per-pair loop, the rounds planned and resolved on the host
     # (round 3's loop), and device rounds with so few candidates that a round resolves a handful of samples per pair and
     # most of a share is one window (many rounds, windows cut by the share, pairs that finish rounds apart)
+    # ... and with a step table that holds three or five diagonals only: every gap column takes the walk to cells whose
+    # entries the walkers compute themselves (the table's band is 129+ diagonals by default: these pairs never leave it)
     variants = [{}, {"COATI_HIP_SAMPLE_SEQUENTIAL": "1"}, {"COATI_HIP_SPEC_HOST_ROUNDS": "1"}, {"COATI_HIP_SPEC_CANDS": "1024"},
-                {"COATI_HIP_SPEC_CANDS": "1024", "COATI_HIP_SPEC_Z": "0.5"}]
+                {"COATI_HIP_SPEC_CANDS": "1024", "COATI_HIP_SPEC_Z": "0.5"}, {"COATI_HIP_SAMPLE_BAND": "1"}, {"COATI_HIP_SAMPLE_BAND": "2", "COATI_HIP_SPEC_HOST_ROUNDS": "1"}]
     outs = []
     for extra in variants:
         env = dict(os.environ)
-        for k in ("COATI_HIP_SAMPLE_SEQUENTIAL", "COATI_HIP_SPEC_HOST_ROUNDS", "COATI_HIP_SPEC_CANDS", "COATI_HIP_SPEC_Z"):
+        for k in ("COATI_HIP_SAMPLE_SEQUENTIAL", "COATI_HIP_SPEC_HOST_ROUNDS", "COATI_HIP_SPEC_CANDS", "COATI_HIP_SPEC_Z", "COATI_HIP_SAMPLE_BAND"):
             env.pop(k, None)
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)

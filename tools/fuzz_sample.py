@@ -48,8 +48,10 @@ while time.time() < t_end:
     indep = bool(rng.random() < 0.3)
     # the exact-stream sampler's own switches: candidate budget (1 024: dozens of rounds, windows cut by the share) and where
     # the rounds are planned and resolved (device: default; host: round 3's loop)
-    for k in ("COATI_HIP_SPEC_CANDS", "COATI_HIP_SPEC_HOST_ROUNDS", "COATI_HIP_SPEC_Z"):
+    for k in ("COATI_HIP_SPEC_CANDS", "COATI_HIP_SPEC_HOST_ROUNDS", "COATI_HIP_SPEC_Z", "COATI_HIP_SAMPLE_BAND"):
         os.environ.pop(k, None)
+    if rng.random() < 0.35:  # a step table of a few diagonals: the walkers compute the entries of every cell off them
+        os.environ["COATI_HIP_SAMPLE_BAND"] = str(int(rng.choice([1, 2, 5, 12])))
     pick = rng.random()
     if pick < 0.3:
         os.environ["COATI_HIP_SPEC_CANDS"] = str(int(rng.choice([1024, 4096])))
