@@ -28,6 +28,12 @@
 #include <utility>
 #include <vector>
 
+namespace coati_hip_detail {
+// sampleback.hip: the samples' ops, right-aligned in slots of la + lb bytes, packed back to back (offsets by an exclusive scan
+// over the lengths; *total = bytes in `packed`)
+hipError_t launch_ops_pack(const uint8_t* ops, const uint64_t* start, const uint32_t* len, uint64_t n, uint64_t* packed_off, uint64_t* total, uint8_t* packed,
+                           hipStream_t stream);
+}
 using namespace coati_hip_detail;
 
 /* A few helper threads that live as long as their model (started by the first call that wants them): the streamed call

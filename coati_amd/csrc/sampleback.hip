@@ -1016,4 +1016,49 @@ hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool 
     return hipGetLastError();
 }
 
+// ---- the results leave the device PACKED.  The walkers write a sample's ops right-aligned into its slot of la + lb bytes
+// (they walk from the last column to the first and do not know the length beforehand); a sample of a 1 kb pair fills
+// ~1 012 of its 2 000 bytes, so half of what a download of the slots moves is padding.  Two launches pack them: an
+// exclusive scan over the lengths (one workgroup: tens of thousands of samples) and a copy, one workgroup per sample.
+namespace {
+__global__ __launch_bounds__(1024) void ops_scan_kernel(const uint32_t* __restrict__ len, uint64_t n, uint64_t* __restrict__ packed_off,
+                                                        uint64_t* __restrict__ total) {
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry;
+    if(threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for(uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t q = base + threadIdx.x;
+        const uint64_t mine = q < n ? len[q] : 0;
+        part[threadIdx.x] = mine;
+        __syncthreads();
+        for(uint32_t sh = 1; sh < 1024; sh <<= 1) {  // inclusive scan of the chunk
+            const uint64_t add = threadIdx.x >= sh ? part[threadIdx.x - sh] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if(q < n) packed_off[q] = carry + part[threadIdx.x] - mine;
+        __syncthreads();
+        if(threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if(threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(64) void ops_pack_kernel(const uint8_t* __restrict__ ops, const uint64_t* __restrict__ start, const uint32_t* __restrict__ len,
+                                                      const uint64_t* __restrict__ packed_off, uint8_t* __restrict__ packed) {
+    const uint64_t q = blockIdx.x;
+    const uint8_t* src = ops + start[q];
+    uint8_t* dst = packed + packed_off[q];
+    for(uint32_t t = threadIdx.x; t < len[q]; t += blockDim.x) dst[t] = src[t];
+}
+}  // namespace
+hipError_t launch_ops_pack(const uint8_t* ops, const uint64_t* start, const uint32_t* len, uint64_t n, uint64_t* packed_off, uint64_t* total, uint8_t* packed,
+                           hipStream_t stream) {
+    if(n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ops_scan_kernel, dim3(1), dim3(1024), 0, stream, len, n, packed_off, total);
+    hipLaunchKernelGGL(ops_pack_kernel, dim3(static_cast<uint32_t>(n)), dim3(64), 0, stream, ops, start, len, packed_off, packed);
+    return hipGetLastError();
+}
+
 }  // namespace coati_hip_detail

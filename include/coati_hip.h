@@ -226,7 +226,8 @@ int coati_hip_debug_forward_matrices(coati_hip_batch_t* batch, uint64_t pair, fl
  *                      (all samples in parallel; sample 0 equals the reference's first).
  * Outputs (any may be NULL), sample s of pair p at index p * n_samples + s:
  *   log_weights[]  aln.data.score of the sample
- *   ops / ops_off[] / ops_len[]  as for Viterbi; ops_capacity >= n_samples * sum(len_a+len_b) */
+ *   ops / ops_off[] / ops_len[]  as for Viterbi; ops_capacity >= n_samples * sum(len_a+len_b) (the bound; the samples'
+ *                                ops are written back to back from ops[0] on, in output order: ops_off[] is ascending) */
 int coati_hip_sampleback(coati_hip_batch_t* batch, uint32_t n_samples, const uint64_t* rng_state,
                          int independent_streams, float* log_weights, uint8_t* ops, uint64_t ops_capacity,
                          uint64_t* ops_off, uint32_t* ops_len, uint64_t* rng_state_out);
