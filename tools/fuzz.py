@@ -107,8 +107,15 @@ while time.time() < t_end:
     if L == 1 and rng.random() < 0.5:
         os.environ.pop("COATI_HIP_STREAM_UNIT", None)
         os.environ.pop("COATI_HIP_STREAM_PARTS", None)
-        if rng.random() < 0.5:
-            os.environ["COATI_HIP_STREAM_PARTS"] = "1"  # (the call's last chunks cut into row parts: off by default)
+        os.environ.pop("COATI_HIP_STREAM_HELPERS", None)
+        # the streamed call's end game (default: ONE last chunk in three row parts, from a model's second call on; 0: none; 1:
+        # round 3's small tail chunks; 22 / 24: two / four parts) and which of its helper-thread uses are on
+        parts = str(rng.choice(["", "", "0", "1", "22", "24"]))
+        if parts:
+            os.environ["COATI_HIP_STREAM_PARTS"] = parts
+        helpers = str(rng.choice(["", "", "0", "1", "2", "6"]))
+        if helpers:
+            os.environ["COATI_HIP_STREAM_HELPERS"] = helpers
         form = str(rng.choice(["stream", "stream", "chunks"]))
         os.environ["COATI_HIP_PIPE"] = form
         if form == "stream":
@@ -118,6 +125,8 @@ while time.time() < t_end:
         if pinned:
             a_cat, b_cat = hip.pinned_copy(a_cat), hip.pinned_copy(b_cat)
         s3, o3, f3, l3 = model.viterbi(a_cat, a_off, b_cat, b_off, pinned=pinned)
+        if form == "stream" and rng.random() < 0.6:  # (a model's SECOND streamed call is the first that may cut its last chunk into row parts)
+            s3, o3, f3, l3 = model.viterbi(a_cat, a_off, b_cat, b_off, pinned=pinned)
         os.environ.pop("COATI_HIP_PIPE", None)
         for p, (a, b) in enumerate(enc):
             w_ops, w_sc = orc.viterbi(tables[0], consts, L, a, b, lowmem=len(a) * len(b) > 4_000_000)
