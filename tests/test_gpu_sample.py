@@ -207,7 +207,9 @@ crc = 0
 for p in range(len(enc)):
     for s in range(150):
         crc = zlib.crc32(ops[int(off[p, s]):int(off[p, s]) + int(ln[p, s])].tobytes(), crc)
-print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum()), "st": zlib.crc32(st.tobytes())}))
+flat_off, flat_len = off.reshape(-1).astype(np.int64), ln.reshape(-1).astype(np.int64)
+packed = bool(flat_off[0] == 0 and (flat_off[1:] == flat_off[:-1] + flat_len[:-1]).all())  # the ops come back to back, in output order
+print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum()), "st": zlib.crc32(st.tobytes()), "packed": packed}))
 ''' % str(root)
     # the same call: device rounds (default), the one-walker-per-pair loop, the rounds planned and resolved on the host
     # (round 3's loop), and device rounds with so few candidates that a round resolves a handful of samples per pair and
@@ -225,5 +227,6 @@ print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum(
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["packed"]
     for extra, out in zip(variants[1:], outs[1:]):
         assert out == outs[0], (extra, out, outs[0])
