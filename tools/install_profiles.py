@@ -23,6 +23,10 @@ strm = ROOT / "gpurun_out" / "prof_stream"
 if (strm / "kernel_stats.csv").exists():
     shutil.copy(strm / "kernel_stats.csv", dst / "stream_kernel_stats.csv")
     shutil.copy(strm / "stream_probe.txt", dst / "stream_probe_under_rocprof.txt")
+# the exact-stream sampler: kernel statistics of tools/sample_bench.py
+smp = ROOT / "gpurun_out" / "prof_sample"
+if (smp / "kernel_stats.csv").exists():
+    shutil.copy(smp / "kernel_stats.csv", dst / "sample_kernel_stats.csv")
 # (steady.txt and short_pairs.txt are hand-kept records of several tool runs: not overwritten here)
 for extra in ("bench_n1.json",
               ):

@@ -23,6 +23,12 @@ mkdir -p "$STR"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$STR/stats" -o stream -- \
     python3 "$ROOT/tools/stream_probe.py" 40000 4 > "$STR/stream_probe.txt" 2> "$STR/stream_probe.stderr"
 cp "$(find "$STR/stats" -name '*kernel_stats.csv' | head -1)" "$STR/kernel_stats.csv" 2>/dev/null
+# the exact-stream sampler (configs[3]: 16 pairs x 1 000 samples): kernel statistics of tools/sample_bench.py
+SMP="$ROOT/gpurun_out/prof_sample"
+mkdir -p "$SMP"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$SMP/stats" -o sample -- \
+    python3 "$ROOT/tools/sample_bench.py" --pairs 64 > "$SMP/sample_bench.json" 2> "$SMP/sample_bench.stderr"
+cp "$(find "$SMP/stats" -name '*kernel_stats.csv' | head -1)" "$SMP/kernel_stats.csv" 2>/dev/null
 # the exact Forward fill (configs[3]): kernel statistics and the counters that say what its ~440 VALU slots per
 # cell and its spills cost (separate passes, same command)
 FWD="$ROOT/gpurun_out/prof_fwd"
