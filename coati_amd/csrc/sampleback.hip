@@ -1023,27 +1023,25 @@ hipError_t launch_sampleback(const BatchDeviceView& v, uint32_t n_samples, bool 
 namespace {
 __global__ __launch_bounds__(1024) void ops_scan_kernel(const uint32_t* __restrict__ len, uint64_t n, uint64_t* __restrict__ packed_off,
                                                         uint64_t* __restrict__ total) {
+    // a thread sums its run of consecutive lengths, one scan over the 1 024 sums, then the run again with its prefix
     __shared__ uint64_t part[1024];
-    __shared__ uint64_t carry;
-    if(threadIdx.x == 0) carry = 0;
+    const uint64_t per = (n + 1023) / 1024, q0 = threadIdx.x * per, q1 = q0 + per < n ? q0 + per : n;
+    uint64_t mine = 0;
+    for(uint64_t q = q0; q < q1; ++q) mine += len[q];
+    part[threadIdx.x] = mine;
     __syncthreads();
-    for(uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t q = base + threadIdx.x;
-        const uint64_t mine = q < n ? len[q] : 0;
-        part[threadIdx.x] = mine;
+    for(uint32_t sh = 1; sh < 1024; sh <<= 1) {  // inclusive scan of the sums
+        const uint64_t add = threadIdx.x >= sh ? part[threadIdx.x - sh] : 0;
         __syncthreads();
-        for(uint32_t sh = 1; sh < 1024; sh <<= 1) {  // inclusive scan of the chunk
-            const uint64_t add = threadIdx.x >= sh ? part[threadIdx.x - sh] : 0;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if(q < n) packed_off[q] = carry + part[threadIdx.x] - mine;
-        __syncthreads();
-        if(threadIdx.x == 1023) carry += part[1023];
+        part[threadIdx.x] += add;
         __syncthreads();
     }
-    if(threadIdx.x == 0) *total = carry;
+    uint64_t at = part[threadIdx.x] - mine;
+    for(uint64_t q = q0; q < q1; ++q) {
+        packed_off[q] = at;
+        at += len[q];
+    }
+    if(threadIdx.x == 1023) *total = part[1023];
 }
 __global__ __launch_bounds__(64) void ops_pack_kernel(const uint8_t* __restrict__ ops, const uint64_t* __restrict__ start, const uint32_t* __restrict__ len,
                                                       const uint64_t* __restrict__ packed_off, uint8_t* __restrict__ packed) {
