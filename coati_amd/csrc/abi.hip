@@ -206,9 +206,17 @@ hipError_t model_take_arena(coati_hip_model* m, uint64_t need, void** ptr, uint6
     // A fresh block is a size CLASS, not the exact need (up to an eighth above it, in steps of at least 32 MB): consecutive chunks of one job
     // differ by a few pairs, and a cached block that is a few KB short is a fresh multi-GB hipMalloc -- 0.25-0.5 s when
     // the driver has to find the pages (round 4: a 1 000 000-pair sharded job in 48 000-pair chunks took 12 s that way)
-    uint64_t step = 32ull << 20;
-    while(step * 16 <= need) step *= 2;  // (a sixteenth to an eighth of the need)
-    need = (need + need / 16 + step - 1) / step * step;  // (and a sixteenth of headroom: a need just above a class boundary must not start a new class)
+    // Small needs are taken as they are (rounded to 2 MB): a one-pair batch must not pin 32 MB of HBM, and a fresh small
+    // hipMalloc is cheap.  And when the class does not fit, the EXACT need is tried before giving up -- a request close to
+    // what is free must not fail because of its padding (the chunk pipeline budgets 0.8 of the free memory per slot set).
+    const uint64_t exact = (need + (2ull << 20) - 1) / (2ull << 20) * (2ull << 20);
+    if(need >= (256ull << 20)) {
+        uint64_t step = 32ull << 20;
+        while(step * 16 <= need) step *= 2;  // (a sixteenth to an eighth of the need)
+        need = (need + need / 16 + step - 1) / step * step;  // (and a sixteenth of headroom: a need just above a class boundary must not start a new class)
+    } else {
+        need = exact;
+    }
     hipError_t e = hipMalloc(ptr, need);
     if(e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -219,6 +227,11 @@ hipError_t model_take_arena(coati_hip_model* m, uint64_t need, void** ptr, uint6
         }
         for(const auto& a : drop) (void)hipFree(a.ptr);
         e = hipMalloc(ptr, need);
+        if(e == hipErrorOutOfMemory && exact < need) {
+            (void)hipGetLastError();
+            need = exact;
+            e = hipMalloc(ptr, need);
+        }
     }
     if(e != hipSuccess) {
         *ptr = nullptr;

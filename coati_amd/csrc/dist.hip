@@ -735,9 +735,17 @@ struct GpuLocalChunks {
         if(rc != COATI_HIP_OK) return fail(rc, "%s", coati_hip_last_error());
         if(out.summary && n > 0) {
             D_HIP(hipMalloc(&d_summary, n * (sizeof(float) + sizeof(uint32_t))));
-            D_HIP(hipMemcpyAsync(d_summary, scores, n * sizeof(float), hipMemcpyHostToDevice, stream));
-            D_HIP(hipMemcpyAsync(static_cast<char*>(d_summary) + n * sizeof(float), len, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            D_HIP(hipStreamSynchronize(stream));
+            // (*h is only set on success, so the caller never calls release() for a start() that failed: free here)
+            const auto upload = [&]() -> int {
+                D_HIP(hipMemcpyAsync(d_summary, scores, n * sizeof(float), hipMemcpyHostToDevice, stream));
+                D_HIP(hipMemcpyAsync(static_cast<char*>(d_summary) + n * sizeof(float), len, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                D_HIP(hipStreamSynchronize(stream));
+                return COATI_HIP_OK;
+            };
+            if(const int up = upload(); up != COATI_HIP_OK) {
+                release(nullptr);
+                return up;
+            }
         }
         n_now = n, nb_now = nb;
         *h = this;

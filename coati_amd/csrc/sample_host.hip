@@ -476,16 +476,17 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
         if(log_weights != nullptr && (e = hipMemcpy(log_weights, d_lw, n_out * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) return e;
         // the ops go home packed back to back (a sample fills about half of its slot of la + lb bytes: 16 x 1 000 samples of
         // 1 kb pairs are 16 MB of ops in 32 MB of slots), ops_off[] says where each sample's start
-        if(ops != nullptr && total > 0 && n_out > 0) {
+        // (ops_off[] ALWAYS means "packed from ops[0]", whether or not the caller takes the ops themselves)
+        if((ops != nullptr || ops_off != nullptr) && total > 0 && n_out > 0) {
             if((e = launch_ops_pack(d_ops, d_start, d_len, n_out, d_packed_off, d_packed_off + n_out, d_packed, m->stream)) != hipSuccess) return e;
             uint64_t packed_bytes = 0;
             if((e = hipMemcpyAsync(&packed_bytes, d_packed_off + n_out, sizeof packed_bytes, hipMemcpyDeviceToHost, m->stream)) != hipSuccess) return e;
             if((e = hipStreamSynchronize(m->stream)) != hipSuccess) return e;
             if(packed_bytes > total) return hipErrorInvalidValue;  // (cannot happen: a sample is at most la + lb columns)
-            if(packed_bytes > 0 && (e = hipMemcpy(ops, d_packed, packed_bytes, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            if(ops != nullptr && packed_bytes > 0 && (e = hipMemcpy(ops, d_packed, packed_bytes, hipMemcpyDeviceToHost)) != hipSuccess) return e;
             if(ops_off != nullptr && (e = hipMemcpy(ops_off, d_packed_off, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
-        } else if(ops_off != nullptr && (e = hipMemcpy(ops_off, d_start, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) {
-            return e;
+        } else if(ops_off != nullptr) {
+            std::memset(ops_off, 0, n_out * sizeof(uint64_t));  // (no op bytes at all: every sample is empty and starts at 0)
         }
         if(ops_len != nullptr && (e = hipMemcpy(ops_len, d_len, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return e;
         if(rng_state_out != nullptr && !independent_streams) {

@@ -645,13 +645,6 @@ bool marg_alignment_batch(alignment_t& aln) {
         }
         return m;
     });
-    struct hint_guard {  // (whatever happens below, the helper thread is not left waiting)
-        std::promise<std::array<uint64_t, 3>>& p;
-        bool set{false};
-        ~hint_guard() {
-            if(!set) p.set_exception(std::make_exception_ptr(std::runtime_error("no input")));
-        }
-    } hguard{hint_promise};
     struct model_guard {
         std::future<coati_hip_model*>& f;
         coati_hip_model* m{nullptr};
@@ -667,6 +660,15 @@ bool marg_alignment_batch(alignment_t& aln) {
             if(m != nullptr && !g_fast_exit) coati_hip_model_destroy(m);
         }
     } guard{model_ready};
+    // (declared AFTER model_guard, so destroyed BEFORE it: on unwind -- missing file, odd number of records -- the helper
+    // thread must be released from hint.get() before ~model_guard waits for it; the other order deadlocks on a GPU box)
+    struct hint_guard {  // (whatever happens below, the helper thread is not left waiting)
+        std::promise<std::array<uint64_t, 3>>& p;
+        bool set{false};
+        ~hint_guard() {
+            if(!set) p.set_exception(std::make_exception_ptr(std::runtime_error("no input")));
+        }
+    } hguard{hint_promise};
     const std::unique_ptr<batch_source_t> src = open_batch_source(aln);
     {
         // mean sequence length from the record sizes (names and line breaks make it a slight overestimate: sizes things only)
@@ -867,15 +869,28 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
     } mguard{model};
     tm.stage("model broadcast");
     // ---- this rank's slice of the output
+    // -o: the result is ASSEMBLED in <output>.tmp and renamed onto the output path by rank 0 only after every rank has
+    // said that its slice is in place -- a run that fails half way (a bad pair on some rank, a NaN score) leaves no
+    // truncated JSON under the user's name.  Rank 0 streams its slice (offset 0) straight into <output>.tmp, the others
+    // into <output>.partN, which they copy to their place and remove.  What a rank leaves behind when it is STOPPED
+    // (the launcher's SIGTERM after another rank failed) the launcher removes (coati_alignpair.cc: launch_ranks).
     const bool to_stdout = aln.output.empty() || aln.output == "-";
     const std::string final_path = to_stdout ? std::string() : extract_file_type(aln.output).path;
+    const std::string tmp_path = final_path + ".tmp";
     const std::string part_path = (to_stdout ? id_file : final_path) + ".part" + std::to_string(rank);
+    struct scratch_guard {  // (an exception on this rank: its own scratch files go)
+        std::vector<std::string> paths;
+        ~scratch_guard() {
+            for(const std::string& p : paths) std::remove(p.c_str());
+        }
+    } scratch;
     std::ofstream file;
     std::ostream* out = &std::cout;
     if(rank != 0 || !to_stdout) {
-        const std::string& path = rank == 0 ? final_path : part_path;
+        const std::string& path = rank == 0 ? tmp_path : part_path;
         file.open(path, std::ios::binary | std::ios::trunc);
-        if(!file) throw std::invalid_argument("Opening output file " + path + " failed.");
+        if(!file) throw std::invalid_argument("Opening output file " + (rank == 0 ? final_path : path) + " failed.");
+        scratch.paths.push_back(path);
         out = &file;
     }
     run_batch_pipeline(aln, *src, s0, s1, n_total, [&]() { return model; }, *out, tm);
@@ -908,21 +923,23 @@ bool marg_alignment_batch_dist(alignment_t& aln, int rank, int world, const std:
     } else if(rank != 0) {
         uint64_t at = 0;
         for(int r = 0; r < rank; ++r) at += static_cast<uint64_t>(sizes[static_cast<std::size_t>(r)]);
-        const int fd = open(final_path.c_str(), O_WRONLY | O_CLOEXEC);  // (rank 0 created it before its pipeline started)
+        const int fd = open(tmp_path.c_str(), O_WRONLY | O_CLOEXEC);  // (rank 0 created it before its pipeline started)
         if(fd < 0) throw std::runtime_error("Opening output file " + final_path + " failed.");
         try {
             copy_into(part_path, fd, at, my_bytes);
         } catch(...) {
             close(fd);
-            std::remove(part_path.c_str());
             throw;
         }
         if(close(fd) != 0) throw std::runtime_error("Writing output failed.");
-        std::remove(part_path.c_str());
     }
     // (all parts are in place when every rank has left this collective)
     double done = 1.0;
     dist_check(api.allreduce_f64(comm, 0, &done, 1));
+    if(!to_stdout && rank == 0) {
+        if(std::rename(tmp_path.c_str(), final_path.c_str()) != 0) throw std::runtime_error("Writing output failed.");
+        scratch.paths.clear();  // (it IS the output now)
+    }
     tm.stage("output assembled");
     return true;
 }

@@ -15,6 +15,7 @@
 
 #include "cli.hpp"
 #include "coati_hip.h"
+#include "io.hpp"
 
 extern char** environ;
 
@@ -23,7 +24,7 @@ namespace {
 // HIP -- so every rank is a fresh process that initialises exactly one device (children are started
 // with posix_spawn of this very binary plus the internal --dist-* flags; no exec from a process that has
 // used the GPU).  Exit status: the first non-zero status of a rank, or 128 + signal.
-int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
+int launch_ranks(const std::vector<int>& devices, int argc, char* argv[], const std::string& output) {
     const int world = static_cast<int>(devices.size());
     // the rendezvous id travels through a file in a directory only this user can enter (mkdtemp: mode 0700), so
     // that nobody else can plant the file -- or a symlink under the name rank 0 writes -- in /tmp
@@ -80,6 +81,13 @@ int launch_ranks(const std::vector<int>& devices, int argc, char* argv[]) {
     std::remove((id_path_s + ".tmp").c_str());
     for(int r = 0; r < world; ++r) std::remove((id_path_s + ".part" + std::to_string(r)).c_str());  // (output on stdout: a failed run's slices)
     rmdir(id_dir);
+    if(status_all != 0 && !(output.empty() || output == "-")) {
+        // -o: the ranks assemble the result in <output>.tmp (renamed onto the output by rank 0 once every slice is in
+        // place) from slices in <output>.partN; ranks that were stopped by the SIGTERM above could not tidy up after themselves
+        const std::string final_path = coati_amd::extract_file_type(output).path;
+        std::remove((final_path + ".tmp").c_str());
+        for(int r = 0; r < world; ++r) std::remove((final_path + ".part" + std::to_string(r)).c_str());
+    }
     return status_all;
 }
 }  // namespace
@@ -89,6 +97,14 @@ int main(int argc, char* argv[]) {
     // The HIP runtime takes 0.06-0.3 s to come up in a fresh process (it is most of a 10 000-pair run): for a batch run on
     // one device start it NOW, on a thread of its own, before the arguments are parsed and the model's matrix exponentials
     // are computed.  (Not in the --devices launcher, which must never touch HIP, see launch_ranks.)
+    // (joined on every return path: a detached thread still inside the runtime's bring-up while main() returns -- a parse
+    // error, --help -- would race the static destructors.  The batch path leaves through _Exit after the device has been used.)
+    struct warm_up_t {
+        std::thread t;
+        ~warm_up_t() {
+            if(t.joinable()) t.join();
+        }
+    } warm;
     {
         bool batch = false, launcher = false;
         for(int i = 1; i < argc; ++i) {
@@ -96,7 +112,7 @@ int main(int argc, char* argv[]) {
             batch = batch || a == "--batch";
             launcher = launcher || a == "--devices";
         }
-        if(batch && !launcher) std::thread([] { (void)coati_hip_device_count(); }).detach();
+        if(batch && !launcher) warm.t = std::thread([] { (void)coati_hip_device_count(); });
     }
     args_t args;
     try {
@@ -116,7 +132,7 @@ int main(int argc, char* argv[]) {
         }
         if(args.dist_rank >= 0)  // a child of the --devices launcher below: rank dist_rank on --device
             return marg_alignment_batch_dist(args.aln, args.dist_rank, args.dist_world, args.dist_id) ? EXIT_SUCCESS : EXIT_FAILURE;
-        if(args.devices.size() > 1) return launch_ranks(args.devices, argc, argv);
+        if(args.devices.size() > 1) return launch_ranks(args.devices, argc, argv, args.aln.output);
         if(args.devices.size() == 1) args.aln.device = args.devices[0];
         if(args.batch) {
             // this process ends with the call: the GBs of HBM workspace the library cached go back with the process,

@@ -194,3 +194,80 @@ def test_msa_errors(tmp_path):
     assert r.returncode != 0 and "MSA only supports marginal models." in r.stderr  # align_msa.cc:260-265
     r, _ = run_msa(tmp_path, MSA_SEQS, "((((A:0.1,B:0.1):0.1,C:0.1):0.1,D:0.1):0.1,E:0.1);", "Z")
     assert r.returncode != 0 and "not found" in r.stderr
+
+
+def test_user_rate_matrix_reference_doctest(tmp_path):
+    """src/lib/align_marginal.cc:304-343, "User-provided codon substitution matrix": the mg94Q CSV through --sub gives
+    the default model's alignment, written as FASTA."""
+    from tests.test_host_io_cli import write_reference_rate_csv
+
+    known = write_reference_rate_csv(tmp_path / "test-marg-matrix.csv")
+    fa = tmp_path / "test-marg.fasta"
+    fa.write_text(">1\n%s\n>2\n%s\n" % tuple(known["seqs"]))
+    out = tmp_path / "test-marg_alignment-fasta.fasta"
+    r = run("coati-alignpair", fa, "--sub", tmp_path / "test-marg-matrix.csv", "-o", out)
+    assert r.returncode == 0, r.stderr
+    assert out.read_text().split() == [">1", known["out"][0], ">2", known["out"][1]]
+    # ... and the same score as the built-in model to the accuracy of the CSV's six significant digits
+    js, js0 = tmp_path / "sub.json", tmp_path / "mg.json"
+    assert run("coati-alignpair", fa, "--sub", tmp_path / "test-marg-matrix.csv", "-o", js).returncode == 0
+    assert run("coati-alignpair", fa, "-m", "mar-mg", "-o", js0).returncode == 0
+    assert json.loads(js.read_text())["score"] == pytest.approx(json.loads(js0.read_text())["score"], rel=1e-4)
+    # a CSV with a line too many is refused (src/lib/io.cc:137-170)
+    write_reference_rate_csv(tmp_path / "bad.csv", extra_line=True)
+    r = run("coati-alignpair", fa, "--sub", tmp_path / "bad.csv")
+    assert r.returncode == 1 and r.stderr.startswith("ERROR:")
+
+
+def test_gtr_sigma_end_to_end(tmp_path, oracle):
+    """-x / --sigma (src/lib/mutation_coati.cc:317-354, utils.cc:137): the CLI's alignment and score under a GTR
+    nucleotide model equal the reference DP engine's on the table the build computes for those parameters."""
+    from coati_amd import host
+    from tests import util
+
+    sigma = KNOWN["gtr_q"]["sigma"]
+    rng = np.random.default_rng(5)
+    anc = util.random_anc(rng, 60)
+    des = util.mutate(rng, anc, sub=0.08, n_indel=3)
+    fa = tmp_path / "gtr.fasta"
+    fa.write_text(f">anc\n{anc}\n>des\n{des}\n")
+    out = tmp_path / "gtr.json"
+    r = run("coati-alignpair", fa, "-x", *sigma, "-o", out)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(out.read_text())
+    table = host.set_subst("mar-mg", sigma=sigma)
+    assert np.abs(table - host.set_subst("mar-mg")).max() > 1e-3  # (the parameters do change the model)
+    consts = host.gap_consts()
+    a, b = util.encode_anc(anc), util.encode_des(des)
+    ops, score = oracle.viterbi(table, consts, 1, a, b)
+    want = oracle.ops_to_strings(ops, anc, des)
+    assert (got["alignment"]["anc"], got["alignment"]["des"]) == want
+    assert np.float32(got["score"]).view(np.uint32) == np.float32(score).view(np.uint32)
+    if oracle.ref_available():  # the unmodified engine itself (oracle/_ref travels to the GPU box as a binary)
+        g, e = np.float32(0.001), np.float32(1.0) - np.float32(1.0) / np.float32(6.0)
+        _, _, _, sa, sb, sc = oracle.ref_viterbi(table, g, e, 1, anc, des, a, b)
+        assert (sa, sb) == want and np.float32(sc).view(np.uint32) == np.float32(score).view(np.uint32)
+
+
+def test_marg_sample_failures(tmp_path):
+    """src/lib/align_marginal.cc:673-720: every failure subcase of marg_sample, through coati-sample."""
+    for k, case in enumerate(KNOWN["marg_sample_fail"]):
+        fa = tmp_path / f"sf{k}.fasta"
+        fa.write_text("".join(f">{n}\n{s}\n" for n, s in zip(case["names"], case["seqs"])))
+        args = [fa, "-n", 1]
+        if "gap_len" in case:
+            args += ["-k", case["gap_len"]]
+        if "output" in case:
+            args += ["-o", tmp_path / case["output"]]
+        r = run("coati-sample", *args)
+        assert r.returncode == 1 and r.stderr.startswith("ERROR:"), (case, r.returncode, r.stderr)
+
+
+def test_batch_input_errors_are_reported_not_hung(tmp_path):
+    """--batch brings the model up on a helper thread while the input is indexed: an input that fails (missing file,
+    odd number of records) must unwind -- report and exit -- not wait for that thread for ever."""
+    odd = tmp_path / "odd.fasta"
+    odd.write_text(">a1\nCTCTGGATAGTG\n>b1\nCTATAGTG\n>a2\nGCGATTGCTGTT\n")
+    for bad in (tmp_path / "missing.fasta", odd):
+        r = subprocess.run([str(BIN / "coati-alignpair"), str(bad), "--batch"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and r.stderr.startswith("ERROR:"), (bad, r.returncode, r.stderr)

@@ -130,6 +130,47 @@ def test_user_rate_matrix_csv(tmp_path):
         host.parse_matrix_csv(short)
 
 
+def write_reference_rate_csv(path, extra_line=False):
+    """The CSV of the reference's own doctests (src/lib/io.cc:105-125, src/lib/align_marginal.cc:319-336): branch length
+    0.0133, then codon,codon,rate for the 61 x 61 sense codons in table order, rates = mg94Q (src/include/coati/mg94q.tcc;
+    the VALUES are the fixture tests/golden/mg94Q_rate_matrix.npy) printed the way `ostream << float` prints them (%g)."""
+    known = json.loads((GOLD / "reference_known_answers.json").read_text())["user_matrix"]
+    Q = np.load(GOLD / "mg94Q_rate_matrix.npy")
+    assert Q.shape == (61, 61) and Q.dtype == np.float32 and np.count_nonzero(Q) == 587
+    cod = lambda c: "ACGT"[(c >> 4) & 3] + "ACGT"[(c >> 2) & 3] + "ACGT"[c & 3]
+    sense = [cod(c) for c in range(64) if c not in (48, 50, 56)]
+    with open(path, "w") as f:
+        f.write(known["br_len"] + "\n")
+        for i in range(61):
+            for j in range(61):
+                f.write("%s,%s,%g\n" % (sense[i], sense[j], float(Q[i, j])))
+        if extra_line:
+            f.write("%s,%s,%g\n" % (sense[0], sense[0], float(Q[0, 0])))
+    return known
+
+
+def doctest_approx(a, b):
+    """doctest::Approx (contrib/doctest/doctest/doctest.h:3545,3565-3569): |a - b| < 100 * FLT_EPSILON * (1 + max(|a|, |b|))."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) < float(np.finfo(np.float32).eps) * 100 * (1.0 + np.maximum(np.abs(a), np.abs(b)))
+
+
+def test_parse_matrix_csv_reference_doctest(tmp_path):
+    """src/lib/io.cc:92-172: parse_matrix_csv of the mg94Q CSV == mg94_p(0.0133, 0.2, pi) entry by entry (Approx);
+    a file that cannot be opened and a file with one line too many are errors."""
+    known = write_reference_rate_csv(tmp_path / "test-marg-matrix.csv")
+    P_test = host.parse_matrix_csv(tmp_path / "test-marg-matrix.csv")
+    P = host.mg94_p(float(known["br_len"]), known["omega"], known["pi"])
+    assert P.shape == P_test.shape == (61, 61)
+    assert doctest_approx(P, P_test).all(), float(np.abs(P - P_test).max())
+    assert np.abs(P.astype(np.float64) - P_test).max() < 2e-6  # (what the build actually achieves: far inside Approx)
+    with pytest.raises(host.CoatiHostError):
+        host.parse_matrix_csv("")
+    write_reference_rate_csv(tmp_path / "too-many.csv", extra_line=True)
+    with pytest.raises(host.CoatiHostError):
+        host.parse_matrix_csv(tmp_path / "too-many.csv")
+
+
 def run(binary, *args):
     return subprocess.run([str(BIN / binary), *args], capture_output=True, text=True, timeout=120)
 

@@ -42,6 +42,17 @@ np.save(OUT / "mg94P_golden.npy", P.astype(np.float64))
 table = host.marginal_p(P.astype(np.float32))
 np.save(OUT / "table_mg94_goldenP.npy", table)
 
+# ---- 1b. the MG94 rate matrix the reference's --sub / parse_matrix_csv doctests write into their CSV
+# (src/include/coati/mg94q.tcc:26,77 scattered as align_marginal.cc:324-327 / io.cc:110-113 do): 61 x 61 fp32 VALUES
+text = re.sub(r"/\*.*?\*/", "", (REF / "src/include/coati/mg94q.tcc").read_text(), flags=re.S)
+num = r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?"
+idx = [int(x) for x in re.findall(num, re.search(r"mg94_indexes\[587\]\s*=\s*\{(.*?)\};", text, flags=re.S).group(1))]
+val = [float(x) for x in re.findall(num, re.search(r"mg94Q\[587\]\s*=\s*\{(.*?)\};", text, flags=re.S).group(1))]
+assert len(idx) == 587 and len(val) == 587
+Q = np.zeros(3721, np.float32)
+Q[idx] = np.array(val, np.float64).astype(np.float32)  # (float Q[3721]: the literals are rounded to fp32 there)
+np.save(OUT / "mg94Q_rate_matrix.npy", Q.reshape(61, 61))
+
 # ---- 2. Viterbi cases through the reference ----
 def read_fasta(path):
     names, seqs = [], []
@@ -161,6 +172,16 @@ known = {
         {"seqs": ["CCCCCC", "CCCCCCCC"], "out": [["CC--CCCC", "CCCCCCCC"], ["CCCCCC--", "CCCCCCCC"], ["CCCC--CC", "CCCCCCCC"]],
          "scores": ["-1.9466571807861328", "-1.9466569423675537", "-1.9466572999954224"]},
     ],
+    "marg_sample_fail": [  # align_marginal.cc:673-720: every subcase throws std::invalid_argument
+        {"what": "length of reference not multiple of 3", "names": ["seq1", "seq2"], "seqs": ["AC", "ACG"]},
+        {"what": "length of descendant no multiple of gap len", "names": ["A", "B"], "seqs": ["CCC", "CCCC"], "gap_len": 3},
+        {"what": "error opening output file", "names": ["A", "B"], "seqs": ["CCC", "CCC"], "output": "no-such-directory/x.json"},
+        {"what": "Number of seqs != 2", "names": ["A"], "seqs": ["CCC"]},
+        {"what": "Number of seqs != 2", "names": ["A", "B", "C"], "seqs": ["CCC", "CCC", "CCC"]},
+    ],
+    "user_matrix": {  # align_marginal.cc:304-343 and io.cc:92-133: the CSV holds mg94Q (tests/golden/mg94Q_rate_matrix.npy) and this branch length
+        "br_len": "0.0133", "omega": 0.2, "pi": [0.308, 0.185, 0.199, 0.308],
+        "seqs": ["CTCTGGATAGTG", "CTATAGTG"], "out": ["CTCTGGATAGTG", "CT----ATAGTG"]},
     "marginal_seq_encoding": {  # src/lib/utils.cc:532-586
         "anc": "AAAGGGTTTCCCACTAGA", "anc_codes": [0, 1, 2, 126, 127, 128, 180, 181, 182, 63, 64, 65, 21, 22, 23, 24, 25, 26],
         "des": "ACGTRYMKSWBDHVN-", "des_codes": list(range(16)),
