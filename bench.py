@@ -109,6 +109,84 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def recorded_profile(name):
+    """A tracked record under profiles/ that tools/install_profiles.py tied to the kernel sources it was measured on (PMC
+    passes cannot run inside a timed bench run): the record, or None when the kernel sources have changed since."""
+    f = ROOT / "profiles" / name
+    try:
+        rec = json.loads(f.read_text())
+        return rec if rec.get("kernel_sources_sha16") == kernel_sources_sha16() else None
+    except Exception:
+        return None
+
+
+def roofline_record(algo_bytes, fill_ms, cells, traffic, traffic_rec, sq_rec, band_rec, power):
+    """The headline kernel against the HBM roof SURVEY.md 8(d) prices it on -- and what actually binds it.  `bound` names
+    the roof `achieved`/`peak`/`frac` refer to (the contract's figure); `binding` is what the counters say limits the
+    kernel: vector instruction issue, at the clock the board's power limit leaves."""
+    achieved = algo_bytes / (fill_ms * 1e-3) / 1e9
+    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": "recorded" if traffic is not None else None,
+           "kernel": "viterbi_ck", "algorithmic_bytes_per_launch": algo_bytes, "band": band_rec, "binding": "valu_issue"}
+    if traffic_rec:
+        rec["traffic_detail"] = {"WRITE_SIZE_bytes": traffic_rec["WRITE_SIZE_KB"] * 1024, "FETCH_SIZE_bytes_raw": traffic_rec["FETCH_SIZE_KB_raw"] * 1024,
+                                 "bytes_with_fetch_x2": traffic, "bytes_with_fetch_raw": (traffic_rec["WRITE_SIZE_KB"] + traffic_rec["FETCH_SIZE_KB_raw"]) * 1024,
+                                 "source": traffic_rec.get("source"),
+                                 "note": "recorded by tools/profile.sh on this kernel build (source hash checked), not measured in this run; the "
+                                         "gfx950 FETCH_SIZE x 2 correction is specified for wide coalesced streams -- the traceback's reads are 8-byte "
+                                         "and 16-byte gathers, so `traffic` is an upper bound and bytes_with_fetch_raw a lower one"}
+    sclk = watts = cap = None
+    if power and not power.get("error"):
+        sclk = float(np.mean(power["sclk_mhz"])) if power.get("sclk_mhz") else None
+        watts = float(np.mean(power["package_power_w"])) if power.get("package_power_w") else None
+        cap = power.get("package_power_cap_w")
+    valu = {"sclk_mhz": sclk, "watts": watts, "power_cap_w": cap, "power_source": "rocm-smi in this run (extra.power)" if watts else None}
+    if sq_rec:
+        ipc = sq_rec["SQ_INSTS_VALU"] * 64.0 / sq_rec["cells"]
+        cyc = (sq_rec["GRBM_GUI_ACTIVE"] / 8.0) / (sq_rec["SQ_INSTS_VALU"] / 1024.0)  # shader cycles per VALU instruction and SIMD
+        valu.update({"instr_per_cell": ipc, "cycles_per_instr_per_simd": cyc, "issue_frac": 2.0 / cyc,
+                     "issue_frac_note": "against one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md); the cell's mix "
+                                        "(11 v_add_f32 at ~2.15 cycles, v_max_f32 and 2 v_max3_f32 at ~4.2, DPP / readlane / LDS at their "
+                                        "own cadence: tools/ubench) cannot issue at 2",
+                     "clock_under_counters_mhz": sq_rec["GRBM_GUI_ACTIVE"] / 8.0 / (sq_rec["kernel_ms"] * 1e-3) / 1e6 if sq_rec.get("kernel_ms") else None,
+                     "lds_bank_conflict_frac": sq_rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(sq_rec.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
+                     "counters_source": "recorded: " + str(sq_rec.get("source"))})
+        if sclk:
+            valu["gcups_at_2_cycles_per_instr"] = 1024 * 64 * sclk * 1e6 / (ipc * 2.0) / 1e9
+            valu["frac_of_that"] = cells / (fill_ms * 1e-3) / 1e9 / valu["gcups_at_2_cycles_per_instr"]
+    rec["valu"] = valu
+    rec["valu_ceiling_gcups"] = VALU_PEAK_GCUPS
+    rec["valu_frac"] = cells / (fill_ms * 1e-3) / 1e9 / VALU_PEAK_GCUPS
+    rec["note"] = ("frac is priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell of traceback state); the kernel is NOT "
+                   "HBM-bound (counter traffic is about half the algorithmic bytes: checkpoints are kept in a band around each pair's "
+                   "diagonals only).  What binds is vector instruction issue -- `valu`: instructions per cell and cycles per instruction "
+                   "from the recorded SQ counters of this build, clock and board power from this run -- with the clock held down by the "
+                   "package power limit; valu_ceiling_gcups is the register-only replay of the 15-instruction cell at 2.35 GHz "
+                   "(tools/ubench/gen_step.py), a third reference point.  DESIGN.md 4.1, 5.6")
+    return rec
+
+
+def roofline_by_kernel(algo_bytes, fill_ms, extras):
+    """One map with the roofline fraction of every kernel the line reports, so that nobody has to dig through `extra`."""
+    out = {"viterbi_ck (configs[1]: 10 000 x 1 kb, fill + traceback)": {"bound": "hbm", "bytes_per_cell": 1.0, "achieved_GBps": algo_bytes / (fill_ms * 1e-3) / 1e9,
+                                                                          "frac": algo_bytes / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "binding": "valu_issue"}}
+    smp = extras.get("sample") or {}
+    ff = smp.get("forward_fill")
+    if ff:
+        out["forward_l1_exact_narrow (configs[3] fill, 6 144 x 1 kb, bit-exact)"] = {
+            "bound": "hbm", "bytes_per_cell": 12.0, "achieved_GBps": ff["gcups"] * 12.0, "frac": ff["hbm_frac_12B_per_cell"],
+            "binding": "valu_issue (glibc expf / log1pf restated: 417 instructions per cell, a third of them 4-8-cycle classes)"}
+    lp = extras.get("long_pair") or {}
+    if lp.get("gcups"):
+        out["viterbi_lp (configs[2]: one 160 002 x 160 002 pair)"] = {"bound": "hbm", "bytes_per_cell": 1.0, "achieved_GBps": lp["gcups"],
+                                                                      "frac": lp["hbm_frac_1B_per_cell"], "binding": "latency: a chain of ~215 000 dependent wavefront steps"}
+    s16 = smp.get("sample_16x1000_exact_stream")
+    if s16:
+        out["configs[3] as stated: 16 pairs, forward + 16 000 samples"] = {"forward_ms": s16["forward_ms"], "sampleback_ms": s16["sampleback_ms"],
+                                                                         "binding": "latency: 16 narrow strips in a row per pair; ~13 speculation rounds"}
+    return out
+
+
 def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, cells, args):
     """Informational records next to the headline (never `value`): the PCIe-inclusive streamed call
     (H2D -> kernels -> D2H), the CLI batch mode end to end, and BASELINE configs[2] and [3].
@@ -214,6 +292,33 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
              "ms": ms, "gcups": cl / ms / 1e6, "hbm_frac_1B_per_cell": cl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
              "bit_exact_vs_golden": bool(ok), "device_bytes": bt.device_bytes}
         bt.close()
+        # the same pair with viterbi_ck forced (lean 15-instruction cell + checkpoint recompute, 4-column strips) next to the
+        # planner's choice (viterbi_lp: 25-instruction bit cell, 2-column strips): which of the two a lone wavefront prefers
+        forced = {}
+        for name, env in (("viterbi_ck_4_columns", {"COATI_HIP_VITERBI_CK": "1", "COATI_HIP_STRIP_W": "4"}),
+                          ("viterbi_ck_8_columns", {"COATI_HIP_VITERBI_CK": "1", "COATI_HIP_STRIP_W": "8"})):
+            try:
+                os.environ.update(env)
+                hip.reload_env()
+                b2 = hip.Batch(m, *hip.pack_pairs([(a, b)]))
+                t2 = []
+                for _ in range(3):
+                    b2.viterbi_launch()
+                    b2.sync()
+                    t2.append(b2.viterbi_timing()[0])
+                sc2, ops2, off2, ln2 = b2.viterbi_fetch()
+                got2 = ops2[int(off2[0]):int(off2[0]) + int(ln2[0])]
+                forced[name] = {"ms": float(np.median(t2[1:])), "gcups": cl / float(np.median(t2[1:])) / 1e6,
+                                "bit_exact_vs_golden": bool(int(np.float32(sc2[0]).view(np.uint32)) == int(case["score_bits"], 16)
+                                                            and "%08x" % zlib.crc32(got2.tobytes()) == case["ops_crc32"])}
+                b2.close()
+            except Exception as exc:
+                forced[name] = {"error": repr(exc)[:200]}
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+                hip.reload_env()
+        r["forced"] = forced
         m.close()
         return r
 
@@ -249,6 +354,44 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
         r["sample_16x1000_exact_stream"] = {"forward_ms": t_f * 1e3, "sampleback_ms": best * 1e3, "sampleback_first_call_ms": first * 1e3,
                                             "samples_per_s": 16000 / best, "finite": bool(np.isfinite(lw).all())}
         bt.close()
+        # the CPU beside it (comparison leg, outside every timed GPU region): the same 16 pairs, forward + 1 000 samples each,
+        # through the unmodified reference engine where oracle/_ref travelled (align_pair.cc:149,401-458 via oracle/ref_shim.cc),
+        # else the bit-identical port; one thread, and one pair per thread
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+
+            from oracle import pyoracle as orc  # checker / baseline only
+
+            g, e = np.float32(0.001), np.float32(1.0) - np.float32(1.0) / np.float32(6.0)
+            raw = [host.synth_raw(i) for i in range(16)]
+            enc = [host.encode(anc, des) for anc, des in raw]
+            use_ref = orc.ref_available()
+
+            def one(i):
+                (anc, des), (a, b) = raw[i], enc[i]
+                if use_ref:
+                    _, _, sc = orc.ref_forward_sample(table, g, e, 1, anc, des, a, b, ["42"], 1000, want_matrices=False)
+                    return float(sc[0])
+                M, D, I, E = orc.fill(orc.LOG, table, consts, 1, a, b, edges=True)
+                mats, rng = np.concatenate([np.stack([M, D, I]), E]), orc.rng_seed(["42"])
+                return float([orc.sampleback(mats, 1, rng)[1] for _ in range(1000)][0])
+
+            t0 = time.perf_counter()
+            first = [one(i) for i in range(4)]
+            t1 = (time.perf_counter() - t0) / 4 * 16
+            threads = min(16, os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as ex:
+                allp = list(ex.map(one, range(16)))
+            tn = time.perf_counter() - t0
+            gpu_ms = r["sample_16x1000_exact_stream"]["forward_ms"] + r["sample_16x1000_exact_stream"]["sampleback_ms"]
+            r["cpu_baseline"] = {"kind": "reference" if use_ref else "port", "what": "forward + 1 000 samples for each of the same 16 pairs",
+                                 "one_thread_ms": t1 * 1e3, "one_thread_note": "4 pairs timed, scaled to 16",
+                                 "one_pair_per_thread_ms": tn * 1e3, "threads": threads, "gpu_ms": gpu_ms,
+                                 "gpu_over_one_thread": t1 * 1e3 / gpu_ms, "gpu_over_threads": tn * 1e3 / gpu_ms,
+                                 "first_log_weight_equal": bool(np.float32(lw.reshape(16, -1)[0, 0]).view(np.uint32) == np.float32(allp[0]).view(np.uint32))}
+        except Exception as exc:  # (never fails the line)
+            r["cpu_baseline"] = {"error": repr(exc)}
         return r
 
     def cli_batch():
@@ -594,15 +737,11 @@ def main():
         algo_bytes = cells * ALGO_BYTES_PER_CELL + seq_bytes
         # HBM bytes per launch from the PMC counters: a recorded measurement of THIS kernel build (tools/profile.sh
         # stores the hash of the kernel sources next to it); null when the sources have changed since
-        traffic = None
-        tfile = ROOT / "profiles" / "traffic_latest.json"
-        if tfile.exists() and n_mine == 10000 and args.model == "mar-mg":
-            try:
-                rec = json.loads(tfile.read_text())
-                if rec.get("kernel_sources_sha16") == kernel_sources_sha16():
-                    traffic = rec.get("viterbi_ck_bytes_per_launch_10000_pairs")
-            except Exception:
-                traffic = None
+        traffic = traffic_rec = None
+        if n_mine == 10000 and args.model == "mar-mg":
+            traffic_rec = recorded_profile("traffic_latest.json")
+            traffic = traffic_rec.get("viterbi_ck_bytes_per_launch_10000_pairs") if traffic_rec else None
+        sq_rec = recorded_profile("sq_latest.json") if n_mine == 10000 and args.model == "mar-mg" else None
         # The headline kernel keeps its traceback checkpoints in a BAND around each pair's straight line; a pair whose
         # path leaves it is filled twice (same bits).  What that did on THIS workload, and what the same launches cost
         # with everything kept (COATI_HIP_OPT_CK_BAND = 0): part of the roofline record, measured here, never `value`.
@@ -679,19 +818,8 @@ def main():
                                       "through libcoati_hip_dist.so (RCCL linked directly)" if multi else "1 GPU"},
             "pairs_per_s": global_pairs * args.steps / elapsed,
             "kernel_ms": kernel_ms,
-            "roofline": {"bound": "hbm", "achieved": algo_bytes / (fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": algo_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "viterbi_ck", "algorithmic_bytes_per_launch": algo_bytes, "band": band_rec,
-                         "valu_ceiling_gcups": VALU_PEAK_GCUPS, "valu_frac": cells / (fill * 1e-3) / 1e9 / VALU_PEAK_GCUPS,
-                         "note": "priced against the HBM roof as SURVEY.md 8(d) defines it (1 B/cell of traceback state); the "
-                                 "limit this recurrence runs into is SIMD instruction issue (19 instructions per cell at ~2.2 "
-                                 "cycles) and the clock the chip holds, which is the board's POWER limit: back-to-back launches "
-                                 "draw 1 335-1 350 W of the 1 400 W cap (tools/power_probe.sh, profiles/r03/power_probe.txt), and "
-                                 "cycles saved by a leaner step come back as a lower clock -- valu_ceiling_gcups is the "
-                                 "register-only replay of the 15-instruction fill cell at 2.35 GHz, valu_frac the kernel against it "
-                                 "(DESIGN.md 4, 5b).  "
-                                 "Since round 3 the kernel WRITES less than the algorithmic 1 B/cell: checkpoints are kept "
-                                 "in a band around each pair's straight line only (traffic = what the counters saw)"},
+            "roofline": roofline_record(algo_bytes, fill, cells, traffic, traffic_rec, sq_rec, band_rec, extras.get("power")),
+            "roofline_by_kernel": roofline_by_kernel(algo_bytes, fill, extras),
             "strong_1M": strong,
             "two_stream_pipeline": pipelined,
             "pcie_inclusive": extras.get("pcie_inclusive"),

@@ -144,7 +144,7 @@ struct coati_hip_model {
     std::mutex pipeline_lock;  // one pipelined call at a time per model
     uint32_t stream_calls = 0;     // streamed calls this model has served (the first one allocates lazily: a one-shot process pays for what it uses)
     bool stream_unusable = false;  // the persistent kernel's first upload did not arrive in time once (copies not on the copy engine): never again on this model
-    uint32_t ck_band = 96;  // viterbi_ck: half width of the kept checkpoint band, kCkBandOff = keep everything (COATI_HIP_OPT_CK_BAND; default: ck_band_setting())
+    uint32_t ck_band = 64;  // viterbi_ck: half width of the kept checkpoint band, kCkBandOff = keep everything (COATI_HIP_OPT_CK_BAND; default: ck_band_setting())
     bool stream_forbidden = false;  // coati_hip_model_set_option(COATI_HIP_OPT_PERSISTENT_CALL, 0): the embedder shares the GPU
     std::unique_ptr<HelperPool> helpers;  // the streamed call's planning helpers (pipeline.hip), made by its first use or by coati_hip_model_prepare
 };

@@ -428,6 +428,24 @@ __device__ __forceinline__ float log_plus_exact(float a, float b, const uint64_t
         l = libm::log1pf_mid(e);
     return hi + (y <= -16.0f ? e : l);
 }
+// Two independent plus operations side by side (round 5): plus(a0, b0) and plus(a1, b1), each exactly as log_plus_exact
+// computes it -- the two dependent chains (fp64 expf, reciprocal + Newton steps, the degree-7 polynomial) in ONE basic block,
+// so that the scheduler can overlap them.  The wave-uniform choice of log1pf's k = 0 route is made for both at once.
+__device__ __forceinline__ void log_plus_exact_x2(float a0, float b0, float a1, float b1, const uint64_t* exp_tab, float& out0, float& out1) {
+    const float hi0 = fmaxf(a0, b0), hi1 = fmaxf(a1, b1);
+    const float y0 = -fabsf(a0 - b0), y1 = -fabsf(a1 - b1);
+    const float e0 = libm::expf_nonpos(y0, exp_tab), e1 = libm::expf_nonpos(y1, exp_tab);
+    const bool small = (y0 <= -16.0f || e0 < libm::u2f(0x3ed413d7u)) && (y1 <= -16.0f || e1 < libm::u2f(0x3ed413d7u));
+    float l0, l1;
+    if(__builtin_amdgcn_ballot_w64(small) == __builtin_amdgcn_ballot_w64(true)) {
+        l0 = libm::log1pf_small(e0);
+        l1 = libm::log1pf_small(e1);
+    } else {
+        libm::log1pf_mid_x2(e0, e1, l0, l1);
+    }
+    out0 = hi0 + (y0 <= -16.0f ? e0 : l0);
+    out1 = hi1 + (y1 <= -16.0f ? e1 : l1);
+}
 __device__ __forceinline__ void load_exp_table(uint64_t* lds_tab, int tid) {
     constexpr uint64_t kTab[32] = {COATI_EXP2F_TABLE};
     if(tid < 32) lds_tab[tid] = kTab[tid];
@@ -481,7 +499,7 @@ struct EnvOptions {
     int fill_blocks_per_cu = 0;      // COATI_HIP_FILL_BLOCKS_PER_CU
     int lp_blocks_per_cu = 0;        // COATI_HIP_LP_BLOCKS_PER_CU
     long long tail_pairs = -1;       // COATI_HIP_TAIL_PAIRS (-1: the planner's rule)
-    uint32_t ck_band = 96;           // COATI_HIP_CK_BAND: default of COATI_HIP_OPT_CK_BAND (0 -> kCkBandOff)
+    uint32_t ck_band = 64;           // COATI_HIP_CK_BAND: default of COATI_HIP_OPT_CK_BAND (0 -> kCkBandOff)
     uint32_t ck_debug = 0;           // COATI_HIP_CK_DEBUG: bit 0 fill only, bit 1 traceback statistics
     bool ck_split_set = false;       // COATI_HIP_CK_SPLIT="pairs,parts[,t]"
     uint64_t ck_split_pairs = 0, ck_split_parts = 3;
@@ -583,7 +601,7 @@ volatile uint32_t* ck_stream_host_done_flag(void* host, int slot);
 // wave_ck: ck_scratch_waves() checkpoint slots of wave_slot_dwords each; wave_scratch: as many traceback scratch areas
 hipError_t launch_viterbi_ck_stream(const float* table, GapConsts k, bool shared_tab, void* ctl, const void* host_words, uint32_t* wave_ck,
                                     uint64_t wave_slot_dwords, uint32_t* wave_scratch, uint32_t band, hipStream_t stream);
-uint32_t ck_band_setting();  // the default half width of the kept checkpoint band (COATI_HIP_CK_BAND, else 96 steps)
+uint32_t ck_band_setting();  // the default half width of the kept checkpoint band (COATI_HIP_CK_BAND, else 64 steps)
 hipError_t launch_ck_all_flags(const BatchDeviceView& v, uint32_t pair, uint32_t* scratch, uint32_t n_waves, uint8_t* out,
                                hipStream_t stream);
 hipError_t launch_dp_generic(const BatchDeviceView& v, bool forward, hipStream_t stream);

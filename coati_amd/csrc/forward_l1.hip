@@ -115,8 +115,23 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint3
             const float d2d = upD + kv.ge;
             const float m2i = lfM + kv.go;
             const float i2i = lfI + kv.ge;
-            const float M = plus2<kFast>(cx, plus2<kFast>(cx, m2m, d2m), i2m);
-            const float D = plus2<kFast>(cx, plus2<kFast>(cx, m2d, d2d), i2d);
+            float M, D;
+            if constexpr(kFast) {
+                M = log_plus(log_plus(m2m, d2m), i2m);
+                D = log_plus(log_plus(m2d, d2d), i2d);
+            } else if constexpr(W <= 4) {
+                // the M and the D sums do not depend on each other: their two dependent chains side by side (common.hpp).
+                // Narrow strips only -- few pairs, every wavefront alone on its SIMD: 16 pairs 3.41 -> 3.27 ms (round 5, same
+                // box, alternating); with four wavefronts per SIMD the others already fill the chain's latencies and the joint
+                // choice of log1pf's short route is taken less often: 6 144 pairs 60.6 -> 62.1 ms, so the bulk shape keeps
+                // one chain at a time
+                float m12, d12;
+                log_plus_exact_x2(m2m, d2m, m2d, d2d, cx.exp_tab, m12, d12);
+                log_plus_exact_x2(m12, i2m, d12, i2d, cx.exp_tab, M, D);
+            } else {
+                M = plus2<kFast>(cx, plus2<kFast>(cx, m2m, d2m), i2m);
+                D = plus2<kFast>(cx, plus2<kFast>(cx, m2d, d2d), i2d);
+            }
             const float I = plus2<kFast>(cx, m2i, i2i);
             dgM = upM;
             dgD = upD;

@@ -205,6 +205,42 @@ COATI_MATH_FN float log1pf_small(float x) {
     return f - (hfsq - t);
 }
 
+// Two independent log1pf_mid side by side, as ONE straight-line block (the rare |f| < 2^-20 routes are redone after both):
+// the exact Forward cell has two such dependent chains at a time that do not depend on each other (the M and the D sums),
+// and a chain of ~40 fp64 / reciprocal / fp32 steps issues no faster than its latencies allow.  Same operations on the
+// same values as log1pf_mid, so the same bits.
+COATI_MATH_FN void log1pf_mid_x2(float x0, float x1, float& out0, float& out1) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, Lp1 = 6.6666668653e-01f,
+                    Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f, Lp4 = 2.2222198546e-01f, Lp5 = 1.8183572590e-01f,
+                    Lp6 = 1.5313838422e-01f, Lp7 = 1.4798198640e-01f;
+    const float x[2] = {x0, x1};
+    float res[2], u[2];
+    uint32_t mant[2];
+    bool rare[2];
+#pragma unroll
+    for(int q = 0; q < 2; ++q) {
+        const bool small = x[q] < u2f(0x3ed413d7u);
+        u[q] = 1.0f + x[q];
+        mant[q] = f2u(u[q]) & 0x007fffffu;
+        const bool halve = !small && mant[q] >= 0x3504f7u;
+        const float f = small ? x[q] : __builtin_fmaf(u[q], halve ? 0.5f : 1.0f, -1.0f);
+        const float c = (x[q] - (u[q] - 1.0f)) * recip_rn(u[q]);
+        const float hfsq = 0.5f * f * f;
+        const float s = div_rn(f, 2.0f + f);
+        const float z = s * s;
+        const float R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+        const float t = s * (hfsq + R);
+        const float r0 = f - (hfsq - t);
+        const float r1 = ln2_hi - ((hfsq - (t + (ln2_lo + c))) - f);
+        res[q] = halve ? r1 : r0;
+        rare[q] = !small && mant[q] - 1u >= 0x7ffffcu;
+    }
+    if(__builtin_expect(rare[0], 0)) res[0] = log1pf_near2(x[0], u[0], mant[0]);
+    if(__builtin_expect(rare[1], 0)) res[1] = log1pf_near2(x[1], u[1], mant[1]);
+    out0 = res[0];
+    out1 = res[1];
+}
+
 // logf for normal positive x (x = sum of up to three expf values in (0, 3]).
 COATI_MATH_FN float logf_pos(float x) {
     // {1/c, log(c)} for the 16 sub-intervals of [sqrt(2)/2, sqrt(2)) * 2^k

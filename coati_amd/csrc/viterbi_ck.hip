@@ -40,8 +40,8 @@ namespace coati_hip_detail {
 __device__ unsigned long long g_ck_trace[4096 * 16];
 #define COATI_CK_STAMP(slot)                                                                     \
     do {                                                                                         \
-        if(lane_id == 0 && trace_n + (slot) < 15)                                                \
-            g_ck_trace[trace_wave * 16 + trace_n + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+        if(lane_id == 0) /* (items from the seventh on share the last record: a wavefront's LAST stamps are always there) */ \
+            g_ck_trace[trace_wave * 16 + (trace_n + (slot) < 15 ? trace_n + (slot) : 13 + (slot))] = __builtin_amdgcn_s_memrealtime(); \
     } while(0)
 #else
 #define COATI_CK_STAMP(slot) do { } while(0)
@@ -127,7 +127,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
 // least |delta| gap columns of one kind; a path whose gaps are (almost) all of that kind -- related sequences with a few
 // indels -- lies between the diagonal through (0, 0) and the one through (la, lb): at column j its row is between
 // j + min(0, delta) and j + max(0, delta).  So centre(t) = (middle column of the lane) + delta / 2 + t (the lane's
-// skew), and half = band + |delta| / 2: the band setting (COATI_HIP_OPT_CK_BAND, default 96) is the slack for gaps of the
+// skew), and half = band + |delta| / 2: the band setting (COATI_HIP_OPT_CK_BAND, default 64) is the slack for gaps of the
 // OTHER kind, and a pair with one 300-base deletion keeps a wider band instead of being filled twice (round 3 centred
 // the band on the straight line (0, 0) -> (la, lb) with a fixed half width: a bag in which a quarter of the pairs
 // carry a 90-300 nt indel ran 26 % SLOWER than with everything kept; bench.py extra.band_sensitivity).
@@ -941,9 +941,19 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             publish_progress(progress + ticket, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
+#ifdef COATI_FILL_TRACE
+            COATI_CK_STAMP(1);  // (trace build: a row part is an item of the timeline too)
+            trace_n += 2;
+#endif
             continue;
         }
-        if((!redo && strip + 1 < pd.v_strips) || (dbg & 1u)) continue;  // not the last strip of its pair: no traceback here
+        if((!redo && strip + 1 < pd.v_strips) || (dbg & 1u)) {  // not the last strip of its pair: no traceback here
+#ifdef COATI_FILL_TRACE
+            COATI_CK_STAMP(1);
+            trace_n += 2;
+#endif
+            continue;
+        }
         // ---- traceback of this pair by the wavefront of its last strip.  What the wave wrote
         // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
         // strips): they released before publishing "complete", which this wave polled; acquire.
@@ -1406,8 +1416,10 @@ extern "C" int coati_hip_debug_trace(unsigned long long* out) {
 uint32_t ck_scratch_waves() { return 256u * 4u * 4u; }  // 4 wavefronts on each of the 1 024 SIMDs
 uint64_t ck_scratch_dwords_per_wave() { return kCkScratchDwords; }
 
-// (the default half width of the kept checkpoint band -- COATI_HIP_CK_BAND, else 96 steps: a lane keeps 13 of a 1 kb pair's 67
-// bands -- is ck_band_setting() in abi.hip, from the process' options)
+// (the default half width of the kept checkpoint band -- COATI_HIP_CK_BAND, else 64 steps: a lane keeps 9 of a 1 kb pair's 67
+// bands -- is ck_band_setting() in abi.hip, from the process' options.  Round 5, tools/band_bags.py on one box: 64 against 96
+// on the bench's four bags 3.95 / 4.25 / 4.74 / 4.08 ms against 4.01 / 4.30 / 4.76 / 4.19; 48 and 56 are faster still on the
+// synthetic bag and up to 0.7 ms slower where pairs are filled twice -- a refill that lands at the end of a launch is a whole pair)
 
 hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStream_t stream) {
     hipError_t e = zero_queue_and_progress(v, v.n_items, stream);  // ticket counter + polled words: zero every launch

@@ -110,7 +110,7 @@ int coati_hip_model_trim(coati_hip_model_t* model);
  *     any other kernel of the process (and any copy the runtime does with a kernel) waits for it.  With 0 every
  *     call uses one launch per chunk (identical results, ~0.85 instead of ~0.95 of the resident kernel's rate)
  *     and other streams of the embedder interleave normally.
- *   COATI_HIP_OPT_CK_BAND (default 96, or the environment's COATI_HIP_CK_BAND): half width, in wavefront steps, of the
+ *   COATI_HIP_OPT_CK_BAND (default 64, or the environment's COATI_HIP_CK_BAND): half width, in wavefront steps, of the
  *     band around a pair's straight line (0,0) -> (len_a, len_b) inside which the gap_len-1 kernel keeps the
  *     checkpoints its traceback recomputes decisions from; 0 keeps all of them.  A narrower band writes fewer bytes
  *     (the kernel is power-bound: bytes are clock); an alignment whose path leaves the band is detected by the walk and

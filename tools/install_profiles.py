@@ -2,6 +2,8 @@
 """Copy the summaries tools/profile.sh left under gpurun_out/ into profiles/<round>/ (tracked)."""
 import json
 import shutil
+
+import numpy as np
 import sys
 from pathlib import Path
 
@@ -46,3 +48,27 @@ t = json.loads((dst / "bench_n1_traffic.json").read_text())["viterbi_ck"]
     "WRITE_SIZE_KB": t["WRITE_SIZE_KB"], "FETCH_SIZE_KB_raw": t["FETCH_SIZE_KB_raw"], "round": int(rnd[1:]),
     "source": f"profiles/{rnd}/bench_n1_pmc_summary.csv"}, indent=1))
 print(t)
+# SQ counters of the headline kernel (tools/pmc_fill.sh <tag> 10000 libcoati_hip.so -> gpurun_out/pmc_<tag>/libcoati_hip.txt):
+# the record bench.py's roofline.valu is computed from, tied to the kernel sources like the traffic record
+sq_src = ROOT / "gpurun_out" / (sys.argv[2] if len(sys.argv) > 2 else "pmc_headline") / "libcoati_hip.txt"
+if sq_src.exists():
+    shutil.copy(sq_src, dst / "pmc_fill_sq_counters.txt")
+    rec = {}
+    for line in sq_src.read_text().splitlines():
+        f = line.split()
+        if len(f) == 4 and f[0].startswith("viterbi_ck"):
+            rec[f[1]] = float(f[3])
+    from coati_amd import host  # noqa: E402
+
+    la, lb = host.synth_lengths(0, 10000)
+    ns = rec.get("KERNEL_NS_group3") or rec.get("KERNEL_NS_group1")
+    out = {k: rec[k] for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+                               "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_SALU",
+                               "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD") if k in rec}
+    out.update({"cells": float((la.astype(np.float64) * lb).sum()), "pairs": 10000, "kernel_ms": ns * 1e-6 if ns else None,
+                "kernel_sources_sha16": bench.kernel_sources_sha16(), "round": int(rnd[1:]),
+                "how": "tools/pmc_fill.sh: one rocprofv3 --pmc pass per counter group over 4 launches of the resident 10 000-pair batch "
+                       "(tools/fill_loop.py); means over the dispatches; kernel_ms = the kernel's duration in the GRBM_GUI_ACTIVE pass",
+                "source": f"profiles/{rnd}/pmc_fill_sq_counters.txt"})
+    (ROOT / "profiles" / "sq_latest.json").write_text(json.dumps(out, indent=1))
+    print(out)
