@@ -112,6 +112,7 @@ const EnvOptions* read_env() {
         o->ck_split_pairs = std::strtoull(e, &rest, 10);
         if(rest != nullptr && *rest == ',') o->ck_split_parts = std::strtoull(rest + 1, &rest, 10);
         o->ck_split_taper = rest != nullptr && rest[0] == ',' && rest[1] == 't';
+        if(rest != nullptr && rest[0] == ',' && rest[1] == 's') o->ck_split_short_last = static_cast<uint32_t>(std::min<long>(7, std::max<long>(0, std::atol(rest + 2))));
     }
     if(const long long v = num("COATI_HIP_SPEC_CANDS", 0); v >= 1024 && v <= (1 << 22)) o->spec_cands = static_cast<uint32_t>(v);
     if(const char* e = std::getenv("COATI_HIP_SPEC_Z")) {

@@ -79,23 +79,27 @@ struct PairDesc {
     // whichever wavefront takes the next part (0 or 1: not cut).  Finer items for the ragged end of a launch.
     uint8_t v_parts;
 };
-// PairDesc::v_parts: the number of row parts in the low seven bits; bit 7 = TAPERED parts (below)
+// PairDesc::v_parts: the number of row parts in the low four bits; bit 7 = TAPERED parts (below); bits 4-6 = how many
+// 64-step chunks the LAST part is shorter than an equal split would make it (round 5: the wavefront of the last part also
+// walks the pair -- ~0.17 ms, two chunks' worth -- and the items at the end of the queue are the last parts)
 constexpr uint8_t kCkPartsTaper = 0x80;
-__host__ __device__ inline uint32_t ck_parts_count(uint8_t v_parts) { return v_parts & 0x7fu; }
+__host__ __device__ inline uint32_t ck_parts_count(uint8_t v_parts) { return v_parts & 0x0fu; }
+__host__ __device__ inline uint32_t ck_parts_short_last(uint8_t v_parts) { return (v_parts >> 4) & 7u; }
 // steps [begin, end) of row part `part` of a strip of nsteps wavefront steps: whole 64-step chunks.  Equal parts, or --
 // tapered -- parts whose lengths fall linearly (weights parts, parts - 1, ... 1): what is left of a launch when its
 // ticket queue runs dry is at most one item per wavefront, and the items at the end of the queue are the LAST parts
 // of the cut pairs, so short last parts shorten the ragged end while long first parts keep the hand-overs few.
-__host__ __device__ inline uint32_t ck_part_cut(uint32_t chunks, uint32_t parts, uint32_t p, bool taper) {
-    if(!taper) return p * chunks / parts;
+__host__ __device__ inline uint32_t ck_part_cut(uint32_t chunks, uint32_t parts, uint32_t p, bool taper, uint32_t short_last = 0) {
+    if(p >= parts) return chunks;
+    if(!taper) return p * (chunks + short_last) / parts;  // (short_last: the first parts share what the last one gives up)
     const uint32_t total = parts * (parts + 1u) / 2u, upto = p * parts - p * (p - 1u) / 2u;  // (p = 0: 0 - 0)
     return upto * chunks / total;
 }
 __host__ __device__ inline void ck_part_range(uint32_t nsteps, uint8_t v_parts, uint32_t part, uint32_t& begin, uint32_t& end) {
     const uint32_t chunks = (nsteps + 63u) / 64u, parts = ck_parts_count(v_parts);
     const bool taper = (v_parts & kCkPartsTaper) != 0;
-    begin = 64u * ck_part_cut(chunks, parts, part, taper);
-    end = part + 1u == parts ? nsteps : 64u * ck_part_cut(chunks, parts, part + 1u, taper);
+    begin = 64u * ck_part_cut(chunks, parts, part, taper, ck_parts_short_last(v_parts));
+    end = part + 1u == parts ? nsteps : 64u * ck_part_cut(chunks, parts, part + 1u, taper, ck_parts_short_last(v_parts));
 }
 // every part of a strip of nsteps steps is at least one chunk long
 __host__ __device__ inline bool ck_parts_fit(uint32_t nsteps, uint32_t parts, bool taper) {
@@ -504,6 +508,7 @@ struct EnvOptions {
     bool ck_split_set = false;       // COATI_HIP_CK_SPLIT="pairs,parts[,t]"
     uint64_t ck_split_pairs = 0, ck_split_parts = 3;
     bool ck_split_taper = false;
+    uint32_t ck_split_short_last = 0;  // COATI_HIP_CK_SPLIT="pairs,parts,s<k>": the last part k chunks shorter (0-7)
     uint32_t spec_cands = 3u << 16;  // COATI_HIP_SPEC_CANDS (196 608: 16 x 1 000 samples 6.1 ms; 2^17: 6.4, 2^18: 6.4, 2^16: 7.8 -- tools/sample_bench.py, round 4)
     double spec_z = 2.0;             // COATI_HIP_SPEC_Z
     uint32_t sample_band = 64;       // COATI_HIP_SAMPLE_BAND: half width, in diagonals, of the sampler's step table (tests: 1 or 2 force the walkers' own entries)

@@ -382,7 +382,11 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                 PairDesc& d = b->desc[p];
                 if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && ck_strip_dwords(d.la, kW) <= (1ull << 20) &&
                    ck_parts_fit(d.la + (std::min<uint32_t>(kStrip, d.lb) + kW - 1) / kW - 1, opts->tail_parts, false)) {
-                    d.v_parts = static_cast<uint8_t>(opts->tail_parts);
+                    // (the last part shorter by what its wavefront spends on the pair's traceback: as in the resident plan below)
+                    const uint32_t chunks = (d.la + (std::min<uint32_t>(kStrip, d.lb) + kW - 1) / kW - 1 + 63u) / 64u;
+                    const uint32_t want = std::min<uint32_t>(7u, (3u * d.lb + 500u) / 1000u);
+                    const uint32_t sl = chunks >= want + 2u * opts->tail_parts + 2u ? want : 0u;
+                    d.v_parts = static_cast<uint8_t>(opts->tail_parts | (sl << 4));
                     cut.push_back(p);
                 } else {
                     whole.push_back(p);
@@ -445,10 +449,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             if(split_pairs < 256) split_pairs = 0;
         }
         bool taper = false;
+        uint32_t short_last = 0;
         if(env.ck_split_set) {  // COATI_HIP_CK_SPLIT="pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
             split_pairs = env.ck_split_pairs;
             parts = env.ck_split_parts;
             taper = env.ck_split_taper;
+            short_last = taper ? 0u : env.ck_split_short_last;
             if(parts < 2 || parts > 8) split_pairs = 0;
         }
         split_pairs = std::min<uint64_t>(split_pairs, n_pairs);
@@ -459,7 +465,14 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             const uint32_t nsteps = d.la + (std::min<uint32_t>(kStrip, d.lb) + kW - 1) / kW - 1;
             if(d.la > 0 && d.lb > 0 && d.v_strips == 1 && d.v_wlast == kW && need_of(d) <= kSlotCap &&
                ck_parts_fit(nsteps, static_cast<uint32_t>(parts), taper)) {
-                d.v_parts = static_cast<uint8_t>(parts | (taper ? kCkPartsTaper : 0u));
+                // The wavefront of a pair's LAST part also walks the pair (a 1 kb pair: ~0.17 ms, two to three chunks' worth), and
+                // the last parts are the items at the end of the queue: the last part gives that many chunks to the others
+                // (round 5, tools/split_ab.py on one box: 10 000 pairs 4.01 -> 3.93 ms, 40 000 14.53 -> 14.41; cuts 5+6+6 -> 6+7+4
+                // chunks).  Only where every part keeps at least two chunks.
+                const uint32_t chunks = (nsteps + 63u) / 64u;
+                const uint32_t want = env.ck_split_set ? short_last : std::min<uint32_t>(7u, (3u * d.lb + 500u) / 1000u);
+                const uint32_t sl = (!taper && chunks >= want + 2u * static_cast<uint32_t>(parts) + 2u) ? want : 0u;
+                d.v_parts = static_cast<uint8_t>(parts | (taper ? kCkPartsTaper : 0u) | (sl << 4));
                 cut.push_back(order[q]);
             }
         }

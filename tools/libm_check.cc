@@ -50,6 +50,17 @@ int main(int argc, char** argv) {
     bad += sweep("expf<<", bits(-104.0f), bits(-3.4e38f), 4099u * stride, [](float x) { return ::expf(x); }, [](float x) { return expf_nonpos(x, kTab); });
     bad += sweep("log1pf", bits(0.0f), bits(1.0f), stride, [](float x) { return ::log1pf(x); }, [](float x) { return log1pf_unit(x); });
     bad += sweep("log1p/m", bits(0x1p-29f), bits(1.0f), stride, [](float x) { return ::log1pf(x); }, [](float x) { return log1pf_mid(x); });
+    // the two-wide form (round 5, narrow Forward strips): both halves, the partner input running through the range the other way
+    bad += sweep("l1p/x2a", bits(0x1p-29f), bits(1.0f), stride, [](float x) { return ::log1pf(x); }, [](float x) {
+        float r0, r1;
+        log1pf_mid_x2(x, from_bits(bits(0x1p-29f) + bits(1.0f) - bits(x)), r0, r1);
+        return r0;
+    });
+    bad += sweep("l1p/x2b", bits(0x1p-29f), bits(1.0f), stride, [](float x) { return ::log1pf(x); }, [](float x) {
+        float r0, r1;
+        log1pf_mid_x2(from_bits(bits(0x1p-29f) + bits(1.0f) - bits(x)), x, r0, r1);
+        return r1;
+    });
     bad += sweep("logf", bits(0x1p-126f), bits(4.0f), stride, [](float x) { return ::logf(x); }, [](float x) { return logf_pos(x); });
     return bad == 0 ? 0 : 1;
 }
