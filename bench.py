@@ -104,7 +104,7 @@ def kernel_sources_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("viterbi_ck.hip", "viterbi_cell.hpp", "common.hpp"):
+    for f in ("viterbi_ck.hip", "viterbi_cell.hpp", "common.hpp", "plan.hip"):  # (plan.hip: which items the kernel works through)
         h.update((ROOT / "coati_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 

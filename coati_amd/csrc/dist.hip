@@ -439,6 +439,25 @@ struct RcclEnv {
     }
 };
 
+// Where the ROOT's thread of the last sharded job spent its time (coati_hip_dist_debug_job_times; tools/dist_sim_bench.py):
+// seconds in [0] the whole job loop, [1] making / waiting for its own chunks (Chunks::start of the first, the helper thread's of the others, Chunks::finish), [2] the count exchanges, [3] the
+// send / receive group (Env::transfer), [4] unpack + placement + offset rebase (Env::copy_out inside), [5] rounds.
+// [0] - [1] - [2] - [3] - [4] is the loop's own logic (plans, validation, transfer lists).  One writer (the root's thread).
+struct JobTimes {
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ([6]: reserving the landing zone; [7]: the rank's own copy-out in the local form)
+};
+JobTimes g_job_times;
+thread_local JobTimes* t_job_times = nullptr;  // set on the root's thread for the duration of a job
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct PhaseTimer {  // adds the time until its end to t_job_times->v[slot] (no-op on other threads)
+    int slot;
+    double t0;
+    explicit PhaseTimer(int s) : slot(s), t0(t_job_times != nullptr ? now_s() : 0.0) {}
+    ~PhaseTimer() {
+        if(t_job_times != nullptr) t_job_times->v[slot] += now_s() - t0;
+    }
+};
+
 // Host memory in place of HBM, an abstract transport in place of RCCL.
 struct HostTransport {
     virtual ~HostTransport() = default;
@@ -495,7 +514,11 @@ int gather_round(Env& env, int root, const Block& own, const uint64_t* mine, uin
                  Validate&& validate, bool presized, float* scores, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
     const int world = env.world(), rank = env.rank();
     // 1. everybody learns everybody's counts and status
-    int rc = env.exchange_counts(mine, counts3);
+    int rc;
+    {
+        const PhaseTimer timed(2);
+        rc = env.exchange_counts(mine, counts3);
+    }
     if(rc != COATI_HIP_OK) return rc;
     if(const int bad = failed_rank(world, counts3); bad >= 0) {
         if(bad == rank) return static_cast<int>(counts3[kCountWords * bad + 2]);  // (its own message is already set)
@@ -535,10 +558,14 @@ int gather_round(Env& env, int root, const Block& own, const uint64_t* mine, uin
     } else if(root_status != COATI_HIP_OK) {
         return root_status;  // (a presized job cannot get here: the sizes were reserved and checked before round 0)
     }
-    rc = env.transfer(root, xfer, own);
+    {
+        const PhaseTimer timed(3);
+        rc = env.transfer(root, xfer, own);
+    }
     if(rc != COATI_HIP_OK) return rc;
     if(rank != root) return env.sync();  // the block's arrays may be reused after the call
     // 3. root: download, every block to its place
+    const PhaseTimer timed_unpack(4);
     rc = unpack_blocks(world, root, counts3, mask, place.data(), own, env.landing(), land.data(), scores, ops, ops_off, ops_len,
                        [&env](void* dst, const void* src, uint64_t bytes) { return env.copy_out(dst, src, bytes); });
     const int rs = env.sync();
@@ -570,6 +597,18 @@ struct JobOut {
 template <typename Env, typename Chunks>
 int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint64_t n_pairs, const JobOut& out) {
     const int world = env.world(), rank = env.rank();
+    struct TimesScope {  // (the root's thread records where its time goes: JobTimes)
+        bool on;
+        explicit TimesScope(bool root_thread) : on(root_thread) {
+            if(on) {
+                g_job_times = JobTimes{};
+                t_job_times = &g_job_times;
+            }
+        }
+        ~TimesScope() { t_job_times = nullptr; }
+    } times_scope(rank == root);
+    const PhaseTimer timed_total(0);
+    if(t_job_times != nullptr) t_job_times->v[5] = static_cast<double>(plan.rounds);
     int my_status = env.begin();
     const auto& mine = plan.cuts[static_cast<size_t>(rank)];
     const uint64_t shard0 = plan.bounds[static_cast<size_t>(rank)], shard_ops0 = plan.op_prefix[shard0];
@@ -581,7 +620,10 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
     if(my_status == COATI_HIP_OK && out.local && out.ops != nullptr && out.ops_capacity < shard_ops)
         my_status = fail(COATI_HIP_EINVAL, "dist_viterbi: ops_capacity of rank %d too small for its shard", rank);
     if(my_status == COATI_HIP_OK) my_status = chunks.check(mine.front());
-    if(my_status == COATI_HIP_OK && rank == root && mask != 0u) my_status = env.landing_reserve(job_landing_need(plan, world, root, mask));
+    if(my_status == COATI_HIP_OK && rank == root && mask != 0u) {
+        const PhaseTimer timed(6);
+        my_status = env.landing_reserve(job_landing_need(plan, world, root, mask));
+    }
     std::vector<uint64_t> counts(static_cast<size_t>(kCountWords) * static_cast<size_t>(world));
     std::vector<Place> place(static_cast<size_t>(world));
     auto start = [&](size_t k, void** h) -> int {
@@ -590,7 +632,10 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
         return chunks.start(mine[k], mine[k + 1] - mine[k], h);
     };
     void *cur = nullptr, *next = nullptr;
-    if(my_status == COATI_HIP_OK) my_status = start(0, &cur);
+    if(my_status == COATI_HIP_OK) {
+        const PhaseTimer timed(1);  // (the first chunk is made on this thread)
+        my_status = start(0, &cur);
+    }
     int rc = COATI_HIP_OK;
     // The next chunk is planned, uploaded and launched on a HELPER thread while this thread gathers the current one:
     // planning 48 000 pairs is ~10 ms of host work, gathering them (count exchange, 100 MB of downloads) another ~5-10,
@@ -612,6 +657,7 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
             });
         auto join_start = [&]() {
             if(!starting.valid()) return;
+            const PhaseTimer timed(1);  // (waiting for the helper thread that makes the next chunk)
             Started st = starting.get();
             next = st.handle;
             if(st.rc != COATI_HIP_OK && my_status == COATI_HIP_OK) my_status = fail(st.rc, "%s", st.error.c_str());
@@ -619,6 +665,7 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
         Block own;
         uint64_t word[kCountWords] = {0, 0, static_cast<uint64_t>(my_status)};
         if(cur != nullptr && my_status == COATI_HIP_OK) {
+            const PhaseTimer timed(1);
             my_status = chunks.finish(cur, own, word[0], word[1]);
             if(my_status != COATI_HIP_OK) word[0] = word[1] = 0;
             word[2] = static_cast<uint64_t>(my_status);
@@ -628,6 +675,7 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
         const uint64_t lp = p0 - shard0, lo = plan.op_prefix[p0] - shard_ops0;  // this chunk in the rank's own arrays
         if(out.local && !Chunks::kDeliversLocal && my_status == COATI_HIP_OK && word[0] == n && word[1] == nb && n > 0) {
             // the rank's own download, on its own link, under the exchange of the summaries
+            const PhaseTimer timed(7);
             int lc = COATI_HIP_OK;
             if(out.scores != nullptr) lc = env.copy_out(out.scores + lp, own.scores, n * sizeof(float));
             if(lc == COATI_HIP_OK && out.ops_off != nullptr) lc = env.copy_out(out.ops_off + lp, own.off, n * sizeof(uint64_t));
@@ -950,6 +998,13 @@ int coati_hip_dist_viterbi(coati_hip_comm_t* c, int root, coati_hip_model_t* mod
                            const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off, float* scores, uint8_t* ops,
                            uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len) {
     return coati_hip_dist_viterbi_shard(c, root, model, n_pairs, a_cat, 0, a_off, b_cat, 0, b_off, scores, ops, ops_capacity, ops_off, ops_len);
+}
+
+// Debug: where the root's thread of the LAST sharded job of this process spent its time (JobTimes above).
+int coati_hip_dist_debug_job_times(double* out8) {
+    if(out8 == nullptr) return fail(COATI_HIP_EINVAL, "dist_debug_job_times: bad argument");
+    std::copy(g_job_times.v, g_job_times.v + 8, out8);
+    return COATI_HIP_OK;
 }
 
 // ---- plan exports and the host-memory job (no device, no communicator) --------------------------------------

@@ -30,6 +30,7 @@ EXPORTS = (
     "coati_hip_dist_viterbi_shard_local",
     "coati_hip_dist_chunk_plan",
     "coati_hip_dist_landing_plan",
+    "coati_hip_dist_debug_job_times",
     "coati_hip_dist_simulate",
     "coati_hip_dist_simulate_local",
     "coati_hip_dist_job_host",

@@ -112,6 +112,13 @@ int coati_hip_dist_chunk_plan(uint64_t n_pairs, const uint64_t* a_off, const uin
  * order, nothing for the root itself), *need = bytes of HBM the zone takes. */
 int coati_hip_dist_landing_plan(int world, int root, const uint64_t* counts, uint64_t* land4, uint64_t* need);
 
+/* Debug / measurement: where the ROOT's thread of the last sharded job of this process (any of the entry points above or
+ * below) spent its time, in seconds: out8[0] the whole job loop, [1] making / waiting for its own chunks, [2] count
+ * exchanges, [3] the send / receive group, [4] unpack + placement + offset rebase, [5] the number of rounds, [6] reserving
+ * the landing zone, [7] the rank's own copy-out (local form).  What is left of [0] is the loop's own logic (plans,
+ * validation, transfer lists).  tools/dist_sim_bench.py. */
+int coati_hip_dist_debug_job_times(double* out8);
+
 /* The per-rank job loop of coati_hip_dist_viterbi_shard[_local] is one piece of code over an ENVIRONMENT: RCCL + HIP
  * in the entry points above, host memory + a host transport in the three below (test infrastructure, exported so
  * that the tests reach it through the ABI).  Every rank "computes" its chunks from given per-pair results: pair p's

@@ -443,12 +443,12 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
     model.close()
 
 
-@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t"])
+@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t", "40,3,s3", "60,2,s7", "60,4,s1"])
 def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, plan):
     """viterbi_ck cuts the last pairs of a large batch's LPT order into row parts (own work items; a part leaves
     the lane state at a 64-step boundary, whichever wavefront takes the next part continues -- abi.hip "the ragged
     end"; by itself from 4 352 pairs, forced here on a small batch): scores, ops and every decision byte as the
-    oracle has them, for 2, 3, 4 and 8 parts, with whole pairs, two-strip pairs, short pairs (too short to cut)
+    oracle has them, for 2, 3, 4 and 8 parts (equal, tapered, and with a last part 1 .. 7 chunks shorter: round 5), with whole pairs, two-strip pairs, short pairs (too short to cut)
     and empty sides in the same batch; twice on the same batch (the progress words are reset per launch)."""
     if kernel_choice == "bits":
         pytest.skip("viterbi_l1 forced: row parts are viterbi_ck's")

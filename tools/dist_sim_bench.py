@@ -7,6 +7,7 @@ ranks' "kernels" are copies out of given per-pair results, so what is timed is t
 root (and every rank) does per round for BASELINE configs[4]'s size: DESIGN.md section 6 budgets it as "per-round host
 work".  No device is touched.
 usage: python3 tools/dist_sim_bench.py [pairs] [out.json]"""
+import ctypes as C
 import json
 import os
 import sys
@@ -31,8 +32,12 @@ ops_len = (np.maximum(la, lb) + rng.integers(0, 8, n)).astype(np.uint32)  # (a r
 ops = np.empty(total, np.uint8)
 ops[:] = 1  # (first touch here, not under the clock)
 rec = {"pairs": n, "op_slot_bytes": total, "op_bytes": int(ops_len.sum()), "host_cores": os.cpu_count(),
-       "what": "wall time of coati_hip_dist_simulate / _simulate_local (all ranks as threads, host memory, memcpy transport): plan + "
-               "count exchange + landing zone + unpack / rebase / placement; median of 3 after one warm-up"}
+       "what": "wall time of coati_hip_dist_simulate / _simulate_local (all ranks as threads, host memory, memcpy transport; median of 3 "
+               "after one warm-up), and where the ROOT's thread spent the last run (coati_hip_dist_debug_job_times).  In this "
+               "simulation the ranks' kernels, ncclSend/ncclRecv and the root's D2H are host memcpy (waiting_for_own_chunks, "
+               "send_receive_group, own_copy_out, most of unpack_placement_rebase; landing_zone_reserve is a vector fill here, a cached "
+               "HBM block there): what carries over to hardware is count_exchanges + loop_logic_plans_validation + the per-block "
+               "bookkeeping inside unpack"}
 from coati_amd import hip  # noqa: E402  (only its pointer helper; no device call)
 
 lib = dist.load()
@@ -64,7 +69,15 @@ for world in (1, 2, 4, 8):
             fn(world)
             ts.append(time.perf_counter() - t0)
         _, rounds = dist.chunk_plan(a_off, b_off, world)
-        rec[f"world{world}_{name}"] = {"s": round(float(np.median(ts[1:])), 4), "rounds": rounds}
+        t6 = (C.c_double * 8)()
+        assert lib.coati_hip_dist_debug_job_times(t6) == 0  # (of the last run: the root's thread)
+        loop_s, own_wait, exchange, transfer, unpack = (float(t6[i]) for i in range(5))
+        rec[f"world{world}_{name}"] = {"s": round(float(np.median(ts[1:])), 4), "rounds": rounds,
+                                       "root_thread_s": {"job_loop": round(loop_s, 4), "waiting_for_own_chunks": round(own_wait, 4),
+                                                         "count_exchanges": round(exchange, 4), "send_receive_group": round(transfer, 4),
+                                                         "unpack_placement_rebase": round(unpack, 4),
+                                                         "landing_zone_reserve": round(float(t6[6]), 4), "own_copy_out_local_form": round(float(t6[7]), 4),
+                                                         "loop_logic_plans_validation": round(loop_s - own_wait - exchange - transfer - unpack - float(t6[6]) - float(t6[7]), 4)}}
         print(world, name, rec[f"world{world}_{name}"], flush=True)
 text = json.dumps(rec, indent=1)
 if len(sys.argv) > 2:
