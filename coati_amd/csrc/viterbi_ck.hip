@@ -198,7 +198,7 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
 // whatever it holds (never looked at), and at step l it takes the state of the margin row.  ONE
 // instantiation serves every chunk: a separate start-up copy of the loop (as viterbi_l1.hip has)
 // cost ~50 VGPRs here and with them the fourth wavefront per SIMD.
-template <int W, bool kSub>
+template <int W, bool kSub, bool kSingle>
 __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
                                         uint32_t a_chunk, float bx, float bz, uint32_t colin_voff) {
@@ -229,7 +229,8 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
     // lane 63 just did body row kstep - 63: its last column is the next strip's boundary
-    if(!cx.last_strip && lane == kWave - 1 && kstep >= static_cast<uint32_t>(kWave - 1) && kstep - (kWave - 1) < cx.la) {
+    // (kSingle -- the pair has one strip, known where the call is made: no test, ~11 scalar instructions per step less)
+    if(!kSingle && !cx.last_strip && lane == kWave - 1 && kstep >= static_cast<uint32_t>(kWave - 1) && kstep - (kWave - 1) < cx.la) {
         const uint32_t r = kstep - (kWave - 1);  // (wave-uniform: the addresses stay in SGPRs)
         store_through(&cx.bnd_x[r + 1], st.X[W - 1]);
         store_through(&cx.bnd_z[r], st.zlast);
@@ -243,7 +244,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
 // strip loads the 16 rows of its next sub-block past the L2 until none is the pattern.  A strip then follows its
 // neighbour at 63 (the skew of the 64 lanes) + 16 + a round trip steps instead of 63 + 64 + a drain + a poll + an
 // L2 invalidate (viterbi_l1 / viterbi_lp do the same).  Returns false if values never arrived.
-template <int W, bool kSub>
+template <int W, bool kSub, bool kSingle>
 __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                          float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk,
                                          float bx, float bz) {
@@ -292,10 +293,10 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         // allocator ping-pongs X between two register sets instead of copying W values per step
         uint32_t kk = kb;
         for(; kk + 1 < ke; kk += 2) {
-            ck_step<W, kSub>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
-            ck_step<W, kSub>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
         }
-        if(kk < ke) ck_step<W, kSub>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+        if(kk < ke) ck_step<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
     }
     return ok;
 }
@@ -319,7 +320,7 @@ __device__ __forceinline__ void ck_report_bad(unsigned long long* bad, uint32_t 
 
 // One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
 // the left neighbour's boundary column did not arrive within the spin bound.
-template <int W, bool kSub = false>
+template <int W, bool kSub = false, bool kSingle = false>
 __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip,
                                               uint32_t ticket, int lane, uint32_t lds_tab, const char* tab_bytes,
                                               const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
@@ -435,7 +436,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
         const CkChunkMem mem{make_rsrc(ck_strip + static_cast<uint64_t>(kbase) * (2 * kWave)),
                              make_rsrc(rowck_strip + static_cast<uint64_t>(kbase / kCkRows) * (2 * W * kWave))};
-        handoff_ok = ck_chunk<W, kSub>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz) && handoff_ok;
+        handoff_ok = ck_chunk<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz) && handoff_ok;
         if(!kSub && !last_strip) {  // (kSub: the boundary values validate themselves: no per-chunk drain, no progress word)
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
@@ -920,19 +921,19 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         const uint32_t band_now = (!redo && pd.la > 0 && pd.lb > 0 && (multi ? strip < 64u : w_item == 16)) ? band_pair : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
+                handoff_ok = ck_fill_strip<16, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
             else if(multi && w_item == 16)
                 handoff_ok = ck_fill_strip<16, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(multi && w_item == 8)
                 handoff_ok = ck_fill_strip<8, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(multi)
                 handoff_ok = ck_fill_strip<4, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
-            else if(w_item == 16)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+            else if(w_item == 16)  // (from here on: single-strip pairs -- `multi` took the others)
+                handoff_ok = ck_fill_strip<16, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(w_item == 8)
-                handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
+                handoff_ok = ck_fill_strip<8, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
             else
-                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
+                handoff_ok = ck_fill_strip<4, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
         }
         COATI_CK_STAMP(0);  // fill of this item done
         if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? ck_band_half(band, pd.la, pd.lb) : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {
             if(cut)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
+                handoff_ok = ck_fill_strip<16, false, true>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
             else if(w_item == 16)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad, band_now);
             else if(w_item == 8)
