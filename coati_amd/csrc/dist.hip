@@ -694,7 +694,10 @@ int run_shard_job(Env& env, Chunks& chunks, int root, const JobPlan& plan, uint6
                 for(uint64_t i = 0; i < n; ++i) out.ops_off[lp + i] += lo;
         }
         join_start();
-        if(cur != nullptr) chunks.release(cur);
+        if(cur != nullptr) {
+            const PhaseTimer timed(1);  // (giving the chunk back: part of making chunks)
+            chunks.release(cur);
+        }
         cur = next;
         next = nullptr;
     }
