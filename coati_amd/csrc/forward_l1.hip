@@ -192,14 +192,16 @@ __device__ __forceinline__ void publish(uint32_t* word, uint32_t rows, bool lead
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if(leader) __hip_atomic_store(word, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (no acquire fence -- on this chip an invalidate of the XCD's L2, once per hand-over: round 5 -- the boundary values the
+// wait is for were stored THROUGH the producer's L2 (store_through) and are read past this one's: load_through)
 __device__ __forceinline__ bool wait_rows(const uint32_t* word, uint32_t need) {
     for(uint32_t spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spins) {
         if(spins > (1u << 26)) return false;
         __builtin_amdgcn_s_sleep(4);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return true;
 }
+__device__ __forceinline__ float load_through(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One strip (64 * W descendant columns) of one pair by one wavefront.
 template <int W, bool kFast>
@@ -266,11 +268,11 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
                 if(crow < la && static_cast<uint32_t>(lane) >= k0 && static_cast<uint32_t>(lane) < k1) {
                     const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
                     const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
-                    chDM = dgp[0];
-                    chDD = dgp[1];
-                    chDI = dgp[2];
-                    chLM = lfp[0];
-                    chLI = lfp[2];
+                    chDM = load_through(dgp + 0);
+                    chDD = load_through(dgp + 1);
+                    chDI = load_through(dgp + 2);
+                    chLM = load_through(lfp + 0);
+                    chLI = load_through(lfp + 2);
                 }
             }
             asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));

@@ -158,6 +158,16 @@ __device__ __forceinline__ bool wait_progress(const uint32_t* word, uint32_t nee
     return true;
 }
 
+// the same without the acquire: for a consumer that reads what it waited for PAST its L2 (agent-scope loads), viterbi_ck's
+// row parts
+__device__ __forceinline__ bool wait_progress_relaxed(const uint32_t* word, uint32_t need) {
+    for(uint32_t spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spins) {
+        if(spins > (1u << 26)) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
+
 }  // namespace
 }  // namespace coati_hip_detail
 #endif

@@ -114,6 +114,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (num_records = 2 GiB: a lane whose offset register holds kCkDropOffset is OUT OF RANGE and its part of the store is
 // discarded by the address unit -- how a lane that keeps no checkpoint for a band skips its stores without a branch)
 constexpr uint32_t kCkDropOffset = 0x80000000u;
+// Cache policy of a raw buffer access (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  kAuxAgent = sc1: the store goes
+// THROUGH the XCD's L2 to memory, the load is served from memory -- what an agent-scope atomic access is.  Used for
+// everything a pair that is cut into row parts hands from one wavefront to another (round 5): with it a hand-over needs
+// no release fence (on this chip: a write-back of the XCD's whole L2) and no acquire fence (an invalidate of it).
+constexpr int kAuxPlain = 0, kAuxAgent = 16;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffff0u, 0x00020000);
 }
@@ -179,8 +184,9 @@ struct CkChunkMem {
 };
 
 // lane state -> row checkpoint of the band that starts at chunk step kb (state BEFORE that step)
-template <int W>
+template <int W, bool kThrough = false>
 __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, const CkLane<W>& st, uint32_t kb, bool keep = true) {
+    constexpr int kAux = kThrough ? kAuxAgent : kAuxPlain;
     const uint32_t soff = (kb / kCkRows) * (ck_rowck_quads(W) * kWave * 16u);
     uint32_t voff = static_cast<uint32_t>(lane);
     asm volatile("" : "+v"(voff));  // (derived here, once per kCkRows steps: not another VGPR held across the hot loop)
@@ -189,8 +195,8 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
     for(int q = 0; q < W / 4; ++q) {
         const u32x4 x = {fbits(st.X[4 * q]), fbits(st.X[4 * q + 1]), fbits(st.X[4 * q + 2]), fbits(st.X[4 * q + 3])};
         const u32x4 y = {fbits(st.Y[4 * q]), fbits(st.Y[4 * q + 1]), fbits(st.Y[4 * q + 2]), fbits(st.Y[4 * q + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * (kWave * 16u), 0);
-        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * (kWave * 16u), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * (kWave * 16u), kAux);
+        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * (kWave * 16u), kAux);
     }
 }
 
@@ -198,7 +204,7 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
 // whatever it holds (never looked at), and at step l it takes the state of the margin row.  ONE
 // instantiation serves every chunk: a separate start-up copy of the loop (as viterbi_l1.hip has)
 // cost ~50 VGPRs here and with them the fourth wavefront per SIMD.
-template <int W, bool kSub, bool kSingle>
+template <int W, bool kSub, bool kSingle, bool kThrough>
 __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
                                         uint32_t a_chunk, float bx, float bz, uint32_t colin_voff) {
@@ -224,7 +230,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     const float zl = shift_in(st.zlast, read_lane(bz, kSub ? static_cast<int>(kk & 15u) : static_cast<int>(kk)));
     const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
     // ---- checkpoint: what this lane received (one coalesced 512-byte row per wavefront step)
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, kk * (kWave * 8u), 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, kk * (kWave * 8u), kThrough ? kAuxAgent : kAuxPlain);
     // ---- the W cells (and the LDS gather for the next step)
     row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
@@ -244,7 +250,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
 // strip loads the 16 rows of its next sub-block past the L2 until none is the pattern.  A strip then follows its
 // neighbour at 63 (the skew of the 64 lanes) + 16 + a round trip steps instead of 63 + 64 + a drain + a poll + an
 // L2 invalidate (viterbi_l1 / viterbi_lp do the same).  Returns false if values never arrived.
-template <int W, bool kSub, bool kSingle>
+template <int W, bool kSub, bool kSingle, bool kThrough>
 __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                          float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk,
                                          float bx, float bz) {
@@ -256,7 +262,7 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         uint32_t colin_voff = static_cast<uint32_t>(cx.lane);
         asm volatile("" : "+v"(colin_voff));
         colin_voff = keep ? colin_voff * 8u : kCkDropOffset;
-        store_rowck<W>(mem, cx.lane, st, kb, keep);
+        store_rowck<W, kThrough>(mem, cx.lane, st, kb, keep);
         if constexpr(kSub) {
             static_assert(kCkRows == 16, "the boundary sub-blocks are the checkpoint bands");
             uint32_t row = kbase + kb + (static_cast<uint32_t>(cx.lane) & 15u);  // (lanes 16-63 repeat lanes 0-15)
@@ -293,10 +299,10 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         // allocator ping-pongs X between two register sets instead of copying W values per step
         uint32_t kk = kb;
         for(; kk + 1 < ke; kk += 2) {
-            ck_step<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
-            ck_step<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
         }
-        if(kk < ke) ck_step<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+        if(kk < ke) ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
     }
     return ok;
 }
@@ -320,7 +326,7 @@ __device__ __forceinline__ void ck_report_bad(unsigned long long* bad, uint32_t 
 
 // One work item: one strip (64*W descendant columns) of one pair, all its rows.  Returns false if
 // the left neighbour's boundary column did not arrive within the spin bound.
-template <int W, bool kSub = false, bool kSingle = false>
+template <int W, bool kSub = false, bool kSingle = false, bool kThrough = false>
 __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t strip,
                                               uint32_t ticket, int lane, uint32_t lds_tab, const char* tab_bytes,
                                               const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
@@ -372,17 +378,38 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     uint32_t arow;
     if(kbegin != 0) {
         // a continuation: X, Y are the row checkpoint of the band that starts here (the predecessor wrote it early)
-        const float4* __restrict__ rq =
-            reinterpret_cast<const float4*>(rowck_strip + static_cast<uint64_t>(kbegin / kCkRows) * (2 * W * kWave));
+        const uint32_t* __restrict__ rq_words = rowck_strip + static_cast<uint64_t>(kbegin / kCkRows) * (2 * W * kWave);
+        if constexpr(kThrough) {
+            // (what another wavefront -- another XCD, possibly -- stored THROUGH its L2: read past this one's)
+            const rsrc_t rq = make_rsrc(rq_words);
 #pragma unroll
-        for(int q = 0; q < W / 4; ++q) {
-            const float4 x = rq[q * kWave + lane], y = rq[(W / 4 + q) * kWave + lane];
-            st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
-            st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
+            for(int q = 0; q < W / 4; ++q) {
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rq, static_cast<uint32_t>(lane) * 16u, q * (kWave * 16u), kAuxAgent);
+                const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(rq, static_cast<uint32_t>(lane) * 16u, (W / 4 + q) * (kWave * 16u), kAuxAgent);
+                // (through scalar copies: hipcc 7.2 compiles `__builtin_bit_cast(float, x[e])` on an ext_vector element into
+                // ONE dword load splatted over the four -- DESIGN.md 5.24; found in the ISA, not by a test)
+#pragma unroll
+                for(int e = 0; e < 4; ++e) {
+                    const uint32_t xw = x[e], yw = y[e];
+                    st.X[4 * q + e] = __builtin_bit_cast(float, xw);
+                    st.Y[4 * q + e] = __builtin_bit_cast(float, yw);
+                }
+            }
+            st.xlast_old = __builtin_bit_cast(float, __hip_atomic_load(part_state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            st.zlast = __builtin_bit_cast(float, __hip_atomic_load(part_state + kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            arow = __hip_atomic_load(part_state + 2 * kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const float4* __restrict__ rq = reinterpret_cast<const float4*>(rq_words);
+#pragma unroll
+            for(int q = 0; q < W / 4; ++q) {
+                const float4 x = rq[q * kWave + lane], y = rq[(W / 4 + q) * kWave + lane];
+                st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
+                st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
+            }
+            st.xlast_old = __builtin_bit_cast(float, part_state[lane]);
+            st.zlast = __builtin_bit_cast(float, part_state[kWave + lane]);
+            arow = part_state[2 * kWave + lane];
         }
-        st.xlast_old = __builtin_bit_cast(float, part_state[lane]);
-        st.zlast = __builtin_bit_cast(float, part_state[kWave + lane]);
-        arow = part_state[2 * kWave + lane];
     } else {
         const uint32_t bj0 = col0 + lane * W;
 #pragma unroll
@@ -436,7 +463,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
         const CkChunkMem mem{make_rsrc(ck_strip + static_cast<uint64_t>(kbase) * (2 * kWave)),
                              make_rsrc(rowck_strip + static_cast<uint64_t>(kbase / kCkRows) * (2 * W * kWave))};
-        handoff_ok = ck_chunk<W, kSub, kSingle>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz) && handoff_ok;
+        handoff_ok = ck_chunk<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz) && handoff_ok;
         if(!kSub && !last_strip) {  // (kSub: the boundary values validate themselves: no per-chunk drain, no progress word)
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
@@ -446,10 +473,16 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         // a row part ends here: the lane state for whoever continues (X, Y as the row checkpoint of the next band --
         // the continuation stores the same values there again --, the rest behind the strip's checkpoints)
         const CkChunkMem next{make_rsrc(ck_strip), make_rsrc(rowck_strip + static_cast<uint64_t>(kend / kCkRows) * (2 * W * kWave))};
-        store_rowck<W>(next, lane, st, 0);
-        part_state[lane] = fbits(st.xlast_old);
-        part_state[kWave + lane] = fbits(st.zlast);
-        part_state[2 * kWave + lane] = arow;
+        store_rowck<W, kThrough>(next, lane, st, 0);
+        if constexpr(kThrough) {
+            __hip_atomic_store(part_state + lane, fbits(st.xlast_old), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part_state + kWave + lane, fbits(st.zlast), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part_state + 2 * kWave + lane, arow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            part_state[lane] = fbits(st.xlast_old);
+            part_state[kWave + lane] = fbits(st.zlast);
+            part_state[2 * kWave + lane] = arow;
+        }
         return handoff_ok;
     }
     // score = max(M,D,I) of the terminal-adjusted last cell (align_pair.cc:130-138,265) = X of the
@@ -576,7 +609,8 @@ template <int W>
 __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc& pd, const CkStrip& sp, bool valid,
                                              int32_t t, int32_t c, uint32_t lds_tab, const char* tab_bytes,
                                              const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                             uint32_t* __restrict__ bits /* wave scratch + lane */, uint32_t band = kCkBandOff) {
+                                             uint32_t* __restrict__ bits /* wave scratch + lane */, uint32_t band = kCkBandOff,
+                                             bool through = false /* the checkpoints were stored through other wavefronts' L2s (a cut pair): read past this one's */) {
     const int32_t la = static_cast<int32_t>(pd.la);
     const int32_t k0 = c * static_cast<int32_t>(kCkRows);
     // rows this tile covers: k0 - t + [0, kCkRows)
@@ -599,7 +633,17 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
         const float4* rk = sp.rowck + (static_cast<uint64_t>(c) * ck_rowck_quads(W)) * kWave + t;
 #pragma unroll
         for(int q = 0; q < W / 4; ++q) {
-            const float4 x = rk[q * kWave], y = rk[(W / 4 + q) * kWave];
+            float4 x, y;
+            if(through) {  // (wave-uniform)
+                const float* xp = reinterpret_cast<const float*>(rk + q * kWave);
+                const float* yp = reinterpret_cast<const float*>(rk + (W / 4 + q) * kWave);
+                x = make_float4(__hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(xp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                __hip_atomic_load(xp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(xp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                y = make_float4(__hip_atomic_load(yp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(yp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                __hip_atomic_load(yp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(yp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            } else {
+                x = rk[q * kWave], y = rk[(W / 4 + q) * kWave];
+            }
             st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
             st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
         }
@@ -630,7 +674,14 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
     auto inputs_of = [&](int32_t ks, float2& in, uint32_t& code) {
         const int32_t kstep = k0 + ks, r = kstep - t;
         const bool act = valid && ks < static_cast<int32_t>(kCkRows) && r >= 0 && r < la;
-        in = act ? cin[static_cast<uint64_t>(kstep) * kWave] : make_float2(0.0f, 0.0f);
+        if(!act) {
+            in = make_float2(0.0f, 0.0f);
+        } else if(through) {
+            const float* ip = reinterpret_cast<const float*>(cin + static_cast<uint64_t>(kstep) * kWave);
+            in = make_float2(__hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(ip + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else {
+            in = cin[static_cast<uint64_t>(kstep) * kWave];
+        }
         code = row_code(r + 1);
     };
     float2 in_next;
@@ -704,6 +755,7 @@ struct CkWalkArgs {
     bool stats;
     uint32_t band;    // banded checkpoints: what the fill of this pair kept (kCkBandOff: everything)
     unsigned long long kept_all = 0;  // multi-strip pairs: strips (bit s, s < 64) that were filled again with everything kept
+    bool through = false;             // a pair cut into row parts: its checkpoints were stored through other wavefronts' L2s
     // what the fill of strip `strip` kept (strips from 64 on of a very long pair are never banded)
     __device__ __forceinline__ uint32_t band_of(uint32_t strip, uint32_t n_strips) const {
         if(n_strips == 1) return band;
@@ -756,11 +808,11 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             // this round's bits are written and then read by the same wavefront through L2
             bool done;
             if(sp.w == 16)
-                done = ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips));
+                done = ck_recompute<16>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips), wa.through);
             else if(sp.w == 8)
-                done = ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips));
+                done = ck_recompute<8>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips), wa.through);
             else
-                done = ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips));
+                done = ck_recompute<4>(wa.k, pd, sp, valid, t, c, wa.lds_tab, wa.tab_bytes, wa.a, wa.b, wa.wbits + lane, wa.band_of(sp.strip, pd.v_strips), wa.through);
             ts.computed = __builtin_amdgcn_ballot_w64(done);
             // the wavefront reads back what it stored itself: once the stores are acknowledged its
             // loads see them (same L1, write-through)
@@ -902,7 +954,10 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
             if(part > 0) {
                 const unsigned long long t_wait = (dbg & 2u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                handoff_ok = wait_progress(progress + ticket - split_items, kbegin);  // (acquires)
+                // (no acquire: the predecessor stored the lane state and its checkpoints THROUGH its L2 and this wavefront reads the
+                // state past its own -- kAuxAgent; round 5: the release / acquire fence pair per hand-over, an L2 write-back and an
+                // L2 invalidate on this chip, cost a 10 000-pair launch 2.8 %)
+                handoff_ok = wait_progress_relaxed(progress + ticket - split_items, kbegin);
                 if(__hip_atomic_load(progress + ticket - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
                 if((dbg & 2u) && lane == 0) {  // (statistics: how long did this part wait for its predecessor? 100 MHz clock)
                     const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t_wait;
@@ -921,7 +976,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         const uint32_t band_now = (!redo && pd.la > 0 && pd.lb > 0 && (multi ? strip < 64u : w_item == 16)) ? band_pair : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
-                handoff_ok = ck_fill_strip<16, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
+                handoff_ok = ck_fill_strip<16, false, true, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
             else if(multi && w_item == 16)
                 handoff_ok = ck_fill_strip<16, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(multi && w_item == 8)
@@ -939,8 +994,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
             // not the pair's last row part: release what this wavefront wrote for the pair (checkpoints, lane state),
             // then say how far the pair has got (or that it is lost)
+            // (no release fence: everything this part wrote for the pair went through the L2 -- ck_fill_strip's kThrough)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             publish_progress(progress + ticket, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
 #ifdef COATI_FILL_TRACE
             COATI_CK_STAMP(1);  // (trace build: a row part is an item of the timeline too)
@@ -959,6 +1014,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
         // strips): they released before publishing "complete", which this wave polled; acquire.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (a cut pair: its earlier parts' checkpoints were stored through other wavefronts' L2s, and this wavefront's L2 may hold
+        // the lines of an earlier launch: its walk reads them past the L2 -- CkWalkArgs::through -- instead of invalidating it)
         if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if(pd.la == 0 || pd.lb == 0) {
             float m, d, in, score;
@@ -967,7 +1024,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             if(lane == 0) scores[pair] = score;
         }
         // (multi-strip: the band the pair's strips were filled with, minus the strips filled again since)
-        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u, multi ? band_pair : band_now, redo_kept_all};
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u, multi ? band_pair : band_now, redo_kept_all, cut};
         if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[redo ? 4 : 3], 1ull);
         uint32_t failed_strip = 0;
         const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len, &failed_strip);
@@ -1254,8 +1311,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         if(cut) {  // (as in viterbi_ck)
             const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
             ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
-            if(part > 0) {
-                handoff_ok = wait_progress(ch_progress + local - split_items, kbegin);
+            if(part > 0) {  // (no acquire: the lane state and the checkpoints go through the L2s, as in viterbi_ck)
+                handoff_ok = wait_progress_relaxed(ch_progress + local - split_items, kbegin);
                 if(__hip_atomic_load(ch_progress + local - split_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
             }
         }
@@ -1264,7 +1321,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? ck_band_half(band, pd.la, pd.lb) : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {
             if(cut)
-                handoff_ok = ck_fill_strip<16, false, true>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
+                handoff_ok = ck_fill_strip<16, false, true, true>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
             else if(w_item == 16)
                 handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad, band_now);
             else if(w_item == 8)
@@ -1273,8 +1330,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
                 handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
         }
         if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no release fence: kThrough)
             publish_progress(ch_progress + local, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
             continue;
         }
@@ -1287,7 +1343,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
             margin_mdi(k, 1u, pd.la, pd.lb, m, d, in);
             (void)terminal_state(k, m, d, in, score);
         }
-        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, false, band_now};
+        const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, false, band_now, 0ull, cut};
         const bool walk_ok = ck_walk_pair<true>(lane, wa, pd, pair, ch_ops, ch_start, ch_len);
         if(!walk_ok && band_now != kCkBandOff) {  // (left the kept band: the same item again, everything kept)
             redo_ticket = ticket;
