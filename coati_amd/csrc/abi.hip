@@ -106,6 +106,7 @@ const EnvOptions* read_env() {
         o->ck_band = x <= 0 ? kCkBandOff : static_cast<uint32_t>(x);
     }
     o->ck_debug = static_cast<uint32_t>(num("COATI_HIP_CK_DEBUG", 0));
+    o->ck_walk_items = static_cast<int>(num("COATI_HIP_CK_WALK_ITEMS", -1));
     if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {  // "pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
         char* rest = nullptr;
         o->ck_split_set = true;
@@ -179,7 +180,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_desc,   b->d_order, static_cast<uint32_t>(b->n_pairs),
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
-                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items,
+                           b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items | (b->ck_walk_items ? kCkWalkItemsFlag : 0u),
                            b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u, b->multi_strip ? 1u : 0u};
 }
 

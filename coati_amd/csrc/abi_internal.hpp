@@ -181,6 +181,7 @@ struct coati_hip_batch {
     uint32_t* d_wscratch = nullptr;  // viterbi_ck: traceback scratch of the persistent wavefronts
     uint64_t ck_slot_dwords = 0;     // viterbi_ck: per-wavefront checkpoint slots at the start of d_flags (0: none)
     uint32_t ck_split_items = 0;     // viterbi_ck: pairs cut into row parts (the last ones of the LPT order); 0: none
+    bool ck_walk_items = false;      // ... and their tracebacks are work items of their own, behind the last row parts (resident batches, round 5)
     bool ck = false;                 // gap_len 1 runs viterbi_ck (checkpoint layout in d_flags)
     float *d_bnd = nullptr, *d_scores = nullptr;
     float *d_mdi = nullptr, *d_final_mdi = nullptr;  // Forward (parts of mdi_block)

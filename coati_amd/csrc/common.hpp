@@ -83,6 +83,7 @@ struct PairDesc {
 // 64-step chunks the LAST part is shorter than an equal split would make it (round 5: the wavefront of the last part also
 // walks the pair -- ~0.17 ms, two chunks' worth -- and the items at the end of the queue are the last parts)
 constexpr uint8_t kCkPartsTaper = 0x80;
+constexpr uint32_t kCkWalkItemsFlag = 0x80000000u;  // in BatchDeviceView::ck_split_items: the cut pairs' tracebacks are items of their own (part number = number of parts)
 __host__ __device__ inline uint32_t ck_parts_count(uint8_t v_parts) { return v_parts & 0x0fu; }
 __host__ __device__ inline uint32_t ck_parts_short_last(uint8_t v_parts) { return (v_parts >> 4) & 7u; }
 // steps [begin, end) of row part `part` of a strip of nsteps wavefront steps: whole 64-step chunks.  Equal parts, or --
@@ -508,6 +509,7 @@ struct EnvOptions {
     bool ck_split_set = false;       // COATI_HIP_CK_SPLIT="pairs,parts[,t]"
     uint64_t ck_split_pairs = 0, ck_split_parts = 3;
     bool ck_split_taper = false;
+    int ck_walk_items = -1;            // COATI_HIP_CK_WALK_ITEMS=0 / 1: the traceback of a pair cut into row parts stays with its last part / is an item of its own (-1: the planner's rule)
     uint32_t ck_split_short_last = 0;  // COATI_HIP_CK_SPLIT="pairs,parts,s<k>": the last part k chunks shorter (0-7)
     uint32_t spec_cands = 3u << 16;  // COATI_HIP_SPEC_CANDS (196 608: 16 x 1 000 samples 6.1 ms; 2^17: 6.4, 2^18: 6.4, 2^16: 7.8 -- tools/sample_bench.py, round 4)
     double spec_z = 2.0;             // COATI_HIP_SPEC_Z

@@ -450,6 +450,13 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         }
         bool taper = false;
         uint32_t short_last = 0;
+        // The cut pairs' TRACEBACKS as work items of their own, behind the last row parts in the queue (round 5): the items at
+        // the end of the queue are then 0.2 ms walks instead of 0.5 ms of rows + walk, and every wavefront stays busy 0.3 ms
+        // longer (idle wavefront time before the end of a 10 000-pair launch 8.5 -> 4.6 %).  It pays since a hand-over needs no
+        // fences and a cut pair's checkpoints are read past the L2 by whoever walks it (viterbi_ck.hip, kThrough): 10 000 pairs
+        // +1.2 % (same box, alternating, six passes), 40 000 +-0, 16 000 -0.7 %: by default for launches of up to three rounds
+        // of wavefronts.  With fences (earlier in round 5) the same change LOST 1.7 %.  COATI_HIP_CK_WALK_ITEMS=0 / 1 forces.
+        const bool walk_items = env.ck_walk_items >= 0 ? env.ck_walk_items != 0 : n_pairs <= 3ull * ck_scratch_waves();
         if(env.ck_split_set) {  // COATI_HIP_CK_SPLIT="pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
             split_pairs = env.ck_split_pairs;
             parts = env.ck_split_parts;
@@ -470,7 +477,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                 // (round 5, tools/split_ab.py on one box: 10 000 pairs 4.01 -> 3.93 ms, 40 000 14.53 -> 14.41; cuts 5+6+6 -> 6+7+4
                 // chunks).  Only where every part keeps at least two chunks.
                 const uint32_t chunks = (nsteps + 63u) / 64u;
-                const uint32_t want = env.ck_split_set ? short_last : std::min<uint32_t>(7u, (3u * d.lb + 500u) / 1000u);
+                // (with the traceback as an item of its own -- COATI_HIP_CK_WALK_ITEMS -- the last part is a part like the others)
+                const uint32_t want = walk_items ? 0u : env.ck_split_set ? short_last : std::min<uint32_t>(7u, (3u * d.lb + 500u) / 1000u);
                 const uint32_t sl = (!taper && chunks >= want + 2u * static_cast<uint32_t>(parts) + 2u) ? want : 0u;
                 d.v_parts = static_cast<uint8_t>(parts | (taper ? kCkPartsTaper : 0u) | (sl << 4));
                 cut.push_back(order[q]);
@@ -483,6 +491,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             whole.insert(whole.end(), cut.begin(), cut.end());
             order.swap(whole);
             b->ck_split_items = static_cast<uint32_t>(cut.size());
+            b->ck_walk_items = walk_items;
         }
         if(use_slots || !cut.empty()) {
             // re-lay the arena: [wave slots | pairs that keep their own storage]
@@ -533,7 +542,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     }
     if(b->ck_split_items > 0) {
         const uint32_t parts = ck_parts_count(b->desc[order[n_pairs - 1]].v_parts);
-        for(uint32_t part = 1; part < parts; ++part)
+        // (+ one item per cut pair for its traceback where that is an item of its own: "part" number `parts`)
+        for(uint32_t part = 1; part < parts + (b->ck_walk_items ? 1u : 0u); ++part)
             for(uint64_t q = n_pairs - b->ck_split_items; q < n_pairs; ++q) items.push_back(WorkItem{order[q], part << 16});
     }
     b->n_items = static_cast<uint32_t>(items.size());

@@ -875,7 +875,10 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat, const uint8_t* __restrict__ b_cat,
     uint32_t* __restrict__ ck, float* __restrict__ bnd, float* __restrict__ scores, uint8_t* __restrict__ ops,
     uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t* __restrict__ wscratch,
-    uint64_t ck_slot_dwords, uint32_t split_items, uint32_t dbg, uint32_t band) {
+    uint64_t ck_slot_dwords, uint32_t split_items_word, uint32_t dbg, uint32_t band) {
+    // (the cut pairs' tracebacks as items of their own: flag in the word's top bit, abi.hip)
+    const bool walk_items = (split_items_word & kCkWalkItemsFlag) != 0u;
+    const uint32_t split_items = split_items_word & ~kCkWalkItemsFlag;
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
     float* tab = tab_all[kSharedTab ? 0 : threadIdx.x / kWave];
@@ -949,9 +952,14 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // on whatever wavefront took it -- stopped
         uint32_t kbegin = 0, kend = 0xffffffffu;
         const bool cut = pd.v_parts >= 2 && !redo;  // (redo: the wavefront of the last part fills the whole pair again, all rows)
+        // the traceback of a cut pair as an item of its own (walk_items): "part" number = the number of parts; nothing but the walk
+        const bool walk_item = cut && walk_items && part == ck_parts_count(pd.v_parts);
         if(cut) {
             const uint32_t nlanes = (min(static_cast<uint32_t>(kWave * kW), pd.lb) + kW - 1) / kW;
-            ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
+            if(walk_item)
+                kbegin = kend = pd.la + nlanes - 1;  // (waits until the last row part has said "all steps done")
+            else
+                ck_part_range(pd.la + nlanes - 1, pd.v_parts, part, kbegin, kend);
             if(part > 0) {
                 const unsigned long long t_wait = (dbg & 2u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 // (no acquire: the predecessor stored the lane state and its checkpoints THROUGH its L2 and this wavefront reads the
@@ -974,7 +982,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // multi-strip pair (round 4) a wider one, strips from 64 on everything; a redo everything
         const uint32_t band_pair = multi ? ck_band_half_long(band, pd.la, pd.lb) : ck_band_half(band, pd.la, pd.lb);
         const uint32_t band_now = (!redo && pd.la > 0 && pd.lb > 0 && (multi ? strip < 64u : w_item == 16)) ? band_pair : kCkBandOff;
-        if(pd.la > 0 && pd.lb > 0) {  // (without body cells only the margins are walked)
+        if(pd.la > 0 && pd.lb > 0 && !walk_item) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
                 handoff_ok = ck_fill_strip<16, false, true, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
             else if(multi && w_item == 16)
@@ -991,8 +999,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
                 handoff_ok = ck_fill_strip<4, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress);
         }
         COATI_CK_STAMP(0);  // fill of this item done
-        if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
-            // not the pair's last row part: release what this wavefront wrote for the pair (checkpoints, lane state),
+        if(cut && !walk_item && (part + 1 < ck_parts_count(pd.v_parts) || walk_items)) {
+            // not the pair's last row part (or any part of a pair whose traceback is an item of its own): release what this wavefront wrote for the pair (checkpoints, lane state),
             // then say how far the pair has got (or that it is lost)
             // (no release fence: everything this part wrote for the pair went through the L2 -- ck_fill_strip's kThrough)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -443,8 +443,9 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
     model.close()
 
 
+@pytest.mark.parametrize("walk_items", ["0", "1"])
 @pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t", "40,3,s3", "60,2,s7", "60,4,s1"])
-def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, plan):
+def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, plan, walk_items):
     """viterbi_ck cuts the last pairs of a large batch's LPT order into row parts (own work items; a part leaves
     the lane state at a 64-step boundary, whichever wavefront takes the next part continues -- abi.hip "the ragged
     end"; by itself from 4 352 pairs, forced here on a small batch): scores, ops and every decision byte as the
@@ -453,6 +454,8 @@ def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, 
     if kernel_choice == "bits":
         pytest.skip("viterbi_l1 forced: row parts are viterbi_ck's")
     monkeypatch.setenv("COATI_HIP_CK_SPLIT", plan)
+    # (round 5) the cut pairs' tracebacks with their last row part, or as work items of their own behind the last parts
+    monkeypatch.setenv("COATI_HIP_CK_WALK_ITEMS", walk_items)
     monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")  # (a batch this small would go to viterbi_l1's planner rule otherwise)
     monkeypatch.setenv("COATI_HIP_STRIP_W", "16")    # (... and be narrowed to 4-column strips: only 16-column single-strip pairs are cut)
     rng = np.random.default_rng(5)
