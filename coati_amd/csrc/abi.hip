@@ -83,6 +83,7 @@ const EnvOptions* read_env() {
     o->l1_progress = set("COATI_HIP_L1_PROGRESS");
     o->ck_per_pair = set("COATI_HIP_CK_PER_PAIR");
     o->stream_parts = static_cast<int>(num("COATI_HIP_STREAM_PARTS", -1));
+    o->stream_tail_units_x10 = static_cast<int>(num("COATI_HIP_STREAM_TAIL_UNITS", 0));
     o->spec_host_rounds = set("COATI_HIP_SPEC_HOST_ROUNDS");
     if(const long long v = num("COATI_HIP_SAMPLE_BAND", 0); v >= 1 && v <= (1 << 24)) o->sample_band = static_cast<uint32_t>(v);
     o->stream_helpers = static_cast<int>(num("COATI_HIP_STREAM_HELPERS", 7));

@@ -486,6 +486,7 @@ struct EnvOptions {
     bool l1_lp_off = false;          // COATI_HIP_L1_LP=0: viterbi_l1 where viterbi_lp would run
     bool l1_progress = false;        // COATI_HIP_L1_PROGRESS: progress-word boundary protocol in viterbi_l1
     bool ck_per_pair = false;        // COATI_HIP_CK_PER_PAIR: no per-wavefront checkpoint slots
+    int stream_tail_units_x10 = 0;   // COATI_HIP_STREAM_TAIL_UNITS (x 10): size of the streamed call's last chunk in units of 10^9 cells (0: 2.6)
     int stream_parts = -1;           // COATI_HIP_STREAM_PARTS: -1 (default) = ONE large last chunk of a streamed call cut into 3 row parts, 22 .. 28 = into 2 .. 8,
                                      // 0 = no row parts, 1 = row parts in the last ~1 000-pair chunks (round 3's form)
     int stream_helpers = 7;          // COATI_HIP_STREAM_HELPERS (A/B): 1 = chunks planned ahead, 2 = results unstaged, 4 = slots allocated on the model's helper threads

@@ -140,7 +140,9 @@ StagingNeed stream_staging(uint64_t n_pairs, long double total_cells, uint64_t t
 }
 // The streamed call's last chunk (viterbi_batch_stream: "ONE last chunk"): at most kBigTailUnits units of cells, its pairs cut
 // into row parts that keep their own checkpoints (1.09 MB per 1 kb pair) -- one workspace of ~3 GB, kept on the model.
-constexpr long double kBigTailUnits = 2.6L;
+// (COATI_HIP_STREAM_TAIL_UNITS: tuning / A-B switch, tenths of a unit)
+inline long double big_tail_units() { return env_options().stream_tail_units_x10 > 0 ? env_options().stream_tail_units_x10 / 10.0L : 2.6L; }
+#define kBigTailUnits big_tail_units()
 int stream_big_tail_parts() {  // 0 = off
     const int v = env_options().stream_parts;
     return v < 0 ? 3 : (v >= 22 && v <= 28) ? v - 20 : 0;
