@@ -28,6 +28,7 @@ while time.time() < t_end:
     os.environ.pop("COATI_HIP_VITERBI_BITS", None)
     forced = rng.choice(["auto", "auto", "ck", "ck", "bits", "l1"])
     os.environ.pop("COATI_HIP_CK_SPLIT", None)
+    os.environ.pop("COATI_HIP_CK_WALK_ITEMS", None)
     os.environ.pop("COATI_HIP_L1_LP", None)
     os.environ.pop("COATI_HIP_STRIP_W", None)
     os.environ.pop("COATI_HIP_LP_PAIRTAB", None)
@@ -43,7 +44,11 @@ while time.time() < t_end:
     if forced == "ck":
         os.environ["COATI_HIP_VITERBI_CK"] = "1"
         if rng.random() < 0.5:  # the last pairs of the LPT order cut into row parts (default only from 4 352 pairs)
-            os.environ["COATI_HIP_CK_SPLIT"] = "%d,%d" % (int(rng.integers(1, 40)), int(rng.integers(2, 9)))
+            # (round 5: equal / tapered parts / a last part 1-7 chunks shorter; the cut pairs' tracebacks with their last part or
+            # as items of their own)
+            shape = str(rng.choice(["", "", ",t", ",s%d" % int(rng.integers(1, 8))]))
+            os.environ["COATI_HIP_CK_SPLIT"] = "%d,%d%s" % (int(rng.integers(1, 40)), int(rng.integers(2, 9)), shape)
+            os.environ["COATI_HIP_CK_WALK_ITEMS"] = str(rng.choice(["0", "1"]))
     elif forced == "bits":
         os.environ["COATI_HIP_VITERBI_BITS"] = "1"
     n_tables = int(rng.integers(1, 4))
