@@ -30,6 +30,10 @@
 namespace coati_hip_detail {
 namespace {
 
+// hand-over granule of strips of 1 or 2 columns per lane (round 5, same box: 16 pairs 3.18 -> 3.13 ms, one pair 3.12 -> 3.04 with 8
+// instead of 16 rows; 4 rows: 3.27 / 3.17 -- a publish drains the strip's M/D/I stores)
+constexpr uint32_t kFwdSubRowsNarrow = 8;
+
 template <int W>
 struct FwdLane {
     float M[W], D[W], I[W];        // the lane's W columns of the row it processed last
@@ -245,9 +249,9 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
     // Hand-over between the strips of a pair.  Wide strips: once per 64-step chunk (the consumer waits for the 64 rows its
     // next chunk needs, the producer publishes its progress at the end of a chunk: a strip follows its neighbour at ~130-190
     // steps).  Strips of <= 4 columns per lane -- few pairs: `coati sample` works on one, and a 1 kb pair is 16 such strips in
-    // a row -- hand over every kSubRows = 16 steps instead (the cost is a drain of the M/D/I stores per publish, nothing
+    // a row -- hand over every kSubRows = 16 (one or two columns per lane: 8) steps instead (the cost is a drain of the M/D/I stores per publish, nothing
     // when a step is ~1 us of arithmetic): the pipeline of 16 strips fills in 16 x ~85 steps instead of 16 x ~160.
-    constexpr uint32_t kSubRows = W <= 4 ? 16u : static_cast<uint32_t>(kWave);
+    constexpr uint32_t kSubRows = W <= 2 ? kFwdSubRowsNarrow : W <= 4 ? 16u : static_cast<uint32_t>(kWave);
     bool ok = true;
     for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
         const uint32_t crow = kbase + lane;  // the body row lane 0 processes at step kbase + lane
