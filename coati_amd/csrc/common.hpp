@@ -127,10 +127,14 @@ __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
     return static_cast<uint64_t>((la + kWave - 1 + mc - 1) / mc) * kPairDwords;
 }
 // viterbi_ck.hip (gap_len 1) keeps no per-cell bits: per strip of W columns per lane it stores
-//   colin  float2[k][lane]      what lane `lane` received from its left neighbour at wavefront step k
-//                               (diagonal X, left Z); k < la + 63
-//   rowck  float4[c][q][lane]   the lane state before step c*kCkRows: X[0..W) then Y[0..W) as W/2
-//                               float4 (q), one band c per kCkRows steps
+//   colin  float2[c][lane][k%16] what lane `lane` received from its left neighbour at wavefront step k = c*kCkRows + k%16
+//                               (diagonal X, left Z); k < la + 63.  TILE-major (round 5): the 16 values of a (band, lane)
+//                               tile are one 128-byte line, which is what a recompute reads (step-major, rounds 2-4: 8 bytes
+//                               out of each of 16 512-byte rows -- 1.45 GB fetched per 10 000-pair launch for 0.5 GB used).
+//                               The row parts of a CUT pair keep the step-major float2[k][lane]: their stores go through
+//                               the L2 one by one, and a step's lanes are neighbours there
+//   rowck  float4[c][lane][q]   the lane state before step c*kCkRows: X[0..W) then Y[0..W) as W/2
+//                               float4 (q), one band c per kCkRows steps (tile-major too; cut pairs [c][q][lane])
 // from which any (band, lane) tile can be recomputed on its own.  8/W + 8/kCkRows bytes per cell.
 constexpr uint32_t kCkRowsLog2 = 4, kCkRows = 1u << kCkRowsLog2;
 // A single-strip pair needs its checkpoints only until its own wavefront has walked it, so a large
@@ -142,7 +146,7 @@ constexpr uint64_t kCkWaveSlot = ~0ull;
 constexpr uint32_t kCkBandOff = 0xffffffffu;  // banded checkpoints (viterbi_ck.hip): no band, every tile keeps its checkpoints
 __host__ __device__ constexpr uint32_t ck_rowck_quads(uint32_t w) { return w / 2; }
 __host__ __device__ inline uint32_t ck_bands(uint32_t la) { return (la + kWave + kCkRows - 1) / kCkRows; }
-__host__ __device__ inline uint64_t ck_colin_dwords(uint32_t la) { return static_cast<uint64_t>(la + kWave) * (2 * kWave); }
+__host__ __device__ inline uint64_t ck_colin_dwords(uint32_t la) { return static_cast<uint64_t>(ck_bands(la)) * (kCkRows * 2 * kWave); }
 __host__ __device__ inline uint64_t ck_strip_dwords(uint32_t la, uint32_t w) {
     return ck_colin_dwords(la) + static_cast<uint64_t>(ck_bands(la)) * (2 * w * kWave);
 }

@@ -444,12 +444,6 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // cut pairs too: 10 000 pairs 2 048 / 4 096 / 5 904 / 8 000 / all pairs cut in 3: 2 320 / 2 423 / 2 495 / 2 488 /
         // 2 404 GCUPS, in 2: 2 435 (5 904), in 4: 2 310 (all); 40 000 pairs 2 048 / 8 192 / 16 384 / all: 2 738 / 2 775 /
         // 2 719 / 2 542; 6 000 pairs 1 904 / all: 2 272 / 2 158.  So: every pair beyond the first round of wavefronts, up to 8 192.)
-        if(use_slots && n_pairs > ck_scratch_waves()) {
-            split_pairs = std::min<uint64_t>(2 * ck_scratch_waves(), n_pairs - ck_scratch_waves());
-            if(split_pairs < 256) split_pairs = 0;
-        }
-        bool taper = false;
-        uint32_t short_last = 0;
         // The cut pairs' TRACEBACKS as work items of their own, behind the last row parts in the queue (round 5): the items at
         // the end of the queue are then 0.2 ms walks instead of 0.5 ms of rows + walk, and every wavefront stays busy 0.3 ms
         // longer (idle wavefront time before the end of a 10 000-pair launch 8.5 -> 4.6 %).  It pays since a hand-over needs no
@@ -457,6 +451,19 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // +1.2 % (same box, alternating, six passes), 40 000 +-0, 16 000 -0.7 %: by default for launches of up to three rounds
         // of wavefronts.  With fences (earlier in round 5) the same change LOST 1.7 %.  COATI_HIP_CK_WALK_ITEMS=0 / 1 forces.
         const bool walk_items = env.ck_walk_items >= 0 ? env.ck_walk_items != 0 : n_pairs <= 3ull * ck_scratch_waves();
+        if(use_slots && n_pairs > ck_scratch_waves()) {
+            split_pairs = std::min<uint64_t>(2 * ck_scratch_waves(), n_pairs - ck_scratch_waves());
+            // (later in round 5: whole pairs keep TILE-major checkpoints and are ~3 % cheaper than cut ones, whose stores go through
+            // the L2 one by one.  Where the tracebacks are items of their own, ONE round of wavefronts' worth of pairs in 4 parts --
+            // tools/split_ab.py, one box, four runs each, 10 000 pairs: 5 904 x 3 / 4 608 x 3 / 4 096 x 4 / 4 096 x 3 / 3 584 x 3 =
+            // 2 590 / 2 641 / 2 632 / 2 595 / 2 586 GCUPS; the two builds alternating: 3.926 -> 3.827 ms; 6 000 and 8 000 pairs +-0.
+            // Without walk items the rule above stands: 16 000 pairs 8 192 x 3 / 8 192 x 4 / 4 096 x 4 / 4 096 x 3 = 5.94 / 5.91 /
+            // 6.03 / 6.06 ms, 40 000 pairs 13.84 / 13.88 / 13.99 / 14.00.  profiles/r05/cut_sweep.txt)
+            if(walk_items) split_pairs = std::min<uint64_t>(ck_scratch_waves(), n_pairs - ck_scratch_waves()), parts = 4;
+            if(split_pairs < 256) split_pairs = 0;
+        }
+        bool taper = false;
+        uint32_t short_last = 0;
         if(env.ck_split_set) {  // COATI_HIP_CK_SPLIT="pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
             split_pairs = env.ck_split_pairs;
             parts = env.ck_split_parts;

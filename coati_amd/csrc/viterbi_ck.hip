@@ -179,8 +179,8 @@ struct CkCtx {
 };
 // HBM windows of one 64-step chunk (rebased per chunk so that offsets stay far below 2^32)
 struct CkChunkMem {
-    rsrc_t colin;  // float2[kk][lane] of this chunk's steps
-    rsrc_t rowck;  // float4[band in chunk][q][lane]
+    rsrc_t colin;  // float2[band in chunk][lane][step in band] of this chunk's steps
+    rsrc_t rowck;  // float4[band in chunk][lane][q]
 };
 
 // lane state -> row checkpoint of the band that starts at chunk step kb (state BEFORE that step)
@@ -190,13 +190,15 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
     const uint32_t soff = (kb / kCkRows) * (ck_rowck_quads(W) * kWave * 16u);
     uint32_t voff = static_cast<uint32_t>(lane);
     asm volatile("" : "+v"(voff));  // (derived here, once per kCkRows steps: not another VGPR held across the hot loop)
-    voff = keep ? voff * 16u : kCkDropOffset;
+    // (tile-major like colin: the W/2 quads of a lane are one line; a cut pair's -- kThrough -- stay [q][lane]: common.hpp)
+    constexpr uint32_t kQuadStride = kThrough ? kWave * 16u : 16u;
+    voff = keep ? voff * (kThrough ? 16u : ck_rowck_quads(W) * 16u) : kCkDropOffset;
 #pragma unroll
     for(int q = 0; q < W / 4; ++q) {
         const u32x4 x = {fbits(st.X[4 * q]), fbits(st.X[4 * q + 1]), fbits(st.X[4 * q + 2]), fbits(st.X[4 * q + 3])};
         const u32x4 y = {fbits(st.Y[4 * q]), fbits(st.Y[4 * q + 1]), fbits(st.Y[4 * q + 2]), fbits(st.Y[4 * q + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * (kWave * 16u), kAux);
-        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * (kWave * 16u), kAux);
+        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * kQuadStride, kAux);
+        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * kQuadStride, kAux);
     }
 }
 
@@ -207,7 +209,7 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
 template <int W, bool kSub, bool kSingle, bool kThrough>
 __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
-                                        uint32_t a_chunk, float bx, float bz, uint32_t colin_voff) {
+                                        uint32_t a_chunk, float bx, float bz, uint32_t colin_voff, uint32_t colin_band_soff) {
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
     const uint32_t kstep = kbase + kk;
@@ -229,8 +231,13 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     const float diag = shift_in(st.xlast_old, read_lane(bx, kSub ? static_cast<int>(kk & 15u) : static_cast<int>(kk)));
     const float zl = shift_in(st.zlast, read_lane(bz, kSub ? static_cast<int>(kk & 15u) : static_cast<int>(kk)));
     const uint32_t arow_next = shift_in(arow, read_lane(a_chunk, kk));
-    // ---- checkpoint: what this lane received (one coalesced 512-byte row per wavefront step)
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, kk * (kWave * 8u), kThrough ? kAuxAgent : kAuxPlain);
+    // ---- checkpoint: what this lane received, into the lane's 128-byte line of the band (tile-major: common.hpp; the
+    // lanes that keep a band at this step are ~2 * half / (W + 1) neighbours, so a store is that many 8-byte pieces
+    // which the L2 merges over the band's 16 steps)
+    // (kThrough -- a row part of a cut pair: every store goes to memory on its own, so the lanes' 8 bytes of a step stay
+    // next to each other as in rounds 2-4, float2[k][lane])
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, colin_band_soff + kk * (kThrough ? kWave * 8u : 8u),
+                                          kThrough ? kAuxAgent : kAuxPlain);
     // ---- the W cells (and the LDS gather for the next step)
     row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
@@ -261,7 +268,9 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         const bool keep = ck_tile_kept(cx.band, cx.centre, static_cast<int32_t>((kbase + kb) / kCkRows));
         uint32_t colin_voff = static_cast<uint32_t>(cx.lane);
         asm volatile("" : "+v"(colin_voff));
-        colin_voff = keep ? colin_voff * 8u : kCkDropOffset;
+        colin_voff = keep ? colin_voff * (kThrough ? 8u : kCkRows * 8u) : kCkDropOffset;
+        // (scalar part of a step's address: band kb / kCkRows of the chunk, then 8 bytes per step of the band)
+        const uint32_t colin_band_soff = kThrough ? 0u : (kb >> kCkRowsLog2) * (kWave * kCkRows * 8u) - kb * 8u;
         store_rowck<W, kThrough>(mem, cx.lane, st, kb, keep);
         if constexpr(kSub) {
             static_assert(kCkRows == 16, "the boundary sub-blocks are the checkpoint bands");
@@ -299,10 +308,10 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         // allocator ping-pongs X between two register sets instead of copying W values per step
         uint32_t kk = kb;
         for(; kk + 1 < ke; kk += 2) {
-            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
-            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff);
+            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff, colin_band_soff);
+            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff, colin_band_soff);
         }
-        if(kk < ke) ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff);
+        if(kk < ke) ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff, colin_band_soff);
     }
     return ok;
 }
@@ -402,7 +411,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             const float4* __restrict__ rq = reinterpret_cast<const float4*>(rq_words);
 #pragma unroll
             for(int q = 0; q < W / 4; ++q) {
-                const float4 x = rq[q * kWave + lane], y = rq[(W / 4 + q) * kWave + lane];
+                const float4 x = rq[lane * ck_rowck_quads(W) + q], y = rq[lane * ck_rowck_quads(W) + W / 4 + q];
                 st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
                 st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
             }
@@ -630,19 +639,20 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
     }
     LaneState<W> st;
     if(valid && t < k0) {
-        const float4* rk = sp.rowck + (static_cast<uint64_t>(c) * ck_rowck_quads(W)) * kWave + t;
+        const float4* rk = sp.rowck + (static_cast<uint64_t>(c) * ck_rowck_quads(W)) * kWave + (through ? t : t * static_cast<int32_t>(ck_rowck_quads(W)));
 #pragma unroll
         for(int q = 0; q < W / 4; ++q) {
             float4 x, y;
-            if(through) {  // (wave-uniform)
-                const float* xp = reinterpret_cast<const float*>(rk + q * kWave);
-                const float* yp = reinterpret_cast<const float*>(rk + (W / 4 + q) * kWave);
-                x = make_float4(__hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(xp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(xp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(xp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                y = make_float4(__hip_atomic_load(yp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(yp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(yp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(yp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if(through) {  // (wave-uniform) one 16-byte load past the L2 per quad (the scalar copies: ck_fill_strip)
+                const rsrc_t rr = make_rsrc(sp.rowck);
+                const uint32_t voff = static_cast<uint32_t>((static_cast<uint64_t>(c) * ck_rowck_quads(W) * kWave + static_cast<uint32_t>(t)) * 16u);
+                const u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(rr, voff, q * (kWave * 16u), kAuxAgent);
+                const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(rr, voff, (W / 4 + q) * (kWave * 16u), kAuxAgent);
+                const uint32_t x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3], y0 = yv[0], y1 = yv[1], y2 = yv[2], y3 = yv[3];
+                x = make_float4(__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), __builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3));
+                y = make_float4(__builtin_bit_cast(float, y0), __builtin_bit_cast(float, y1), __builtin_bit_cast(float, y2), __builtin_bit_cast(float, y3));
             } else {
-                x = rk[q * kWave], y = rk[(W / 4 + q) * kWave];
+                x = rk[q], y = rk[W / 4 + q];
             }
             st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
             st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
@@ -668,7 +678,10 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
     float s[W];
 #pragma unroll
     for(int cc = 0; cc < W; ++cc) s[cc] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[cc]);
-    const float2* cin = sp.colin + t;
+    // the tile's line -- or, of a cut pair, the lane's column of the step-major rows (ck_step), read past the L2 with one
+    // 8-byte load per step (byte offset from the strip's colin: cut pairs are single-strip, far below 2 GiB)
+    const float2* cin = sp.colin + (static_cast<uint64_t>(c) * kWave + static_cast<uint32_t>(t)) * kCkRows;
+    const uint32_t through_voff = static_cast<uint32_t>((static_cast<uint64_t>(k0) * kWave + static_cast<uint32_t>(t)) * 8u);
     // the left inputs and the row code of a step are loaded one step ahead (a round is otherwise 16 dependent
     // load -> compute steps: what the traceback of the last items of a launch waits for)
     auto inputs_of = [&](int32_t ks, float2& in, uint32_t& code) {
@@ -677,10 +690,11 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
         if(!act) {
             in = make_float2(0.0f, 0.0f);
         } else if(through) {
-            const float* ip = reinterpret_cast<const float*>(cin + static_cast<uint64_t>(kstep) * kWave);
-            in = make_float2(__hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(ip + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(sp.colin), through_voff, static_cast<uint32_t>(ks) * (kWave * 8u), kAuxAgent);
+            const uint32_t v0 = v[0], v1 = v[1];
+            in = make_float2(__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1));
         } else {
-            in = cin[static_cast<uint64_t>(kstep) * kWave];
+            in = cin[ks];
         }
         code = row_code(r + 1);
     };
