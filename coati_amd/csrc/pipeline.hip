@@ -148,7 +148,9 @@ int stream_big_tail_parts() {  // 0 = off
     return v < 0 ? 3 : (v >= 22 && v <= 28) ? v - 20 : 0;
 }
 uint64_t stream_big_tail_bytes(uint64_t wave_slot_bytes) {
-    return std::min<uint64_t>(8ull << 30, static_cast<uint64_t>(kBigTailUnits * 1040) * (wave_slot_bytes + 4096) + (64ull << 20));
+    // (+ 1/8: the cutter's own safety margin on a chunk's workspace, + the chunk's descriptors and sequences: without them a
+    // call whose remainder was just under kBigTailUnits left a last chunk of a few WHOLE pairs behind the row parts)
+    return std::min<uint64_t>(8ull << 30, static_cast<uint64_t>(kBigTailUnits * 1040) * ((wave_slot_bytes + 4096) / 8 * 9 + (32u << 10)) + (64ull << 20));
 }
 void stream_reserve_big_tail(coati_hip_model_t* model, uint64_t wave_slot_bytes) {  // (a failed allocation: the call runs without row parts)
     const uint64_t big = stream_big_tail_bytes(wave_slot_bytes);

@@ -23,7 +23,7 @@ print(f"{n} pairs: resident kernel {resident:.2f} ms", flush=True)
 os.environ["COATI_HIP_PIPE"] = "stream"
 pa, pb = hip.pinned_copy(a[0]), hip.pinned_copy(a[2])
 for rep in range(2):
-    for units, parts in ((26, 23), (36, 23), (46, 23), (56, 23), (36, 24), (46, 22), (26, 23)):
+    for units, parts in ((26, 23), (26, 24), (36, 23), (36, 24), (46, 24), (46, 23), (26, 23)):
         os.environ["COATI_HIP_STREAM_TAIL_UNITS"] = str(units)
         os.environ["COATI_HIP_STREAM_PARTS"] = str(parts)
         model = hip.Model(table, consts, 1)  # (the tail workspace is sized per model)
