@@ -164,6 +164,13 @@ __device__ __forceinline__ bool ck_tile_kept(uint32_t half, int32_t centre, int3
 }
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
 
+// LAYOUT of an item's checkpoints (wave-uniform; the fill and the walk evaluate it on the same values).  Tile-major (common.hpp)
+// pays because a banded fill stores from ~9 lanes per step and a recompute reads whole lines.  A fill that keeps EVERYTHING
+// (band off: the refill of a pair whose walk left the band, strips from 64 on, narrow strips, the debug export) stores from all
+// 64 lanes: there the coalesced 512-byte row per step of rounds 2-4 is the better store (10 000 pairs with everything kept:
+// 5.0 ms step-major, 6.6 ms tile-major), and the row parts of a cut pair store through the L2 (ck_step).  Both: step-major.
+__device__ __forceinline__ bool ck_step_major(uint32_t band, bool through) { return through || band == kCkBandOff; }
+
 // Read-only per-strip context of one wavefront.
 struct CkCtx {
     GapConsts k;
@@ -176,6 +183,7 @@ struct CkCtx {
     bool first_strip;
     uint32_t band;   // banded checkpoints: kCkBandOff or the half width in steps (ck_band_half)
     int32_t centre;  // this lane's centre step
+    bool step_major;  // layout of this item's checkpoints (ck_step_major)
 };
 // HBM windows of one 64-step chunk (rebased per chunk so that offsets stay far below 2^32)
 struct CkChunkMem {
@@ -185,20 +193,22 @@ struct CkChunkMem {
 
 // lane state -> row checkpoint of the band that starts at chunk step kb (state BEFORE that step)
 template <int W, bool kThrough = false>
-__device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, const CkLane<W>& st, uint32_t kb, bool keep = true) {
+__device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, const CkLane<W>& st, uint32_t kb, bool keep, bool step_major) {
     constexpr int kAux = kThrough ? kAuxAgent : kAuxPlain;
     const uint32_t soff = (kb / kCkRows) * (ck_rowck_quads(W) * kWave * 16u);
     uint32_t voff = static_cast<uint32_t>(lane);
     asm volatile("" : "+v"(voff));  // (derived here, once per kCkRows steps: not another VGPR held across the hot loop)
-    // (tile-major like colin: the W/2 quads of a lane are one line; a cut pair's -- kThrough -- stay [q][lane]: common.hpp)
-    constexpr uint32_t kQuadStride = kThrough ? kWave * 16u : 16u;
-    voff = keep ? voff * (kThrough ? 16u : ck_rowck_quads(W) * 16u) : kCkDropOffset;
+    // (tile-major like colin: the W/2 quads of a lane are one line; step-major -- a cut pair, a fill that keeps everything --
+    // they stay [q][lane]: common.hpp, ck_step_major)
+    const bool sm = kThrough || step_major;  // (wave-uniform)
+    const uint32_t quad_stride = sm ? kWave * 16u : 16u;
+    voff = keep ? voff * (sm ? 16u : ck_rowck_quads(W) * 16u) : kCkDropOffset;
 #pragma unroll
     for(int q = 0; q < W / 4; ++q) {
         const u32x4 x = {fbits(st.X[4 * q]), fbits(st.X[4 * q + 1]), fbits(st.X[4 * q + 2]), fbits(st.X[4 * q + 3])};
         const u32x4 y = {fbits(st.Y[4 * q]), fbits(st.Y[4 * q + 1]), fbits(st.Y[4 * q + 2]), fbits(st.Y[4 * q + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * kQuadStride, kAux);
-        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * kQuadStride, kAux);
+        __builtin_amdgcn_raw_buffer_store_b128(x, mem.rowck, voff, soff + q * quad_stride, kAux);
+        __builtin_amdgcn_raw_buffer_store_b128(y, mem.rowck, voff, soff + (W / 4 + q) * quad_stride, kAux);
     }
 }
 
@@ -209,7 +219,7 @@ __device__ __forceinline__ void store_rowck(const CkChunkMem& mem, int lane, con
 template <int W, bool kSub, bool kSingle, bool kThrough>
 __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                         float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t kk,
-                                        uint32_t a_chunk, float bx, float bz, uint32_t colin_voff, uint32_t colin_band_soff) {
+                                        uint32_t a_chunk, float bx, float bz, uint32_t colin_voff, uint32_t colin_band_soff, uint32_t colin_step_shift) {
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
     const uint32_t kstep = kbase + kk;
@@ -234,9 +244,9 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     // ---- checkpoint: what this lane received, into the lane's 128-byte line of the band (tile-major: common.hpp; the
     // lanes that keep a band at this step are ~2 * half / (W + 1) neighbours, so a store is that many 8-byte pieces
     // which the L2 merges over the band's 16 steps)
-    // (kThrough -- a row part of a cut pair: every store goes to memory on its own, so the lanes' 8 bytes of a step stay
-    // next to each other as in rounds 2-4, float2[k][lane])
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, colin_band_soff + kk * (kThrough ? kWave * 8u : 8u),
+    // (step-major items -- ck_step_major -- keep the lanes' 8 bytes of a step next to each other as in rounds 2-4,
+    // float2[k][lane]: a row part of a cut pair, whose every store goes to memory on its own, and fills that keep everything)
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(diag), fbits(zl)}, mem.colin, colin_voff, colin_band_soff + (kk << colin_step_shift),
                                           kThrough ? kAuxAgent : kAuxPlain);
     // ---- the W cells (and the LDS gather for the next step)
     row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
@@ -268,10 +278,13 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         const bool keep = ck_tile_kept(cx.band, cx.centre, static_cast<int32_t>((kbase + kb) / kCkRows));
         uint32_t colin_voff = static_cast<uint32_t>(cx.lane);
         asm volatile("" : "+v"(colin_voff));
-        colin_voff = keep ? colin_voff * (kThrough ? 8u : kCkRows * 8u) : kCkDropOffset;
-        // (scalar part of a step's address: band kb / kCkRows of the chunk, then 8 bytes per step of the band)
-        const uint32_t colin_band_soff = kThrough ? 0u : (kb >> kCkRowsLog2) * (kWave * kCkRows * 8u) - kb * 8u;
-        store_rowck<W, kThrough>(mem, cx.lane, st, kb, keep);
+        const bool sm = kThrough || cx.step_major;  // (wave-uniform)
+        colin_voff = keep ? colin_voff * (sm ? 8u : kCkRows * 8u) : kCkDropOffset;
+        // (scalar part of a step's address, tile-major: band kb / kCkRows of the chunk, then 8 bytes per step of the band;
+        // step-major: 512 bytes per step)
+        const uint32_t colin_band_soff = sm ? 0u : (kb >> kCkRowsLog2) * (kWave * kCkRows * 8u) - kb * 8u;
+        const uint32_t colin_step_shift = sm ? 9u : 3u;
+        store_rowck<W, kThrough>(mem, cx.lane, st, kb, keep, sm);
         if constexpr(kSub) {
             static_assert(kCkRows == 16, "the boundary sub-blocks are the checkpoint bands");
             uint32_t row = kbase + kb + (static_cast<uint32_t>(cx.lane) & 15u);  // (lanes 16-63 repeat lanes 0-15)
@@ -308,10 +321,10 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         // allocator ping-pongs X between two register sets instead of copying W values per step
         uint32_t kk = kb;
         for(; kk + 1 < ke; kk += 2) {
-            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff, colin_band_soff);
-            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff, colin_band_soff);
+            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff, colin_band_soff, colin_step_shift);
+            ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk + 1, a_chunk, bx, bz, colin_voff, colin_band_soff, colin_step_shift);
         }
-        if(kk < ke) ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff, colin_band_soff);
+        if(kk < ke) ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kk, a_chunk, bx, bz, colin_voff, colin_band_soff, colin_step_shift);
     }
     return ok;
 }
@@ -377,7 +390,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     }
     const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z, reinterpret_cast<const uint32_t*>(in_x),
                    reinterpret_cast<const uint32_t*>(in_z), strip == 0, band,
-                   band == kCkBandOff ? 0 : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane), col0)};
+                   band == kCkBandOff ? 0 : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane), col0), ck_step_major(band, kThrough)};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
     // ge*float(j-1)); a lane takes it again at its first step (ck_step)
@@ -411,7 +424,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             const float4* __restrict__ rq = reinterpret_cast<const float4*>(rq_words);
 #pragma unroll
             for(int q = 0; q < W / 4; ++q) {
-                const float4 x = rq[lane * ck_rowck_quads(W) + q], y = rq[lane * ck_rowck_quads(W) + W / 4 + q];
+                const float4 x = cx.step_major ? rq[q * kWave + lane] : rq[lane * ck_rowck_quads(W) + q];
+                const float4 y = cx.step_major ? rq[(W / 4 + q) * kWave + lane] : rq[lane * ck_rowck_quads(W) + W / 4 + q];
                 st.X[4 * q] = x.x, st.X[4 * q + 1] = x.y, st.X[4 * q + 2] = x.z, st.X[4 * q + 3] = x.w;
                 st.Y[4 * q] = y.x, st.Y[4 * q + 1] = y.y, st.Y[4 * q + 2] = y.z, st.Y[4 * q + 3] = y.w;
             }
@@ -482,7 +496,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         // a row part ends here: the lane state for whoever continues (X, Y as the row checkpoint of the next band --
         // the continuation stores the same values there again --, the rest behind the strip's checkpoints)
         const CkChunkMem next{make_rsrc(ck_strip), make_rsrc(rowck_strip + static_cast<uint64_t>(kend / kCkRows) * (2 * W * kWave))};
-        store_rowck<W, kThrough>(next, lane, st, 0);
+        store_rowck<W, kThrough>(next, lane, st, 0, true, cx.step_major);
         if constexpr(kThrough) {
             __hip_atomic_store(part_state + lane, fbits(st.xlast_old), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(part_state + kWave + lane, fbits(st.zlast), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -637,17 +651,23 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
         const uint32_t bj = sp.col0 + static_cast<uint32_t>(t) * W + cc;
         boff[cc] = (valid && bj < pd.lb) ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
     }
+    // the layout the fill of this strip used (ck_step_major); step-major values are loaded with buffer loads off the strip's
+    // base -- past the L2 when another wavefront stored them through its own (a cut pair) -- in 8- and 16-byte pieces
+    const bool sm = ck_step_major(band, through);
+    auto load_b128 = [&](const rsrc_t& rr, uint32_t voff, uint32_t soff) {
+        return through ? __builtin_amdgcn_raw_buffer_load_b128(rr, voff, soff, kAuxAgent) : __builtin_amdgcn_raw_buffer_load_b128(rr, voff, soff, kAuxPlain);
+    };
     LaneState<W> st;
     if(valid && t < k0) {
-        const float4* rk = sp.rowck + (static_cast<uint64_t>(c) * ck_rowck_quads(W)) * kWave + (through ? t : t * static_cast<int32_t>(ck_rowck_quads(W)));
+        const float4* rk = sp.rowck + (static_cast<uint64_t>(c) * ck_rowck_quads(W)) * kWave + t * static_cast<int32_t>(ck_rowck_quads(W));
 #pragma unroll
         for(int q = 0; q < W / 4; ++q) {
             float4 x, y;
-            if(through) {  // (wave-uniform) one 16-byte load past the L2 per quad (the scalar copies: ck_fill_strip)
+            if(sm) {  // (wave-uniform; the scalar copies: ck_fill_strip)
                 const rsrc_t rr = make_rsrc(sp.rowck);
                 const uint32_t voff = static_cast<uint32_t>((static_cast<uint64_t>(c) * ck_rowck_quads(W) * kWave + static_cast<uint32_t>(t)) * 16u);
-                const u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(rr, voff, q * (kWave * 16u), kAuxAgent);
-                const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(rr, voff, (W / 4 + q) * (kWave * 16u), kAuxAgent);
+                const u32x4 xv = load_b128(rr, voff, q * (kWave * 16u));
+                const u32x4 yv = load_b128(rr, voff, (W / 4 + q) * (kWave * 16u));
                 const uint32_t x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3], y0 = yv[0], y1 = yv[1], y2 = yv[2], y3 = yv[3];
                 x = make_float4(__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), __builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3));
                 y = make_float4(__builtin_bit_cast(float, y0), __builtin_bit_cast(float, y1), __builtin_bit_cast(float, y2), __builtin_bit_cast(float, y3));
@@ -678,8 +698,8 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
     float s[W];
 #pragma unroll
     for(int cc = 0; cc < W; ++cc) s[cc] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[cc]);
-    // the tile's line -- or, of a cut pair, the lane's column of the step-major rows (ck_step), read past the L2 with one
-    // 8-byte load per step (byte offset from the strip's colin: cut pairs are single-strip, far below 2 GiB)
+    // the tile's line -- or the lane's column of the step-major rows (ck_step), one 8-byte load per step (byte offset from
+    // the strip's colin: below 2 GiB up to la = 4 M rows)
     const float2* cin = sp.colin + (static_cast<uint64_t>(c) * kWave + static_cast<uint32_t>(t)) * kCkRows;
     const uint32_t through_voff = static_cast<uint32_t>((static_cast<uint64_t>(k0) * kWave + static_cast<uint32_t>(t)) * 8u);
     // the left inputs and the row code of a step are loaded one step ahead (a round is otherwise 16 dependent
@@ -689,8 +709,9 @@ __device__ __forceinline__ bool ck_recompute(const GapConsts& k, const PairDesc&
         const bool act = valid && ks < static_cast<int32_t>(kCkRows) && r >= 0 && r < la;
         if(!act) {
             in = make_float2(0.0f, 0.0f);
-        } else if(through) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(sp.colin), through_voff, static_cast<uint32_t>(ks) * (kWave * 8u), kAuxAgent);
+        } else if(sm) {
+            const u32x2 v = through ? __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(sp.colin), through_voff, static_cast<uint32_t>(ks) * (kWave * 8u), kAuxAgent)
+                                    : __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(sp.colin), through_voff, static_cast<uint32_t>(ks) * (kWave * 8u), kAuxPlain);
             const uint32_t v0 = v[0], v1 = v[1];
             in = make_float2(__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1));
         } else {
