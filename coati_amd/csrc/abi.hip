@@ -99,6 +99,7 @@ const EnvOptions* read_env() {
     if(const char* e = std::getenv("COATI_HIP_PIPE")) o->pipe = std::strcmp(e, "chunks") == 0 ? 1 : (std::strcmp(e, "stream") == 0 ? 2 : 0);
     o->strip_w = static_cast<int>(num("COATI_HIP_STRIP_W", 0));
     o->fwd_w = static_cast<int>(num("COATI_HIP_FWD_W", 0));
+    o->fwd_quad = static_cast<int>(num("COATI_HIP_FWD_QUAD", -1));
     o->fill_blocks_per_cu = static_cast<int>(num("COATI_HIP_FILL_BLOCKS_PER_CU", 0));
     o->lp_blocks_per_cu = static_cast<int>(num("COATI_HIP_LP_BLOCKS_PER_CU", 0));
     o->tail_pairs = num("COATI_HIP_TAIL_PAIRS", -1);
@@ -182,7 +183,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items | (b->ck_walk_items ? kCkWalkItemsFlag : 0u),
-                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u, b->multi_strip ? 1u : 0u};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u, b->multi_strip ? 1u : 0u, b->fwd_quad ? 1u : 0u};
 }
 
 

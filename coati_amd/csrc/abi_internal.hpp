@@ -173,6 +173,7 @@ struct coati_hip_batch {
     bool long_pairs = false;     // decision-bit plan with 4-column strips throughout (a few long pairs): viterbi_lp runs it
     bool multi_strip = false;    // the Viterbi strip plan has a pair of more than one strip
     bool ck_keep_all = false;    // viterbi_ck keeps every checkpoint (no band): the debug export decodes every tile
+    bool fwd_quad = false;       // the Forward items are quad strips (common.hpp: kFwdQuadCols)
     uint32_t fwd_wlog2_max = 4;  // widest Forward strip shape of the batch (forward_l1 has a leaner build for <= 8 columns per lane)
     uint32_t* d_progress = nullptr;
     uint32_t n_items = 0;

@@ -385,6 +385,11 @@ __host__ __device__ inline uint64_t strip_mdi_floats_w(uint32_t la, uint32_t w) 
     return static_cast<uint64_t>(la + kWave) * (3 * w * kWave);
 }
 __host__ __device__ inline uint32_t fwd_strips_w(uint32_t lb, uint32_t w) { return (lb + kWave * w - 1) / (kWave * w); }
+// Quad strips (a handful of pairs; forward_l1.hip: forward_quad_strip): four lanes per column -- one each for the M, the D and
+// the I sum of a cell --, kFwdQuadCols columns per wavefront.  The M/D/I LAYOUT stays that of 1-column strips (f_wlog2 = 0):
+// only the work items, their boundary arrays and their progress words are per quad strip.
+constexpr uint32_t kFwdQuadCols = kWave / 4;
+__host__ __device__ inline uint32_t fwd_quad_strips(uint32_t lb) { return (lb + kFwdQuadCols - 1) / kFwdQuadCols; }
 // Compact Forward layout (gap_len L = 2, 3; forward_k.hip): live cells (p*L + r, q*L + r) only.  A
 // lane owns Wf block columns (one shape per L), step k = p + lane:
 //   float[((((k * L + r) * Wf + c) * 64 + lane) * 3 + mat]
@@ -506,6 +511,7 @@ struct EnvOptions {
     int pipe = 0;                    // COATI_HIP_PIPE: 0 = by the input, 1 = "chunks", 2 = "stream"
     int strip_w = 0;                 // COATI_HIP_STRIP_W: 2 / 4 / 8 / 16 columns per lane in every strip but the last
     int fwd_w = 0;                   // COATI_HIP_FWD_W: 1 / 2 / 4 / 8 / 16
+    int fwd_quad = -1;               // COATI_HIP_FWD_QUAD: 0 / 1 force the quad strips of forward_l1 off / on (where the plan is 1 column per lane)
     int fill_blocks_per_cu = 0;      // COATI_HIP_FILL_BLOCKS_PER_CU
     int lp_blocks_per_cu = 0;        // COATI_HIP_LP_BLOCKS_PER_CU
     long long tail_pairs = -1;       // COATI_HIP_TAIL_PAIRS (-1: the planner's rule)
@@ -564,6 +570,7 @@ struct BatchDeviceView {
     uint32_t ck_band;        // viterbi_ck: half width of the kept checkpoint band in wavefront steps, kCkBandOff = keep everything
     uint32_t long_pairs;     // decision-bit plan of a few long pairs (every strip 4 columns per lane): viterbi_lp fills it
     uint32_t multi_strip;    // the Viterbi plan has pairs of several strips (their boundary arrays start every launch as NaN patterns)
+    uint32_t fwd_quad;       // forward_l1: the items are QUAD strips (kFwdQuadCols columns, four lanes per column: forward_l1.hip)
 };
 // Before every launch of a persistent kernel: the ticket counter and the polled progress words start at zero.  The
 // planner lays the counter out right in front of the words (plan.hip), so this is ONE fill, not two.

@@ -294,10 +294,187 @@ __device__ __forceinline__ void forward_strip(const GapConsts& k, const PairDesc
     if(!ok && last_strip && lane == 0) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
 }
 
+// ---------------------------------------------------------------------------------------------
+// QUAD strips (round 5): a handful of pairs -- `coati sample` works on ONE, BASELINE configs[3] on 16.
+// Every wavefront is then alone on its SIMD and issues one instruction per ~6 cycles whatever its lanes hold: a step of
+// the 1-column strip above costs the 417 instructions of a cell, 1.4 us, and a 1 kb pair is la + lb ~ 2 000 of them in a
+// row (+ the hand-overs of its 16 strips): 3.1 ms.  Here the three sums of a cell go to three lanes of a QUAD --
+//     lane 4c + 0:  M = plus(plus(m2m, d2m), i2m)      from the DIAGONAL cell  (left column, the row before)
+//     lane 4c + 1:  D = plus(plus(m2d, d2d), i2d)      from the cell ABOVE     (own column)
+//     lane 4c + 2:  I = plus(m2i, i2i)                 from the cell to the LEFT (left column, same row)
+// (lane 4c + 3 idles) -- so a step is two `plus` instead of five, and a wavefront holds 16 columns instead of 64: a 1 kb
+// pair is 63 wavefronts.  Column c of a strip does body row r = step - c.  Every lane keeps the value it computed last
+// (`cur`: row r - 1 of its column before the step) and the one before (`old`: row r - 2); four wave_shr:1 bring both of
+// the LEFT column to the lane of the same role, quad-wide DPP broadcasts hand each lane the three values its sum needs.
+// The expressions, their order and the adds are align_pair.cc:97-119's: an operand a role does not have is -0.0f, the
+// exact additive identity (x + -0.0f == x for every x, both zeros included).
+// M/D/I go to the SAME places as from 1-column strips (common.hpp: fwd index with f_wlog2 = 0), the boundary arrays
+// and progress words are per quad strip (plan.hip: BatchDeviceView::fwd_quad).
+template <bool kFast>
+__device__ __forceinline__ float quad_plus(float a, float b, const uint64_t* exp_tab) {
+    if constexpr(kFast) return log_plus(a, b);
+    return log_plus_exact(a, b, exp_tab);
+}
+template <int kCtrl>
+__device__ __forceinline__ float quad_bcast(float v) {  // quad_perm: every lane of a quad reads lane kCtrl & 3 of its quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, false));
+}
+// lane l receives lane l - 4's `v`; lanes 0 .. 3 receive f0 .. f3
+__device__ __forceinline__ float shift_in4(float v, float f0, float f1, float f2, float f3) {
+    return shift_in(shift_in(shift_in(shift_in(v, f3), f2), f1), f0);
+}
+
+template <bool kFast>
+__device__ __forceinline__ void forward_quad_strip(const GapConsts& k, const PairDesc& pd, uint32_t pair, uint32_t sub,
+                                                   uint32_t ticket, int lane, const uint8_t* __restrict__ a_cat,
+                                                   const uint8_t* __restrict__ b_cat, float* __restrict__ bnd,
+                                                   float* __restrict__ mdi, float* __restrict__ final_mdi,
+                                                   uint32_t* __restrict__ progress, const uint64_t* exp_tab,
+                                                   const char* tab_bytes) {
+    const uint32_t la = pd.la, lb = pd.lb;
+    const uint8_t* __restrict__ a = a_cat + pd.a_off;
+    const uint8_t* __restrict__ b = b_cat + pd.b_off;
+    const uint32_t subs = fwd_quad_strips(lb);
+    const uint32_t col0 = sub * kFwdQuadCols;
+    const uint32_t ncol = min(kFwdQuadCols, lb - col0);
+    const uint32_t nsteps = la + ncol - 1;
+    const bool last_sub = sub + 1 == subs;
+    const uint64_t bstride = 3 * (static_cast<uint64_t>(la) + 1);
+    float* __restrict__ bnd_out = bnd + pd.bnd_off + sub * bstride;
+    const float* __restrict__ bnd_in = bnd + pd.bnd_off + (sub - 1) * bstride;  // sub > 0 only
+
+    const int role = lane & 3;
+    const uint32_t c = static_cast<uint32_t>(lane) >> 2;  // column of the strip
+    const uint32_t bj = col0 + c;
+    const bool live = c < ncol && role < 3;  // this lane computes a value that is stored
+    const bool is_m = role == 0, is_d = role == 1, is_i = role == 2;
+    const uint32_t boff = c < ncol ? static_cast<uint32_t>(b[bj]) * 4u : 0u;
+    // the constants of the role's three inputs (align_pair.cc:97-119; -0.0f where the expression has no such add)
+    const float kz = -0.0f;
+    const float ka1 = is_m ? k.ng : is_d ? k.ng : k.go, ka2 = is_m ? k.ng : is_d ? k.go : kz;
+    const float kb1 = is_m ? k.gs : k.ge, kb2 = kz;
+    const float kc1 = is_m ? k.gs : is_d ? k.gs : kz, kc2 = is_m ? k.ng : is_d ? k.go : kz;
+    // where the lane's value of body row r goes: 1-column strip layout, strip bj / 64, lane t = bj % 64, step r + t
+    const uint32_t t64 = bj & (kWave - 1);
+    float* const mout = mdi + pd.mdi_off + static_cast<uint64_t>(bj >> 6) * strip_mdi_floats_w(la, 1) + (static_cast<uint64_t>(t64) * kWave + t64) * 3 + role;
+    // the margin row (matrix row 0, align_pair.cc:88-90) as this role sees it
+    const float margin = is_i ? k.go + k.ge * static_cast<float>(bj) : kLowest;
+
+    float cur = kLowest, old = kLowest;
+    // table-row byte offset of the row this lane's column processes at the CURRENT step (column 0 starts with body row 0; the
+    // others receive theirs from the left as the steps go, like forward_strip's lanes), and that row's score
+    uint32_t arow = c == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
+    float sc = *reinterpret_cast<const float*>(tab_bytes + arow + boff);
+
+    constexpr uint32_t kSubRows = kFwdSubRowsNarrow;
+    // Never hang: a strip whose input does not arrive gives up, says so in its progress word (zero at every launch, otherwise
+    // unused by the quad strips) and stores nothing more; its successors, which then wait themselves, look at that word now
+    // and then and do the same; the last one marks the pair.
+    constexpr uint32_t kQuadGaveUp = 0xffffffffu;
+    for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
+        const uint32_t crow = kbase + lane;  // the body row column 0 processes at step kbase + lane
+        float chDM = kLowest, chDD = kLowest, chDI = kLowest, chLM = kLowest, chLI = kLowest;
+        uint32_t a_chunk = 0;
+        if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
+        if(sub == 0) {
+            // matrix column 0 (align_pair.cc:82-86): diagonal of body row r is matrix cell (r, 0)
+            if(crow == 0) chDM = 0.0f;
+            else if(crow < la) chDD = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
+        }
+        const uint32_t kend = min(static_cast<uint32_t>(kWave), nsteps - kbase);
+        for(uint32_t k0 = 0; k0 < kend; k0 += kSubRows) {
+            const uint32_t k1 = min(k0 + kSubRows, kend);
+            if(sub > 0) {
+                // The left strip's last column, SELF-VALIDATING (as viterbi_ck's strips hand over): the boundary arrays start the
+                // launch as NaN patterns, the producer stores its values through its L2 as it goes -- no drain of its M/D/I
+                // stores, no progress word: a publish every 8 steps cost a wavefront of 0.6-us steps half its time -- and the
+                // consumer loads the rows of its next 8 steps past its own L2 until none is the pattern.
+                const bool mine = crow < la && static_cast<uint32_t>(lane) >= k0 && static_cast<uint32_t>(lane) < k1;
+                const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
+                const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
+                // (the wait itself: three lanes poll the LAST row the block needs -- the producer stores its rows in order --, not
+                // forty loads per round: a consumer on the producer's CU otherwise keeps the CU's memory pipeline busy)
+                const float* lastp = bnd_in + 3 * static_cast<uint64_t>(min(la, kbase + k1));
+                for(uint32_t spins = 0;; ++spins) {
+                    bool valid = true;
+                    if(lane < 3 && __builtin_bit_cast(uint32_t, load_through(lastp + lane)) == 0xffffffffu) valid = false;
+                    if(__builtin_amdgcn_ballot_w64(valid) != __builtin_amdgcn_ballot_w64(true)) {
+                        if(spins > (1u << 24) || ((spins & 255u) == 255u && __hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kQuadGaveUp)) {
+                            if(lane == 0) {
+                                __hip_atomic_store(progress + ticket, kQuadGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if(last_sub) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
+                            }
+                            return;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    if(mine) {
+                        chDM = load_through(dgp + 0);
+                        chDD = load_through(dgp + 1);
+                        chDI = load_through(dgp + 2);
+                        chLM = load_through(lfp + 0);
+                        chLI = load_through(lfp + 2);
+                        valid = __builtin_bit_cast(uint32_t, chDM) != 0xffffffffu && __builtin_bit_cast(uint32_t, chDD) != 0xffffffffu &&
+                                __builtin_bit_cast(uint32_t, chDI) != 0xffffffffu && __builtin_bit_cast(uint32_t, chLM) != 0xffffffffu &&
+                                __builtin_bit_cast(uint32_t, chLI) != 0xffffffffu;
+                    }
+                    // (the rows before the last one were stored earlier, but nothing orders their arrival: checked, tried again)
+                    if(__builtin_amdgcn_ballot_w64(valid) == __builtin_amdgcn_ballot_w64(true)) break;
+                }
+            }
+            asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
+            for(uint32_t kk = k0; kk < k1; ++kk) {
+                const uint32_t kstep = kbase + kk;
+                const int32_t r = static_cast<int32_t>(kstep) - static_cast<int32_t>(c);  // body row of this lane's column
+                if(kstep == c) {  // the column starts: the row above is the margin row
+                    cur = margin;
+                    if(!last_sub && c == ncol - 1 && role < 3) store_through(&bnd_out[role], margin);
+                }
+                // the next step's row and its score (gathered now, consumed a step later)
+                const uint32_t a_next = read_lane(a_chunk, static_cast<int>(kk));
+                const uint32_t arow_next = shift_in(shift_in(shift_in(shift_in(arow, a_next), a_next), a_next), a_next);
+                const float sc_next = *reinterpret_cast<const float*>(tab_bytes + arow_next + boff);
+                // ---- the left column's values, to the lane of the same role (column 0: the strip's left boundary)
+                const float l1 = shift_in4(cur, read_lane(chLM, static_cast<int>(kk)), kLowest, read_lane(chLI, static_cast<int>(kk)), kLowest);
+                const float l2 = shift_in4(old, read_lane(chDM, static_cast<int>(kk)), read_lane(chDD, static_cast<int>(kk)), read_lane(chDI, static_cast<int>(kk)), kLowest);
+                // ---- the three inputs of this lane's sum
+                // (every broadcast by ALL lanes, then the choice: a DPP read under a role's EXEC mask finds its source lane off)
+                const float dgM = quad_bcast<0x00>(l2), dgD = quad_bcast<0x55>(l2), dgI = quad_bcast<0xaa>(l2);
+                const float upM = quad_bcast<0x00>(cur), upD = quad_bcast<0x55>(cur), upI = quad_bcast<0xaa>(cur);
+                const float lfM = quad_bcast<0x00>(l1), lfI = quad_bcast<0xaa>(l1);
+                const float a1 = is_m ? dgM : is_d ? upM : lfM;
+                const float a2 = is_m ? dgD : is_d ? upD : lfI;
+                const float a3 = is_m ? dgI : is_d ? upI : kLowest;
+                const float scm = is_m ? sc : kz;
+                const float t1 = ((a1 + ka1) + ka2) + scm;
+                const float t2 = ((a2 + kb1) + kb2) + scm;
+                const float t3 = ((a3 + kc1) + kc2) + scm;
+                const float r12 = quad_plus<kFast>(t1, t2, exp_tab);
+                const float r123 = quad_plus<kFast>(r12, t3, exp_tab);
+                const float val = is_i ? r12 : r123;
+                old = cur;
+                cur = val;
+                sc = sc_next;
+                arow = arow_next;
+                if(live && r >= 0 && r < static_cast<int32_t>(la)) {
+                    mout[static_cast<uint64_t>(r) * (3 * kWave)] = val;
+                    if(!last_sub && c == ncol - 1) store_through(&bnd_out[3 * static_cast<uint64_t>(r + 1) + role], val);
+                    if(last_sub && r == static_cast<int32_t>(la) - 1 && bj == lb - 1) {
+                        // terminal adjustment (align_pair.cc:130-138): (m + ng) + ng, d + gs, (in + gs) + ng
+                        const float f1 = is_m ? k.ng : k.gs, f2 = is_d ? kz : k.ng;
+                        final_mdi[3 * static_cast<uint64_t>(pair) + role] = (val + f1) + f2;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // kNarrow: strips of at most 8 columns per lane only -- half the lane state, so the build fits 128 VGPRs and four
 // wavefronts share a SIMD (the latency of the fp64 / reciprocal chains of the exact `plus` is what the wide build
 // cannot hide with three).
-template <bool kFast, bool kNarrow>
+template <bool kFast, bool kNarrow, bool kQuad = false>
 __device__ __forceinline__ void forward_l1_body(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
@@ -345,6 +522,10 @@ __device__ __forceinline__ void forward_l1_body(
             }
             continue;
         }
+        if constexpr(kQuad) {
+            forward_quad_strip<kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes);
+            continue;
+        }
         // strips are 64 * W columns, W = 16 unless the batch has too few pairs to fill the GPU (abi.hip)
         switch(pd.f_wlog2) {
             case 0: forward_strip<1, kFast>(k, pd, pair, strip, ticket, lane, a_cat, b_cat, bnd, mdi, final_mdi, progress, exp_tab, tab_bytes); break;
@@ -360,7 +541,7 @@ __device__ __forceinline__ void forward_l1_body(
 
 // The four builds.  The narrow ones are held to 128 VGPRs (amdgpu_num_vgpr: __launch_bounds__' second argument is only
 // a request -- left alone the compiler took 135-138 registers and with them the fourth wavefront per SIMD).
-#define COATI_FWD_KERNEL(NAME, FAST, NARROW, ATTR)                                                                       \
+#define COATI_FWD_KERNEL(NAME, FAST, NARROW, ATTR, ...)                                                                  \
     __global__ ATTR void NAME(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,          \
                               const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,        \
                               uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,                        \
@@ -368,13 +549,16 @@ __device__ __forceinline__ void forward_l1_body(
                               float* __restrict__ final_mdi) {                                                           \
         __shared__ float tab_all[NARROW ? 1 : kFillWaves][kTabRows * kTabStride]; /* wide: one table per wavefront */     \
         __shared__ uint64_t exp_tab[32];                                                                                 \
-        forward_l1_body<FAST, NARROW>(table, k, pairs, items, n_items, queue, progress, a_cat, b_cat, bnd, mdi, final_mdi, \
+        forward_l1_body<FAST, NARROW __VA_OPT__(,) __VA_ARGS__>(table, k, pairs, items, n_items, queue, progress, a_cat, b_cat, bnd, mdi, final_mdi, \
                                       tab_all, exp_tab);                                                                 \
     }
 COATI_FWD_KERNEL(forward_l1_exact_wide, false, false, __launch_bounds__(kFillWaves* kWave, 3))
 COATI_FWD_KERNEL(forward_l1_fast_wide, true, false, __launch_bounds__(kFillWaves* kWave, 2))
 COATI_FWD_KERNEL(forward_l1_exact_narrow, false, true, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
 COATI_FWD_KERNEL(forward_l1_fast_narrow, true, true, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
+// (quad strips: one table per workgroup like the narrow builds; a wavefront per SIMD is all there is to place)
+COATI_FWD_KERNEL(forward_l1_exact_quad, false, true, __launch_bounds__(kFillWaves* kWave), true)
+COATI_FWD_KERNEL(forward_l1_fast_quad, true, true, __launch_bounds__(kFillWaves* kWave), true)
 #undef COATI_FWD_KERNEL
 
 }  // namespace
@@ -392,6 +576,16 @@ hipError_t launch_forward_l1(const BatchDeviceView& v, bool one_table, hipStream
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs, v.fwd_items, v.n_fwd_items,
                            v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi);
     };
+    if(v.fwd_quad != 0 && one_table) {
+        // (the quad strips' boundary values validate themselves: every launch starts from NaN patterns)
+        if(v.bnd_bytes != 0) {
+            e = hipMemsetAsync(v.bnd, 0xff, v.bnd_bytes, stream);
+            if(e != hipSuccess) return e;
+        }
+        if(fast) go(forward_l1_fast_quad);
+        else go(forward_l1_exact_quad);
+        return hipGetLastError();
+    }
     if(fast && narrow) go(forward_l1_fast_narrow);
     else if(fast) go(forward_l1_fast_wide);
     else if(narrow) go(forward_l1_exact_narrow);

@@ -128,6 +128,19 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         if(fwd_wlog2 == 2 && count_strips(2) <= 2304) fwd_wlog2 = 1;
         if(fwd_wlog2 == 1 && count_strips(1) <= 1536) fwd_wlog2 = 0;
         if(const int w = env.fwd_w; w == 1 || w == 2 || w == 4 || w == 8 || w == 16) fwd_wlog2 = w == 1 ? 0u : w == 2 ? 1u : w == 4 ? 2u : (w == 8 ? 3u : 4u);
+        // Fewer still (`coati sample`: ONE pair; BASELINE configs[3]: 16): a wavefront that is alone on its SIMD issues one
+        // instruction per ~6 cycles whatever its lanes hold, so the 417 instructions of a cell are spread over FOUR lanes -- one
+        // each for the M, the D and the I sum, 16 columns per wavefront (forward_l1.hip: forward_quad_strip): a step is two
+        // `plus` instead of five, a 1 kb pair 63 wavefronts instead of 16.  While the quad strips fit one per SIMD and the
+        // model has one table.  COATI_HIP_FWD_QUAD=0 / 1 forces (1: wherever the plan is 1 column per lane).
+        if(fwd_wlog2 == 0 && model->n_tables == 1) {
+            uint64_t quads = 0;
+            for(uint64_t p = 0; p < n_pairs && quads <= 1024; ++p) {
+                const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
+                quads += (la > 0 && lb > 0 && lb <= 0x7fffff00ull) ? fwd_quad_strips(static_cast<uint32_t>(lb)) : 1;
+            }
+            b->fwd_quad = env.fwd_quad >= 0 ? env.fwd_quad != 0 : quads <= 1024;
+        }
     }
     for(uint64_t p = 0; p < n_pairs; ++p) {
         if(a_off[p + 1] < a_off[p] || b_off[p + 1] < b_off[p])
@@ -360,7 +373,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // strip-boundary arrays, 128-byte aligned so that no two waves ever share a cache line:
         // viterbi_l1 one 2(la+1) array per boundary of its plan, forward_l1 one 3(la+1) array per
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
-        const uint64_t nf = viterbi_only ? 1 : fwd_strips_w(d.lb, 1u << d.f_wlog2);
+        const uint64_t nf = viterbi_only ? 1 : (b->fwd_quad && d.f_compact == 0) ? fwd_quad_strips(d.lb) : fwd_strips_w(d.lb, 1u << d.f_wlog2);
         const uint64_t need = std::max<uint64_t>({(ns - 1) * 2 * (la + 1), nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
                                                   nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
                                                   plan_k ? (ns - 1) * ((la / L + 1) + la) : 0,
@@ -544,7 +557,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         uint32_t nf = 1;
         if(b->desc[p].la > 0 && b->desc[p].lb > 0)
             nf = b->desc[p].f_compact != 0 ? fwd_compact_strips(b->desc[p].lb, b->desc[p].f_compact)
-                                             : fwd_strips_w(b->desc[p].lb, 1u << b->desc[p].f_wlog2);
+                 : b->fwd_quad                ? fwd_quad_strips(b->desc[p].lb)
+                                              : fwd_strips_w(b->desc[p].lb, 1u << b->desc[p].f_wlog2);
         for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
     }
     if(b->ck_split_items > 0) {

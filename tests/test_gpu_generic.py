@@ -115,14 +115,15 @@ def test_fast_forward_mode_within_tolerance():
     assert out.returncode == 0, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("w", [2, 4, 8, 16])
+@pytest.mark.parametrize("w", [1, 2, 4, 8, 16])
 def test_forward_strip_shapes(w):
     """forward_l1 narrows its strips (16 -> 8 -> 4 -> 2 -> 1 columns per lane) while a batch has few
-    strips for the GPU's SIMDs, so the small batches of this suite run the 1-column shape.
-    COATI_HIP_FWD_W forces the others: same bits (matrices, final cells, samples)."""
+    strips for the GPU's SIMDs, and a handful of pairs run QUAD strips (four lanes per column): what the small
+    batches of this suite get.  COATI_HIP_FWD_W forces the others (1: the 1-column strips, quads off): same bits
+    (matrices, final cells, samples)."""
     if os.environ.get("COATI_HIP_FWD_W") or os.environ.get("COATI_HIP_FORCE_GENERIC") or os.environ.get("COATI_HIP_FORWARD_FAST"):
         pytest.skip("already inside a child run")
-    env = dict(os.environ, COATI_HIP_FWD_W=str(w))
+    env = dict(os.environ, COATI_HIP_FWD_W=str(w), COATI_HIP_FWD_QUAD="0")
     out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", str(ROOT / "tests" / "test_gpu_generic.py"),
                           str(ROOT / "tests" / "test_gpu_sample.py"),
                           "-k", "forward_matrices or forward_golden or exact_stream_matches or marg_sample or golden_sample"],
