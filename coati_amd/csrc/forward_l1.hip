@@ -366,7 +366,7 @@ __device__ __forceinline__ void forward_quad_strip(const GapConsts& k, const Pai
     uint32_t arow = c == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
     float sc = *reinterpret_cast<const float*>(tab_bytes + arow + boff);
 
-    constexpr uint32_t kSubRows = kFwdSubRowsNarrow;
+    constexpr uint32_t kSubRows = 4;  // (rows per hand-over)
     // Never hang: a strip whose input does not arrive gives up, says so in its progress word (zero at every launch, otherwise
     // unused by the quad strips) and stores nothing more; its successors, which then wait themselves, look at that word now
     // and then and do the same; the last one marks the pair.
