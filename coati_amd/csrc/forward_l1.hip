@@ -317,7 +317,7 @@ __device__ __forceinline__ float quad_plus(float a, float b, const uint64_t* exp
 }
 template <int kCtrl>
 __device__ __forceinline__ float quad_bcast(float v) {  // quad_perm: every lane of a quad reads lane kCtrl & 3 of its quad
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, false));
 }
 // lane l receives lane l - 4's `v`; lanes 0 .. 3 receive f0 .. f3
 __device__ __forceinline__ float shift_in4(float v, float f0, float f1, float f2, float f3) {
@@ -360,87 +360,92 @@ __device__ __forceinline__ void forward_quad_strip(const GapConsts& k, const Pai
     // the margin row (matrix row 0, align_pair.cc:88-90) as this role sees it
     const float margin = is_i ? k.go + k.ge * static_cast<float>(bj) : kLowest;
 
-    float cur = kLowest, old = kLowest;
+    // `cur`: the value this lane computed last (row r - 1 of its column before a step); `l1p`: what the step before received
+    // from the left column -- that column's row r - 1, i.e. this step's DIAGONAL cell
+    float cur = kLowest;
     // table-row byte offset of the row this lane's column processes at the CURRENT step (column 0 starts with body row 0; the
     // others receive theirs from the left as the steps go, like forward_strip's lanes), and that row's score
     uint32_t arow = c == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
     float sc = *reinterpret_cast<const float*>(tab_bytes + arow + boff);
+    // the margin row of this strip's last column is the first thing its right neighbour needs
+    if(!last_sub && c == ncol - 1 && role < 3) store_through(&bnd_out[role], margin);
 
     constexpr uint32_t kSubRows = 4;  // (rows per hand-over)
     // Never hang: a strip whose input does not arrive gives up, says so in its progress word (zero at every launch, otherwise
     // unused by the quad strips) and stores nothing more; its successors, which then wait themselves, look at that word now
     // and then and do the same; the last one marks the pair.
     constexpr uint32_t kQuadGaveUp = 0xffffffffu;
+    auto give_up = [&]() {
+        if(lane == 0) {
+            __hip_atomic_store(progress + ticket, kQuadGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(last_sub) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
+        }
+    };
+    // three lanes poll entry `e` of the left boundary (M, D, I of body row e - 1; entry 0 = the margin row) until it is there
+    auto wait_entry = [&](uint64_t e) {
+        for(uint32_t spins = 0;; ++spins) {
+            const bool missing = lane < 3 && __builtin_bit_cast(uint32_t, load_through(bnd_in + 3 * e + lane)) == 0xffffffffu;
+            if(__builtin_amdgcn_ballot_w64(missing) == 0ull) return true;
+            if(spins > (1u << 24) || ((spins & 255u) == 255u && __hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kQuadGaveUp)) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    // what column 0 finds to its left in the row ABOVE its first: matrix cell (0, col0) -- the left strip's margin entry, or
+    // M(0, 0) = 0 (align_pair.cc:82-90); lanes 0 .. 2 hold it by role
+    float l1p = kLowest;
+    if(sub == 0) {
+        if(lane == 0) l1p = 0.0f;
+    } else {
+        if(!wait_entry(0)) return give_up();
+        if(lane < 3) l1p = load_through(bnd_in + lane);
+    }
     for(uint32_t kbase = 0; kbase < nsteps; kbase += kWave) {
         const uint32_t crow = kbase + lane;  // the body row column 0 processes at step kbase + lane
-        float chDM = kLowest, chDD = kLowest, chDI = kLowest, chLM = kLowest, chLI = kLowest;
+        // the cell to the LEFT of column 0 in body row crow: matrix column 0 (align_pair.cc:82-86) or the left strip's entry crow + 1
+        float chM = kLowest, chD = kLowest, chI = kLowest;
         uint32_t a_chunk = 0;
         if(crow + 1 < la) a_chunk = static_cast<uint32_t>(a[crow + 1]) * (kTabStride * 4u);
-        if(sub == 0) {
-            // matrix column 0 (align_pair.cc:82-86): diagonal of body row r is matrix cell (r, 0)
-            if(crow == 0) chDM = 0.0f;
-            else if(crow < la) chDD = (k.ng + k.go) + k.ge * static_cast<float>(crow - 1);
-        }
+        if(sub == 0 && crow < la) chD = (k.ng + k.go) + k.ge * static_cast<float>(crow);
         const uint32_t kend = min(static_cast<uint32_t>(kWave), nsteps - kbase);
         for(uint32_t k0 = 0; k0 < kend; k0 += kSubRows) {
             const uint32_t k1 = min(k0 + kSubRows, kend);
             if(sub > 0) {
                 // The left strip's last column, SELF-VALIDATING (as viterbi_ck's strips hand over): the boundary arrays start the
                 // launch as NaN patterns, the producer stores its values through its L2 as it goes -- no drain of its M/D/I
-                // stores, no progress word: a publish every 8 steps cost a wavefront of 0.6-us steps half its time -- and the
-                // consumer loads the rows of its next 8 steps past its own L2 until none is the pattern.
+                // stores, no progress word: a publish every 8 steps cost a wavefront of 0.8-us steps a third of its time -- and the
+                // consumer loads the rows of its next steps past its own L2 until none is the pattern.  The wait itself is three
+                // lanes polling the LAST row the block needs (the producer stores its rows in order), not a dozen loads per round:
+                // a consumer on the producer's CU otherwise keeps the CU's memory pipeline busy.
                 const bool mine = crow < la && static_cast<uint32_t>(lane) >= k0 && static_cast<uint32_t>(lane) < k1;
-                const float* dgp = bnd_in + 3 * static_cast<uint64_t>(crow);      // body row crow - 1
                 const float* lfp = bnd_in + 3 * static_cast<uint64_t>(crow + 1);  // body row crow
-                // (the wait itself: three lanes poll the LAST row the block needs -- the producer stores its rows in order --, not
-                // forty loads per round: a consumer on the producer's CU otherwise keeps the CU's memory pipeline busy)
-                const float* lastp = bnd_in + 3 * static_cast<uint64_t>(min(la, kbase + k1));
-                for(uint32_t spins = 0;; ++spins) {
+                for(;;) {
+                    if(!wait_entry(min(la, kbase + k1))) return give_up();
                     bool valid = true;
-                    if(lane < 3 && __builtin_bit_cast(uint32_t, load_through(lastp + lane)) == 0xffffffffu) valid = false;
-                    if(__builtin_amdgcn_ballot_w64(valid) != __builtin_amdgcn_ballot_w64(true)) {
-                        if(spins > (1u << 24) || ((spins & 255u) == 255u && __hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kQuadGaveUp)) {
-                            if(lane == 0) {
-                                __hip_atomic_store(progress + ticket, kQuadGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if(last_sub) final_mdi[3 * static_cast<uint64_t>(pair)] = __builtin_nanf("");
-                            }
-                            return;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                        continue;
-                    }
                     if(mine) {
-                        chDM = load_through(dgp + 0);
-                        chDD = load_through(dgp + 1);
-                        chDI = load_through(dgp + 2);
-                        chLM = load_through(lfp + 0);
-                        chLI = load_through(lfp + 2);
-                        valid = __builtin_bit_cast(uint32_t, chDM) != 0xffffffffu && __builtin_bit_cast(uint32_t, chDD) != 0xffffffffu &&
-                                __builtin_bit_cast(uint32_t, chDI) != 0xffffffffu && __builtin_bit_cast(uint32_t, chLM) != 0xffffffffu &&
-                                __builtin_bit_cast(uint32_t, chLI) != 0xffffffffu;
+                        chM = load_through(lfp + 0);
+                        chD = load_through(lfp + 1);
+                        chI = load_through(lfp + 2);
+                        valid = __builtin_bit_cast(uint32_t, chM) != 0xffffffffu && __builtin_bit_cast(uint32_t, chD) != 0xffffffffu &&
+                                __builtin_bit_cast(uint32_t, chI) != 0xffffffffu;
                     }
                     // (the rows before the last one were stored earlier, but nothing orders their arrival: checked, tried again)
                     if(__builtin_amdgcn_ballot_w64(valid) == __builtin_amdgcn_ballot_w64(true)) break;
                 }
             }
-            asm volatile("" : "+v"(a_chunk), "+v"(chDM), "+v"(chDD), "+v"(chDI), "+v"(chLM), "+v"(chLI));
+            asm volatile("" : "+v"(a_chunk), "+v"(chM), "+v"(chD), "+v"(chI));
             for(uint32_t kk = k0; kk < k1; ++kk) {
                 const uint32_t kstep = kbase + kk;
                 const int32_t r = static_cast<int32_t>(kstep) - static_cast<int32_t>(c);  // body row of this lane's column
-                if(kstep == c) {  // the column starts: the row above is the margin row
-                    cur = margin;
-                    if(!last_sub && c == ncol - 1 && role < 3) store_through(&bnd_out[role], margin);
-                }
+                cur = kstep == c ? margin : cur;  // the column starts: the row above is the margin row
                 // the next step's row and its score (gathered now, consumed a step later)
                 const uint32_t a_next = read_lane(a_chunk, static_cast<int>(kk));
                 const uint32_t arow_next = shift_in(shift_in(shift_in(shift_in(arow, a_next), a_next), a_next), a_next);
                 const float sc_next = *reinterpret_cast<const float*>(tab_bytes + arow_next + boff);
-                // ---- the left column's values, to the lane of the same role (column 0: the strip's left boundary)
-                const float l1 = shift_in4(cur, read_lane(chLM, static_cast<int>(kk)), kLowest, read_lane(chLI, static_cast<int>(kk)), kLowest);
-                const float l2 = shift_in4(old, read_lane(chDM, static_cast<int>(kk)), read_lane(chDD, static_cast<int>(kk)), read_lane(chDI, static_cast<int>(kk)), kLowest);
+                // ---- the left column's row r, to the lane of the same role (column 0: the strip's left boundary)
+                const float l1 = shift_in4(cur, read_lane(chM, static_cast<int>(kk)), read_lane(chD, static_cast<int>(kk)), read_lane(chI, static_cast<int>(kk)), kLowest);
                 // ---- the three inputs of this lane's sum
                 // (every broadcast by ALL lanes, then the choice: a DPP read under a role's EXEC mask finds its source lane off)
-                const float dgM = quad_bcast<0x00>(l2), dgD = quad_bcast<0x55>(l2), dgI = quad_bcast<0xaa>(l2);
+                const float dgM = quad_bcast<0x00>(l1p), dgD = quad_bcast<0x55>(l1p), dgI = quad_bcast<0xaa>(l1p);
                 const float upM = quad_bcast<0x00>(cur), upD = quad_bcast<0x55>(cur), upI = quad_bcast<0xaa>(cur);
                 const float lfM = quad_bcast<0x00>(l1), lfI = quad_bcast<0xaa>(l1);
                 const float a1 = is_m ? dgM : is_d ? upM : lfM;
@@ -453,21 +458,22 @@ __device__ __forceinline__ void forward_quad_strip(const GapConsts& k, const Pai
                 const float r12 = quad_plus<kFast>(t1, t2, exp_tab);
                 const float r123 = quad_plus<kFast>(r12, t3, exp_tab);
                 const float val = is_i ? r12 : r123;
-                old = cur;
+                l1p = l1;
                 cur = val;
                 sc = sc_next;
                 arow = arow_next;
                 if(live && r >= 0 && r < static_cast<int32_t>(la)) {
                     mout[static_cast<uint64_t>(r) * (3 * kWave)] = val;
                     if(!last_sub && c == ncol - 1) store_through(&bnd_out[3 * static_cast<uint64_t>(r + 1) + role], val);
-                    if(last_sub && r == static_cast<int32_t>(la) - 1 && bj == lb - 1) {
-                        // terminal adjustment (align_pair.cc:130-138): (m + ng) + ng, d + gs, (in + gs) + ng
-                        const float f1 = is_m ? k.ng : k.gs, f2 = is_d ? kz : k.ng;
-                        final_mdi[3 * static_cast<uint64_t>(pair) + role] = (val + f1) + f2;
-                    }
                 }
             }
         }
+    }
+    // the last column's last step was the strip's last: `cur` is its value of body row la - 1.  Terminal adjustment
+    // (align_pair.cc:130-138): (m + ng) + ng, d + gs, (in + gs) + ng
+    if(last_sub && live && c == ncol - 1) {
+        const float f1 = is_m ? k.ng : k.gs, f2 = is_d ? kz : k.ng;
+        final_mdi[3 * static_cast<uint64_t>(pair) + role] = (cur + f1) + f2;
     }
 }
 
