@@ -183,7 +183,7 @@ def roofline_by_kernel(algo_bytes, fill_ms, extras):
     s16 = smp.get("sample_16x1000_exact_stream")
     if s16:
         out["configs[3] as stated: 16 pairs, forward + 16 000 samples"] = {"forward_ms": s16["forward_ms"], "sampleback_ms": s16["sampleback_ms"],
-                                                                         "binding": "latency: 16 narrow strips in a row per pair; ~13 speculation rounds"}
+                                                                         "binding": "latency: 63 quad strips of 16 columns in a row per pair (two log-sums per step); ~13 speculation rounds"}
     return out
 
 
