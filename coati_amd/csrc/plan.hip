@@ -131,17 +131,17 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // Fewer still (`coati sample`: ONE pair; BASELINE configs[3]: 16): a wavefront that is alone on its SIMD issues one
         // instruction per ~6 cycles whatever its lanes hold, so the 417 instructions of a cell are spread over FOUR lanes -- one
         // each for the M, the D and the I sum, 16 columns per wavefront (forward_l1.hip: forward_quad_strip): a step is two
-        // `plus` instead of five, a 1 kb pair 63 wavefronts instead of 16.  While the quad strips fit four per SIMD and the
+        // `plus` instead of five, a 1 kb pair 63 wavefronts instead of 16.  While the quad strips fit three per SIMD and the
         // model has one table (tools/experiments/quad_sweep.py, 1 kb pairs, 1-column strips -> quad strips: 1 pair 3.07 -> 1.86 ms,
         // 16: 3.11 -> 1.91, 32: 3.18 -> 2.17, 48: 3.19 -> 2.66, 64: 3.37 -> 3.27).  COATI_HIP_FWD_QUAD=0 / 1 forces (1: wherever
         // the plan is 1 column per lane).
         if(fwd_wlog2 == 0 && model->n_tables == 1) {
             uint64_t quads = 0;
-            for(uint64_t p = 0; p < n_pairs && quads <= 4096; ++p) {
+            for(uint64_t p = 0; p < n_pairs && quads <= 3072; ++p) {
                 const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
                 quads += (la > 0 && lb > 0 && lb <= 0x7fffff00ull) ? fwd_quad_strips(static_cast<uint32_t>(lb)) : 1;
             }
-            b->fwd_quad = env.fwd_quad >= 0 ? env.fwd_quad != 0 : quads <= 4096;
+            b->fwd_quad = env.fwd_quad >= 0 ? env.fwd_quad != 0 : quads <= 3072;
         }
     }
     for(uint64_t p = 0; p < n_pairs; ++p) {
