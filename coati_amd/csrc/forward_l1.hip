@@ -547,7 +547,7 @@ __device__ __forceinline__ void forward_l1_body(
 
 // The four builds.  The narrow ones are held to 128 VGPRs (amdgpu_num_vgpr: __launch_bounds__' second argument is only
 // a request -- left alone the compiler took 135-138 registers and with them the fourth wavefront per SIMD).
-#define COATI_FWD_KERNEL(NAME, FAST, NARROW, ATTR, ...)                                                                  \
+#define COATI_FWD_KERNEL(NAME, FAST, NARROW, QUAD, ATTR)                                                                  \
     __global__ ATTR void NAME(const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,          \
                               const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,        \
                               uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,                        \
@@ -555,16 +555,16 @@ __device__ __forceinline__ void forward_l1_body(
                               float* __restrict__ final_mdi) {                                                           \
         __shared__ float tab_all[NARROW ? 1 : kFillWaves][kTabRows * kTabStride]; /* wide: one table per wavefront */     \
         __shared__ uint64_t exp_tab[32];                                                                                 \
-        forward_l1_body<FAST, NARROW __VA_OPT__(,) __VA_ARGS__>(table, k, pairs, items, n_items, queue, progress, a_cat, b_cat, bnd, mdi, final_mdi, \
+        forward_l1_body<FAST, NARROW, QUAD>(table, k, pairs, items, n_items, queue, progress, a_cat, b_cat, bnd, mdi, final_mdi, \
                                       tab_all, exp_tab);                                                                 \
     }
-COATI_FWD_KERNEL(forward_l1_exact_wide, false, false, __launch_bounds__(kFillWaves* kWave, 3))
-COATI_FWD_KERNEL(forward_l1_fast_wide, true, false, __launch_bounds__(kFillWaves* kWave, 2))
-COATI_FWD_KERNEL(forward_l1_exact_narrow, false, true, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
-COATI_FWD_KERNEL(forward_l1_fast_narrow, true, true, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
+COATI_FWD_KERNEL(forward_l1_exact_wide, false, false, false, __launch_bounds__(kFillWaves* kWave, 3))
+COATI_FWD_KERNEL(forward_l1_fast_wide, true, false, false, __launch_bounds__(kFillWaves* kWave, 2))
+COATI_FWD_KERNEL(forward_l1_exact_narrow, false, true, false, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
+COATI_FWD_KERNEL(forward_l1_fast_narrow, true, true, false, __launch_bounds__(kFillWaves* kWave, 4) __attribute__((amdgpu_num_vgpr(128))))
 // (quad strips: one table per workgroup like the narrow builds; a wavefront per SIMD is all there is to place)
-COATI_FWD_KERNEL(forward_l1_exact_quad, false, true, __launch_bounds__(kFillWaves* kWave), true)
-COATI_FWD_KERNEL(forward_l1_fast_quad, true, true, __launch_bounds__(kFillWaves* kWave), true)
+COATI_FWD_KERNEL(forward_l1_exact_quad, false, true, true, __launch_bounds__(kFillWaves* kWave))
+COATI_FWD_KERNEL(forward_l1_fast_quad, true, true, true, __launch_bounds__(kFillWaves* kWave))
 #undef COATI_FWD_KERNEL
 
 }  // namespace
