@@ -171,7 +171,11 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     if(device_rounds) {
         // ---- device rounds: plan + walks + chain per round, enqueued several rounds at a time; the host reads the number
         // of unfinished pairs each round started with (a round that starts with none is three empty launches)
-        constexpr uint32_t kBatch = 6;
+        // (How many: six, then six more ... -- or, when this model has sampled before, as many as that call needed and then two at
+        // a time: a call of 13 rounds otherwise pays for 18 and a third synchronisation.)
+        constexpr uint32_t kBatch = 24;
+        uint32_t batch_now = m->spec_rounds_hint != 0 ? std::min<uint32_t>(m->spec_rounds_hint, kBatch) : 6u;
+        const uint32_t batch_next = m->spec_rounds_hint != 0 ? 2u : 6u;
         const uint32_t max_width = widest;
         void* host_block = nullptr;
         S_TRY(model_pinned(m, kBatch * sizeof(SpecRound) + n * sizeof(SpecPairState) + 64, &host_block));
@@ -181,20 +185,22 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         S_TRY(hipMemcpyAsync(d_states, h_states, n * sizeof(SpecPairState), hipMemcpyHostToDevice, m->stream));
         const bool timing = env_options().timing;
         for(bool finished = n_samples == 0 || n == 0; !finished;) {
-            for(uint32_t r = 0; r < kBatch; ++r) {
+            for(uint32_t r = 0; r < batch_now; ++r) {
                 S_TRY(launch_spec_round(view, d_tab_off, band_half, d_steps, d_state0, d_pow, n_samples, kMaxCands, max_width, kZ, d_states, d_windows, d_rank_pair, d_round,
                                         d_draw_table, d_thr_off, d_thr, d_cdraws, d_sample_off, m->stream));
                 S_TRY(hipMemcpyAsync(h_round + r, d_round, sizeof(SpecRound), hipMemcpyDeviceToHost, m->stream));
             }
             S_TRY(hipStreamSynchronize(m->stream));
-            for(uint32_t r = 0; r < kBatch; ++r) {
+            for(uint32_t r = 0; r < batch_now; ++r) {
                 if(h_round[r].active == 0) {
                     finished = true;
                     break;
                 }
                 ++dbg_rounds;
             }
+            batch_now = batch_next;
         }
+        m->spec_rounds_hint = static_cast<uint32_t>(std::min<uint64_t>(dbg_rounds + 1, kBatch));  // (+ the round that finds nothing left)
         // every sample's start in its pair's stream is known (on the device): one walker per (pair, sample), results in place
         S_TRY(launch_final_walk(view, d_tab_off, band_half, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipMemcpyAsync(h_states, d_states, n * sizeof(SpecPairState), hipMemcpyDeviceToHost, m->stream));
