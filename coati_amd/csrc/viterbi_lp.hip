@@ -341,22 +341,59 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
     uint32_t i = la, j = lb;  // matrix coordinates of the last cell (gap_len 1: body cell (i-1, j-1))
     uint64_t pos = pd.ops_off + la + lb;
     int st = (i < 1 && j < 1) ? kWalkEnd : start_state;
+    // The decision words along the path were written tens of milliseconds ago: every iteration's lookup is a miss all the way
+    // to HBM, ~0.75 us, and a real pair has thousands of runs (the reference's 160 kb sample: 9 521 runs, 10 333 iterations, ~8 ms
+    // of a 44.6-ms launch).  So every 64 diagonal moves the wavefront ASKS for the words of the diagonal 64 ... 230 moves ahead
+    // -- 26 groups of steps x their 5 rows, two loads per lane, nobody waits for them (their values are folded into `sink` one
+    // window later) -- and the lookups find them in the L2.
+    uint32_t pf_window = 0xffffffffu, pf0 = 0u, pf1 = 0u, sink = 0u;
     while(st != kWalkEnd) {
         const uint32_t di = st != COATI_HIP_OP_INS ? 1u : 0u, dj = st != COATI_HIP_OP_DEL ? 1u : 0u;
         const uint32_t step = static_cast<uint32_t>(lane) + 1u;
         const bool valid = di * step <= i && dj * step <= j;
         const uint32_t ci = i - di * step, cj = j - dj * step;  // where the walk is after `step` more moves of kind st
         int next = kWalkEnd;
-        if(valid && ci >= 1 && cj >= 1) {
+        const bool body = valid && ci >= 1 && cj >= 1;
+        uint32_t word = 0u, shift = 0u;
+        if(body) {  // the lookup's load first ...
             const uint32_t bi = ci - 1, bj = cj - 1;
             const uint32_t strip = bj >> lg_cols, colin = bj & ((1u << lg_cols) - 1u), t = colin >> lgW, c = colin & (W - 1u);
             const uint32_t kstep = bi + t, g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
             const uint32_t* __restrict__ grp = fl + (strip * sd + static_cast<uint64_t>(g) * kPairDwords + t);
             if(st == COATI_HIP_OP_INS) {  // (wave-uniform)
-                next = ((grp[4 * kWave] >> (31u - ((q << lgW) + c))) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+                word = grp[4 * kWave];
+                shift = 31u - ((q << lgW) + c);
             } else {
                 const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
-                const uint32_t two = (grp[half * (2u * kWave) + (st == COATI_HIP_OP_DEL ? kWave : 0)] >> (30u - 2u * ((tt << lgW) + c))) & 3u;
+                word = grp[half * (2u * kWave) + (st == COATI_HIP_OP_DEL ? kWave : 0)];
+                shift = 30u - 2u * ((tt << lgW) + c);
+            }
+        }
+        // ... then the requests for the words further ahead (loads retire in order: issued BEFORE the lookup they would make it
+        // wait for memory too) ...
+        if(((i + j) >> 7) != pf_window) {  // (wave-uniform)
+            pf_window = (i + j) >> 7;
+            sink ^= pf0 ^ pf1;  // last window's loads: long since back
+            pf0 = pf1 = 0u;
+#pragma unroll
+            for(uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t m = static_cast<uint32_t>(lane) / 5u + 13u * half, row = static_cast<uint32_t>(lane) % 5u;
+                const uint32_t ahead = 64u + (m * 32u) / 5u;  // moves along the diagonal: a group of 8 steps is 6.4 of them (W = 4)
+                if(i > ahead && j > ahead) {
+                    const uint32_t bi = i - ahead - 1u, bj = j - ahead - 1u;
+                    const uint32_t strip = bj >> lg_cols, t = (bj & ((1u << lg_cols) - 1u)) >> lgW, g = (bi + t) >> lg_mc;
+                    const uint32_t v = fl[strip * sd + static_cast<uint64_t>(g) * kPairDwords + row * kWave + t];
+                    if(half == 0) pf0 = v;
+                    else pf1 = v;
+                }
+            }
+        }
+        // ... then the lookup's value
+        if(body) {
+            if(st == COATI_HIP_OP_INS) {
+                next = ((word >> shift) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+            } else {
+                const uint32_t two = (word >> shift) & 3u;
                 next = !(two & 2u) ? COATI_HIP_OP_MATCH : ((two & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL);
             }
         } else if(valid && (ci >= 1 || cj >= 1)) {  // a margin cell: by formula (align_pair.cc:82-91)
@@ -374,10 +411,13 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
         j -= dj * moves;
         if(run < kWave) st = __builtin_amdgcn_readlane(next, static_cast<int>(run));
     }
+    sink ^= pf0 ^ pf1;
     if(lane == 0) {
         ops_start[pair] = pos;
         ops_len[pair] = static_cast<uint32_t>(pd.ops_off + la + lb - pos);
     }
+    // (keeps the requests above alive: no lane has this number)
+    if(lane == 64 + static_cast<int>(sink & 1u)) ops_len[pair] = sink;
 }
 
 __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
