@@ -174,8 +174,9 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         // (How many: six, then six more ... -- or, when this model has sampled before, as many as that call needed and then two at
         // a time: a call of 13 rounds otherwise pays for 18 and a third synchronisation.)
         constexpr uint32_t kBatch = 24;
-        uint32_t batch_now = m->spec_rounds_hint != 0 ? std::min<uint32_t>(m->spec_rounds_hint, kBatch) : 6u;
-        const uint32_t batch_next = m->spec_rounds_hint != 0 ? 2u : 6u;
+        const bool hinted = m->spec_rounds_hint != 0 && n_samples <= 2 * m->spec_rounds_samples && m->spec_rounds_samples <= 2 * n_samples;
+        uint32_t batch_now = hinted ? std::min<uint32_t>(m->spec_rounds_hint, kBatch) : 6u;
+        const uint32_t batch_next = hinted ? 2u : 6u;
         const uint32_t max_width = widest;
         void* host_block = nullptr;
         S_TRY(model_pinned(m, kBatch * sizeof(SpecRound) + n * sizeof(SpecPairState) + 64, &host_block));
@@ -201,6 +202,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             batch_now = batch_next;
         }
         m->spec_rounds_hint = static_cast<uint32_t>(std::min<uint64_t>(dbg_rounds + 1, kBatch));  // (+ the round that finds nothing left)
+        m->spec_rounds_samples = n_samples;
         // every sample's start in its pair's stream is known (on the device): one walker per (pair, sample), results in place
         S_TRY(launch_final_walk(view, d_tab_off, band_half, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipMemcpyAsync(h_states, d_states, n * sizeof(SpecPairState), hipMemcpyDeviceToHost, m->stream));
