@@ -92,7 +92,10 @@ __host__ __device__ inline uint32_t ck_parts_short_last(uint8_t v_parts) { retur
 // of the cut pairs, so short last parts shorten the ragged end while long first parts keep the hand-overs few.
 __host__ __device__ inline uint32_t ck_part_cut(uint32_t chunks, uint32_t parts, uint32_t p, bool taper, uint32_t short_last = 0) {
     if(p >= parts) return chunks;
-    if(!taper) return p * (chunks + short_last) / parts;  // (short_last: the first parts share what the last one gives up)
+    if(!taper) {  // (short_last: the first parts share what the last one gives up; no part is ever left without a chunk)
+        const uint32_t cut = p * (chunks + short_last) / parts, cap = chunks > parts - p ? chunks - (parts - p) : 0u;
+        return cut < cap ? cut : cap;
+    }
     const uint32_t total = parts * (parts + 1u) / 2u, upto = p * parts - p * (p - 1u) / 2u;  // (p = 0: 0 - 0)
     return upto * chunks / total;
 }
@@ -106,6 +109,20 @@ __host__ __device__ inline void ck_part_range(uint32_t nsteps, uint8_t v_parts, 
 __host__ __device__ inline bool ck_parts_fit(uint32_t nsteps, uint32_t parts, bool taper) {
     const uint32_t chunks = (nsteps + 63u) / 64u;
     return taper ? chunks >= parts * (parts + 1u) / 2u && chunks >= 2u * parts : chunks >= 2u * parts;
+}
+// the largest shortening <= want of the last part that leaves EVERY part of the real cut (ck_part_cut) at least two chunks:
+// the last part begins at (parts - 1) * (chunks + sl) / parts, which reaches `chunks` when (parts - 1) * sl >= chunks
+__host__ __device__ inline uint32_t ck_fit_short_last(uint32_t chunks, uint32_t parts, uint32_t want) {
+    if(parts < 2u) return 0u;
+    for(uint32_t sl = want < 7u ? want : 7u; sl > 0u; --sl) {
+        bool ok = true;
+        for(uint32_t p = 0; p < parts && ok; ++p) {
+            const uint32_t b = p * (chunks + sl) / parts, e = p + 1u == parts ? chunks : (p + 1u) * (chunks + sl) / parts;
+            ok = e >= b + 2u;
+        }
+        if(ok) return sl;
+    }
+    return 0u;
 }
 constexpr uint32_t kCkPartStateDwords = 3u * 64u;  // what a part leaves for the next besides the row checkpoint: per lane xlast_old, zlast, table row
 

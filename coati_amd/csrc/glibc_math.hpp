@@ -14,6 +14,13 @@
 //                products are fused) is the one that build has.
 //   log1pf       sysdeps/ieee754/flt-32/s_log1pf.c -- the fdlibm (Sun) algorithm in float; no FMA
 //                variant exists.
+// Licence of what is restated: glibc is LGPL-2.1-or-later; e_expf.c / e_logf.c carry the ARM optimized-routines
+// notice (Copyright (C) 2017-2022 Free Software Foundation / Arm Ltd., LGPL-2.1-or-later in glibc, MIT OR
+// Apache-2.0 WITH LLVM-exception upstream), s_log1pf.c the fdlibm notice ("Copyright (C) 1993 by Sun
+// Microsystems, Inc. ... Permission to use, copy, modify, and distribute this software is freely granted,
+// provided that this notice is preserved").  What is here is a re-derivation of the published ALGORITHMS
+// (polynomial coefficients and table values are mathematical constants of those algorithms) written for the
+// device, not a copy of glibc's source text; the constants' provenance is the files named above.
 // Parity is pinned, not assumed: tools/libm_check.cc compares these restatements (compiled for the
 // host) with the container's libm on EVERY float of the ranges the path can produce -- expf on
 // [-104, 0] (1 120 927 745 inputs), log1pf on [0, 1] (1 065 353 217), logf on [2^-126, 4]

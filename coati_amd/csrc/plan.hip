@@ -400,7 +400,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                     // (the last part shorter by what its wavefront spends on the pair's traceback: as in the resident plan below)
                     const uint32_t chunks = (d.la + (std::min<uint32_t>(kStrip, d.lb) + kW - 1) / kW - 1 + 63u) / 64u;
                     const uint32_t want = std::min<uint32_t>(7u, (3u * d.lb + 500u) / 1000u);
-                    const uint32_t sl = chunks >= want + 2u * opts->tail_parts + 2u ? want : 0u;
+                    const uint32_t sl = ck_fit_short_last(chunks, opts->tail_parts, want);  // (every part keeps >= 2 chunks of the REAL cut)
                     d.v_parts = static_cast<uint8_t>(opts->tail_parts | (sl << 4));
                     cut.push_back(p);
                 } else {
@@ -501,7 +501,7 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                 const uint32_t chunks = (nsteps + 63u) / 64u;
                 // (with the traceback as an item of its own -- COATI_HIP_CK_WALK_ITEMS -- the last part is a part like the others)
                 const uint32_t want = walk_items ? 0u : env.ck_split_set ? short_last : std::min<uint32_t>(7u, (3u * d.lb + 500u) / 1000u);
-                const uint32_t sl = (!taper && chunks >= want + 2u * static_cast<uint32_t>(parts) + 2u) ? want : 0u;
+                const uint32_t sl = taper ? 0u : ck_fit_short_last(chunks, static_cast<uint32_t>(parts), want);  // (every part keeps >= 2 chunks of the REAL cut)
                 d.v_parts = static_cast<uint8_t>(parts | (taper ? kCkPartsTaper : 0u) | (sl << 4));
                 cut.push_back(order[q]);
             }

@@ -2,10 +2,13 @@
 //
 // C-ABI shim over the *unmodified* reference DP engine, compiled from the
 // sources where they lie under /root/reference (see oracle/Makefile, target
-// `_ref`).  It exists only in the build container: the GPU box has no
-// /root/reference, so nothing at run time there may need this library.  It is
-// used (a) to pin oracle/coati_oracle.cc bit-for-bit against the reference and
-// (b) by tools/make_golden.py to generate the fixtures under tests/golden/.
+// `ref`).  It can only be BUILT in the build container (the GPU box has no
+// /root/reference); the built oracle/_ref/libcoati_ref.so travels to the GPU box
+// with the snapshot like the product's own .so files and is used there as a
+// checker (tests) and as bench.py's cpu_baseline (kind "reference") only.  It is
+// used (a) to pin oracle/coati_oracle.cc bit-for-bit against the reference,
+// (b) by tools/make_golden*.py to generate the fixtures under tests/golden/, and
+// (c) as the timed CPU baseline beside the GPU numbers.
 //
 // Reference entry points driven here (src/include/coati/align_pair.hpp:157-182):
 //   viterbi_mem + traceback_viterbi   (align_pair.cc:195, :319)

@@ -103,7 +103,7 @@ def test_generic_kernel_still_serves_gap_len_2_and_3():
 
 
 def test_fast_forward_mode_within_tolerance():
-    """COATI_HIP_FORWARD_FAST=1 swaps the libm restatement for hardware exp2/log2 (7x faster fill);
+    """COATI_HIP_FORWARD_FAST=1 swaps the libm restatement for hardware exp2/log2 (3.5x faster fill);
     the Forward and sampling suites must then still hold north_star's 1e-5 relative bound."""
     if os.environ.get("COATI_HIP_FORWARD_FAST") or os.environ.get("COATI_HIP_FORCE_GENERIC"):
         pytest.skip("already inside a child run")

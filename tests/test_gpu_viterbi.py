@@ -444,7 +444,8 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
 
 
 @pytest.mark.parametrize("walk_items", ["0", "1"])
-@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t", "40,3,s3", "60,2,s7", "60,4,s1"])
+@pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t", "40,3,s3", "60,2,s7", "60,4,s1",
+                                  "60,4,s5", "60,8,s3", "60,8,s7"])  # (round 6: shortenings the old guard let empty the last part)
 def test_last_pairs_cut_into_row_parts(hip, oracle, kernel_choice, monkeypatch, plan, walk_items):
     """viterbi_ck cuts the last pairs of a large batch's LPT order into row parts (own work items; a part leaves
     the lane state at a 64-step boundary, whichever wavefront takes the next part continues -- abi.hip "the ragged

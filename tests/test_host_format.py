@@ -5,6 +5,8 @@ from pathlib import Path
 
 import pytest
 
+pytestmark = pytest.mark.host_answers  # also run under `-m gpu` (tests/conftest.py)
+
 ROOT = Path(__file__).resolve().parent.parent
 BIN = ROOT / "coati_amd" / "_build" / "coati-format"
 

@@ -16,6 +16,7 @@ KNOWN = json.loads((GOLD / "reference_known_answers.json").read_text())
 BIN = ROOT / "coati_amd" / "_build"
 
 
+@pytest.mark.host_answers
 def test_extract_file_type_known_answers():
     """src/lib/utils.cc:657-676."""
     for path, want in (("foo.bar", ("foo.bar", ".bar")), ("my:foo.bar", ("foo.bar", ".my")), (".bar", (".bar", "")),
@@ -78,6 +79,7 @@ def test_json_format(tmp_path):
     assert host.json_number(0.0) == "0.0" and host.json_number(2.0) == "2.0" and host.json_number(1.5) == "1.5"
 
 
+@pytest.mark.host_answers
 def test_alignment_score_known_answers():
     """align_marginal.cc:489-508: 19 scores, doctest::Approx."""
     for anc, des, want in KNOWN["alignment_score"]:
@@ -108,6 +110,7 @@ def test_alignment_score_equals_viterbi_score_on_golden_alignments(oracle):
     assert n > 50
 
 
+@pytest.mark.host_answers
 def test_user_rate_matrix_csv(tmp_path):
     """--sub (io.cc:48-88): branch length, then 3721 'cod,cod,rate' lines -> exp(Q t)."""
     sense = [c for c in range(64) if c not in (48, 50, 56)]
@@ -155,6 +158,7 @@ def doctest_approx(a, b):
     return np.abs(a - b) < float(np.finfo(np.float32).eps) * 100 * (1.0 + np.maximum(np.abs(a), np.abs(b)))
 
 
+@pytest.mark.host_answers
 def test_parse_matrix_csv_reference_doctest(tmp_path):
     """src/lib/io.cc:92-172: parse_matrix_csv of the mg94Q CSV == mg94_p(0.0133, 0.2, pi) entry by entry (Approx);
     a file that cannot be opened and a file with one line too many are errors."""

@@ -5,6 +5,8 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+
+pytestmark = pytest.mark.host_answers  # also run under `-m gpu` (tests/conftest.py)
 import scipy.linalg
 
 from coati_amd import host

@@ -2,6 +2,8 @@
 insertion columns, against the reference's own doctest cases (tree.cc, insertions.cc).  No GPU."""
 import pytest
 
+pytestmark = pytest.mark.host_answers  # also run under `-m gpu` (tests/conftest.py)
+
 from coati_amd import host
 
 O, C = 111, 99  # open / closed insertion flags
