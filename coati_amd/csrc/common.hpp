@@ -139,7 +139,16 @@ constexpr uint32_t kCkPartStateDwords = 3u * 64u;  // what a part leaves for the
 // step q (0..mC-1) of the group, column c at bit 31 - (q*W + c).
 // (W = 16: one step per A/B dword, even/odd step = first/second half, C = two steps.)
 // Every store is a fully coalesced 256-byte row: 5 bits per DP cell.
+// 3 columns per lane (viterbi_lp only, round 6): 3 does not divide the 32-bit words above, so the bits are kept PER COLUMN, in
+// groups of 16 steps, LANE-major, kLp3GroupDwords = 512 dwords (2 048 bytes) per group:
+//   [g*512 +       3*lane + c]  A of column c (dword: step tt of the group at bits 31-2tt, 30-2tt)
+//   [g*512 + 192 + 3*lane + c]  B of column c (same positions)
+//   bytes g*2048 + 1536 + 8*lane + 2*c: C of column c (a 16-bit short: step tt at bit 15-tt; 2 bytes per lane unused)
+// -- 5.33 bits per cell, three stores per 16 steps (12-, 12- and 8-byte pieces per lane; the 4-column layout: ten), and the
+// cells a walk looks up along a diagonal -- a lane's three columns, the neighbouring lanes -- share a cache line.
+constexpr uint32_t kLp3GroupDwords = 512;
 __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
+    if(w == 3u) return static_cast<uint64_t>((la + kWave - 1 + 15u) / 16u) * kLp3GroupDwords;
     const uint32_t mc = 32u / w;
     return static_cast<uint64_t>((la + kWave - 1 + mc - 1) / mc) * kPairDwords;
 }
@@ -244,6 +253,13 @@ __device__ __forceinline__ CellAddr cell_addr(const PairDesc& pd, uint32_t bi, u
     }
     const uint32_t full = kWave * pd.v_wmain;
     uint32_t strip = bj / full, w = pd.v_wmain;
+    if(pd.v_wmain == 3u) {  // per-column words (layout above); every strip of the pair has this shape
+        const uint32_t colin = bj - strip * full, t = colin / 3u, c = colin - 3u * t;
+        const uint32_t kstep = bi + t, g = kstep >> 4, tt = kstep & 15u;
+        const uint64_t base = pd.flags_off + strip * strip_dwords(pd.la, 3u) + static_cast<uint64_t>(g) * kLp3GroupDwords;
+        return {base + 3u * t + c, base + 3u * kWave + 3u * t + c, base + 6u * kWave + 2u * t + (c >> 1),
+                30u - 2u * tt, ((c & 1u) << 4) + 15u - tt};
+    }
     if(strip + 1 >= pd.v_strips) {
         strip = pd.v_strips - 1;
         w = pd.v_wlast;
@@ -521,6 +537,7 @@ struct EnvOptions {
     bool sample_table_off = false;   // COATI_HIP_SAMPLE_TABLE=0: exact-stream sampler without the step table
     bool fwd_wide_build = false;     // COATI_HIP_FWD_WIDE_BUILD: forward_l1's 16-column build for narrow strips too
     bool lp_pairtab_off = false;     // COATI_HIP_LP_PAIRTAB=0
+    bool lp3_off = false;            // COATI_HIP_LP3=0: the planner never chooses 3-column strips (A/B: the round-5 plan)
     bool forward_fast = false;       // COATI_HIP_FORWARD_FAST: hardware exp / log in the log-semiring plus (not a parity mode)
     bool timing = false;             // COATI_HIP_TIMING: host stage times on stderr
     bool pipe_timing = false;        // COATI_HIP_PIPE_TIMING: timeline of a one-shot call on stderr

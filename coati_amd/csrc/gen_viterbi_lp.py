@@ -9,7 +9,18 @@ instructions per step -- and there v_pk_add_f32 does two of the cell's additions
 one (profiles/r03/ubench_issue_model.txt, "pure v_pk_add_f32": 5.1 cycles alone, like v_add_f32).
 The packed form needs its operands in even-aligned register PAIRS and the maxima read the halves
 of those pairs: inline-asm operands cannot name half of a 64-bit operand, so the block names its
-registers itself (COATI_LP_* pins them in viterbi_lp.hip).  Two shapes: 4 and 2 columns per lane.
+registers itself (COATI_LP_* pins them in viterbi_lp.hip).  Three shapes: 4, 3 and 2 columns per lane.
+
+3 columns per lane (round 6: 834 strips for a 160 kb pair where 4 columns make 626 and 2 columns 1 251 -- more than the
+1 024 SIMDs) do not divide the 32-bit decision words of the 4- and 2-column layout, so that shape keeps its decision bits
+PER COLUMN: nine accumulators (A, B, C of each column) in pinned consecutive registers, one group per 16-step block,
+stored LANE-major with three instructions -- [A0 A1 A2] and [B0 B1 B2] as dwordx3, the three 16-bit C words packed into a
+dwordx2 (common.hpp: "3 columns per lane"; a vector memory instruction costs a lone wavefront ~4 ordinary ones, and the
+walk along a diagonal finds a lane's three columns in one cache line).  Same five bits per cell, same deposits.
+
+The strip's right boundary leaves as ONE store per step: [Z : X] of lane 63's last column (v28 and a copy of X in v29, which
+is free once column 0 has read the Z handed in) into the interleaved boundary array of viterbi_lp.hip, and a chunk of 16
+rows arrives with one dwordx2 load per lane.
 
 One step of one lane (its 4 columns of one row), in the reference's evaluation order
 (src/lib/align_pair.cc:97-124, gap_len 1) -- the same fp32 operations as viterbi_cell.hpp's
@@ -42,6 +53,9 @@ T1, T2, T3, T4, T5 = 32, 34, 36, 38, 40
 TS, ADDR = 42, 43
 SA, SB = 44, 48                # the two score sets (v44.., v48..): a step reads one and gathers the next step's into the other
 PINNED_CLOBBERS = [29, 30, 31] + list(range(32, 44))
+# 3 columns per lane: A of columns 0..2 in v52..v54, B in v56..v58, C in v62, v63, v61; v60 = C0 | C1 << 16 at the block's end,
+# so that v[52:54], v[56:58], v[60:61] are what the three stores send (tuples even-aligned: gfx90a+)
+ACC3_A, ACC3_B, ACC3_C, ACC3_PACK = [52, 53, 54], [56, 57, 58], [62, 63, 61], 60
 
 
 def pair(r):
@@ -54,6 +68,7 @@ def step(W, j, first, bnd, pairtab):
     pairtab: the scores of two adjacent columns come from the 16-entry pair table (A/C/G/T descendants) with ONE
     ds_read_b64 -- an LDS instruction costs a lone wavefront ~18 cycles of issue, four times a vector instruction"""
     L = []
+    colacc = W == 3  # decision bits per column (aa0.., ab0.., ac0..) instead of three accumulators shared by the columns
     P = [PBASE + 2 * c for c in range(W - 1)]
     PA, PB = PBASE + 2 * (W - 1), PBASE + 2 * W
     even = j % 2 == 0
@@ -86,11 +101,15 @@ def step(W, j, first, bnd, pairtab):
         for h in range(W // 2):  # (pair table rows are twice as long: 2 x the row offset)
             L.append(f"v_lshl_add_u32 v{ADDR}, {ar_dst}, 1, %[blp{h}]")
             L.append(f"ds_read_b64 v[{nxt(2 * h)[1:]}:{int(nxt(2 * h)[1:]) + 1}], v{ADDR}")
+        if W % 2:  # the odd column out: a single gather from the plain table
+            L.append(f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{W - 1}]")
+            L.append(f"ds_read_b32 {nxt(W - 1)}, v{ADDR}")
     else:
         for c in range(W):
             L.append(f"v_add_u32 v{ADDR}, {ar_dst}, %[bl{c}]")
             L.append(f"ds_read_b32 {nxt(c)}, v{ADDR}")
     for c in range(W):
+        aa, ab, ac = (f"v{ACC3_A[c]}", f"v{ACC3_B[c]}", f"v{ACC3_C[c]}") if colacc else ("%[aa]", "%[ab]", "%[ac]")
         rd = P[c] if c < W - 1 else cur3
         wr = P[c] if c < W - 1 else new3
         zsel = "op_sel:[1,0] op_sel_hi:[1,1]" if c == 0 else "op_sel:[0,0] op_sel_hi:[0,1]"
@@ -108,17 +127,28 @@ def step(W, j, first, bnd, pairtab):
             f"v_sub_f32 v{TS}, v{T2}, v{T1}",                                                 # z2 - z1
             f"v_max3_f32 v{wr}, v{T3}, v{T4}, v{T5}",                                         # X
             f"v_max3_f32 v{wr + 1}, v{T3 + 1}, v{T4 + 1}, v{T5 + 1}",                         # Y
-            f"v_alignbit_b32 %[ac], %[ac], v{TS}, 31",                                        # IM
+            f"v_alignbit_b32 {ac}, {ac}, v{TS}, 31",                                          # IM
             f"v_pk_add_f32 {pair(T3)}, {pair(T3)}, {pair(wr)} neg_lo:[0,1] neg_hi:[0,1]",     # [x1-X : y1-Y]
             f"v_pk_add_f32 {pair(T4)}, {pair(T4)}, {pair(wr)} neg_lo:[0,1] neg_hi:[0,1]",     # [x2-X : y2-Y]
-            f"v_alignbit_b32 %[aa], %[aa], v{T3}, 31",                                        # M1
-            f"v_alignbit_b32 %[aa], %[aa], v{T4}, 31",                                        # M2
-            f"v_alignbit_b32 %[ab], %[ab], v{T3 + 1}, 31",                                    # D1
-            f"v_alignbit_b32 %[ab], %[ab], v{T4 + 1}, 31",                                    # D2
+            f"v_alignbit_b32 {aa}, {aa}, v{T3}, 31",                                          # M1
+            f"v_alignbit_b32 {aa}, {aa}, v{T4}, 31",                                          # M2
+            f"v_alignbit_b32 {ab}, {ab}, v{T3 + 1}, 31",                                      # D1
+            f"v_alignbit_b32 {ab}, {ab}, v{T4 + 1}, 31",                                      # D2
         ]
-    if bnd:
-        L.append(f"buffer_store_dword v{new3}, %[offx], %[rs_out], %[so_out] offen offset:{4 * j + 4} sc1")
-        L.append(f"buffer_store_dword v{ZL}, %[offz], %[rs_out], %[so_out] offen offset:{4 * j} sc1")
+    if bnd:  # [Z : X] of the row lane 63 just finished, at float index 1 + 2 * row of the interleaved boundary array
+        L.append(f"v_mov_b32 v{ZL + 1}, v{new3}")
+        L.append(f"buffer_store_dwordx2 {pair(ZL)}, %[offx], %[rs_out], %[so_out] offen offset:{8 * j + 4} sc1")
+    if colacc:
+        # the group of this block, lane-major (common.hpp): [A0 A1 A2] at lane * 12, [B0 B1 B2] at 768 + lane * 12,
+        # [C0 | C1 << 16, C2] at 1536 + lane * 8 -- 2 048 bytes per group.  s_nop 1: a store of more than 64 bits reads its data
+        # registers late, and the next block's deposits write them
+        if j == 15:
+            L.append(f"v_perm_b32 v{ACC3_PACK}, v{ACC3_C[1]}, v{ACC3_C[0]}, %[sel_lo16]")
+            L.append(f"buffer_store_dwordx3 v[{ACC3_A[0]}:{ACC3_A[2]}], %[offb], %[rs_bits], %[so_bits] offen")
+            L.append(f"buffer_store_dwordx3 v[{ACC3_B[0]}:{ACC3_B[2]}], %[offb], %[rs_bits], %[so_bits] offen offset:768")
+            L.append(f"buffer_store_dwordx2 v[{ACC3_PACK}:{ACC3_PACK + 1}], %[offb2], %[rs_bits], %[so_bits] offen offset:1536")
+            L.append("s_nop 1")
+        return L
     # decision rows (layout: common.hpp): an A/B dword holds 16/W steps, a group of 32/W steps is 1280 bytes
     ma, mc = 16 // W, 32 // W
     group, q = j // mc, j % mc
@@ -134,13 +164,12 @@ def step(W, j, first, bnd, pairtab):
 # Step of the block before which the NEXT chunk's loads are issued: as late as the load latency (~0.6 us) allows, so
 # that a strip follows its left neighbour more closely (160 kb pair, 4 columns: at step 0 43.3 ms, 8: 42.5, 12: 42.4,
 # 14: 43.1, 15: 45.2 -- the block then ends waiting for them; 2-column steps are shorter: 8).
-LOAD_AT = {4: 12, 2: 8}
+LOAD_AT = {4: 12, 3: 10, 2: 8}
 
 
 def block(W, first, pairtab):
     bnd = not first
-    loads = ["buffer_load_dword %[nx], %[vin_x], %[rs_in], 0 offen sc1",
-             "buffer_load_dword %[nz], %[vin_z], %[rs_in], 0 offen sc1",
+    loads = ["buffer_load_dwordx2 %[nxz], %[vin_x], %[rs_in], 0 offen sc1",
              "buffer_load_ubyte %[na], %[vin_a], %[rs_a], 0 offen"]
     L = []
     vmem_after = 0
@@ -171,7 +200,7 @@ def main():
         for w in LOAD_AT:
             LOAD_AT[w] = int(os.environ["COATI_LP_LOAD_AT"])
     text = "// GENERATED by gen_viterbi_lp.py -- do not edit (see that script for what the text does)\n"
-    for W in (2, 4):
+    for W in (2, 3, 4):
         for pairtab in (False, True):
             first, n_first = block(W, True, pairtab)
             main_, n_main = block(W, False, pairtab)

@@ -265,8 +265,11 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // and hold the whole pipeline back: 66 ms against 44.  viterbi_lp only (COATI_HIP_L1_LP=0 keeps viterbi_l1).
         const bool lp_allowed = !env.l1_lp_off && !env.l1_progress;
         const bool ck_forced = env.viterbi_ck || (opts != nullptr && (opts->force_w_main != 0 || opts->force_ck));
+        // Round 6: 3 columns per lane where 2 do not fit the SIMDs but 3 do (the 160 kb pair: 834 strips; 4 columns leave 398 of
+        // the 1 024 SIMDs without a strip): a 3-column step is 64 instructions against 81, the chain grows by lb/3 - lb/4 steps.
         if(lp_allowed && !ck_forced && w_main == 4 && count_items(2) <= kSimds) w_main = 2;
-        if(const int w = env.strip_w; w == 4 || w == 8 || w == 16 || (w == 2 && lp_allowed && !ck_forced)) w_main = static_cast<uint32_t>(w);
+        else if(lp_allowed && !ck_forced && !env.lp3_off && w_main == 4 && count_items(3) <= kSimds) w_main = 3;
+        if(const int w = env.strip_w; w == 4 || w == 8 || w == 16 || ((w == 2 || w == 3) && lp_allowed && !ck_forced)) w_main = static_cast<uint32_t>(w);
         if(opts != nullptr && opts->force_w_main != 0) w_main = opts->force_w_main;
         // Which gap_len-1 kernel.  viterbi_ck (lean fill + checkpoint traceback) wins where the fill
         // dominates; viterbi_l1 (decision bits written by the fill) keeps two regimes, both measured

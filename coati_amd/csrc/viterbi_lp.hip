@@ -1,6 +1,7 @@
 // viterbi_lp: the gap_len-1 Viterbi fill for a FEW LONG pairs (BASELINE configs[2]: one 160 kb pair) --
-// the batches whose strip plan has fewer strips than the GPU has SIMDs, so that every strip is 4 columns per
-// lane wide and every wavefront is alone on its SIMD.  Same recurrence, same five decision bits per cell in
+// the batches whose strip plan has fewer strips than the GPU has SIMDs, so that every strip is 4, 3 or 2 columns per
+// lane wide and every wavefront is alone on its SIMD (3 columns, round 6: the 160 kb pair is 834 strips on 1 024 SIMDs
+// where 4 columns leave 398 SIMDs without one; its decision words are kept per column, common.hpp).  Same recurrence, same five decision bits per cell in
 // the same HBM layout as viterbi_l1.hip (the traceback of common.hpp reads both), same strip pipeline through
 // self-validating boundary values; what differs is how a step is issued.
 //
@@ -51,37 +52,45 @@ struct LpStrip {
     uint32_t bl[W];   // LDS byte address of the lane's column c in table row 0
     uint32_t blp[W / 2];  // ... of the lane's column pair (2h, 2h+1) in row 0 of the pair table
     bool pairtab;     // (wave-uniform) the strip's descendant columns are all A/C/G/T and the launch has pair tables
-    uint32_t offx, offz, offb;  // per-lane offsets: boundary X / Z stores (lane 63, or kLpDrop), decision rows
+    uint32_t offx, offb;  // per-lane offsets: the boundary store (lane 63: 0, else kLpDrop), decision rows (3 columns: lane * 12)
+    uint32_t offb2;       // (3 columns) the lane's offset in the group's C block: lane * 8
     u32x4 rs_in, rs_out, rs_bits, rs_a;
     float mx[W], my[W];  // the lane's margin-row state (taken at step == lane)
+};
+
+// 3 columns per lane: the decision bits of each column in accumulators of its own (common.hpp: the per-column layout)
+struct LpColAcc {
+    uint32_t a[3], b[3], c[3];
 };
 
 // 16 wavefront steps from `kbase`.  In: the chunk (bx, bz, ach: lane j < 16 holds the strip's left boundary of row
 // kbase + j and the table row offset of ancestor row kbase + j + 1).  Out: the raw next chunk (rows kbase + 16 ...).
 template <int W, bool kFirst>
 __device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st, uint32_t& arow, float (&s)[W], uint32_t kbase,
-                                         int lane, uint32_t la, float bx, float bz, uint32_t ach, uint32_t& nx, uint32_t& nz,
-                                         uint32_t& na) {
-    static_assert(W == 4 || W == 2, "gen_viterbi_lp.py writes these two shapes");
+                                         int lane, uint32_t la, float bx, float bz, uint32_t ach, uint64_t& nxz, uint32_t& na,
+                                         LpColAcc& ca) {
+    static_assert(W == 4 || W == 3 || W == 2, "gen_viterbi_lp.py writes these three shapes");
     uint32_t arb;
     const uint32_t next = kbase + kLpRows + static_cast<uint32_t>(lane);
-    const uint32_t vin_x = next * 4u, vin_z = (la + 1u + next) * 4u, vin_a = next + 1u;
-    const uint32_t so_bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase / (32u / W)) * (kPairDwords * 4u))));
+    // (the interleaved boundary array, below: row r's pair (X of row r - 1, Z of row r) is floats 2r, 2r + 1)
+    const uint32_t vin_x = next * 8u, vin_a = next + 1u;
+    const uint32_t so_bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(W == 3 ? (kbase / kLpRows) * (kLp3GroupDwords * 4u) : (kbase / (32u / (W == 3 ? 4 : W))) * (kPairDwords * 4u))));
     const uint32_t lrel = static_cast<uint32_t>(lane) - kbase;  // (first blocks) the lane starts at step kbase + lrel
-    // (main blocks) lane 63 did body row kbase + j - 63 at step j: X of its last column goes to bnd_x[row + 1], Z to bnd_z[row]
-    const uint32_t so_out = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase - (kWave - 1u)) * 4u)));
+    // (main blocks) lane 63 did body row kbase + j - 63 at step j: [Z : X] of its last column go to floats 1 + 2 row, 2 + 2 row
+    const uint32_t so_out = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((kbase - (kWave - 1u)) * 8u)));
+    const uint32_t sel_lo16 = 0x05040100u;  // v_perm_b32: the low halves of two registers side by side
     // [X:Y] of column c in v[8+2c : 9+2c]; the last column's pair alternates with the pair after it, whose low half is
     // xlast_old between blocks; the scores in v44.. (the other set, v48.., is scratch) -- gen_viterbi_lp.py
-#define COATI_LP_COMMON_OUT                                                                                                   \
-    "+{v28}"(st.zlast), "+{v44}"(s[0]), "+{v45}"(s[1]), [ara] "+v"(arow), [arb] "=&v"(arb), [aa] "+v"(st.acc[ACC_A]),          \
-        [ab] "+v"(st.acc[ACC_B]), [ac] "+v"(st.acc[ACC_C]), [nx] "=&v"(nx), [nz] "=&v"(nz), [na] "=&v"(na)
+#define COATI_LP_STATE_OUT                                                                                                    \
+    "+{v28}"(st.zlast), "+{v44}"(s[0]), "+{v45}"(s[1]), [ara] "+v"(arow), [arb] "=&v"(arb), [nxz] "=&v"(nxz), [na] "=&v"(na)
+#define COATI_LP_COMMON_OUT COATI_LP_STATE_OUT, [aa] "+v"(st.acc[ACC_A]), [ab] "+v"(st.acc[ACC_B]), [ac] "+v"(st.acc[ACC_C])
 #define COATI_LP_COMMON_IN                                                                                                    \
     "{v2}"(sp.kv.go), "{v3}"(sp.kv.ng), "{v4}"(sp.kv.ge), "{v5}"(sp.kv.gs), [bx] "v"(bx), [bz] "v"(bz), [ach] "v"(ach),       \
         [bl0] "v"(sp.bl[0]), [bl1] "v"(sp.bl[1]), [blp0] "v"(sp.blp[0]), [offb] "v"(sp.offb), [vin_x] "v"(vin_x),             \
-        [vin_z] "v"(vin_z), [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits), [rs_a] "s"(sp.rs_a),        \
-        [so_bits] "s"(so_bits)
+        [vin_a] "v"(vin_a), [rs_in] "s"(sp.rs_in), [rs_bits] "s"(sp.rs_bits), [rs_a] "s"(sp.rs_a), [so_bits] "s"(so_bits)
 #define COATI_LP_FIRST_IN [lrel] "v"(lrel), [mx0] "v"(sp.mx[0]), [mx1] "v"(sp.mx[1]), [my0] "v"(sp.my[0]), [my1] "v"(sp.my[1])
-#define COATI_LP_MAIN_IN [offx] "v"(sp.offx), [offz] "v"(sp.offz), [rs_out] "s"(sp.rs_out), [so_out] "s"(so_out)
+#define COATI_LP_MAIN_IN [offx] "v"(sp.offx), [rs_out] "s"(sp.rs_out), [so_out] "s"(so_out)
     if constexpr(W == 4) {
 #define COATI_LP4_OUT                                                                                                         \
     "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.X[2]), "+{v13}"(st.Y[2]),          \
@@ -104,6 +113,31 @@ __device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st,
 #undef COATI_LP4_IN
 #undef COATI_LP4_CLOBBERS
 #undef COATI_LP4_FIRST_IN
+    } else if constexpr(W == 3) {
+        // [X:Y] of columns 0, 1 in v[8:9], v[10:11]; column 2 alternates between v[12:13] and v[14:15] (v14 = xlast_old between blocks);
+        // the accumulators where the block's three decision stores take them from (gen_viterbi_lp.py: ACC3_*)
+#define COATI_LP3_OUT                                                                                                         \
+    "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.X[2]), "+{v13}"(st.Y[2]),          \
+        "+{v14}"(st.xlast_old), "+{v46}"(s[2]), COATI_LP_STATE_OUT, "+{v52}"(ca.a[0]), "+{v53}"(ca.a[1]), "+{v54}"(ca.a[2]),     \
+        "+{v56}"(ca.b[0]), "+{v57}"(ca.b[1]), "+{v58}"(ca.b[2]), "+{v62}"(ca.c[0]), "+{v63}"(ca.c[1]), "+{v61}"(ca.c[2])
+#define COATI_LP3_IN COATI_LP_COMMON_IN, [bl2] "v"(sp.bl[2]), [offb2] "v"(sp.offb2), [sel_lo16] "s"(sel_lo16)
+#define COATI_LP3_CLOBBERS COATI_LP_SCRATCH_CLOBBERS, "v15", "v48", "v49", "v50", "v60", "memory"
+#define COATI_LP3_FIRST_IN COATI_LP3_IN, COATI_LP_FIRST_IN, [mx2] "v"(sp.mx[2]), [my2] "v"(sp.my[2])
+        if(sp.pairtab) {  // (wave-uniform)
+            if constexpr(kFirst)
+                asm volatile(COATI_LP3P_BLOCK_FIRST_ASM : COATI_LP3_OUT : COATI_LP3_FIRST_IN : COATI_LP3_CLOBBERS, "vcc");
+            else
+                asm volatile(COATI_LP3P_BLOCK_MAIN_ASM : COATI_LP3_OUT : COATI_LP3_IN, COATI_LP_MAIN_IN : COATI_LP3_CLOBBERS);
+        } else {
+            if constexpr(kFirst)
+                asm volatile(COATI_LP3_BLOCK_FIRST_ASM : COATI_LP3_OUT : COATI_LP3_FIRST_IN : COATI_LP3_CLOBBERS, "vcc");
+            else
+                asm volatile(COATI_LP3_BLOCK_MAIN_ASM : COATI_LP3_OUT : COATI_LP3_IN, COATI_LP_MAIN_IN : COATI_LP3_CLOBBERS);
+        }
+#undef COATI_LP3_OUT
+#undef COATI_LP3_IN
+#undef COATI_LP3_CLOBBERS
+#undef COATI_LP3_FIRST_IN
     } else {
 #define COATI_LP2_OUT "+{v8}"(st.X[0]), "+{v9}"(st.Y[0]), "+{v10}"(st.X[1]), "+{v11}"(st.Y[1]), "+{v12}"(st.xlast_old), COATI_LP_COMMON_OUT
 #define COATI_LP2_CLOBBERS COATI_LP_SCRATCH_CLOBBERS, "v13", "v48", "v49", "memory"
@@ -121,6 +155,7 @@ __device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st,
 #undef COATI_LP2_OUT
 #undef COATI_LP2_CLOBBERS
     }
+#undef COATI_LP_STATE_OUT
 #undef COATI_LP_COMMON_OUT
 #undef COATI_LP_COMMON_IN
 #undef COATI_LP_FIRST_IN
@@ -132,7 +167,7 @@ __device__ __forceinline__ void lp_block(const LpStrip<W>& sp, LaneState<W>& st,
 template <int W, bool kFirst>
 __device__ __forceinline__ void lp_tail_step(const LpStrip<W>& sp, LaneState<W>& st, uint32_t& arow, float (&s)[W],
                                              const uint32_t (&boff)[W], uint32_t lds_tab, uint32_t kstep, uint32_t kk, int lane,
-                                             uint32_t la, bool last_strip, uint32_t* fout, float* bnd_x, float* bnd_z, uint32_t ach,
+                                             uint32_t la, bool last_strip, uint32_t* fout, float* bnd_x, uint32_t ach,
                                              float bx, float bz) {
     constexpr uint32_t kMA = 16 / W, kMC = 32 / W;
     if constexpr(kFirst) {
@@ -158,8 +193,67 @@ __device__ __forceinline__ void lp_tail_step(const LpStrip<W>& sp, LaneState<W>&
     }
     const int r = static_cast<int>(kstep) - lane;
     if(!last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(la)) {
-        store_through(&bnd_x[r + 1], st.X[W - 1]);
-        store_through(&bnd_z[r], st.zlast);
+        store_through(&bnd_x[2 + 2 * r], st.X[W - 1]);
+        store_through(&bnd_x[1 + 2 * r], st.zlast);
+    }
+}
+
+// The same for 3 columns per lane, in plain C++ with the per-column accumulators: the block's operations in the block's order
+// (gen_viterbi_lp.py: step) -- every sum a single fp32 addition, the maxima left to right, the five tests as the sign bits of
+// z2 - z1, x1 - X, x2 - X, y1 - Y, y2 - Y.
+__device__ __forceinline__ uint32_t lp_sign(float v) { return __builtin_bit_cast(uint32_t, v) >> 31; }
+// one group of the per-column layout (common.hpp), the accumulators shifted left by `missing` steps (an incomplete last group)
+__device__ __forceinline__ void lp3_store_group(uint32_t* grp, int lane, const LpColAcc& ca, uint32_t missing) {
+#pragma unroll
+    for(int c = 0; c < 3; ++c) {
+        grp[3 * lane + c] = ca.a[c] << (2u * missing);
+        grp[3 * kWave + 3 * lane + c] = ca.b[c] << (2u * missing);
+        reinterpret_cast<uint16_t*>(grp + 6 * kWave)[4 * lane + c] = static_cast<uint16_t>(ca.c[c] << missing);
+    }
+}
+template <bool kFirst>
+__device__ __forceinline__ void lp3_tail_step(const LpStrip<3>& sp, LaneState<3>& st, LpColAcc& ca, uint32_t& arow, float (&s)[3],
+                                              const uint32_t (&boff)[3], uint32_t lds_tab, uint32_t kstep, uint32_t kk, int lane,
+                                              uint32_t la, bool last_strip, uint32_t* fout_strip, float* bnd_x, uint32_t ach, float bx,
+                                              float bz) {
+    if constexpr(kFirst) {
+        if(kstep == static_cast<uint32_t>(lane)) {
+#pragma unroll
+            for(int c = 0; c < 3; ++c) {
+                st.X[c] = sp.mx[c];
+                st.Y[c] = sp.my[c];
+            }
+        }
+    }
+    float diag = shift_in(st.xlast_old, read_lane(bx, static_cast<int>(kk)));
+    float zl = shift_in(st.zlast, read_lane(bz, static_cast<int>(kk)));
+    const uint32_t arow_next = shift_in(arow, read_lane(ach, static_cast<int>(kk)));
+    st.xlast_old = st.X[2];
+#pragma unroll
+    for(int c = 0; c < 3; ++c) {
+        const float m = diag + s[c];
+        const float z1 = m + sp.kv.go, m1 = m + sp.kv.ng;
+        const float z2 = zl + sp.kv.ge, i1 = zl + sp.kv.gs;
+        const float x1 = m1 + sp.kv.ng, y1 = m1 + sp.kv.go;
+        const float x2 = st.Y[c] + sp.kv.gs, y2 = st.Y[c] + sp.kv.ge;
+        const float x3 = i1 + sp.kv.ng, y3 = i1 + sp.kv.go;
+        const float x = __builtin_fmaxf(__builtin_fmaxf(x1, x2), x3), y = __builtin_fmaxf(__builtin_fmaxf(y1, y2), y3);
+        ca.c[c] = (ca.c[c] << 1) | lp_sign(z2 - z1);
+        ca.a[c] = (ca.a[c] << 2) | (lp_sign(x1 - x) << 1) | lp_sign(x2 - x);
+        ca.b[c] = (ca.b[c] << 2) | (lp_sign(y1 - y) << 1) | lp_sign(y2 - y);
+        zl = __builtin_fmaxf(z1, z2);
+        diag = st.X[c];
+        st.X[c] = x;
+        st.Y[c] = y;
+        s[c] = *reinterpret_cast<const __attribute__((address_space(3))) float*>(lds_tab + arow_next + boff[c]);
+    }
+    st.zlast = zl;
+    arow = arow_next;
+    if((kstep & 15u) == 15u) lp3_store_group(fout_strip + static_cast<uint64_t>(kstep >> 4) * kLp3GroupDwords, lane, ca, 0u);
+    const int r = static_cast<int>(kstep) - lane;
+    if(!last_strip && lane == kWave - 1 && r >= 0 && r < static_cast<int>(la)) {
+        store_through(&bnd_x[2 + 2 * r], st.X[2]);
+        store_through(&bnd_x[1 + 2 * r], st.zlast);
     }
 }
 
@@ -178,12 +272,13 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     const bool last_strip = strip + 1 == pd.v_strips;
     uint32_t* __restrict__ fout_strip = flags + pd.flags_off + strip * strip_dwords(la, W);
     uint32_t* __restrict__ fout = fout_strip + lane;
-    // strip-boundary columns (layout: viterbi_l1.hip fill_strip)
+    // strip-boundary columns, one array of 2 (la + 1) floats per boundary (the plan's size, viterbi_l1's too), INTERLEAVED here
+    // (round 6): float 0 = X of the margin row, floats 1 + 2r, 2 + 2r = Z, X of the strip's last column in row r -- so that a
+    // step's values leave with one 8-byte store and the pair the next strip needs for ITS row r (X of row r - 1: the diagonal
+    // input; Z of row r) are the aligned floats 2r, 2r + 1: one 8-byte load per row of a chunk
     const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
     float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
-    float* __restrict__ bnd_z = bnd_x + (la + 1);
     const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
-    const float* __restrict__ in_z = in_x + (la + 1);
     bool handoff_ok = true;
 
     uint32_t boff[W];
@@ -208,8 +303,8 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     for(int h = 0; h < W / 2; ++h) sp.blp[h] = lds_pair + (boff[2 * h] * 4u + boff[2 * h + 1]) * 2u;  // ((b0 * 4 + b1) * 8; boff = code * 4)
     const bool publisher = !last_strip && lane == kWave - 1;
     sp.offx = publisher ? 0u : kLpDrop;
-    sp.offz = publisher ? (la + 1u) * 4u : kLpDrop;
-    sp.offb = static_cast<uint32_t>(lane) * 4u;
+    sp.offb = static_cast<uint32_t>(lane) * (W == 3 ? 12u : 4u);
+    sp.offb2 = static_cast<uint32_t>(lane) * 8u;
     sp.rs_in = lp_rsrc(in_x, strip > 0 ? bstride * 4u : 0u);
     sp.rs_out = lp_rsrc(bnd_x, bstride * 4u);
     sp.rs_bits = lp_rsrc(fout_strip, strip_dwords(la, W) * 4u);
@@ -223,6 +318,9 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     for(int p = 0; p < kAccs; ++p) st.acc[p] = 0u;
     st.xlast_old = 0.0f;
     st.zlast = 0.0f;
+    LpColAcc ca;
+#pragma unroll
+    for(int c = 0; c < 3; ++c) ca.a[c] = ca.b[c] = ca.c[c] = 0u;
     uint32_t arow = lane == 0 ? static_cast<uint32_t>(a[0]) * (kTabStride * 4u) : 0u;
     float s[W];
 #pragma unroll
@@ -251,8 +349,8 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
                     }
                     __builtin_amdgcn_s_sleep(1);
                     if(mine) {
-                        xb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(in_x) + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        zb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(in_z) + crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        xb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(in_x) + 2u * crow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        zb = __hip_atomic_load(reinterpret_cast<const uint32_t*>(in_x) + 2u * crow + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if(all_there()) break;
                 }
@@ -272,25 +370,34 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     uint32_t kbase = 0;
     // (two loops, not one with a branch: the state stays in the registers the blocks name)
     for(; kbase < static_cast<uint32_t>(kWave) && kbase + kLpRows <= nsteps; kbase += kLpRows) {
-        uint32_t nx, nz, na;
-        lp_block<W, true>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
+        uint64_t nxz;
+        uint32_t na;
+        lp_block<W, true>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nxz, na, ca);
         // step 63 is lane 63's first row
         if(kbase + kLpRows == static_cast<uint32_t>(kWave) && publisher) {
-            store_through(&bnd_x[1], st.X[W - 1]);
-            store_through(&bnd_z[0], st.zlast);
+            store_through(&bnd_x[2], st.X[W - 1]);
+            store_through(&bnd_x[1], st.zlast);
         }
-        take_chunk(kbase + kLpRows, nx, nz, na);
+        take_chunk(kbase + kLpRows, static_cast<uint32_t>(nxz), static_cast<uint32_t>(nxz >> 32), na);
     }
     for(; kbase + kLpRows <= nsteps; kbase += kLpRows) {
-        uint32_t nx, nz, na;
-        lp_block<W, false>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nx, nz, na);
-        take_chunk(kbase + kLpRows, nx, nz, na);
+        uint64_t nxz;
+        uint32_t na;
+        lp_block<W, false>(sp, st, arow, s, kbase, lane, la, bx, bz, ach, nxz, na, ca);
+        take_chunk(kbase + kLpRows, static_cast<uint32_t>(nxz), static_cast<uint32_t>(nxz >> 32), na);
     }
     for(uint32_t kk = 0; kbase + kk < nsteps; ++kk) {
-        if(kbase < static_cast<uint32_t>(kWave))
-            lp_tail_step<W, true>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
-        else
-            lp_tail_step<W, false>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, bnd_z, ach, bx, bz);
+        if constexpr(W == 3) {
+            if(kbase < static_cast<uint32_t>(kWave))
+                lp3_tail_step<true>(sp, st, ca, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout_strip, bnd_x, ach, bx, bz);
+            else
+                lp3_tail_step<false>(sp, st, ca, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout_strip, bnd_x, ach, bx, bz);
+        } else {
+            if(kbase < static_cast<uint32_t>(kWave))
+                lp_tail_step<W, true>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, ach, bx, bz);
+            else
+                lp_tail_step<W, false>(sp, st, arow, s, boff, lds_tab, kbase + kk, kk, lane, la, last_strip, fout, bnd_x, ach, bx, bz);
+        }
     }
     // score = X of the last body cell (align_pair.cc:130-138,265): held by the lane of the last column after the last step
     const int last_lane = static_cast<int>((lb - 1 - col0) / W), last_c = static_cast<int>((lb - 1 - col0) % W);
@@ -301,7 +408,10 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
         scores[pair] = sc;
     }
     // flush the accumulators of an incomplete last dword, left-aligned (layout in common.hpp)
-    {
+    if constexpr(W == 3) {
+        const uint32_t ra = nsteps & 15u;
+        if(ra != 0) lp3_store_group(fout_strip + static_cast<uint64_t>(nsteps >> 4) * kLp3GroupDwords, lane, ca, 16u - ra);
+    } else {
         constexpr uint32_t kMA = 16 / W, kMC = 32 / W;
         const uint32_t g = nsteps / kMC, q = nsteps & (kMC - 1u);
         const uint32_t ra = nsteps & (kMA - 1u);
@@ -325,6 +435,216 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
     return handoff_ok;
 }
 
+// where the decision word of body cell (bi, bj) for a walk in state `st` lies (dword index from the pair's first strip) and
+// the shift that brings its bits to the bottom: common.hpp's layouts for this one shape -- shifts and constant divisions only
+template <int W>
+__device__ __forceinline__ void lp_lookup_addr(uint64_t sd, uint32_t bi, uint32_t bj, int st, uint64_t& idx, uint32_t& shift) {
+    if constexpr(W == 3) {
+        const uint32_t strip = bj / (3u * kWave), colin = bj - strip * (3u * kWave), t = colin / 3u, c = colin - 3u * t;
+        const uint32_t kstep = bi + t, g = kstep >> 4, tt = kstep & 15u;
+        const uint64_t base = strip * sd + static_cast<uint64_t>(g) * kLp3GroupDwords;
+        if(st == COATI_HIP_OP_INS) {  // (wave-uniform)
+            idx = base + 6u * kWave + 2u * t + (c >> 1);
+            shift = ((c & 1u) << 4) + 15u - tt;
+        } else {
+            idx = base + (st == COATI_HIP_OP_DEL ? 3u * kWave : 0u) + 3u * t + c;
+            shift = 30u - 2u * tt;
+        }
+    } else {
+        constexpr uint32_t lgW = W == 4 ? 2u : 1u, lg_mc = 5u - lgW, lg_ma = 4u - lgW, lg_cols = 6u + lgW;
+        const uint32_t strip = bj >> lg_cols, colin = bj & ((1u << lg_cols) - 1u), t = colin >> lgW, c = colin & (W - 1u);
+        const uint32_t kstep = bi + t, g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
+        const uint64_t grp = strip * sd + static_cast<uint64_t>(g) * kPairDwords + t;
+        if(st == COATI_HIP_OP_INS) {  // (wave-uniform)
+            idx = grp + 4 * kWave;
+            shift = 31u - ((q << lgW) + c);
+        } else {
+            const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
+            idx = grp + half * (2u * kWave) + (st == COATI_HIP_OP_DEL ? kWave : 0);
+            shift = 30u - 2u * ((tt << lgW) + c);
+        }
+    }
+}
+// the dword a lane asks for AHEAD of the walk (below): slot 0 .. 127 of the request -> one row of one group of steps on the
+// diagonal `64 + ...` moves ahead; false: nothing to ask for
+template <int W>
+__device__ __forceinline__ bool lp_ahead_addr(uint64_t sd, uint32_t i, uint32_t j, uint32_t slot, uint64_t& idx) {
+    if constexpr(W == 3) {
+        // A group is 16 steps = 12 diagonal moves (a move is 1 + 1/3 steps); the diagonal crosses the lanes t - 4 ... t of it.  What the
+        // walk may look up there: A words along the diagonal; B words of a deletion run that comes UP a column from the groups
+        // after it (the diagonal was up to 16 lanes further right there); C words of an insertion run along a row (up to 21 lanes
+        // further left).  A lane's words are 12, 12 and 8 bytes, a cache line 10 or 16 lanes: eight requests per group -- A at lanes
+        // t - 4, t; B at t - 4, t + 6, t + 16; C at t - 21, t - 10, t -- 16 groups: 64 ... 256 moves ahead.
+        const uint32_t m = slot >> 3, piece = slot & 7u, ahead = 64u + m * 12u;
+        if(i <= ahead || j <= ahead) return false;
+        const uint32_t bi = i - ahead - 1u, bj = j - ahead - 1u;
+        const uint32_t strip = bj / (3u * kWave), t = (bj - strip * (3u * kWave)) / 3u, g = (bi + t) >> 4;
+        constexpr int kLaneOff[8] = {-4, 0, -4, 6, 16, -21, -10, 0};
+        const int tl = min(max(static_cast<int>(t) + kLaneOff[piece], 0), kWave - 1);
+        const uint32_t blk = piece < 2u ? 0u : (piece < 5u ? 1u : 2u);  // A, B, C
+        idx = strip * sd + static_cast<uint64_t>(g) * kLp3GroupDwords + (blk < 2u ? blk * 3u * kWave + 3u * tl : 6u * kWave + 2u * tl);
+        return true;
+    } else {
+        constexpr uint32_t lgW = W == 4 ? 2u : 1u, lg_mc = 5u - lgW, lg_cols = 6u + lgW;
+        const uint32_t m = slot / 5u, row = slot % 5u;  // (slot = lane + 64 * half: m = lane / 5 + 13 * half as before for half 0; 12.8 -> 13 groups per half)
+        const uint32_t ahead = 64u + (m * 32u) / 5u;  // moves along the diagonal: a group of 8 steps is 6.4 of them (W = 4)
+        if(i <= ahead || j <= ahead) return false;
+        const uint32_t bi = i - ahead - 1u, bj = j - ahead - 1u;
+        const uint32_t strip = bj >> lg_cols, t = (bj & ((1u << lg_cols) - 1u)) >> lgW, g = (bi + t) >> lg_mc;
+        idx = strip * sd + static_cast<uint64_t>(g) * kPairDwords + row * kWave + t;
+        return true;
+    }
+}
+
+// ---- the walk away from the margins (round 6) --------------------------------------------------------------------------
+// The round-5 loop (kept below for the last 64 rows / columns) took 0.6 us per iteration on the 160 kb pair, and its lookup
+// was the smaller part: ~250 instructions with a dozen taken branches (a lone wavefront pays ~4.5 cycles for each), 64-bit
+// index arithmetic, margin code, and an `s_waitcnt vmcnt(0)` in front of the lookup's load that drained the ops store of the
+// iteration before (the counter retires in order).  Here an iteration is compiled for its kind of move (ST), works with 32-bit
+// offsets into a window of two strips behind a buffer descriptor, and ONE asm statement issues the lookup's load, the ops
+// store of the iteration BEFORE (dropped by its offset where there is nothing to store) and -- when the walk enters a new
+// window of 64 diagonal moves -- the requests for the words further ahead, and waits for the lookup alone: `vmcnt(n)` with the
+// n operations behind it.  The requests are LDS-DMA loads: no register that would have to stay free while they are in flight
+// (an asm load's VGPR destination is the compiler's to reuse at once); what they write -- 256 bytes of this wavefront's table,
+// which the walk does not read and the kernel reloads for the next item -- is ignored; M0 is the compiler's, saved and
+// restored inside the statement.  s_nop 4: the descriptor's SGPRs may have been written by scalar instructions just before
+// (five wait states; the hazard recognizer does not look into inline asm: DESIGN.md 5.2).
+struct LpWalk {
+    uint32_t i, j, pos32;        // matrix cell the walk is at; ops written so far end here (within the pair's slot)
+    int st;
+    uint32_t pend_off, pend_st;  // the ops store of the iteration before (per lane; kLpDrop: nothing to store)
+    uint32_t pf_window, strip_held;
+    uint64_t base;               // address of the window's first strip
+#ifdef COATI_FILL_TRACE
+    uint64_t tr_iter, tr_wait, tr_ask;
+#endif
+};
+template <int W, int ST>
+__device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t* __restrict__ fl, uint64_t sd, uint32_t win_bytes,
+                                             const u32x4& rs_ops, uint32_t lds_sink) {
+    constexpr uint32_t di = ST != COATI_HIP_OP_INS ? 1u : 0u, dj = ST != COATI_HIP_OP_DEL ? 1u : 0u;
+    constexpr uint32_t kCols = kWave * W;
+    // the window: the strip of column j - 1 and the one before it (the 64 cells ahead span at most two)
+    const uint32_t strip_cur = (w.j - 1u) / kCols, strip0 = strip_cur > 0u ? strip_cur - 1u : 0u;
+    if(strip0 != w.strip_held) {  // (wave-uniform; once per strip)
+        w.strip_held = strip0;
+        const uint64_t a = reinterpret_cast<uint64_t>(fl + strip0 * sd);
+        w.base = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32)))) << 32) |
+                 static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
+    }
+    u32x4 rs_fl;
+    rs_fl.x = static_cast<uint32_t>(w.base);
+    rs_fl.y = static_cast<uint32_t>(w.base >> 32) & 0xffffu;
+    rs_fl.z = win_bytes;
+    rs_fl.w = 0x00020000u;
+    const uint32_t step = static_cast<uint32_t>(lane) + 1u;
+    const uint32_t bi = w.i - 1u - di * step, bj = w.j - 1u - dj * step;
+    const uint32_t sd4 = static_cast<uint32_t>(sd) * 4u;
+    uint32_t off, lsh;  // byte offset in the window; the cell's bits are the top bits of (word << lsh)
+    if constexpr(W == 3) {
+        const uint32_t q3 = bj / 3u, strip = q3 >> 6, t = q3 & 63u, c = bj - 3u * q3;
+        const uint32_t kstep = bi + t, g = kstep >> 4;
+        const uint32_t row = (strip != strip0 ? sd4 : 0u) + g * (kLp3GroupDwords * 4u);
+        if constexpr(ST == COATI_HIP_OP_INS) {
+            off = row + 6u * kWave * 4u + t * 8u + c * 2u;  // (the short itself: an aligned 16-bit load)
+            lsh = 16u + (kstep & 15u);
+        } else {
+            off = row + (ST == COATI_HIP_OP_DEL ? 3u * kWave * 4u : 0u) + t * 12u + c * 4u;
+            lsh = (kstep & 15u) << 1;
+        }
+    } else {
+        constexpr uint32_t lgW = W == 4 ? 2u : 1u, lg_mc = 5u - lgW, lg_ma = 4u - lgW, lg_cols = 6u + lgW;
+        const uint32_t strip = bj >> lg_cols, colin = bj & ((1u << lg_cols) - 1u), t = colin >> lgW, c = colin & (W - 1u);
+        const uint32_t kstep = bi + t, g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
+        const uint32_t row = (strip != strip0 ? sd4 : 0u) + g * (kPairDwords * 4u) + t * 4u;
+        if constexpr(ST == COATI_HIP_OP_INS) {
+            off = row + 4u * kWave * 4u;
+            lsh = (q << lgW) + c;
+        } else {
+            const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
+            off = row + half * (2u * kWave * 4u) + (ST == COATI_HIP_OP_DEL ? kWave * 4u : 0u);
+            lsh = 2u * ((tt << lgW) + c);
+        }
+    }
+#ifdef COATI_WALK_NO_ASK  // (experiment: the walk without its requests ahead)
+    const bool ask = false;
+#else
+    const bool ask = ((w.i + w.j) >> 7) != w.pf_window;  // (wave-uniform)
+#endif
+    uint64_t p0 = reinterpret_cast<uint64_t>(fl), p1 = p0;
+    if(ask) {
+        w.pf_window = (w.i + w.j) >> 7;
+        uint64_t idx;
+        if(lp_ahead_addr<W>(sd, w.i, w.j, static_cast<uint32_t>(lane), idx)) p0 = reinterpret_cast<uint64_t>(fl + idx);
+        if(lp_ahead_addr<W>(sd, w.i, w.j, static_cast<uint32_t>(lane) + kWave + (W == 3 ? 0u : 1u), idx)) p1 = reinterpret_cast<uint64_t>(fl + idx);
+    }
+#if defined(COATI_FILL_TRACE) && defined(COATI_WALK_TRACE_WAIT)
+    const uint64_t tr_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    uint32_t word;
+#define COATI_LP_WALK_STEP(LOAD)                                                                                                            \
+    if(ask) {                                                                                                                               \
+        uint32_t keep;                                                                                                                      \
+        asm volatile("s_nop 4\n\t" LOAD " %[w], %[off], %[rs], 0 offen\n\t"                                                                \
+                     "buffer_store_byte %[pst], %[poff], %[rso], 0 offen\n\t"                                                               \
+                     "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"                                                       \
+                     "global_load_lds_dword %[p0], off\n\tglobal_load_lds_dword %[p1], off\n\t"                                            \
+                     "s_mov_b32 m0, %[keep]\n\ts_waitcnt vmcnt(3)"                                                                          \
+                     : [w] "=&v"(word), [keep] "=&s"(keep)                                                                                  \
+                     : [off] "v"(off), [rs] "s"(rs_fl), [pst] "v"(w.pend_st), [poff] "v"(w.pend_off), [rso] "s"(rs_ops),                    \
+                       [lds] "s"(lds_sink), [p0] "v"(p0), [p1] "v"(p1)                                                                      \
+                     : "memory");                                                                                                           \
+    } else {                                                                                                                                \
+        asm volatile("s_nop 4\n\t" LOAD " %[w], %[off], %[rs], 0 offen\n\t"                                                                \
+                     "buffer_store_byte %[pst], %[poff], %[rso], 0 offen\n\t"                                                               \
+                     "s_waitcnt vmcnt(1)"                                                                                                   \
+                     : [w] "=&v"(word)                                                                                                      \
+                     : [off] "v"(off), [rs] "s"(rs_fl), [pst] "v"(w.pend_st), [poff] "v"(w.pend_off), [rso] "s"(rs_ops)                     \
+                     : "memory");                                                                                                           \
+    }
+    if constexpr(W == 3 && ST == COATI_HIP_OP_INS) {
+        COATI_LP_WALK_STEP("buffer_load_ushort")
+    } else {
+        COATI_LP_WALK_STEP("buffer_load_dword")
+    }
+#undef COATI_LP_WALK_STEP
+#ifdef COATI_FILL_TRACE
+    // (trace build: iterations and windows asked ahead; -DCOATI_WALK_TRACE_WAIT also times the statement above -- two SMEM round
+    // trips per iteration, which then weigh more than what they measure)
+    w.tr_iter += 1;
+    w.tr_ask += ask ? 1u : 0u;
+#ifdef COATI_WALK_TRACE_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    w.tr_wait += __builtin_amdgcn_s_memtime() - tr_t0;
+#endif
+#endif
+    // the decision of every lane's cell: does the run go on there?  (max_mdi's two bits: bit 1 = the M argument is not the
+    // maximum, bit 0 = the D argument is not; max_mi's one: M is the maximum)
+    const uint32_t top = word << lsh;
+    bool go_on;
+    uint32_t code;
+    if constexpr(ST == COATI_HIP_OP_INS) {
+        code = top >> 31;
+        go_on = code == 0u;
+    } else {
+        code = top >> 30;
+        go_on = ST == COATI_HIP_OP_MATCH ? code < 2u : code == 2u;
+    }
+    const unsigned long long cont = __builtin_amdgcn_ballot_w64(go_on);
+    const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));
+    const uint32_t moves = run == kWave ? kWave : run + 1u;
+    w.pend_off = static_cast<uint32_t>(lane) < moves ? w.pos32 - 1u - static_cast<uint32_t>(lane) : kLpDrop;
+    w.pend_st = static_cast<uint32_t>(ST);
+    w.pos32 -= moves;
+    w.i -= di * moves;
+    w.j -= dj * moves;
+    if(run < kWave) {
+        const uint32_t cr = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(code), static_cast<int>(run)));
+        if constexpr(ST == COATI_HIP_OP_INS) w.st = COATI_HIP_OP_MATCH;  // (the run ended: M is the maximum)
+        else w.st = !(cr & 2u) ? COATI_HIP_OP_MATCH : ((cr & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL);
+    }
+}
+
 // traceback<tropical> (align_pair.cc:249-303) for a pair whose strips all have W columns per lane: common.hpp's
 // wave-cooperative walk_pair (64 lanes look up the states after 1..64 more moves of the current kind, a ballot finds where
 // the run ends) with the cell address computed for this one shape -- shifts by constants, one strip size, no compact layout,
@@ -333,11 +653,12 @@ __device__ __forceinline__ bool fill_strip_lp(const GapConsts& k, const PairDesc
 template <int W>
 __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const PairDesc& pd, uint32_t pair, int start_state,
                                              const uint32_t* __restrict__ flags, uint8_t* __restrict__ ops,
-                                             uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len) {
-    constexpr uint32_t lgW = W == 4 ? 2u : 1u, lg_mc = 5u - lgW, lg_ma = 4u - lgW, lg_cols = 6u + lgW;
+                                             uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t lds_scratch) {
     const uint32_t la = pd.la, lb = pd.lb;
     const uint32_t* __restrict__ fl = flags + pd.flags_off;
     const uint64_t sd = strip_dwords(la, W);
+    // 256 bytes of LDS the walk may scribble on (the wavefront's own table: the kernel reloads it for the next item)
+    const uint32_t lds_sink = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_scratch)));
     uint32_t i = la, j = lb;  // matrix coordinates of the last cell (gap_len 1: body cell (i-1, j-1))
     uint64_t pos = pd.ops_off + la + lb;
     int st = (i < 1 && j < 1) ? kWalkEnd : start_state;
@@ -347,6 +668,49 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
     // -- 26 groups of steps x their 5 rows, two loads per lane, nobody waits for them (their values are folded into `sink` one
     // window later) -- and the lookups find them in the L2.
     uint32_t pf_window = 0xffffffffu, pf0 = 0u, pf1 = 0u, sink = 0u;
+    // Round 6: the walk away from the margins (i, j > 64: every lane's cell is a body cell) as a loop of its own
+    // (lp_walk_iter above).
+    {
+        LpWalk w;
+        w.i = i;
+        w.j = j;
+        w.pos32 = la + lb;  // (pos - pd.ops_off: within the pair's slot)
+        w.st = st;
+        w.pend_off = kLpDrop;
+        w.pend_st = 0u;
+        w.pf_window = 0xffffffffu;
+        w.strip_held = 0xffffffffu;
+        w.base = 0;
+#ifdef COATI_FILL_TRACE
+        w.tr_iter = w.tr_wait = w.tr_ask = 0;
+        const uint64_t tr_begin = __builtin_amdgcn_s_memtime();
+#endif
+        const u32x4 rs_ops = lp_rsrc(ops + pd.ops_off, static_cast<uint64_t>(la) + lb);
+        const uint32_t win_bytes = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(std::min<uint64_t>(2u * sd * 4u, 0x7ffffff0ull))));
+        // (every vector memory operation the COMPILER knows of -- the fill's last stores -- is waited for here, as an instruction
+        // its bookkeeping understands: it does not count the loop's asm operations, and a store it believes outstanding at the
+        // loop's head would make it drain the counter -- our ops store included -- in every iteration)
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        while(w.st != kWalkEnd && w.i > kWave && w.j > kWave) {
+            if(w.st == COATI_HIP_OP_MATCH) lp_walk_iter<W, COATI_HIP_OP_MATCH>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink);
+            else if(w.st == COATI_HIP_OP_DEL) lp_walk_iter<W, COATI_HIP_OP_DEL>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink);
+            else lp_walk_iter<W, COATI_HIP_OP_INS>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink);
+        }
+        asm volatile("buffer_store_byte %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");
+#ifdef COATI_FILL_TRACE
+        if(lane == 0 && la > 100000u) {
+            g_lp_trace[4000 * 4 + 0] = w.tr_iter;
+            g_lp_trace[4000 * 4 + 1] = w.tr_wait;
+            g_lp_trace[4000 * 4 + 2] = __builtin_amdgcn_s_memtime() - tr_begin;
+            g_lp_trace[4000 * 4 + 3] = w.tr_ask;
+        }
+#endif
+        i = w.i;
+        j = w.j;
+        st = w.st;
+        pos = pd.ops_off + w.pos32;
+    }
+    // the margins' neighbourhood (and W-generic reference form of the loop above): the last <= 64 rows or columns
     while(st != kWalkEnd) {
         const uint32_t di = st != COATI_HIP_OP_INS ? 1u : 0u, dj = st != COATI_HIP_OP_DEL ? 1u : 0u;
         const uint32_t step = static_cast<uint32_t>(lane) + 1u;
@@ -356,18 +720,9 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
         const bool body = valid && ci >= 1 && cj >= 1;
         uint32_t word = 0u, shift = 0u;
         if(body) {  // the lookup's load first ...
-            const uint32_t bi = ci - 1, bj = cj - 1;
-            const uint32_t strip = bj >> lg_cols, colin = bj & ((1u << lg_cols) - 1u), t = colin >> lgW, c = colin & (W - 1u);
-            const uint32_t kstep = bi + t, g = kstep >> lg_mc, q = kstep & ((1u << lg_mc) - 1u);
-            const uint32_t* __restrict__ grp = fl + (strip * sd + static_cast<uint64_t>(g) * kPairDwords + t);
-            if(st == COATI_HIP_OP_INS) {  // (wave-uniform)
-                word = grp[4 * kWave];
-                shift = 31u - ((q << lgW) + c);
-            } else {
-                const uint32_t half = q >> lg_ma, tt = q & ((1u << lg_ma) - 1u);
-                word = grp[half * (2u * kWave) + (st == COATI_HIP_OP_DEL ? kWave : 0)];
-                shift = 30u - 2u * ((tt << lgW) + c);
-            }
+            uint64_t idx;
+            lp_lookup_addr<W>(sd, ci - 1, cj - 1, st, idx, shift);
+            word = fl[idx];
         }
         // ... then the requests for the words further ahead (loads retire in order: issued BEFORE the lookup they would make it
         // wait for memory too) ...
@@ -377,12 +732,9 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
             pf0 = pf1 = 0u;
 #pragma unroll
             for(uint32_t half = 0; half < 2u; ++half) {
-                const uint32_t m = static_cast<uint32_t>(lane) / 5u + 13u * half, row = static_cast<uint32_t>(lane) % 5u;
-                const uint32_t ahead = 64u + (m * 32u) / 5u;  // moves along the diagonal: a group of 8 steps is 6.4 of them (W = 4)
-                if(i > ahead && j > ahead) {
-                    const uint32_t bi = i - ahead - 1u, bj = j - ahead - 1u;
-                    const uint32_t strip = bj >> lg_cols, t = (bj & ((1u << lg_cols) - 1u)) >> lgW, g = (bi + t) >> lg_mc;
-                    const uint32_t v = fl[strip * sd + static_cast<uint64_t>(g) * kPairDwords + row * kWave + t];
+                uint64_t idx;
+                if(lp_ahead_addr<W>(sd, i, j, static_cast<uint32_t>(lane) + kWave * half + (W == 3 ? 0u : half), idx)) {
+                    const uint32_t v = fl[idx];
                     if(half == 0) pf0 = v;
                     else pf1 = v;
                 }
@@ -469,6 +821,9 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
             if(pd.v_wmain == 2)
                 handoff_ok = fill_strip_lp<2>(k, pd, pair, strip, ticket, lane, lds_tab, lds_pair, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
                                               flags, bnd, scores, progress);
+            else if(pd.v_wmain == 3)
+                handoff_ok = fill_strip_lp<3>(k, pd, pair, strip, ticket, lane, lds_tab, lds_pair, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
+                                              flags, bnd, scores, progress);
             else
                 handoff_ok = fill_strip_lp<4>(k, pd, pair, strip, ticket, lane, lds_tab, lds_pair, tab_bytes, a_cat + pd.a_off, b_cat + pd.b_off,
                                               flags, bnd, scores, progress);
@@ -486,9 +841,12 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
             // max_mdi of the terminal-adjusted last cell == its "after match" decision (common.hpp viterbi_finish)
             const int start_state = __builtin_amdgcn_readfirstlane(state_after(flags, pd, pd.la - 1, pd.lb - 1, COATI_HIP_OP_MATCH));
             if(pd.v_wmain == 2)
-                walk_pair_lp<2>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len);
+                walk_pair_lp<2>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab);
+            else if(pd.v_wmain == 3)
+                walk_pair_lp<3>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab);
             else
-                walk_pair_lp<4>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len);
+                walk_pair_lp<4>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab);
+            tab_held = 0xffffffffu;  // (the walk's requests ahead land in this wavefront's table: reload it for the next item)
         } else {
             viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);  // (margins only)
         }

@@ -16,9 +16,9 @@ def test_viterbi_lp_blocks_match_their_generator(tmp_path):
 
 def test_block_text_has_the_shapes_the_kernel_names():
     text = (ROOT / "coati_amd" / "csrc" / "viterbi_lp_block.inc").read_text()
-    for w in ("2", "4"):
+    for w in ("2", "3", "4"):
         for tab in ("", "P"):
             for kind in ("FIRST", "MAIN"):
                 assert f"#define COATI_LP{w}{tab}_BLOCK_{kind}_ASM" in text
     # every block ends with the counted wait that makes the chunk loads (its oldest vector-memory operations) visible
-    assert text.count("s_waitcnt vmcnt(") == 8
+    assert text.count("s_waitcnt vmcnt(") == 12

@@ -98,7 +98,7 @@ def test_reference_doctest_alignments_default_model():
         assert [sa, sb] == case["out"], case
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ck"])
+@pytest.mark.parametrize("kernel", ["auto", "ck", "lp4", "lp3"])
 @pytest.mark.parametrize("key", ["10k", "20k", "40k", "80k", "160k"])
 def test_long_sample_pairs(key, kernel, monkeypatch):
     """BASELINE configs[2]: the reference's long sample pairs (sanitised)
@@ -112,10 +112,15 @@ def test_long_sample_pairs(key, kernel, monkeypatch):
     # (a lone long pair is the planner's case for viterbi_l1; "ck" forces the checkpoint kernel through the
     # same narrow pipelined strips)
     monkeypatch.delenv("COATI_HIP_VITERBI_BITS", raising=False)
+    monkeypatch.delenv("COATI_HIP_STRIP_W", raising=False)
     if kernel == "ck":
         monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")
     else:
         monkeypatch.delenv("COATI_HIP_VITERBI_CK", raising=False)
+    # (round 6) viterbi_lp's shapes forced: 4 columns per lane (the round-5 plan for the 160 kb pair) and 3 (per-column
+    # decision words; the planner's choice for the 160 kb pair only -- the shorter ones take 2 columns)
+    if kernel in ("lp4", "lp3"):
+        monkeypatch.setenv("COATI_HIP_STRIP_W", kernel[2])
     a, b, case, doc = util.load_long_pair(key)
     table = np.load(GOLD / doc["table"])
     consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])

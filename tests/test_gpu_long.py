@@ -1,5 +1,6 @@
 """viterbi_lp (round 3): the decision-bit fill for batches with fewer strips than the GPU has SIMDs -- a few long
-pairs, and every small batch -- in 16-step blocks of hand-allocated instructions, 4 or 2 columns per lane.  It shares the
+pairs, and every small batch -- in 16-step blocks of hand-allocated instructions, 4, 3 or 2 columns per lane (3: round 6,
+decision words per column).  It shares the
 decision-bit layout and the traceback with viterbi_l1; results must be the reference's bits (oracle) and equal to
 viterbi_l1's."""
 import numpy as np
@@ -39,7 +40,7 @@ def run(hip, table, consts, enc, flags_of=()):
     return scores.copy(), [ops[int(off[p]):int(off[p]) + int(ln[p])].copy() for p in range(len(enc))], flags
 
 
-@pytest.mark.parametrize("strip_w", ["2", "4"])
+@pytest.mark.parametrize("strip_w", ["2", "3", "4"])
 def test_block_and_chunk_boundaries_against_the_oracle(hip, oracle, monkeypatch, strip_w):
     """Ancestor lengths around the 16-step blocks, the 64 steps in which the lanes start and the 16-row boundary chunks;
     descendant lengths around one, two and several strips of both shapes; ambiguous nucleotides; every pair against
@@ -50,7 +51,7 @@ def test_block_and_chunk_boundaries_against_the_oracle(hip, oracle, monkeypatch,
     consts = oracle.gap_consts()
     pairs = []
     for la3 in (1, 5, 6, 15, 16, 17, 21, 22, 26, 27, 32, 43, 70):       # codons: 3 ... 210 rows
-        for nb in (1, 2, 7, 127, 128, 129, 255, 256, 257, 385, 520, 700):
+        for nb in (1, 2, 7, 127, 128, 129, 191, 192, 193, 255, 256, 257, 385, 520, 577, 700):
             anc = util.random_anc(rng, la3)
             des = "".join(rng.choice(list(util.NT16 if nb % 5 == 0 else util.NT), nb))
             pairs.append((anc, des))
@@ -70,7 +71,7 @@ def test_block_and_chunk_boundaries_against_the_oracle(hip, oracle, monkeypatch,
 
 
 def test_long_pairs_equal_viterbi_l1_and_the_oracle(hip, oracle, monkeypatch):
-    """Three related pairs of 9-31 kb (2-column strips, then 4-column strips forced) with long indels and a stretch of
+    """Three related pairs of 9-31 kb (2-column strips, then 4- and 3-column strips forced) with long indels and a stretch of
     ambiguous nucleotides: identical to viterbi_l1 (COATI_HIP_L1_LP=0) and to the oracle's low-memory Viterbi."""
     rng = np.random.default_rng(31)
     table = util.random_table(rng)
@@ -85,13 +86,13 @@ def test_long_pairs_equal_viterbi_l1_and_the_oracle(hip, oracle, monkeypatch):
         pairs.append((a, "".join(d)))
     enc = util.encode_pairs(pairs)
     got = {}
-    for name, env in (("lp2", {}), ("lp4", {"COATI_HIP_STRIP_W": "4"}), ("l1", {"COATI_HIP_L1_LP": "0"})):
+    for name, env in (("lp2", {}), ("lp4", {"COATI_HIP_STRIP_W": "4"}), ("lp3", {"COATI_HIP_STRIP_W": "3"}), ("l1", {"COATI_HIP_L1_LP": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got[name] = run(hip, table, consts, enc)
         for k in env:
             monkeypatch.delenv(k)
-    for name in ("lp4", "l1"):
+    for name in ("lp4", "lp3", "l1"):
         assert (bits(got[name][0]) == bits(got["lp2"][0])).all(), name
         for p in range(len(enc)):
             assert np.array_equal(got[name][1][p], got["lp2"][1][p]), (name, p)

@@ -17,9 +17,14 @@ for _ in range(3):
     batch.viterbi_launch(); batch.sync()
 f, w = batch.viterbi_timing()
 assert lib.coati_hip_debug_trace_lp(tr.ctypes.data_as(C.c_void_p)) == 0
-raw = tr.reshape(4096, 4)
+raw = tr.reshape(4096, 4).copy()
+wk = raw[4000].copy()  # (round 6) the walk's fast loop: iterations, cycles in its load-and-wait statement, cycles in all, windows asked ahead
+raw[4000] = 0
 t = raw[raw[:, 1] > 0].astype(np.float64)
 t0 = t[:, 0].min()
 walk = t[:, 2] > 0
 print(f"{key}: kernel {f:.2f} ms; {len(t)} strips; first strip done at {(t[:, 1].min() - t0) / 100:.0f} us, last at {(t[:, 1].max() - t0) / 100:.0f} us; "
       f"traceback {((t[walk, 2] - t[walk, 1]).max()) / 100.0:.0f} us")
+if wk[0]:
+    print(f"walk (fast loop): {int(wk[0])} iterations, {wk[2] / wk[0]:.0f} shader cycles each of which {wk[1] / wk[0]:.0f} in the load-and-wait statement; "
+          f"{int(wk[3])} windows asked ahead")

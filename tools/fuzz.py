@@ -33,7 +33,7 @@ while time.time() < t_end:
     os.environ.pop("COATI_HIP_STRIP_W", None)
     os.environ.pop("COATI_HIP_LP_PAIRTAB", None)
     if forced in ("auto", "bits"):  # small batches run on viterbi_lp: both strip shapes, with and without the pair table
-        w = str(rng.choice(["", "", "2", "4"]))
+        w = str(rng.choice(["", "", "2", "3", "4"]))
         if w:
             os.environ["COATI_HIP_STRIP_W"] = w
         if rng.random() < 0.5:  # ... the single-column gathers (the library re-reads its switches per entry of this plumbing)
