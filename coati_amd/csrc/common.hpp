@@ -147,6 +147,16 @@ constexpr uint32_t kCkPartStateDwords = 3u * 64u;  // what a part leaves for the
 // -- 5.33 bits per cell, three stores per 16 steps (12-, 12- and 8-byte pieces per lane; the 4-column layout: ten), and the
 // cells a walk looks up along a diagonal -- a lane's three columns, the neighbouring lanes -- share a cache line.
 constexpr uint32_t kLp3GroupDwords = 512;
+// viterbi_lp's spliced traceback (round 6; viterbi_lp.hip: lp_spec_walk): behind the boundary arrays of a pair of several
+// strips every strip has a record area -- kSpOps bytes of ops its speculative walk recorded (right to left), then a list of up to
+// kSpEntries run starts, 32 bytes each: {i, j, state, ops recorded before, exit row, arriving move, ops in all, check word}.
+// The areas start every launch as 0xff bytes with the boundary arrays (launch_viterbi_lp): an entry that was not written, or
+// only half, matches nothing.
+constexpr uint32_t kSpOps = 1024, kSpEntries = 64, kSpStrideBytes = kSpOps + kSpEntries * 32u;
+__host__ __device__ inline uint64_t lp_splice_first_float(uint32_t la, uint32_t strips) {  // (16-byte aligned)
+    return ((static_cast<uint64_t>(strips) - 1u) * 2u * (static_cast<uint64_t>(la) + 1u) + 3u) & ~3ull;
+}
+__host__ __device__ inline uint64_t lp_splice_floats(uint32_t strips) { return strips > 1u ? static_cast<uint64_t>(strips) * (kSpStrideBytes / 4u) + 4u : 0u; }
 __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
     if(w == 3u) return static_cast<uint64_t>((la + kWave - 1 + 15u) / 16u) * kLp3GroupDwords;
     const uint32_t mc = 32u / w;
@@ -538,6 +548,7 @@ struct EnvOptions {
     bool fwd_wide_build = false;     // COATI_HIP_FWD_WIDE_BUILD: forward_l1's 16-column build for narrow strips too
     bool lp_pairtab_off = false;     // COATI_HIP_LP_PAIRTAB=0
     bool lp3_off = false;            // COATI_HIP_LP3=0: the planner never chooses 3-column strips (A/B: the round-5 plan)
+    int lp_splice = -1;              // COATI_HIP_LP_SPLICE: 0 = viterbi_lp walks every strip itself, 1 = spliced traceback, 2 ("miss") = records that never match (tests); -1: the default (on for multi-strip pairs)
     bool forward_fast = false;       // COATI_HIP_FORWARD_FAST: hardware exp / log in the log-semiring plus (not a parity mode)
     bool timing = false;             // COATI_HIP_TIMING: host stage times on stderr
     bool pipe_timing = false;        // COATI_HIP_PIPE_TIMING: timeline of a one-shot call on stderr

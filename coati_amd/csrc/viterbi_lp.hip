@@ -515,13 +515,27 @@ struct LpWalk {
     uint32_t pend_off, pend_st;  // the ops store of the iteration before (per lane; kLpDrop: nothing to store)
     uint32_t pf_window, strip_held;
     uint64_t base;               // address of the window's first strip
+    // the spliced traceback (MODE 1 and 2 of lp_walk_iter)
+    bool fresh;                  // the iteration before ended a run: the walk is at a run start
+    bool exited;                 // (MODE 2) the speculative walk has left its strip; exit_mv = the move that took it out
+    bool hit;                    // the walk stands on a run start of the strip's recorded walk: e_* = that entry
+    uint32_t exit_mv, e_cnt, e_exit_i, e_exit_mv, e_total;
+    uint32_t list_strip;         // the true walk holds the run starts of this strip's record, one entry per lane: ...
+    u32x4 ea, eb;                // ... {i, j, state, ops before}, {exit row, arriving move, ops in all, check word}
 #ifdef COATI_FILL_TRACE
-    uint64_t tr_iter, tr_wait, tr_ask;
+    uint64_t tr_iter, tr_wait, tr_ask, tr_hits;
 #endif
 };
-template <int W, int ST>
+__device__ __forceinline__ uint8_t* lp_splice_area(float* bnd, const PairDesc& pd, uint32_t strip) {
+    return reinterpret_cast<uint8_t*>(bnd + pd.bnd_off + lp_splice_first_float(pd.la, pd.v_strips)) + static_cast<uint64_t>(strip) * kSpStrideBytes;
+}
+constexpr uint32_t kSpCheck = 0x5a5a5a5au;
+// MODE 0: the walk.  MODE 2: a strip's speculative walk -- confined to its strip (lanes whose cell lies left of body column
+// `col0` end the run; landing there is the exit), its ops stored through the L2 into the strip's record area, no requests
+// ahead (the strip's words are this wavefront's own, fresh in its L2).
+template <int W, int ST, int MODE>
 __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t* __restrict__ fl, uint64_t sd, uint32_t win_bytes,
-                                             const u32x4& rs_ops, uint32_t lds_sink) {
+                                             const u32x4& rs_ops, uint32_t lds_sink, uint32_t col0) {
     constexpr uint32_t di = ST != COATI_HIP_OP_INS ? 1u : 0u, dj = ST != COATI_HIP_OP_DEL ? 1u : 0u;
     constexpr uint32_t kCols = kWave * W;
     // the window: the strip of column j - 1 and the one before it (the 64 cells ahead span at most two)
@@ -532,10 +546,10 @@ __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t
         w.base = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32)))) << 32) |
                  static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
     }
-    u32x4 rs_fl;
-    rs_fl.x = static_cast<uint32_t>(w.base);
-    rs_fl.y = static_cast<uint32_t>(w.base >> 32) & 0xffffu;
-    rs_fl.z = win_bytes;
+    u32x4 rs_fl;  // (readfirstlane: free where the value is in SGPRs already, and keeps the descriptor out of VGPRs where the compiler is not sure)
+    rs_fl.x = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(w.base))));
+    rs_fl.y = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(w.base >> 32) & 0xffffu)));
+    rs_fl.z = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(win_bytes)));
     rs_fl.w = 0x00020000u;
     const uint32_t step = static_cast<uint32_t>(lane) + 1u;
     const uint32_t bi = w.i - 1u - di * step, bj = w.j - 1u - dj * step;
@@ -569,7 +583,7 @@ __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t
 #ifdef COATI_WALK_NO_ASK  // (experiment: the walk without its requests ahead)
     const bool ask = false;
 #else
-    const bool ask = ((w.i + w.j) >> 7) != w.pf_window;  // (wave-uniform)
+    const bool ask = MODE != 2 && ((w.i + w.j) >> 7) != w.pf_window;  // (wave-uniform)
 #endif
     uint64_t p0 = reinterpret_cast<uint64_t>(fl), p1 = p0;
     if(ask) {
@@ -582,37 +596,49 @@ __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t
     const uint64_t tr_t0 = __builtin_amdgcn_s_memtime();
 #endif
     uint32_t word;
-#define COATI_LP_WALK_STEP(LOAD)                                                                                                            \
-    if(ask) {                                                                                                                               \
-        uint32_t keep;                                                                                                                      \
-        asm volatile("s_nop 4\n\t" LOAD " %[w], %[off], %[rs], 0 offen\n\t"                                                                \
-                     "buffer_store_byte %[pst], %[poff], %[rso], 0 offen\n\t"                                                               \
-                     "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"                                                       \
-                     "global_load_lds_dword %[p0], off\n\tglobal_load_lds_dword %[p1], off\n\t"                                            \
-                     "s_mov_b32 m0, %[keep]\n\ts_waitcnt vmcnt(3)"                                                                          \
-                     : [w] "=&v"(word), [keep] "=&s"(keep)                                                                                  \
-                     : [off] "v"(off), [rs] "s"(rs_fl), [pst] "v"(w.pend_st), [poff] "v"(w.pend_off), [rso] "s"(rs_ops),                    \
-                       [lds] "s"(lds_sink), [p0] "v"(p0), [p1] "v"(p1)                                                                      \
-                     : "memory");                                                                                                           \
-    } else {                                                                                                                                \
-        asm volatile("s_nop 4\n\t" LOAD " %[w], %[off], %[rs], 0 offen\n\t"                                                                \
-                     "buffer_store_byte %[pst], %[poff], %[rso], 0 offen\n\t"                                                               \
-                     "s_waitcnt vmcnt(1)"                                                                                                   \
-                     : [w] "=&v"(word)                                                                                                      \
-                     : [off] "v"(off), [rs] "s"(rs_fl), [pst] "v"(w.pend_st), [poff] "v"(w.pend_off), [rso] "s"(rs_ops)                     \
-                     : "memory");                                                                                                           \
+#define COATI_LP_WALK_ASK_TAIL                                                                                                 \
+    "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"                                                           \
+    "global_load_lds_dword %[p0], off\n\tglobal_load_lds_dword %[p1], off\n\t"                                                \
+    "s_mov_b32 m0, %[keep]\n\ts_waitcnt vmcnt(3)"
+#define COATI_LP_WALK_STEP(LOAD, STORE_BITS)                                                                                   \
+    if(ask) {                                                                                                                  \
+        uint32_t keep;                                                                                                         \
+        asm volatile("s_nop 4\n\t" LOAD " %[w], %[off], %[rs], 0 offen\n\t"                                                   \
+                     "buffer_store_byte %[pst], %[poff], %[rso], 0 offen" STORE_BITS "\n\t" COATI_LP_WALK_ASK_TAIL             \
+                     : [w] "=&v"(word), [keep] "=&s"(keep)                                                                     \
+                     : [off] "v"(off), [rs] "s"(rs_fl), [pst] "v"(w.pend_st), [poff] "v"(w.pend_off), [rso] "s"(rs_ops),       \
+                       [lds] "s"(lds_sink), [p0] "v"(p0), [p1] "v"(p1)                                                         \
+                     : "memory");                                                                                              \
+    } else {                                                                                                                   \
+        asm volatile("s_nop 4\n\t" LOAD " %[w], %[off], %[rs], 0 offen\n\t"                                                   \
+                     "buffer_store_byte %[pst], %[poff], %[rso], 0 offen" STORE_BITS "\n\t"                                    \
+                     "s_waitcnt vmcnt(1)"                                                                                      \
+                     : [w] "=&v"(word)                                                                                         \
+                     : [off] "v"(off), [rs] "s"(rs_fl), [pst] "v"(w.pend_st), [poff] "v"(w.pend_off), [rso] "s"(rs_ops)        \
+                     : "memory");                                                                                              \
     }
-    if constexpr(W == 3 && ST == COATI_HIP_OP_INS) {
-        COATI_LP_WALK_STEP("buffer_load_ushort")
+    if constexpr(MODE == 2) {
+        if constexpr(W == 3 && ST == COATI_HIP_OP_INS) {
+            COATI_LP_WALK_STEP("buffer_load_ushort", " sc1")
+        } else {
+            COATI_LP_WALK_STEP("buffer_load_dword", " sc1")
+        }
     } else {
-        COATI_LP_WALK_STEP("buffer_load_dword")
+        if constexpr(W == 3 && ST == COATI_HIP_OP_INS) {
+            COATI_LP_WALK_STEP("buffer_load_ushort", "")
+        } else {
+            COATI_LP_WALK_STEP("buffer_load_dword", "")
+        }
     }
 #undef COATI_LP_WALK_STEP
+#undef COATI_LP_WALK_ASK_TAIL
 #ifdef COATI_FILL_TRACE
     // (trace build: iterations and windows asked ahead; -DCOATI_WALK_TRACE_WAIT also times the statement above -- two SMEM round
     // trips per iteration, which then weigh more than what they measure)
-    w.tr_iter += 1;
-    w.tr_ask += ask ? 1u : 0u;
+    if constexpr(MODE != 2) {
+        w.tr_iter += 1;
+        w.tr_ask += ask ? 1u : 0u;
+    }
 #ifdef COATI_WALK_TRACE_WAIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     w.tr_wait += __builtin_amdgcn_s_memtime() - tr_t0;
@@ -630,6 +656,7 @@ __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t
         code = top >> 30;
         go_on = ST == COATI_HIP_OP_MATCH ? code < 2u : code == 2u;
     }
+    if constexpr(MODE == 2 && dj != 0u) go_on = go_on && bj >= col0;
     const unsigned long long cont = __builtin_amdgcn_ballot_w64(go_on);
     const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));
     const uint32_t moves = run == kWave ? kWave : run + 1u;
@@ -638,11 +665,189 @@ __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t
     w.pos32 -= moves;
     w.i -= di * moves;
     w.j -= dj * moves;
+    w.fresh = run < kWave;
     if(run < kWave) {
+        if constexpr(MODE == 2 && dj != 0u) {
+            if(w.j <= col0) {  // (the move landed left of the strip: body column j - 1 = col0 - 1)
+                w.exited = true;
+                w.exit_mv = static_cast<uint32_t>(ST);
+                return;
+            }
+        }
         const uint32_t cr = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(code), static_cast<int>(run)));
         if constexpr(ST == COATI_HIP_OP_INS) w.st = COATI_HIP_OP_MATCH;  // (the run ended: M is the maximum)
         else w.st = !(cr & 2u) ? COATI_HIP_OP_MATCH : ((cr & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL);
     }
+}
+template <int W, int MODE>
+__device__ __forceinline__ void lp_walk_step(LpWalk& w, int lane, const uint32_t* __restrict__ fl, uint64_t sd, uint32_t win_bytes,
+                                             const u32x4& rs_ops, uint32_t lds_sink, uint32_t col0) {
+    if(w.st == COATI_HIP_OP_MATCH) lp_walk_iter<W, COATI_HIP_OP_MATCH, MODE>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink, col0);
+    else if(w.st == COATI_HIP_OP_DEL) lp_walk_iter<W, COATI_HIP_OP_DEL, MODE>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink, col0);
+    else lp_walk_iter<W, COATI_HIP_OP_INS, MODE>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink, col0);
+}
+__device__ __forceinline__ void lp_walk_init(LpWalk& w, uint32_t i, uint32_t j, uint32_t pos32, int st) {
+    w.i = i;
+    w.j = j;
+    w.pos32 = pos32;
+    w.st = st;
+    w.pend_off = kLpDrop;
+    w.pend_st = 0u;
+    w.pf_window = 0xffffffffu;
+    w.strip_held = 0xffffffffu;
+    w.base = 0;
+    w.fresh = true;
+    w.exited = w.hit = false;
+    w.exit_mv = w.e_cnt = w.e_exit_i = w.e_exit_mv = w.e_total = 0u;
+    w.list_strip = 0xffffffffu;
+    w.ea = w.eb = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#ifdef COATI_FILL_TRACE
+    w.tr_iter = w.tr_wait = w.tr_ask = w.tr_hits = 0;
+#endif
+}
+
+// The spliced traceback (round 6).  A long pair's walk was ONE wavefront following the path through hundreds of strips
+// while the strips' own wavefronts, their fill done, idled: 10 333 dependent iterations for the 160 kb pair.  Now every
+// strip's wavefront, as soon as its fill is done, walks ITS strip speculatively: from the strip's right edge, at a row BELOW
+// where the pair's straight line crosses it (a walk that starts below the true path climbs to it by a deletion run and
+// follows it from there: a walk from ABOVE would have to leave the strip sideways), with the same iterations (MODE 2),
+// confined to the strip's own decision words, until it leaves the strip on the left.  It records its ops (right to left) and
+// a list of its run starts (up to 64): {cell, state, ops recorded before it; exit row, arriving move, ops in all}.  The true
+// walk, entering a strip, loads that list -- one entry per lane, the lines asked for a strip earlier -- and before every lookup
+// compares its position with all 64 at once; a hit means both walks stand in the same cell in the same state, so the rest of
+// the strip is the recorded one: it copies the recorded ops behind the hit and continues from the recorded exit with the
+// lookup of the arrival state -- traceback<tropical>'s own walk (align_pair.cc:249-303) from there on.  No hit in a strip
+// (records are absent where the walk came near a margin, overflowed its 1 024 bytes, or -- COATI_HIP_LP_SPLICE=miss -- by
+// request): the walk goes through the strip as before.  Nothing here decides anything: the ops are the walk's own, earlier.
+template <int W>
+__device__ __forceinline__ void lp_spec_walk(int lane, const PairDesc& pd, uint32_t strip, const uint32_t* __restrict__ flags,
+                                             float* __restrict__ bnd, uint32_t lds_scratch, uint32_t mode) {
+    constexpr uint32_t kCols = kWave * W;
+    const uint32_t la = pd.la, lb = pd.lb, col0 = strip * kCols, j_e = col0 + kCols;  // (only strips of full width are followed by another)
+    const uint32_t* __restrict__ fl = flags + pd.flags_off;
+    const uint64_t sd = strip_dwords(la, W);
+    uint32_t i_e = kWave + 1u;  // (mode 2: a walk that ends at once and leaves no record)
+    if(mode != 2u) i_e = static_cast<uint32_t>(std::min<uint64_t>(la, static_cast<uint64_t>(j_e) * la / lb + 256u + ((la + lb) >> 10)));
+    if(i_e <= kWave || j_e <= kWave || col0 == 0u) return;
+    uint8_t* area = lp_splice_area(bnd, pd, strip);
+    LpWalk w;
+    lp_walk_init(w, i_e, j_e, kSpOps, COATI_HIP_OP_MATCH);
+    const u32x4 rs_buf = lp_rsrc(area, kSpOps);
+    const uint32_t win_bytes = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(std::min<uint64_t>(2u * sd * 4u, 0x7ffffff0ull))));
+    auto* ent = reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(lds_scratch));
+    uint32_t n_ent = 0;
+    bool over = false;
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // (see walk_pair_lp)
+    while(w.st != kWalkEnd && w.i > kWave && w.j > kWave && !w.exited) {
+        if(w.pos32 < kWave) {
+            over = true;
+            break;
+        }
+        if(w.fresh && n_ent < static_cast<uint32_t>(kWave)) {
+            if(lane == 0) {
+                ent[4u * n_ent + 0u] = w.i;
+                ent[4u * n_ent + 1u] = w.j;
+                ent[4u * n_ent + 2u] = static_cast<uint32_t>(w.st);
+                ent[4u * n_ent + 3u] = kSpOps - w.pos32;
+            }
+            ++n_ent;
+        }
+        lp_walk_step<W, 2>(w, lane, fl, sd, win_bytes, rs_buf, 0u, col0);
+    }
+    asm volatile("buffer_store_byte %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_buf) : "memory");
+    if(!w.exited || over) return;
+    // every run start's entry, one lane each, through the L2 (both halves carry their own check: a reader may see one without the other)
+    if(static_cast<uint32_t>(lane) < n_ent) {
+        const uint32_t e_i = ent[4u * lane + 0u], e_j = ent[4u * lane + 1u], e_st = ent[4u * lane + 2u], e_cnt = ent[4u * lane + 3u];
+        const u32x4 h0{e_i, e_j, e_st, e_cnt}, h1{w.i, w.exit_mv, kSpOps - w.pos32, e_i ^ e_j ^ kSpCheck};
+        const uint64_t dst = reinterpret_cast<uint64_t>(area + kSpOps + static_cast<uint32_t>(lane) * 32u);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(h0), "v"(h1) : "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+// entering strip `strip` (1 <= strip < last): the list of its record's run starts, one entry per lane (its lines were asked for a
+// strip ago), then the requests for the recorded ops of THIS strip and for the list of the strip after it.  Plain loads: the
+// walk's L2 was invalidated before it began, it touches a record once, and the records were stored through the L2 by their
+// writers.  The order matters: a writer stores its ops, waits for them, then stores the list's entries -- so a list that was
+// read with valid entries proves the ops complete, provided the ops are read AFTER it (hence not a strip ahead with the list:
+// a record still being written when its lines were asked for reads as absent or partial -- no match, the walk goes through that
+// strip itself -- but ops asked for before the list was seen could be stale under a list that is not).
+__device__ __forceinline__ void lp_list_enter(LpWalk& w, int lane, float* __restrict__ bnd, const PairDesc& pd, uint32_t strip, uint32_t lds_sink) {
+    w.list_strip = strip;
+    uint8_t* area = lp_splice_area(bnd, pd, strip);
+    const uint64_t cur = reinterpret_cast<uint64_t>(area + kSpOps + static_cast<uint32_t>(lane) * 32u);
+    const uint64_t opsp = reinterpret_cast<uint64_t>(area + static_cast<uint32_t>(lane) * 16u);
+    const uint64_t nxt = reinterpret_cast<uint64_t>(lp_splice_area(bnd, pd, strip >= 2u ? strip - 1u : strip) + kSpOps + static_cast<uint32_t>(lane) * 16u);
+    uint32_t keep;
+    static_assert(kSpOps == 1024 && kSpEntries * 32u == 2048, "one request of 1 KB for the ops, two for the list");
+    asm volatile("global_load_dwordx4 %[ea], %[cur], off\n\tglobal_load_dwordx4 %[eb], %[cur], off offset:16\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %[opsp], off\n\tglobal_load_lds_dwordx4 %[nxt], off\n\tglobal_load_lds_dwordx4 %[nxt], off offset:1024\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [ea] "=&v"(w.ea), [eb] "=&v"(w.eb), [keep] "=&s"(keep)
+                 : [cur] "v"(cur), [opsp] "v"(opsp), [nxt] "v"(nxt), [lds] "s"(lds_sink)
+                 : "memory");
+}
+// the true walk stands on a recorded run start (w.hit): the recorded ops behind it, then on from the recorded exit.  One memory
+// round trip: the (first 256) recorded bytes and the decision word of the cell the recorded walk left the strip into are
+// loaded together; the copies' stores are left in flight (the next lookup's wait covers them: the counter retires in order).
+template <int W>
+__device__ __forceinline__ void lp_splice_apply(LpWalk& w, int lane, const GapConsts& k, const PairDesc& pd, const uint32_t* __restrict__ flags,
+                                                float* __restrict__ bnd, const u32x4& rs_ops, uint64_t sd) {
+    constexpr uint32_t kCols = kWave * W;
+    const uint32_t strip = (w.j - 1u) / kCols;
+    const uint32_t n = w.e_total - w.e_cnt;  // ops the recorded walk made from here to its exit
+    const u32x4 rs_buf = lp_rsrc(lp_splice_area(bnd, pd, strip), kSpOps);
+    const uint32_t xi = w.e_exit_i, xj = strip * kCols;  // the matrix cell the recorded walk arrived at when it left the strip
+    const int mv = static_cast<int>(w.e_exit_mv);
+    const bool body = xi >= 1u && xj >= 1u;  // (a margin cell: by formula, below)
+    uint64_t aidx = 0;
+    uint32_t ashift = 0;
+    if(body) lp_lookup_addr<W>(sd, xi - 1u, xj - 1u, mv, aidx, ashift);
+    const uint64_t ap = reinterpret_cast<uint64_t>(flags + pd.flags_off + aidx);
+    uint32_t aword = 0;
+    asm volatile("buffer_store_byte %0, %1, %2, 0 offen" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");  // (the iteration before)
+    for(uint32_t done = 0; done < n; done += 4u * kWave) {
+        const uint32_t o = done + static_cast<uint32_t>(lane);  // byte of the piece, from its left (lowest) end
+        const uint32_t so = kSpOps - w.e_total + o, dof = w.pos32 - n + o;
+        uint32_t b0, b1, b2, b3;
+        asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %5, %6, 0 offen\n\tbuffer_load_ubyte %1, %5, %6, 0 offen offset:64\n\t"
+                     "buffer_load_ubyte %2, %5, %6, 0 offen offset:128\n\tbuffer_load_ubyte %3, %5, %6, 0 offen offset:192\n\t"
+                     "global_load_dword %4, %7, off\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(aword)
+                     : "v"(so), "s"(rs_buf), "v"(ap)
+                     : "memory");
+        const uint32_t d0 = o < n ? dof : kLpDrop, d1 = o + kWave < n ? dof + kWave : kLpDrop;
+        const uint32_t d2 = o + 2u * kWave < n ? dof + 2u * kWave : kLpDrop, d3 = o + 3u * kWave < n ? dof + 3u * kWave : kLpDrop;
+        asm volatile("buffer_store_byte %0, %4, %8, 0 offen\n\tbuffer_store_byte %1, %5, %8, 0 offen\n\t"
+                     "buffer_store_byte %2, %6, %8, 0 offen\n\tbuffer_store_byte %3, %7, %8, 0 offen"
+                     :
+                     : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(d0), "v"(d1), "v"(d2), "v"(d3), "s"(rs_ops)
+                     : "memory");
+    }
+    w.pos32 -= n;
+    w.i = xi;
+    w.j = xj;
+    if(body && n > 0u) {  // the state after arriving at (xi, xj) by a move of kind mv: common.hpp state_after on the word loaded above
+        const uint32_t aw = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(aword)));
+        if(mv == COATI_HIP_OP_INS) {
+            w.st = ((aw >> ashift) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+        } else {
+            const uint32_t two = (aw >> ashift) & 3u;
+            w.st = !(two & 2u) ? COATI_HIP_OP_MATCH : ((two & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL);
+        }
+    } else {
+        w.st = __builtin_amdgcn_readfirstlane(arrival_state(k, 1u, flags, pd, xi, xj, mv));
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // (the compiler's own load: see walk_pair_lp)
+    }
+    w.hit = false;
+    w.fresh = true;
+    w.pend_off = kLpDrop;
+#ifdef COATI_FILL_TRACE
+    w.tr_hits += 1;
+#endif
 }
 
 // traceback<tropical> (align_pair.cc:249-303) for a pair whose strips all have W columns per lane: common.hpp's
@@ -653,7 +858,8 @@ __device__ __forceinline__ void lp_walk_iter(LpWalk& w, int lane, const uint32_t
 template <int W>
 __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const PairDesc& pd, uint32_t pair, int start_state,
                                              const uint32_t* __restrict__ flags, uint8_t* __restrict__ ops,
-                                             uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t lds_scratch) {
+                                             uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t lds_scratch,
+                                             float* __restrict__ bnd, bool splice) {
     const uint32_t la = pd.la, lb = pd.lb;
     const uint32_t* __restrict__ fl = flags + pd.flags_off;
     const uint64_t sd = strip_dwords(la, W);
@@ -672,17 +878,8 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
     // (lp_walk_iter above).
     {
         LpWalk w;
-        w.i = i;
-        w.j = j;
-        w.pos32 = la + lb;  // (pos - pd.ops_off: within the pair's slot)
-        w.st = st;
-        w.pend_off = kLpDrop;
-        w.pend_st = 0u;
-        w.pf_window = 0xffffffffu;
-        w.strip_held = 0xffffffffu;
-        w.base = 0;
+        lp_walk_init(w, i, j, la + lb /* pos - pd.ops_off: within the pair's slot */, st);
 #ifdef COATI_FILL_TRACE
-        w.tr_iter = w.tr_wait = w.tr_ask = 0;
         const uint64_t tr_begin = __builtin_amdgcn_s_memtime();
 #endif
         const u32x4 rs_ops = lp_rsrc(ops + pd.ops_off, static_cast<uint64_t>(la) + lb);
@@ -691,16 +888,31 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
         // its bookkeeping understands: it does not count the loop's asm operations, and a store it believes outstanding at the
         // loop's head would make it drain the counter -- our ops store included -- in every iteration)
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        constexpr uint32_t kCols = kWave * W;
         while(w.st != kWalkEnd && w.i > kWave && w.j > kWave) {
-            if(w.st == COATI_HIP_OP_MATCH) lp_walk_iter<W, COATI_HIP_OP_MATCH>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink);
-            else if(w.st == COATI_HIP_OP_DEL) lp_walk_iter<W, COATI_HIP_OP_DEL>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink);
-            else lp_walk_iter<W, COATI_HIP_OP_INS>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink);
+            const uint32_t strip_cur = (w.j - 1u) / kCols;
+            if(splice && strip_cur + 1u < pd.v_strips && strip_cur > 0u) {  // (the last strip has no record: the walk begins there; nor has the first)
+                if(strip_cur != w.list_strip) lp_list_enter(w, lane, bnd, pd, strip_cur, lds_sink);
+                // is the walk on one of the record's run starts?  (all 64 entries at once)
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(w.ea.x == w.i && w.ea.y == w.j && w.ea.z == static_cast<uint32_t>(w.st) &&
+                                                                       w.eb.w == (w.i ^ w.j ^ kSpCheck));
+                if(m != 0ull) {
+                    const int e = __builtin_ctzll(m);
+                    w.e_cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.ea.w), e));
+                    w.e_exit_i = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.x), e));
+                    w.e_exit_mv = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.y), e));
+                    w.e_total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.z), e));
+                    lp_splice_apply<W>(w, lane, k, pd, flags, bnd, rs_ops, sd);
+                    continue;
+                }
+            }
+            lp_walk_step<W, 0>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink, 0u);
         }
         asm volatile("buffer_store_byte %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");
 #ifdef COATI_FILL_TRACE
         if(lane == 0 && la > 100000u) {
             g_lp_trace[4000 * 4 + 0] = w.tr_iter;
-            g_lp_trace[4000 * 4 + 1] = w.tr_wait;
+            g_lp_trace[4000 * 4 + 1] = w.tr_hits;
             g_lp_trace[4000 * 4 + 2] = __builtin_amdgcn_s_memtime() - tr_begin;
             g_lp_trace[4000 * 4 + 3] = w.tr_ask;
         }
@@ -776,7 +988,7 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs, const WorkItem* __restrict__ items,
     uint32_t n_items, uint32_t* __restrict__ queue, uint32_t* __restrict__ progress, const uint8_t* __restrict__ a_cat,
     const uint8_t* __restrict__ b_cat, uint32_t* __restrict__ flags, float* __restrict__ bnd, float* __restrict__ scores,
-    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t pair_tables) {
+    uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start, uint32_t* __restrict__ ops_len, uint32_t pair_tables, uint32_t splice_mode) {
     __shared__ float tab_all[kFillWaves][kTabRows * kTabStride];
     extern __shared__ float lp_dynamic_lds[];  // pair_tables: one pair table per wavefront; else padding (launch_viterbi_lp)
     const int lane_id = threadIdx.x & (kWave - 1);
@@ -834,18 +1046,27 @@ __global__ __launch_bounds__(kFillWaves* kWave, 3) void viterbi_lp(
             g_lp_trace[trace_wave * 4 + 3] = strip;
         }
 #endif
-        if(strip + 1 < pd.v_strips) continue;  // the pair's traceback runs on the wavefront of its LAST strip
+        if(strip + 1 < pd.v_strips) {
+            // the strip's speculative walk for the spliced traceback (lp_spec_walk), while the strips after it still fill
+            if(splice_mode != 0u && pd.la > 0 && pd.lb > 0) {
+                if(pd.v_wmain == 2) lp_spec_walk<2>(lane, pd, strip, flags, bnd, lds_tab, splice_mode);
+                else if(pd.v_wmain == 3) lp_spec_walk<3>(lane, pd, strip, flags, bnd, lds_tab, splice_mode);
+                else lp_spec_walk<4>(lane, pd, strip, flags, bnd, lds_tab, splice_mode);
+                tab_held = 0xffffffffu;  // (its run starts were collected in this wavefront's table)
+            }
+            continue;  // the pair's traceback runs on the wavefront of its LAST strip
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if(pd.la > 0 && pd.lb > 0) {
             // max_mdi of the terminal-adjusted last cell == its "after match" decision (common.hpp viterbi_finish)
             const int start_state = __builtin_amdgcn_readfirstlane(state_after(flags, pd, pd.la - 1, pd.lb - 1, COATI_HIP_OP_MATCH));
             if(pd.v_wmain == 2)
-                walk_pair_lp<2>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab);
+                walk_pair_lp<2>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab, bnd, splice_mode != 0u && pd.v_strips > 1);
             else if(pd.v_wmain == 3)
-                walk_pair_lp<3>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab);
+                walk_pair_lp<3>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab, bnd, splice_mode != 0u && pd.v_strips > 1);
             else
-                walk_pair_lp<4>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab);
+                walk_pair_lp<4>(lane, k, pd, pair, start_state, flags, ops, ops_start, ops_len, lds_tab, bnd, splice_mode != 0u && pd.v_strips > 1);
             tab_held = 0xffffffffu;  // (the walk's requests ahead land in this wavefront's table: reload it for the next item)
         } else {
             viterbi_finish(lane, k, 1u, pd, pair, flags, ops, ops_start, ops_len, scores);  // (margins only)
@@ -886,6 +1107,8 @@ hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
     constexpr size_t kPerBlock[4] = {0, 96 * 1024, 72 * 1024, 52 * 1024};
     // one workgroup per CU: the dynamic LDS holds a pair table per wavefront (99.6 KB, which also keeps a second workgroup
     // off the CU); more: padding only, single-column gathers.  COATI_HIP_LP_PAIRTAB=0: never (A/B)
+    // the spliced traceback (lp_spec_walk): on for plans with multi-strip pairs; COATI_HIP_LP_SPLICE = 0 / 1 / miss forces
+    const uint32_t splice_mode = env_options().lp_splice >= 0 ? static_cast<uint32_t>(env_options().lp_splice) : (v.multi_strip ? 1u : 0u);
     const bool pair_ok = !env_options().lp_pairtab_off;
     const bool pair_tables = best == 1 && pair_ok;
     const size_t dyn = pair_tables ? static_cast<size_t>(kFillWaves) * kTabRows * kLpPairStride : kPerBlock[best] - ((kStatic + 255) / 256) * 256;
@@ -895,7 +1118,7 @@ hipError_t launch_viterbi_lp(const BatchDeviceView& v, hipStream_t stream) {
     }
     hipLaunchKernelGGL(viterbi_lp, dim3(kCUs * static_cast<uint32_t>(best)), dim3(kFillWaves * kWave), dyn, stream, v.table, v.k, v.pairs,
                        v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores, v.ops, v.ops_start,
-                       v.ops_len, pair_tables ? 1u : 0u);
+                       v.ops_len, pair_tables ? 1u : 0u, splice_mode);
     return hipGetLastError();
 }
 

@@ -98,7 +98,7 @@ def test_reference_doctest_alignments_default_model():
         assert [sa, sb] == case["out"], case
 
 
-@pytest.mark.parametrize("kernel", ["auto", "ck", "lp4", "lp3"])
+@pytest.mark.parametrize("kernel", ["auto", "ck", "lp4", "lp3", "nosplice", "miss"])
 @pytest.mark.parametrize("key", ["10k", "20k", "40k", "80k", "160k"])
 def test_long_sample_pairs(key, kernel, monkeypatch):
     """BASELINE configs[2]: the reference's long sample pairs (sanitised)
@@ -121,6 +121,10 @@ def test_long_sample_pairs(key, kernel, monkeypatch):
     # decision words; the planner's choice for the 160 kb pair only -- the shorter ones take 2 columns)
     if kernel in ("lp4", "lp3"):
         monkeypatch.setenv("COATI_HIP_STRIP_W", kernel[2])
+    # (round 6) the planner's shape with the spliced traceback off, and with strip records that never match
+    monkeypatch.delenv("COATI_HIP_LP_SPLICE", raising=False)
+    if kernel in ("nosplice", "miss"):
+        monkeypatch.setenv("COATI_HIP_LP_SPLICE", "0" if kernel == "nosplice" else "miss")
     a, b, case, doc = util.load_long_pair(key)
     table = np.load(GOLD / doc["table"])
     consts = host.gap_consts(doc["gap_open"], doc["gap_extend"])

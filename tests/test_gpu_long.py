@@ -25,7 +25,7 @@ def hip():
 
 @pytest.fixture(autouse=True)
 def decision_bit_plan(monkeypatch):
-    for v in ("COATI_HIP_VITERBI_CK", "COATI_HIP_VITERBI_BITS", "COATI_HIP_L1_LP", "COATI_HIP_STRIP_W", "COATI_HIP_FORCE_GENERIC"):
+    for v in ("COATI_HIP_VITERBI_CK", "COATI_HIP_VITERBI_BITS", "COATI_HIP_L1_LP", "COATI_HIP_STRIP_W", "COATI_HIP_FORCE_GENERIC", "COATI_HIP_LP_SPLICE"):
         monkeypatch.delenv(v, raising=False)
 
 
@@ -86,13 +86,18 @@ def test_long_pairs_equal_viterbi_l1_and_the_oracle(hip, oracle, monkeypatch):
         pairs.append((a, "".join(d)))
     enc = util.encode_pairs(pairs)
     got = {}
-    for name, env in (("lp2", {}), ("lp4", {"COATI_HIP_STRIP_W": "4"}), ("lp3", {"COATI_HIP_STRIP_W": "3"}), ("l1", {"COATI_HIP_L1_LP": "0"})):
+    # (round 6) the spliced traceback -- every strip's wavefront walks its strip speculatively, the true walk splices the records
+    # it meets -- is on by default for these pairs; off, and with records that never match ("miss": the walk must get through
+    # every strip on its own), the same ops
+    for name, env in (("lp2", {}), ("lp4", {"COATI_HIP_STRIP_W": "4"}), ("lp3", {"COATI_HIP_STRIP_W": "3"}), ("l1", {"COATI_HIP_L1_LP": "0"}),
+                      ("lp2_nosplice", {"COATI_HIP_LP_SPLICE": "0"}), ("lp3_nosplice", {"COATI_HIP_STRIP_W": "3", "COATI_HIP_LP_SPLICE": "0"}),
+                      ("lp3_miss", {"COATI_HIP_STRIP_W": "3", "COATI_HIP_LP_SPLICE": "miss"}), ("lp4_miss", {"COATI_HIP_STRIP_W": "4", "COATI_HIP_LP_SPLICE": "miss"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got[name] = run(hip, table, consts, enc)
         for k in env:
             monkeypatch.delenv(k)
-    for name in ("lp4", "lp3", "l1"):
+    for name in ("lp4", "lp3", "l1", "lp2_nosplice", "lp3_nosplice", "lp3_miss", "lp4_miss"):
         assert (bits(got[name][0]) == bits(got["lp2"][0])).all(), name
         for p in range(len(enc)):
             assert np.array_equal(got[name][1][p], got["lp2"][1][p]), (name, p)
