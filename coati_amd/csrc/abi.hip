@@ -185,7 +185,7 @@ BatchDeviceView device_view(const coati_hip_batch* b) {
                            b->d_queue,  b->d_items, b->n_items, b->d_fwd_items, b->n_fwd_items, b->d_progress, b->d_a,    b->d_b,
                            b->d_flags,  b->d_bnd,  b->bnd_floats * sizeof(float), b->d_scores,
                            b->d_ops,    b->d_ops_start, b->d_ops_len, b->d_wscratch, b->ck_slot_dwords, b->ck_split_items | (b->ck_walk_items ? kCkWalkItemsFlag : 0u),
-                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u, b->multi_strip ? 1u : 0u, b->fwd_quad ? 1u : 0u};
+                           b->d_mdi,    b->d_final_mdi, b->fwd_wlog2_max, b->ck_keep_all ? kCkBandOff : m->ck_band, b->long_pairs ? 1u : 0u, b->multi_strip ? 1u : 0u, b->fwd_quad ? 1u : 0u, b->fwd_fast ? 1u : 0u};
 }
 
 
@@ -334,6 +334,7 @@ int coati_hip_model_create_tables(const float* table, uint32_t n_tables, float n
     m->gap_len = gap_len;
     m->ck_band = ck_band_setting();
     m->n_tables = n_tables;
+    m->forward_mode.store(forward_fast_math() ? COATI_HIP_FORWARD_TOLERANCE : COATI_HIP_FORWARD_EXACT);  // (the environment's default)
     m->k = GapConsts{no_gap, gap_stop, gap_open, gap_extend};
     auto cleanup = [&](int rc) {
         coati_hip_model_destroy(m);
@@ -461,6 +462,12 @@ int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t val
     if(option == COATI_HIP_OPT_CK_BAND) {
         if(value < 0 || value > 0x7fffffff) return fail(COATI_HIP_EINVAL, "model_set_option: band of %lld steps", static_cast<long long>(value));
         model->ck_band = value == 0 ? kCkBandOff : static_cast<uint32_t>(value);
+        return COATI_HIP_OK;
+    }
+    if(option == COATI_HIP_OPT_FORWARD_MODE) {
+        if(value != COATI_HIP_FORWARD_EXACT && value != COATI_HIP_FORWARD_TOLERANCE)
+            return fail(COATI_HIP_EINVAL, "model_set_option: Forward mode %lld", static_cast<long long>(value));
+        model->forward_mode.store(static_cast<int>(value));
         return COATI_HIP_OK;
     }
     return fail(COATI_HIP_EINVAL, "model_set_option: unknown option %d", option);

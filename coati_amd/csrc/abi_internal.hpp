@@ -92,6 +92,9 @@ struct coati_hip_model {
     int gap_len = 1;
     GapConsts k{};
     uint32_t n_tables = 1;
+    // COATI_HIP_OPT_FORWARD_MODE: how the log semiring's plus is evaluated by the Forward kernels of batches created from now on
+    // (COATI_HIP_FORWARD_EXACT: glibc's expf / log1pf restated, the CPU's bits; COATI_HIP_FORWARD_TOLERANCE: hardware exp2 / log2)
+    std::atomic<int> forward_mode{0};
     float* d_table = nullptr;  // n_tables * 183*15 floats
     hipStream_t stream = nullptr;
     // Workspaces of destroyed batches, kept for the next batch_create (hipMalloc of a multi-GB
@@ -176,6 +179,7 @@ struct coati_hip_batch {
     bool multi_strip = false;    // the Viterbi strip plan has a pair of more than one strip
     bool ck_keep_all = false;    // viterbi_ck keeps every checkpoint (no band): the debug export decodes every tile
     bool fwd_quad = false;       // the Forward items are quad strips (common.hpp: kFwdQuadCols)
+    bool fwd_fast = false;       // the model's Forward mode when the batch was planned (the strip shapes depend on it)
     uint32_t fwd_wlog2_max = 4;  // widest Forward strip shape of the batch (forward_l1 has a leaner build for <= 8 columns per lane)
     uint32_t* d_progress = nullptr;
     uint32_t n_items = 0;

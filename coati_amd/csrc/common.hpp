@@ -616,6 +616,7 @@ struct BatchDeviceView {
     uint32_t long_pairs;     // decision-bit plan of a few long pairs (every strip 4 columns per lane): viterbi_lp fills it
     uint32_t multi_strip;    // the Viterbi plan has pairs of several strips (their boundary arrays start every launch as NaN patterns)
     uint32_t fwd_quad;       // forward_l1: the items are QUAD strips (kFwdQuadCols columns, four lanes per column: forward_l1.hip)
+    uint32_t fwd_fast;       // Forward kernels: hardware exp2 / log2 (COATI_HIP_FORWARD_TOLERANCE) instead of the libm restatements
 };
 // Before every launch of a persistent kernel: the ticket counter and the polled progress words start at zero.  The
 // planner lays the counter out right in front of the words (plan.hip), so this is ONE fill, not two.

@@ -265,7 +265,7 @@ hipError_t launch_forward_k(const BatchDeviceView& v, hipStream_t stream) {
 #define COATI_LAUNCH_FK(LL, FF)                                                                                        \
     hipLaunchKernelGGL((forward_k<LL, FF>), dim3(blocks), dim3(kFillWaves * kWave), 0, stream, v.table, v.k, v.pairs,   \
                        v.fwd_items, v.n_fwd_items, v.queue, v.progress, v.a_cat, v.b_cat, v.bnd, v.mdi, v.final_mdi)
-    const bool fast = forward_fast_math();
+    const bool fast = v.fwd_fast != 0;
     if(v.gap_len == 2) {
         if(fast) COATI_LAUNCH_FK(2, true); else COATI_LAUNCH_FK(2, false);
     } else {

@@ -574,7 +574,7 @@ hipError_t launch_forward_l1(const BatchDeviceView& v, bool one_table, hipStream
     if(e != hipSuccess) return e;
     // workgroups of 4 wavefronts (one per SIMD); per CU: 2 (fast, 16 columns per lane), 3 (exact, 16 columns), 4 (at most
     // 8 columns per lane: the narrow build); fewer when there are fewer items than wavefronts
-    const bool fast = forward_fast_math(), narrow = one_table && v.fwd_wlog2_max <= 3 && !env_options().fwd_wide_build;
+    const bool fast = v.fwd_fast != 0, narrow = one_table && v.fwd_wlog2_max <= 3 && !env_options().fwd_wide_build;
     const uint32_t per_cu = narrow ? 4u : (fast ? 2u : 3u);
     const uint32_t cus = device_cu_count();
     const uint32_t blocks = std::min<uint32_t>(cus * per_cu, std::max<uint32_t>(cus, (v.n_fwd_items + kFillWaves - 1) / kFillWaves));

@@ -111,8 +111,9 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // that shape fits 128 VGPRs without spills and runs 4 wavefronts per SIMD (forward_l1<false, true>), measured
     // 6 144 pairs of 1 kb: 16 columns (168 VGPRs, 81 spilled values, 3 per SIMD) 68.7 ms, 8 columns in the same build 63.0 ms.
     uint32_t fwd_wlog2 = 4;  // (dp_generic and forward_k lay their cells out for 16 columns per lane)
+    b->fwd_fast = model->forward_mode.load() == COATI_HIP_FORWARD_TOLERANCE;  // (the mode the batch is planned for: COATI_HIP_OPT_FORWARD_MODE)
     if(L == 1 && !force_generic) {
-        if(!forward_fast_math()) fwd_wlog2 = 3;
+        if(!b->fwd_fast) fwd_wlog2 = 3;
         auto count_strips = [&](uint32_t w) {
             uint64_t n = 0;
             for(uint64_t p = 0; p < n_pairs && n < kFwdSlots; ++p) {

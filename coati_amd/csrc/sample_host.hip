@@ -39,8 +39,8 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         for(const auto& a : m->free_arenas) free_b += a.bytes;
     }
     // Round 4: the step table (sampleback.hip) -- thresholds and log-weight increments per (body cell, state), built once
-    // per call -- when it fits 8 GB and a third of the free HBM (16 pairs of 1 kb: 1.15 GB); gap_len 1, the bit-exact
-    // build (the fast build's samplers keep the on-the-fly path: COATI_HIP_FORWARD_FAST is not a parity mode).  With it the
+    // per call -- when it fits 8 GB and a third of the free HBM (16 pairs of 1 kb: 1.15 GB); gap_len 1, either Forward mode
+    // (the sampler's own arithmetic on the stored M/D/I is the libm restatement in both).  With it the
     // candidates only count draws (no temporary ops) and ONE final launch writes every sample from its resolved offset.
     // (a band of diagonals around each pair's straight line: common.hpp step_band; cells outside it are computed by the walkers)
     const uint32_t band_half = env_options().sample_band;
@@ -58,7 +58,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     }
     const bool table_off = env_options().sample_table_off;
     const uint64_t table_bytes = table_entries * step_entry_bytes() + thr_entries * 12 + 256;
-    const bool use_table = m->gap_len == 1 && !forward_fast_math() && !table_off && table_bytes <= (8ull << 30) && table_bytes <= free_b / 3 &&
+    const bool use_table = m->gap_len == 1 && !table_off && table_bytes <= (8ull << 30) && table_bytes <= free_b / 3 &&
                            b->desc[0].f_compact == 0;
     // work arena for the candidates' ops: 2 GB, or a power of two below a quarter of the free HBM
     // (a stable size, so that repeated calls find their block in the cache)

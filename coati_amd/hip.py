@@ -16,7 +16,8 @@ LIB_PATH = _ROOT / "_build" / "libcoati_hip.so"
 
 TABLE_ROWS, TABLE_COLS = 183, 15
 OP_MATCH, OP_DEL, OP_INS = 0, 1, 2
-OPT_PERSISTENT_CALL, OPT_CK_BAND = 1, 2  # coati_hip_model_set_option
+OPT_PERSISTENT_CALL, OPT_CK_BAND, OPT_FORWARD_MODE = 1, 2, 3  # coati_hip_model_set_option
+FORWARD_EXACT, FORWARD_TOLERANCE = 0, 1  # values of OPT_FORWARD_MODE
 
 # every symbol include/coati_hip.h declares
 EXPORTS = (
@@ -210,11 +211,16 @@ def pack_pairs(pairs):
     return a_cat, a_off, b_cat, b_off
 
 
+# Test plumbing: the Forward mode every Model of this process is put into right after its creation (None: the library's
+# default) -- through coati_hip_model_set_option, so that one pytest process runs the sampling suite in both modes.
+DEFAULT_FORWARD_MODE = None
+
+
 class Model:
     """coati_hip_model_t: the 183x15 table (or a stack of n of them, shape (n, 183, 15), for batches
     whose pairs use different tables) + host-computed log gap constants."""
 
-    def __init__(self, table, consts, gap_len: int = 1, device: int = 0):
+    def __init__(self, table, consts, gap_len: int = 1, device: int = 0, forward_mode=None):
         table = np.ascontiguousarray(table, np.float32)
         if table.shape == (TABLE_ROWS, TABLE_COLS):
             table = table[None]
@@ -232,6 +238,9 @@ class Model:
         else:
             _check(lib.coati_hip_model_create_tables(_ptr(table), self.n_tables, c[0], c[1], c[2], c[3], gap_len, device,
                                                      C.byref(self._h)))
+        mode = forward_mode if forward_mode is not None else DEFAULT_FORWARD_MODE
+        if mode is not None:
+            self.set_option(OPT_FORWARD_MODE, mode)
 
     def trim(self):
         """Free the workspaces the model cached from destroyed batches."""

@@ -68,6 +68,7 @@ coati_hip_model* make_model(const alignment_t& aln) {
     coati_hip_model* m = nullptr;
     hip_check(coati_hip_model_create(aln.subst_matrix.data(), k[0], k[1], k[2], k[3], static_cast<int>(aln.gap.len),
                                      aln.device, &m));
+    if(aln.fast_forward) hip_check(coati_hip_model_set_option(m, COATI_HIP_OPT_FORWARD_MODE, COATI_HIP_FORWARD_TOLERANCE));
     return m;
 }
 void release(align_pair_work_mem_t& w) {

@@ -117,8 +117,16 @@ int coati_hip_model_trim(coati_hip_model_t* model);
  *     the pair is filled a second time with everything kept -- same bits, twice the cost for that pair
  *     (coati_hip_viterbi_band_stats counts them).  Related sequences stay inside 96 steps; for inputs with indels of
  *     hundreds of bases in many pairs set a wider band or 0.  Takes effect for batches launched afterwards.
- * Returns COATI_HIP_EINVAL for an unknown option. */
-enum { COATI_HIP_OPT_PERSISTENT_CALL = 1, COATI_HIP_OPT_CK_BAND = 2 };
+ *   COATI_HIP_OPT_FORWARD_MODE (default COATI_HIP_FORWARD_EXACT, or COATI_HIP_FORWARD_TOLERANCE where the environment has
+ *     COATI_HIP_FORWARD_FAST=1): how the Forward kernels evaluate log_sum_exp (semiring.hpp:86-121, utils.hpp:134-156).
+ *     EXACT: device restatements of glibc 2.35's expf / log1pf -- every M/D/I value, hence every sample's log-weight, has the
+ *     bits the reference computes on an x86-64 glibc host (~100 GCUPS of Forward fill).  TOLERANCE: the hardware's exp2 / log2
+ *     instructions -- log-weights within 1e-5 relative of the reference's (the contract's bound), sampled paths may differ from
+ *     the reference's where two branch probabilities are that close (~380 GCUPS).  The sampler's own arithmetic on the stored
+ *     M/D/I is the same in both.  Applies to batches CREATED afterwards (the strip plan depends on the mode).
+ * Returns COATI_HIP_EINVAL for an unknown option or value. */
+enum { COATI_HIP_OPT_PERSISTENT_CALL = 1, COATI_HIP_OPT_CK_BAND = 2, COATI_HIP_OPT_FORWARD_MODE = 3 };
+enum { COATI_HIP_FORWARD_EXACT = 0, COATI_HIP_FORWARD_TOLERANCE = 1 };
 int coati_hip_model_set_option(coati_hip_model_t* model, int option, int64_t value);
 
 /* Warm-up for a coming coati_hip_viterbi_batch call of about n_pairs pairs of about len_a x len_b positions: the
@@ -203,8 +211,8 @@ int coati_hip_batch_result_ptrs(coati_hip_batch_t* batch, void** scores, void** 
  * returns.
  * Numerics: log_sum_exp (semiring.hpp:86-121, utils.hpp:134-156) is evaluated with device
  * restatements of glibc 2.35's expf / log1pf, so every M/D/I value has the bits the reference
- * computes on an x86-64 glibc host.  With COATI_HIP_FORWARD_FAST=1 in the environment the hardware
- * exp2/log2 instructions are used instead (4x the throughput, values within 1e-5 relative). */
+ * computes on an x86-64 glibc host.  A model in COATI_HIP_FORWARD_TOLERANCE mode (COATI_HIP_OPT_FORWARD_MODE above) uses the
+ * hardware exp2/log2 instructions instead (3.8x the throughput, log-weights within 1e-5 relative). */
 int coati_hip_forward_launch(coati_hip_batch_t* batch);
 /* Terminal-adjusted M, D, I of the last cell (align_pair.cc:130-138), 3 floats per
  * pair (synchronises). */

@@ -109,6 +109,16 @@ def test_sample_doctest_cases(tmp_path):
         for got, (wa, wb), ws in zip(arr, case["out"], case["scores"]):
             assert got["alignment"] == {"A": wa, "B": wb}
             assert got["score"] == pytest.approx(float(ws), rel=1e-5)
+    # (round 6) --fast-forward: the C ABI's tolerance mode (COATI_HIP_OPT_FORWARD_MODE) -- the same samples on these inputs,
+    # their log-weights within north_star's 1e-5 relative
+    case = KNOWN["marg_sample"][0]
+    out = tmp_path / "fast.json"
+    r = run("coati-sample", tmp_path / "s0.fasta", "-n", len(case["out"]), "-s", "42", "--fast-forward", "-o", out)
+    assert r.returncode == 0, r.stderr
+    for got, (wa, wb), ws in zip(json.loads(out.read_text()), case["out"], case["scores"]):
+        assert got["alignment"] == {"A": wa, "B": wb}
+        assert got["score"] == pytest.approx(float(ws), rel=1e-5)
+    assert run("coati-alignpair", tmp_path / "s0.fasta", "--fast-forward").returncode != 0  # (a flag of `sample` only)
     # failures (align_marginal.cc:673-722)
     bad = tmp_path / "bad.fasta"
     bad.write_text(">seq1\nAC\n>seq2\nACG\n")

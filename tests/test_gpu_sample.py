@@ -12,6 +12,19 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
 
+@pytest.fixture(autouse=True, params=["exact", "tolerance"])
+def forward_mode(request):
+    """Every test of this module runs in both Forward modes of the C ABI (COATI_HIP_OPT_FORWARD_MODE, set per model through
+    coati_hip_model_set_option -- in this process, no environment): `exact` must reproduce the reference's bits (draw for
+    draw), `tolerance` its log-weights within north_star's 1e-5 relative."""
+    from coati_amd import hip
+
+    old = hip.DEFAULT_FORWARD_MODE
+    hip.DEFAULT_FORWARD_MODE = hip.FORWARD_EXACT if request.param == "exact" else hip.FORWARD_TOLERANCE
+    yield request.param
+    hip.DEFAULT_FORWARD_MODE = old
+
+
 def rel_close(got, want, tol=1e-5):
     got, want = np.float64(got), np.float64(want)
     return abs(got - want) <= tol * max(1.0, abs(want))

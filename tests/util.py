@@ -152,6 +152,10 @@ def forward_exact() -> bool:
     fast log-plus was asked for (COATI_HIP_FORWARD_FAST=1, 1e-5 relative)."""
     import os
 
+    from coati_amd import hip
+
+    if hip.DEFAULT_FORWARD_MODE is not None:  # (the mode the test process put its models into: tests/test_gpu_sample.py)
+        return hip.DEFAULT_FORWARD_MODE == hip.FORWARD_EXACT
     v = os.environ.get("COATI_HIP_FORWARD_FAST", "")
     return v in ("", "0")
 
