@@ -106,9 +106,36 @@ def kernel_sources_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("viterbi_ck.hip", "viterbi_cell.hpp", "common.hpp", "plan.hip"):  # (plan.hip: which items the kernel works through)
+    for f in KERNEL_SOURCE_SETS["viterbi_ck"]:
         h.update((ROOT / "coati_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
+
+
+KERNEL_SOURCE_SETS = {
+    "viterbi_ck": ("viterbi_ck.hip", "viterbi_cell.hpp", "common.hpp", "plan.hip"),  # (plan.hip: which items the kernel works through)
+    "viterbi_lp": ("viterbi_lp.hip", "viterbi_lp_block.inc", "gen_viterbi_lp.py", "viterbi_cell.hpp", "common.hpp", "plan.hip"),
+    "forward_l1": ("forward_l1.hip", "glibc_math.hpp", "common.hpp", "plan.hip"),
+}
+
+
+def sources_sha16(kernel):
+    """Hash of the sources of one kernel family: ties a recorded rocprofv3 figure to the build it was taken from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCE_SETS[kernel]:
+        h.update((ROOT / "coati_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def recorded_kernel_profile(kernel):
+    """profiles/kernel_profiles_latest.json (tools/install_profiles.py): the rocprofv3 record of `kernel` -- average duration
+    under --kernel-trace --stats, PMC counters of separate passes -- or None when its sources have changed since."""
+    try:
+        rec = json.loads((ROOT / "profiles" / "kernel_profiles_latest.json").read_text())[kernel]
+        return rec if rec.get("sources_sha16") == sources_sha16(rec.get("family", kernel)) else None
+    except Exception:
+        return None
 
 
 def recorded_profile(name):
@@ -178,16 +205,22 @@ def roofline_by_kernel(algo_bytes, fill_ms, extras):
     if ff:
         out["forward_l1_exact_narrow (configs[3] fill, 6 144 x 1 kb, bit-exact)"] = {
             "bound": "hbm", "bytes_per_cell": 12.0, "achieved_GBps": ff["gcups"] * 12.0, "frac": ff["hbm_frac_12B_per_cell"],
-            "binding": "valu_issue (glibc expf / log1pf restated: 417 instructions per cell, a third of them 4-8-cycle classes)"}
+            "binding": "valu_issue (glibc expf / log1pf restated: 417 instructions per cell, a third of them 4-8-cycle classes)",
+            "profile": recorded_kernel_profile("forward_l1_exact")}
     ft = (smp.get("forward_fill") or {}).get("tolerance")
     if ft:
         out["forward_l1_fast_wide (configs[3] fill, 6 144 x 1 kb, tolerance mode: log-weights within 1e-5)"] = {
             "bound": "hbm", "bytes_per_cell": 12.0, "achieved_GBps": ft["gcups"] * 12.0, "frac": ft["hbm_frac_12B_per_cell"],
-            "binding": "hbm writes (4.6 of the ~6.2 TB/s a plain store stream reaches on this part)"}
+            "binding": "transcendental issue (8 v_exp_f32 / v_log_f32 per cell at a quarter of the vector rate) next to 5.1 TB/s of "
+                       "writes (a plain store stream reaches ~6.2 on this part)",
+            "profile": recorded_kernel_profile("forward_l1_tolerance")}
     lp = extras.get("long_pair") or {}
     if lp.get("gcups"):
         out["viterbi_lp (configs[2]: one 160 002 x 160 002 pair)"] = {"bound": "hbm", "bytes_per_cell": 1.0, "achieved_GBps": lp["gcups"],
-                                                                      "frac": lp["hbm_frac_1B_per_cell"], "binding": "latency: a chain of ~215 000 dependent wavefront steps"}
+                                                                      "frac": lp["hbm_frac_1B_per_cell"],
+                                                                      "binding": "latency: a chain of ~213 000 dependent wavefront steps (834 strips of 3 columns per lane, "
+                                                                                 "one wavefront per SIMD), then the spliced traceback",
+                                                                      "profile": recorded_kernel_profile("viterbi_lp")}
     s16 = smp.get("sample_16x1000_exact_stream")
     if s16:
         out["configs[3] as stated: 16 pairs, forward + 16 000 samples"] = {"forward_ms": s16["forward_ms"], "sampleback_first_call_ms": s16["sampleback_first_call_ms"],
@@ -355,6 +388,17 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
             t = min(ts[1:])
             r["forward_fill"][mode_name] = {"pairs": n_fwd, "ms": t * 1e3, "gcups": bt.cells / t / 1e9,
                                             "hbm_frac_12B_per_cell": bt.cells * 12 / t / 1e9 / HBM_PEAK_GBS}
+            # the bulk kernel's values (16-column strips: not the quad strips the 16-pair case below runs on): terminal M, D, I of
+            # every 96th pair against the oracle's Forward fill
+            fin = bt.forward_final()
+            a_c, a_o, b_c, b_o = host.synth_encoded(0, n_fwd)
+            worst_f = 0.0
+            for p in range(0, n_fwd, 96):
+                a, b = a_c[int(a_o[p]):int(a_o[p + 1])], b_c[int(b_o[p]):int(b_o[p + 1])]
+                M, D, I = orc.fill(orc.LOG, table, consts, 1, a, b)
+                want = np.array([M[-1, -1], D[-1, -1], I[-1, -1]], np.float64)
+                worst_f = max(worst_f, float(np.max(np.abs(fin[p].astype(np.float64) - want) / np.maximum(1.0, np.abs(want)))))
+            r["forward_fill"][mode_name]["max_rel_error_of_terminal_mdi_vs_oracle_64_pairs"] = worst_f
             bt.close()
             m.trim()
             # configs[3]: ONE call per model, as `coati sample` makes it (first call), then the warm repeats

@@ -145,8 +145,6 @@ struct coati_hip_model {
     size_t stream_waves_bytes = 0;
     hipEvent_t stream_events[2 * kCkStreamSlots] = {};  // [slot]: its download is done; [kCkStreamSlots + slot]: its upload is done
     std::mutex pipeline_lock;  // one pipelined call at a time per model
-    uint32_t spec_rounds_hint = 0; // sampleback: speculation rounds the model's last exact-stream call needed (0: none yet)
-    uint64_t spec_rounds_samples = 0;  // ... and the samples per pair it drew (the hint serves calls of a similar size only)
     uint32_t stream_calls = 0;     // streamed calls this model has served (the first one allocates lazily: a one-shot process pays for what it uses)
     bool stream_unusable = false;  // the persistent kernel's first upload did not arrive in time once (copies not on the copy engine): never again on this model
     uint32_t ck_band = 64;  // viterbi_ck: half width of the kept checkpoint band, kCkBandOff = keep everything (COATI_HIP_OPT_CK_BAND; default: ck_band_setting())

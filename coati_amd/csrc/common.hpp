@@ -526,6 +526,23 @@ __device__ __forceinline__ float log_plus(float a, float b) {
     return hi + __builtin_fmaf(l2, kLn2, resid);
 }
 
+// The tolerance build's three-way sum, plus(plus(a, b), c) of align_pair.cc:97-119 as ONE log-sum-exp (round 6): the largest
+// of the three contributes exp(0) = 1, so two exponentials and one logarithm where the nested form takes four transcendental
+// instructions -- and those, at a quarter of the vector rate, are what the tolerance build's cell consists of (10 of them in
+// ~70 instructions; 8 now).  Mathematically the same sum with one rounding fewer; not the reference's bits (nor is log_plus).
+__device__ __forceinline__ float log_plus3(float a, float b, float c) {
+    constexpr float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(a, b), c);                      // v_max3_f32
+    const float lo = __builtin_fminf(__builtin_fminf(a, b), c);                      // v_min3_f32
+    const float mid = __builtin_amdgcn_fmed3f(a, b, c);                              // v_med3_f32
+    const float e1 = __builtin_amdgcn_exp2f((mid - hi) * kLog2e);                    // in [0, 1]
+    const float e2 = __builtin_amdgcn_exp2f((lo - hi) * kLog2e);                     // in [0, e1]
+    const float t = e1 + e2;                                                         // in [0, 2]
+    const float u = 1.0f + t;
+    const float resid = t - (u - 1.0f);  // the rounding residue of 1 + t (exact up to t = 1, within an ulp of u above)
+    return hi + __builtin_fmaf(__builtin_amdgcn_logf(u), kLn2, resid);
+}
+
 // ---------------------------------------------------------------------------
 // The COATI_HIP_* environment, read ONCE per process (first use) into one struct -- not on every batch_create or launch:
 // the one-pair call path is 0.27 ms.  These are A/B, test and experiment switches; what an embedder needs is a model

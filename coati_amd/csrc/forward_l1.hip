@@ -121,8 +121,8 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint3
             const float i2i = lfI + kv.ge;
             float M, D;
             if constexpr(kFast) {
-                M = log_plus(log_plus(m2m, d2m), i2m);
-                D = log_plus(log_plus(m2d, d2d), i2d);
+                M = log_plus3(m2m, d2m, i2m);
+                D = log_plus3(m2d, d2d, i2d);
             } else if constexpr(W <= 4) {
                 // the M and the D sums do not depend on each other: their two dependent chains side by side (common.hpp).
                 // Narrow strips only -- few pairs, every wavefront alone on its SIMD: 16 pairs 3.41 -> 3.27 ms (round 5, same
@@ -145,7 +145,15 @@ __device__ __forceinline__ void fwd_step(const FwdCtx& cx, FwdLane<W>& st, uint3
             st.M[c] = M;
             st.D[c] = D;
             st.I[c] = I;
-            *reinterpret_cast<Mdi*>(dst + c * (3 * kWave)) = Mdi{M, D, I};
+            if constexpr(kFast) {
+                // (the tolerance build runs at the rate HBM takes its 12 B per cell: the M/D/I stream is written once and read by
+                // the sampler much later -- a non-temporal store keeps it from being allocated in the L2 on its way)
+                typedef float f3_t __attribute__((ext_vector_type(3)));
+                const f3_t v{M, D, I};
+                asm volatile("global_store_dwordx3 %0, %1, off nt\n\ts_nop 1" ::"v"(dst + c * (3 * kWave)), "v"(v) : "memory");
+            } else {
+                *reinterpret_cast<Mdi*>(dst + c * (3 * kWave)) = Mdi{M, D, I};
+            }
         }
         arow = arow_next;
         const int r = static_cast<int>(kstep) - lane;  // body row this lane just did

@@ -171,12 +171,14 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
     if(device_rounds) {
         // ---- device rounds: plan + walks + chain per round, enqueued several rounds at a time; the host reads the number
         // of unfinished pairs each round started with (a round that starts with none is three empty launches)
-        // (How many: six, then six more ... -- or, when this model has sampled before, as many as that call needed and then two at
-        // a time: a call of 13 rounds otherwise pays for 18 and a third synchronisation.)
+        // (How many: a call needs about two learning rounds plus one per ~85 samples of a pair -- the windows' sizes grow with the
+        // square root of the sample's number and a pair's share of the candidates holds a chunk of about that many; 16 x 1 000
+        // samples: 12-13 -- so that many are enqueued at once and two at a time after them.  Round 6: from the call's own size,
+        // not from what the model's LAST call needed -- a hint that was shared, unlocked, by every call on the model and keyed on
+        // the sample count alone; the first call of a process, which is all `coati sample` makes, now starts like the later ones.)
         constexpr uint32_t kBatch = 24;
-        const bool hinted = m->spec_rounds_hint != 0 && n_samples <= 2 * m->spec_rounds_samples && m->spec_rounds_samples <= 2 * n_samples;
-        uint32_t batch_now = hinted ? std::min<uint32_t>(m->spec_rounds_hint, kBatch) : 6u;
-        const uint32_t batch_next = hinted ? 2u : 6u;
+        uint32_t batch_now = static_cast<uint32_t>(std::min<uint64_t>(kBatch, 2u + (static_cast<uint64_t>(n_samples) + 79u) / 80u));
+        const uint32_t batch_next = 2u;
         const uint32_t max_width = widest;
         void* host_block = nullptr;
         S_TRY(model_pinned(m, kBatch * sizeof(SpecRound) + n * sizeof(SpecPairState) + 64, &host_block));
@@ -201,8 +203,6 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             }
             batch_now = batch_next;
         }
-        m->spec_rounds_hint = static_cast<uint32_t>(std::min<uint64_t>(dbg_rounds + 1, kBatch));  // (+ the round that finds nothing left)
-        m->spec_rounds_samples = n_samples;
         // every sample's start in its pair's stream is known (on the device): one walker per (pair, sample), results in place
         S_TRY(launch_final_walk(view, d_tab_off, band_half, d_steps, d_state0, d_pow, d_sample_off, d_base, n_samples, d_ops, d_start, d_len, d_lw, m->stream));
         S_TRY(hipMemcpyAsync(h_states, d_states, n * sizeof(SpecPairState), hipMemcpyDeviceToHost, m->stream));

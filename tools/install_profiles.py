@@ -38,6 +38,50 @@ for extra in ("bench_n1.json",
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402  (kernel_sources_sha16: ties the figure to the kernel build it was measured on)
 
+# the REAL 160 kb pair and the Forward fill in both modes (tools/profile_long.sh): kernel statistics + counters, and ONE record per
+# kernel family tied to its sources (bench.py: recorded_kernel_profile -- the entry goes null when the sources change)
+import csv  # noqa: E402
+
+
+def kernel_record(directory, kernel_prefix, family, files_prefix, workload):
+    d = ROOT / "gpurun_out" / directory
+    if not (d / "kernel_stats.csv").exists():
+        return None
+    shutil.copy(d / "kernel_stats.csv", dst / f"{files_prefix}_kernel_stats.csv")
+    shutil.copy(d / "pmc_summary.csv", dst / f"{files_prefix}_pmc_summary.csv")
+    for extra in ("times.txt", "fwd.txt"):
+        if (d / extra).exists():
+            shutil.copy(d / extra, dst / f"{files_prefix}_{extra}")
+    rec = {"family": family, "sources_sha16": bench.sources_sha16(family), "round": int(rnd[1:]), "workload": workload,
+           "source": [f"profiles/{rnd}/{files_prefix}_kernel_stats.csv", f"profiles/{rnd}/{files_prefix}_pmc_summary.csv"]}
+    for r in csv.DictReader(open(d / "kernel_stats.csv")):
+        if r["Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1].split("<")[0].startswith(kernel_prefix):
+            rec.update({"kernel": r["Name"][:120], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) * 1e-6, "min_ms": float(r["MinNs"]) * 1e-6,
+                        "max_ms": float(r["MaxNs"]) * 1e-6})
+            break
+    for r in csv.DictReader(open(d / "pmc_summary.csv")):
+        if r["kernel"].startswith(kernel_prefix):
+            rec[r["counter"]] = float(r["mean_value"])
+    if "WRITE_SIZE" in rec and "FETCH_SIZE" in rec:
+        rec["hbm_bytes_fetch_x2"] = (rec["WRITE_SIZE"] + 2.0 * rec["FETCH_SIZE"]) * 1024.0
+        rec["hbm_bytes_fetch_raw"] = (rec["WRITE_SIZE"] + rec["FETCH_SIZE"]) * 1024.0
+    return rec
+
+
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+records = {}
+for key, args in (("viterbi_lp", ("prof_long", "viterbi_lp", "viterbi_lp", "long_pair", "tests/golden/long_pairs.npz 160k: 160 002 x 160 002 nt, one pair")),
+                  ("forward_l1_exact", ("prof_fwd_exact", "forward_l1_exact", "forward_l1", "forward_exact", "6 144 synthetic pairs of 1 kb, exact mode")),
+                  ("forward_l1_tolerance", ("prof_fwd_tolerance", "forward_l1_fast", "forward_l1", "forward_tolerance", "6 144 synthetic pairs of 1 kb, tolerance mode"))):
+    rec = kernel_record(*args)
+    if rec is not None:
+        records[key] = rec
+if records:
+    (ROOT / "profiles" / "kernel_profiles_latest.json").write_text(json.dumps(records, indent=1))
+    print(json.dumps(records, indent=1))
+
 t = json.loads((dst / "bench_n1_traffic.json").read_text())["viterbi_ck"]
 (ROOT / "profiles" / "traffic_latest.json").write_text(json.dumps({
     "viterbi_ck_bytes_per_launch_10000_pairs": t["bytes_per_launch"],
