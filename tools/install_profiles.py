@@ -14,12 +14,6 @@ dst.mkdir(parents=True, exist_ok=True)
 for a, b in (("kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("pmc_summary.csv", "bench_n1_pmc_summary.csv"),
              ("traffic.json", "bench_n1_traffic.json"), ("bench.json", "bench_n1_under_rocprof.json")):
     shutil.copy(src / a, dst / b)
-# the exact Forward fill: kernel statistics + PMC counters (tools/profile.sh, second half)
-fwd = ROOT / "gpurun_out" / "prof_fwd"
-if (fwd / "pmc_summary.csv").exists():
-    shutil.copy(fwd / "kernel_stats.csv", dst / "forward_kernel_stats.csv")
-    shutil.copy(fwd / "pmc_summary.csv", dst / "forward_pmc_summary.csv")
-    shutil.copy(fwd / "fwd.json", dst / "forward_fwd_time.txt")
 # the streamed one-shot call: kernel statistics + the probe's wall times
 strm = ROOT / "gpurun_out" / "prof_stream"
 if (strm / "kernel_stats.csv").exists():

@@ -29,30 +29,4 @@ mkdir -p "$SMP"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$SMP/stats" -o sample -- \
     python3 "$ROOT/tools/sample_bench.py" --pairs 64 > "$SMP/sample_bench.json" 2> "$SMP/sample_bench.stderr"
 cp "$(find "$SMP/stats" -name '*kernel_stats.csv' | head -1)" "$SMP/kernel_stats.csv" 2>/dev/null
-# the exact Forward fill (configs[3]): kernel statistics and the counters that say what its ~440 VALU slots per
-# cell and its spills cost (separate passes, same command)
-FWD="$ROOT/gpurun_out/prof_fwd"
-mkdir -p "$FWD"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$FWD/stats" -o fwd -- \
-    python3 "$ROOT/tools/fwd_time.py" 6144 > "$FWD/fwd.json" 2> "$FWD/fwd.stderr"
-for C in SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES WRITE_SIZE FETCH_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$FWD/pmc_$C" -o fwd -- \
-        python3 "$ROOT/tools/fwd_time.py" 6144 > /dev/null 2> "$FWD/pmc_$C.stderr"
-done
-python3 - "$FWD" <<'PY'
-import csv, glob, sys, shutil
-from collections import defaultdict
-from pathlib import Path
-out = Path(sys.argv[1])
-st = glob.glob(str(out / "stats" / "**" / "*kernel_stats.csv"), recursive=True)
-if st: shutil.copy(st[0], out / "kernel_stats.csv")
-acc = defaultdict(list)
-for f in glob.glob(str(out / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]
-        acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
-with open(out / "pmc_summary.csv", "w") as fh:
-    fh.write("kernel,counter,dispatches,mean_value\n")
-    for (name, c), v in sorted(acc.items()):
-        fh.write(f"{name},{c},{len(v)},{sum(v)/len(v):.3f}\n")
-PY
+# (the Forward fill in both modes and the real long pair: tools/profile_long.sh)
