@@ -141,8 +141,11 @@ StagingNeed stream_staging(uint64_t n_pairs, long double total_cells, uint64_t t
 // The streamed call's last chunk (viterbi_batch_stream: "ONE last chunk"): at most kBigTailUnits units of cells, its pairs cut
 // into row parts that keep their own checkpoints (1.09 MB per 1 kb pair) -- one workspace of ~3 GB, kept on the model.
 // (COATI_HIP_STREAM_TAIL_UNITS: tuning / A-B switch, tenths of a unit)
-inline long double big_tail_units() { return env_options().stream_tail_units_x10 > 0 ? env_options().stream_tail_units_x10 / 10.0L : 2.6L; }
-#define kBigTailUnits big_tail_units()
+// (COATI_HIP_STREAM_TAIL_UNITS, tenths, an experiment switch: clamped to 0.5 ... 8 units)
+inline long double big_tail_units() {
+    const int x10 = env_options().stream_tail_units_x10;
+    return x10 > 0 ? std::min(80, std::max(5, x10)) / 10.0L : 2.6L;
+}
 int stream_big_tail_parts() {  // 0 = off
     const int v = env_options().stream_parts;
     return v < 0 ? 3 : (v >= 22 && v <= 28) ? v - 20 : 0;
@@ -150,7 +153,7 @@ int stream_big_tail_parts() {  // 0 = off
 uint64_t stream_big_tail_bytes(uint64_t wave_slot_bytes) {
     // (+ 1/8: the cutter's own safety margin on a chunk's workspace, + the chunk's descriptors and sequences: without them a
     // call whose remainder was just under kBigTailUnits left a last chunk of a few WHOLE pairs behind the row parts)
-    return std::min<uint64_t>(8ull << 30, static_cast<uint64_t>(kBigTailUnits * 1040) * ((wave_slot_bytes + 4096) / 8 * 9 + (32u << 10)) + (64ull << 20));
+    return std::min<uint64_t>(8ull << 30, static_cast<uint64_t>(big_tail_units() * 1040) * ((wave_slot_bytes + 4096) / 8 * 9 + (32u << 10)) + (64ull << 20));
 }
 void stream_reserve_big_tail(coati_hip_model_t* model, uint64_t wave_slot_bytes) {  // (a failed allocation: the call runs without row parts)
     const uint64_t big = stream_big_tail_bytes(wave_slot_bytes);
@@ -520,7 +523,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
     Ahead ahead[kSlots];
     auto cut_chunk = [&](size_t ci, int q, Ahead& a) {
         coati_hip_model::StreamSlot& sl = model->sslots[q];
-        const bool big_tail = big_tail_on && ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= kBigTailUnits * kUnit && tails_used == 0 &&
+        const bool big_tail = big_tail_on && ci >= 2 && cells_done >= 4.1L * kUnit && total_cells - cells_done <= big_tail_units() * kUnit && tails_used == 0 &&
                               model->stream_tail_bytes >= stream_big_tail_bytes(wave_slot_bytes) && model->stream_tail_arena[0] != nullptr;
         const long double target = big_tail ? total_cells : ci == 0 ? kUnit / 2 : (ci == 1 || total_cells - cells_done <= 4 * kUnit) ? kUnit : ci == 2 ? 2 * kUnit : 3 * kUnit;
         // row parts, in the large workspaces: the chunks behind the first 4 100 pairs' worth of cells, while at most

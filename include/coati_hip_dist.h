@@ -116,7 +116,9 @@ int coati_hip_dist_landing_plan(int world, int root, const uint64_t* counts, uin
  * below) spent its time, in seconds: out8[0] the whole job loop, [1] making / waiting for its own chunks, [2] count
  * exchanges, [3] the send / receive group, [4] unpack + placement + offset rebase, [5] the number of rounds, [6] reserving
  * the landing zone, [7] the rank's own copy-out (local form).  What is left of [0] is the loop's own logic (plans,
- * validation, transfer lists).  tools/dist_sim_bench.py. */
+ * validation, transfer lists).  tools/dist_sim_bench.py.  ONE record per process, written by the root's thread of whichever
+ * job ran last: valid only after a job has returned and while no other job of the process is in flight (two communicators
+ * running jobs at once, or a read during a job, race on it -- a measurement aid, not an API to build on). */
 int coati_hip_dist_debug_job_times(double* out8);
 
 /* The per-rank job loop of coati_hip_dist_viterbi_shard[_local] is one piece of code over an ENVIRONMENT: RCCL + HIP
