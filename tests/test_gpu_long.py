@@ -129,3 +129,29 @@ def test_several_long_pairs_with_their_own_tables(hip, oracle):
         assert np.array_equal(ops[int(off[p]):int(off[p]) + int(ln[p])], want_ops), p
     batch.close()
     model.close()
+
+
+def test_spliced_traceback_on_lopsided_and_unrelated_pairs(hip, oracle, monkeypatch):
+    """The spliced traceback (round 6) guesses where a strip's speculative walk should start from the pair's straight line: pairs
+    whose lengths differ by a factor of six either way, a pair of UNRELATED sequences (its path wanders: records that do not
+    match must simply not be used) and a pair with one 3 kb deletion -- splice on (default), off and forced to miss give the
+    oracle's ops."""
+    rng = np.random.default_rng(77)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    anc_long = util.random_anc(rng, 4000)
+    pairs = [(util.random_anc(rng, 700), "".join(rng.choice(list(util.NT), 12500))),        # 2 100 x 12 500
+             (anc_long, util.mutate(rng, anc_long[:2100], n_indel=6)),                        # 12 000 x ~2 100
+             (util.random_anc(rng, 2300), "".join(rng.choice(list(util.NT), 7100))),         # unrelated, 6 900 x 7 100
+             (anc_long, util.mutate(rng, anc_long[:4000] + anc_long[7000:], n_indel=10))]    # one 3 kb deletion
+    enc = util.encode_pairs(pairs)
+    want = [oracle.viterbi(table, consts, 1, a, b, lowmem=True) for a, b in enc]
+    for env in ({}, {"COATI_HIP_LP_SPLICE": "0"}, {"COATI_HIP_LP_SPLICE": "miss"}, {"COATI_HIP_STRIP_W": "3"}, {"COATI_HIP_STRIP_W": "4"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        scores, ops, _ = run(hip, table, consts, enc)
+        for k in env:
+            monkeypatch.delenv(k)
+        for p, (w_ops, w_sc) in enumerate(want):
+            assert bits(scores[p]) == bits(w_sc), (env, p)
+            assert np.array_equal(ops[p], w_ops), (env, p)
