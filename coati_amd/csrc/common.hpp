@@ -152,7 +152,13 @@ constexpr uint32_t kLp3GroupDwords = 512;
 // kSpEntries run starts, 32 bytes each: {i, j, state, ops recorded before, exit row, arriving move, ops in all, check word}.
 // The areas start every launch as 0xff bytes with the boundary arrays (launch_viterbi_lp): an entry that was not written, or
 // only half, matches nothing.
-constexpr uint32_t kSpOps = 1024, kSpEntries = 64, kSpStrideBytes = kSpOps + kSpEntries * 32u;
+constexpr uint32_t kSpOps = 1024, kSpEntries = 64;
+// ... then the BRIDGE (viterbi_lp.hip: lp_spec_walk, second half): kSpOpsB bytes of ops of a second speculative walk, the one that
+// starts where the RIGHT neighbour's recorded walk left that strip and runs until it meets this strip's own record (or leaves the
+// strip), and its 32-byte header {entry row, entry column, entry state | leaving move << 8 | merged << 16, ops in the bridge, ops the
+// own record had made where they met, ops of the own record in all, exit row, check word}.
+constexpr uint32_t kSpOpsB = 512, kSpBridgeOps = kSpOps + kSpEntries * 32u, kSpBridgeHeader = kSpBridgeOps + kSpOpsB, kSpStrideBytes = 4096;
+static_assert(kSpBridgeHeader + 32u <= kSpStrideBytes, "record area");
 __host__ __device__ inline uint64_t lp_splice_first_float(uint32_t la, uint32_t strips) {  // (16-byte aligned)
     return ((static_cast<uint64_t>(strips) - 1u) * 2u * (static_cast<uint64_t>(la) + 1u) + 3u) & ~3ull;
 }

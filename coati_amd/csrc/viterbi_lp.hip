@@ -507,8 +507,9 @@ __device__ __forceinline__ bool lp_ahead_addr(uint64_t sd, uint32_t i, uint32_t 
 // n operations behind it.  The requests are LDS-DMA loads: no register that would have to stay free while they are in flight
 // (an asm load's VGPR destination is the compiler's to reuse at once); what they write -- 256 bytes of this wavefront's table,
 // which the walk does not read and the kernel reloads for the next item -- is ignored; M0 is the compiler's, saved and
-// restored inside the statement.  s_nop 4: the descriptor's SGPRs may have been written by scalar instructions just before
-// (five wait states; the hazard recognizer does not look into inline asm: DESIGN.md 5.2).
+// restored inside the statement.  s_nop 4 -- here and in front of EVERY asm memory instruction of this file that takes a
+// descriptor: its SGPRs may have been written by scalar instructions just before (five wait states; the hazard recognizer
+// does not look into inline asm: DESIGN.md 5.2, 5.30 -- a flush without it lost a bridge's ops in round 6).
 struct LpWalk {
     uint32_t i, j, pos32;        // matrix cell the walk is at; ops written so far end here (within the pair's slot)
     int st;
@@ -522,6 +523,7 @@ struct LpWalk {
     uint32_t exit_mv, e_cnt, e_exit_i, e_exit_mv, e_total;
     uint32_t list_strip;         // the true walk holds the run starts of this strip's record, one entry per lane: ...
     u32x4 ea, eb;                // ... {i, j, state, ops before}, {exit row, arriving move, ops in all, check word}
+    u32x4 ha, hb;                // ... and the strip's bridge header (common.hpp), the same in every lane
 #ifdef COATI_FILL_TRACE
     uint64_t tr_iter, tr_wait, tr_ask, tr_hits;
 #endif
@@ -529,7 +531,7 @@ struct LpWalk {
 __device__ __forceinline__ uint8_t* lp_splice_area(float* bnd, const PairDesc& pd, uint32_t strip) {
     return reinterpret_cast<uint8_t*>(bnd + pd.bnd_off + lp_splice_first_float(pd.la, pd.v_strips)) + static_cast<uint64_t>(strip) * kSpStrideBytes;
 }
-constexpr uint32_t kSpCheck = 0x5a5a5a5au;
+constexpr uint32_t kSpCheck = 0x5a5a5a5au, kSpCheckB = 0x3c3c3c3cu;
 // MODE 0: the walk.  MODE 2: a strip's speculative walk -- confined to its strip (lanes whose cell lies left of body column
 // `col0` end the run; landing there is the exit), its ops stored through the L2 into the strip's record area, no requests
 // ahead (the strip's words are this wavefront's own, fresh in its L2).
@@ -700,7 +702,7 @@ __device__ __forceinline__ void lp_walk_init(LpWalk& w, uint32_t i, uint32_t j, 
     w.exited = w.hit = false;
     w.exit_mv = w.e_cnt = w.e_exit_i = w.e_exit_mv = w.e_total = 0u;
     w.list_strip = 0xffffffffu;
-    w.ea = w.eb = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    w.ea = w.eb = w.ha = w.hb = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #ifdef COATI_FILL_TRACE
     w.tr_iter = w.tr_wait = w.tr_ask = w.tr_hits = 0;
 #endif
@@ -754,13 +756,78 @@ __device__ __forceinline__ void lp_spec_walk(int lane, const PairDesc& pd, uint3
         }
         lp_walk_step<W, 2>(w, lane, fl, sd, win_bytes, rs_buf, 0u, col0);
     }
-    asm volatile("buffer_store_byte %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_buf) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_byte %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_buf) : "memory");
     if(!w.exited || over) return;
     // every run start's entry, one lane each, through the L2 (both halves carry their own check: a reader may see one without the other)
+    u32x4 mya{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     if(static_cast<uint32_t>(lane) < n_ent) {
         const uint32_t e_i = ent[4u * lane + 0u], e_j = ent[4u * lane + 1u], e_st = ent[4u * lane + 2u], e_cnt = ent[4u * lane + 3u];
         const u32x4 h0{e_i, e_j, e_st, e_cnt}, h1{w.i, w.exit_mv, kSpOps - w.pos32, e_i ^ e_j ^ kSpCheck};
+        mya = h0;
         const uint64_t dst = reinterpret_cast<uint64_t>(area + kSpOps + static_cast<uint32_t>(lane) * 32u);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(h0), "v"(h1) : "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    // ---- the bridge.  The true walk will arrive in this strip where the RIGHT neighbour's recorded walk left that strip (once the
+    // walks have met there, its exit is the true one) -- not where this strip's record began -- and would need two or three
+    // iterations of its own to meet this record.  So this wavefront does that piece too, now, while the later strips still fill:
+    // it waits for the neighbour's record, walks from the neighbour's exit until it stands on a run start of its OWN record (or
+    // leaves the strip), and leaves the ops and a header: the true walk, finding its position in the header, copies the bridge and
+    // the rest of the record and is through the strip without a lookup of its own.
+    if(strip + 2u >= pd.v_strips || mode == 2u) return;  // (the last strip has no record: the walk begins there)
+    u32x4 na, nb;
+    {
+        const uint64_t np = reinterpret_cast<uint64_t>(lp_splice_area(bnd, pd, strip + 1u) + kSpOps);
+        bool there = false;
+        for(uint32_t spins = 0; spins < 4096u && !there; ++spins) {  // (~12 us behind this strip's own fill; bounded: no bridge then)
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(na), "=&v"(nb) : "v"(np) : "memory");
+            there = __builtin_amdgcn_readfirstlane(static_cast<int>(na.x != 0xffffffffu && nb.w == (na.x ^ na.y ^ kSpCheck))) != 0;
+            if(!there) __builtin_amdgcn_s_sleep(8);
+        }
+        if(!there) return;
+    }
+    const uint32_t bx_i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(nb.x)));
+    const int bx_mv = __builtin_amdgcn_readfirstlane(static_cast<int>(nb.y));
+    if(bx_i <= kWave) return;
+    int bst;  // the state after arriving at (bx_i, j_e) by that move: this strip's own decision word (common.hpp state_after)
+    {
+        uint64_t aidx;
+        uint32_t ashift;
+        lp_lookup_addr<W>(sd, bx_i - 1u, j_e - 1u, bx_mv, aidx, ashift);
+        const uint32_t aw = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(fl[aidx])));
+        if(bx_mv == COATI_HIP_OP_INS) {
+            bst = ((aw >> ashift) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
+        } else {
+            const uint32_t two = (aw >> ashift) & 3u;
+            bst = !(two & 2u) ? COATI_HIP_OP_MATCH : ((two & 1u) ? COATI_HIP_OP_INS : COATI_HIP_OP_DEL);
+        }
+    }
+    LpWalk b;
+    lp_walk_init(b, bx_i, j_e, kSpOpsB, bst);
+    const u32x4 rs_b = lp_rsrc(area + kSpBridgeOps, kSpOpsB);
+    bool merged = false, over_b = false;
+    uint32_t a_cnt = 0;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    while(b.st != kWalkEnd && b.i > kWave && b.j > kWave && !b.exited) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mya.x == b.i && mya.y == b.j && mya.z == static_cast<uint32_t>(b.st));
+        if(m != 0ull) {
+            a_cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mya.w), __builtin_ctzll(m)));
+            merged = true;
+            break;
+        }
+        if(b.pos32 < kWave) {
+            over_b = true;
+            break;
+        }
+        lp_walk_step<W, 2>(b, lane, fl, sd, win_bytes, rs_b, 0u, col0);
+    }
+    asm volatile("s_nop 4\n\tbuffer_store_byte %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" ::"v"(b.pend_st), "v"(b.pend_off), "s"(rs_b) : "memory");
+    if(over_b || (!merged && !b.exited)) return;
+    if(lane == 0) {
+        const uint32_t leave_mv = merged ? w.exit_mv : b.exit_mv, exit_i = merged ? w.i : b.i;
+        const u32x4 h0{bx_i, j_e, static_cast<uint32_t>(bst) | (leave_mv << 8) | (merged ? 1u << 16 : 0u), kSpOpsB - b.pos32};
+        const u32x4 h1{a_cnt, kSpOps - w.pos32, exit_i, bx_i ^ j_e ^ kSpCheckB};
+        const uint64_t dst = reinterpret_cast<uint64_t>(area + kSpBridgeHeader);
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(h0), "v"(h1) : "memory");
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -775,62 +842,81 @@ __device__ __forceinline__ void lp_spec_walk(int lane, const PairDesc& pd, uint3
 __device__ __forceinline__ void lp_list_enter(LpWalk& w, int lane, float* __restrict__ bnd, const PairDesc& pd, uint32_t strip, uint32_t lds_sink) {
     w.list_strip = strip;
     uint8_t* area = lp_splice_area(bnd, pd, strip);
+    uint8_t* narea = lp_splice_area(bnd, pd, strip >= 2u ? strip - 1u : strip);
     const uint64_t cur = reinterpret_cast<uint64_t>(area + kSpOps + static_cast<uint32_t>(lane) * 32u);
+    const uint64_t hdr = reinterpret_cast<uint64_t>(area + kSpBridgeHeader);
     const uint64_t opsp = reinterpret_cast<uint64_t>(area + static_cast<uint32_t>(lane) * 16u);
-    const uint64_t nxt = reinterpret_cast<uint64_t>(lp_splice_area(bnd, pd, strip >= 2u ? strip - 1u : strip) + kSpOps + static_cast<uint32_t>(lane) * 16u);
+    const uint64_t nxt = reinterpret_cast<uint64_t>(narea + kSpOps + static_cast<uint32_t>(lane) * 16u);
+    const uint64_t nhdr = reinterpret_cast<uint64_t>(narea + kSpBridgeHeader);
     uint32_t keep;
     static_assert(kSpOps == 1024 && kSpEntries * 32u == 2048, "one request of 1 KB for the ops, two for the list");
     asm volatile("global_load_dwordx4 %[ea], %[cur], off\n\tglobal_load_dwordx4 %[eb], %[cur], off offset:16\n\t"
+                 "global_load_dwordx4 %[ha], %[hdr], off\n\tglobal_load_dwordx4 %[hb], %[hdr], off offset:16\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
                  "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %[opsp], off\n\tglobal_load_lds_dwordx4 %[nxt], off\n\tglobal_load_lds_dwordx4 %[nxt], off offset:1024\n\t"
+                 "global_load_lds_dword %[nhdr], off\n\t"
                  "s_mov_b32 m0, %[keep]"
-                 : [ea] "=&v"(w.ea), [eb] "=&v"(w.eb), [keep] "=&s"(keep)
-                 : [cur] "v"(cur), [opsp] "v"(opsp), [nxt] "v"(nxt), [lds] "s"(lds_sink)
+                 : [ea] "=&v"(w.ea), [eb] "=&v"(w.eb), [ha] "=&v"(w.ha), [hb] "=&v"(w.hb), [keep] "=&s"(keep)
+                 : [cur] "v"(cur), [hdr] "v"(hdr), [opsp] "v"(opsp), [nxt] "v"(nxt), [nhdr] "v"(nhdr), [lds] "s"(lds_sink)
                  : "memory");
 }
-// the true walk stands on a recorded run start (w.hit): the recorded ops behind it, then on from the recorded exit.  One memory
-// round trip: the (first 256) recorded bytes and the decision word of the cell the recorded walk left the strip into are
-// loaded together; the copies' stores are left in flight (the next lookup's wait covers them: the counter retires in order).
+// The true walk takes a strip's recorded ops: `n_b` bytes of the bridge (the walk found its position in the bridge's header), then
+// `n_a` bytes of the record behind its `a_cnt`-th op (it met the record there: w.hit, or the bridge did) -- and goes on from the
+// exit (xi, mv).  One memory round trip per 256 bytes of either: the recorded bytes and the decision word of the cell the
+// record left the strip into are loaded together; the copies' stores are left in flight (the next lookup's wait covers them: the
+// counter retires in order).
 template <int W>
 __device__ __forceinline__ void lp_splice_apply(LpWalk& w, int lane, const GapConsts& k, const PairDesc& pd, const uint32_t* __restrict__ flags,
-                                                float* __restrict__ bnd, const u32x4& rs_ops, uint64_t sd) {
+                                                float* __restrict__ bnd, const u32x4& rs_ops, uint64_t sd, uint32_t n_b, uint32_t a_cnt,
+                                                uint32_t a_total, bool with_a, uint32_t xi, int mv) {
     constexpr uint32_t kCols = kWave * W;
     const uint32_t strip = (w.j - 1u) / kCols;
-    const uint32_t n = w.e_total - w.e_cnt;  // ops the recorded walk made from here to its exit
-    const u32x4 rs_buf = lp_rsrc(lp_splice_area(bnd, pd, strip), kSpOps);
-    const uint32_t xi = w.e_exit_i, xj = strip * kCols;  // the matrix cell the recorded walk arrived at when it left the strip
-    const int mv = static_cast<int>(w.e_exit_mv);
+    const uint32_t n_a = with_a ? a_total - a_cnt : 0u;
+    const u32x4 rs_rec = lp_rsrc(lp_splice_area(bnd, pd, strip), kSpStrideBytes);
+    const uint32_t xj = strip * kCols;  // the matrix cell the record arrived at when it left the strip: (xi, xj)
     const bool body = xi >= 1u && xj >= 1u;  // (a margin cell: by formula, below)
     uint64_t aidx = 0;
     uint32_t ashift = 0;
     if(body) lp_lookup_addr<W>(sd, xi - 1u, xj - 1u, mv, aidx, ashift);
     const uint64_t ap = reinterpret_cast<uint64_t>(flags + pd.flags_off + aidx);
     uint32_t aword = 0;
-    asm volatile("buffer_store_byte %0, %1, %2, 0 offen" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");  // (the iteration before)
-    for(uint32_t done = 0; done < n; done += 4u * kWave) {
-        const uint32_t o = done + static_cast<uint32_t>(lane);  // byte of the piece, from its left (lowest) end
-        const uint32_t so = kSpOps - w.e_total + o, dof = w.pos32 - n + o;
-        uint32_t b0, b1, b2, b3;
-        asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %5, %6, 0 offen\n\tbuffer_load_ubyte %1, %5, %6, 0 offen offset:64\n\t"
-                     "buffer_load_ubyte %2, %5, %6, 0 offen offset:128\n\tbuffer_load_ubyte %3, %5, %6, 0 offen offset:192\n\t"
-                     "global_load_dword %4, %7, off\n\t"
+    asm volatile("s_nop 4\n\tbuffer_store_byte %0, %1, %2, 0 offen" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");  // (the iteration before)
+    const uint32_t n_max = n_a > n_b ? n_a : n_b;
+    for(uint32_t done = 0; done < n_max || done == 0u; done += 4u * kWave) {
+        const uint32_t o = done + static_cast<uint32_t>(lane);  // byte of a piece, from its left (lowest) end
+        const uint32_t sa = o < n_a ? kSpOps - a_total + o : kLpDrop, sb = o < n_b ? kSpBridgeOps + kSpOpsB - n_b + o : kLpDrop;
+        const uint32_t da = w.pos32 - n_b - n_a + o, db = w.pos32 - n_b + o;
+        uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+        asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %9, %11, 0 offen\n\tbuffer_load_ubyte %1, %9, %11, 0 offen offset:64\n\t"
+                     "buffer_load_ubyte %2, %9, %11, 0 offen offset:128\n\tbuffer_load_ubyte %3, %9, %11, 0 offen offset:192\n\t"
+                     "buffer_load_ubyte %4, %10, %11, 0 offen sc1\n\tbuffer_load_ubyte %5, %10, %11, 0 offen offset:64 sc1\n\t"
+                     "buffer_load_ubyte %6, %10, %11, 0 offen offset:128 sc1\n\tbuffer_load_ubyte %7, %10, %11, 0 offen offset:192 sc1\n\t"
+                     "global_load_dword %8, %12, off\n\t"
                      "s_waitcnt vmcnt(0)"
-                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(aword)
-                     : "v"(so), "s"(rs_buf), "v"(ap)
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(aword)
+                     : "v"(sa), "v"(sb), "s"(rs_rec), "v"(ap)
                      : "memory");
-        const uint32_t d0 = o < n ? dof : kLpDrop, d1 = o + kWave < n ? dof + kWave : kLpDrop;
-        const uint32_t d2 = o + 2u * kWave < n ? dof + 2u * kWave : kLpDrop, d3 = o + 3u * kWave < n ? dof + 3u * kWave : kLpDrop;
-        asm volatile("buffer_store_byte %0, %4, %8, 0 offen\n\tbuffer_store_byte %1, %5, %8, 0 offen\n\t"
+        auto to = [](uint32_t o_, uint32_t n, uint32_t d) { return o_ < n ? d : kLpDrop; };
+        const uint32_t da0 = to(o, n_a, da), da1 = to(o + kWave, n_a, da + kWave), da2 = to(o + 2u * kWave, n_a, da + 2u * kWave),
+                       da3 = to(o + 3u * kWave, n_a, da + 3u * kWave);
+        const uint32_t db0 = to(o, n_b, db), db1 = to(o + kWave, n_b, db + kWave), db2 = to(o + 2u * kWave, n_b, db + 2u * kWave),
+                       db3 = to(o + 3u * kWave, n_b, db + 3u * kWave);
+        asm volatile("s_nop 4\n\tbuffer_store_byte %0, %4, %8, 0 offen\n\tbuffer_store_byte %1, %5, %8, 0 offen\n\t"
                      "buffer_store_byte %2, %6, %8, 0 offen\n\tbuffer_store_byte %3, %7, %8, 0 offen"
                      :
-                     : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(d0), "v"(d1), "v"(d2), "v"(d3), "s"(rs_ops)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(da0), "v"(da1), "v"(da2), "v"(da3), "s"(rs_ops)
+                     : "memory");
+        asm volatile("s_nop 4\n\tbuffer_store_byte %0, %4, %8, 0 offen\n\tbuffer_store_byte %1, %5, %8, 0 offen\n\t"
+                     "buffer_store_byte %2, %6, %8, 0 offen\n\tbuffer_store_byte %3, %7, %8, 0 offen"
+                     :
+                     : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(db0), "v"(db1), "v"(db2), "v"(db3), "s"(rs_ops)
                      : "memory");
     }
-    w.pos32 -= n;
+    w.pos32 -= n_a + n_b;
     w.i = xi;
     w.j = xj;
-    if(body && n > 0u) {  // the state after arriving at (xi, xj) by a move of kind mv: common.hpp state_after on the word loaded above
+    if(body) {  // the state after arriving at (xi, xj) by a move of kind mv: common.hpp state_after on the word loaded above
         const uint32_t aw = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(aword)));
         if(mv == COATI_HIP_OP_INS) {
             w.st = ((aw >> ashift) & 1u) ? COATI_HIP_OP_MATCH : COATI_HIP_OP_INS;
@@ -892,27 +978,47 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
         while(w.st != kWalkEnd && w.i > kWave && w.j > kWave) {
             const uint32_t strip_cur = (w.j - 1u) / kCols;
             if(splice && strip_cur + 1u < pd.v_strips && strip_cur > 0u) {  // (the last strip has no record: the walk begins there; nor has the first)
-                if(strip_cur != w.list_strip) lp_list_enter(w, lane, bnd, pd, strip_cur, lds_sink);
+                if(strip_cur != w.list_strip) {
+                    lp_list_enter(w, lane, bnd, pd, strip_cur, lds_sink);
+                    // does the walk stand where the strip's bridge began (it does after a splice in the strip before, once the walks
+                    // have met: the bridge started from that record's exit)?  Then the strip is the bridge + the rest of the record.
+                    const uint32_t h_i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.ha.x)));
+                    const uint32_t h_j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.ha.y)));
+                    const uint32_t h_f = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.ha.z)));
+                    const uint32_t h_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.hb.w)));
+                    if(h_i == w.i && h_j == w.j && (h_f & 0xffu) == static_cast<uint32_t>(w.st) && h_c == (w.i ^ w.j ^ kSpCheckB)) {
+                        const uint32_t n_b = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.ha.w)));
+                        const uint32_t a_cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.hb.x)));
+                        const uint32_t a_total = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.hb.y)));
+                        const uint32_t x_i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w.hb.z)));
+                        lp_splice_apply<W>(w, lane, k, pd, flags, bnd, rs_ops, sd, n_b, a_cnt, a_total, ((h_f >> 16) & 1u) != 0u, x_i,
+                                           static_cast<int>((h_f >> 8) & 0xffu));
+#ifdef COATI_FILL_TRACE
+                        w.tr_wait += 1;  // (strips taken by their bridge)
+#endif
+                        continue;
+                    }
+                }
                 // is the walk on one of the record's run starts?  (all 64 entries at once)
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(w.ea.x == w.i && w.ea.y == w.j && w.ea.z == static_cast<uint32_t>(w.st) &&
                                                                        w.eb.w == (w.i ^ w.j ^ kSpCheck));
                 if(m != 0ull) {
                     const int e = __builtin_ctzll(m);
-                    w.e_cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.ea.w), e));
-                    w.e_exit_i = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.x), e));
-                    w.e_exit_mv = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.y), e));
-                    w.e_total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.z), e));
-                    lp_splice_apply<W>(w, lane, k, pd, flags, bnd, rs_ops, sd);
+                    const uint32_t a_cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.ea.w), e));
+                    const uint32_t x_i = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.x), e));
+                    const int x_mv = __builtin_amdgcn_readlane(static_cast<int>(w.eb.y), e);
+                    const uint32_t a_total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w.eb.z), e));
+                    lp_splice_apply<W>(w, lane, k, pd, flags, bnd, rs_ops, sd, 0u, a_cnt, a_total, true, x_i, x_mv);
                     continue;
                 }
             }
             lp_walk_step<W, 0>(w, lane, fl, sd, win_bytes, rs_ops, lds_sink, 0u);
         }
-        asm volatile("buffer_store_byte %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");
+        asm volatile("s_nop 4\n\tbuffer_store_byte %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_ops) : "memory");
 #ifdef COATI_FILL_TRACE
         if(lane == 0 && la > 100000u) {
             g_lp_trace[4000 * 4 + 0] = w.tr_iter;
-            g_lp_trace[4000 * 4 + 1] = w.tr_hits;
+            g_lp_trace[4000 * 4 + 1] = w.tr_hits | (w.tr_wait << 32);
             g_lp_trace[4000 * 4 + 2] = __builtin_amdgcn_s_memtime() - tr_begin;
             g_lp_trace[4000 * 4 + 3] = w.tr_ask;
         }

@@ -26,5 +26,5 @@ walk = t[:, 2] > 0
 print(f"{key}: kernel {f:.2f} ms; {len(t)} strips; first strip done at {(t[:, 1].min() - t0) / 100:.0f} us, last at {(t[:, 1].max() - t0) / 100:.0f} us; "
       f"traceback {((t[walk, 2] - t[walk, 1]).max()) / 100.0:.0f} us")
 if wk[0]:
-    print(f"walk (fast loop): {int(wk[0])} iterations, {wk[2] / wk[0]:.0f} shader cycles each ({wk[2] / 1e6:.2f} M in all); {int(wk[1])} strips spliced; "
+    print(f"walk (fast loop): {int(wk[0])} iterations, {wk[2] / wk[0]:.0f} shader cycles each ({wk[2] / 1e6:.2f} M in all); {int(wk[1]) & 0xffffffff} strips spliced ({int(wk[1]) >> 32} of them by their bridge); "
           f"{int(wk[3])} windows asked ahead")
