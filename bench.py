@@ -434,13 +434,14 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
                     path = ops[int(off[p, sidx]):int(off[p, sidx]) + int(ln[p, sidx])]
                     want = float(orc.path_logweight(M, D, I, table, consts, 1, a, b, path))
                     worst = max(worst, abs(float(lw[p, sidx]) - want) / max(1.0, abs(want)))
-            # ... and as `coati sample` runs it (host/align.cc marg_sample): a fresh model, the forward launch ENQUEUED, then the one
-            # sampleback call at once -- its workspace allocations run while the Forward kernel does
+            # ... and as `coati sample` runs it (host/align.cc marg_sample): a fresh model, the forward launch ENQUEUED, the sampler's
+            # allocations (coati_hip_sampleback_prepare) under the Forward kernel, then the one sampleback call
             m2 = hip.Model(table, consts, 1, forward_mode=mode)
             b2 = hip.Batch(m2, *enc16)
             res2 = tuple(np.ones_like(x) for x in res)
             t0 = time.perf_counter()
             b2.forward_launch()
+            b2.sampleback_prepare(1000)
             res2 = b2.sampleback(1000, states, independent=False, out=res2)
             t_cli = time.perf_counter() - t0
             same_cli = bool((res2[0].view(np.uint32) == lw.view(np.uint32)).all())

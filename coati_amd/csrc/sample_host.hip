@@ -23,7 +23,7 @@ u128 lehmer_pow(uint64_t n) {
 
 hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const uint64_t* rng_state,
                                   const std::vector<uint64_t>& base, uint8_t* d_ops, uint64_t* d_start, uint32_t* d_len,
-                                  float* d_lw, uint64_t* states_out) {
+                                  float* d_lw, uint64_t* states_out, bool prepare_only = false) {
     coati_hip_model* m = b->model;
     const uint64_t n = b->n_pairs;
     constexpr uint32_t kChunkMax = 512;
@@ -74,7 +74,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
         double mean = 0.0, m2 = 0.0;
     };
     std::vector<PairState> ps(n);
-    for(uint64_t p = 0; p < n; ++p) ps[p].st0 = (static_cast<u128>(rng_state[2 * p + 1]) << 64) | rng_state[2 * p];
+    for(uint64_t p = 0; p < n && !prepare_only; ++p) ps[p].st0 = (static_cast<u128>(rng_state[2 * p + 1]) << 64) | rng_state[2 * p];
 
     uint64_t mult_pow[64];
     {
@@ -128,6 +128,18 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
             d_steps = cv.take<char>(table_entries * step_entry_bytes());
         }
     };
+    if(prepare_only) {
+        // coati_hip_sampleback_prepare: the call's temporaries (with the step table: ~170 MB for 16 pairs of 1 kb) and its page-locked
+        // round records exist -- in the model's caches -- before the call needs them
+        Carver sizing;
+        carve(sizing);
+        void* blk = nullptr;
+        uint64_t blk_bytes = 0;
+        if((e = model_take_arena(m, sizing.used, &blk, &blk_bytes)) != hipSuccess) return e;
+        model_give_arena(m, blk, blk_bytes);
+        void* host_block = nullptr;
+        return model_pinned(m, 24 * sizeof(SpecRound) + n * sizeof(SpecPairState) + 64, &host_block);
+    }
     auto release = [&]() {
         if(block == nullptr) return;
         if(hipStreamSynchronize(m->stream) == hipSuccess)
@@ -376,7 +388,7 @@ hipError_t sampleback_speculative(coati_hip_batch* b, uint32_t n_samples, const 
 namespace {
 int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
                     float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
-                    uint64_t* rng_state_out);
+                    uint64_t* rng_state_out, bool prepare_only = false);
 }
 
 int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
@@ -392,11 +404,21 @@ int coati_hip_sampleback(coati_hip_batch_t* b, uint32_t n_samples, const uint64_
     }
 }
 
+int coati_hip_sampleback_prepare(coati_hip_batch_t* b, uint32_t n_samples, int independent_streams) {
+    try {
+        return sampleback_impl(b, n_samples, nullptr, independent_streams, nullptr, nullptr, 0, nullptr, nullptr, nullptr, true);
+    } catch(const std::bad_alloc&) {
+        return fail(COATI_HIP_ENOMEM, "sampleback_prepare: host allocation failed");
+    } catch(const std::exception& ex) {
+        return fail(COATI_HIP_EHIP, "sampleback_prepare: %s", ex.what());
+    }
+}
+
 namespace {
 int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rng_state, int independent_streams,
                     float* log_weights, uint8_t* ops, uint64_t ops_capacity, uint64_t* ops_off, uint32_t* ops_len,
-                    uint64_t* rng_state_out) {
-    if(b == nullptr || rng_state == nullptr) return fail(COATI_HIP_EINVAL, "sampleback: NULL argument");
+                    uint64_t* rng_state_out, bool prepare_only) {
+    if(b == nullptr || (rng_state == nullptr && !prepare_only)) return fail(COATI_HIP_EINVAL, "sampleback: NULL argument");
     if(!b->forward_done) return fail(COATI_HIP_ESTATE, "sampleback: forward was not launched");
     const uint64_t n = b->n_pairs;
     if(n == 0 || n_samples == 0) return COATI_HIP_OK;
@@ -414,7 +436,8 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
                     static_cast<unsigned long long>(total));
     const uint64_t walkers = independent_streams ? n * n_samples : n;
     std::vector<uint64_t> states(2 * walkers);
-    if(independent_streams) {
+    if(prepare_only) {
+    } else if(independent_streams) {
         // sample s of pair p starts s * 2^32 draws into the pair's stream: state * (MULT^(2^32))^s mod 2^128
         using u128 = unsigned __int128;
         u128 jump = static_cast<u128>(0xda942042e4dd58b5ULL);
@@ -468,6 +491,11 @@ int sampleback_impl(coati_hip_batch_t* b, uint32_t n_samples, const uint64_t* rn
         // exact stream with several samples per pair: walked in parallel by speculating the stream
         // offsets (identical results); COATI_HIP_SAMPLE_SEQUENTIAL=1 keeps the one-walker-per-pair loop
         const bool sequential = env_options().sample_sequential;
+        if(prepare_only) {  // (the result block is taken -- and goes back to the model's cache below; now the speculation's temporaries)
+            if(!independent_streams && n_samples >= 4 && !sequential && n <= 1024)
+                return sampleback_speculative(b, n_samples, nullptr, base, d_ops, d_start, d_len, d_lw, nullptr, true);
+            return hipSuccess;
+        }
         // (speculation buys parallelism for FEW pairs with many samples; thousands of pairs are parallel as they are -- one walker
         // per pair, sample after sample -- and a round's per-pair work would only add to it: 3 000 short pairs x 12 samples
         // 6.4 ms sequentially, 9.4-14.5 ms speculated; tools/sample_many_pairs_check.py)

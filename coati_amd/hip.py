@@ -48,6 +48,7 @@ EXPORTS = (
     "coati_hip_forward_final",
     "coati_hip_debug_forward_matrices",
     "coati_hip_sampleback",
+    "coati_hip_sampleback_prepare",
     "coati_hip_debug_rng_f24",
     "coati_hip_debug_libm",
     "coati_hip_viterbi_batch",
@@ -118,6 +119,7 @@ def load() -> C.CDLL:
     lib.coati_hip_forward_final.argtypes = [vp, vp]
     lib.coati_hip_debug_forward_matrices.argtypes = [vp, u64, vp, vp, vp, u64]
     lib.coati_hip_sampleback.argtypes = [vp, C.c_uint32, vp, i32, vp, vp, u64, vp, vp, vp]
+    lib.coati_hip_sampleback_prepare.argtypes = [vp, C.c_uint32, i32]
     lib.coati_hip_debug_rng_f24.argtypes = [vp, vp, C.c_uint32, vp]
     if hasattr(lib, "coati_hip_debug_libm"):
         lib.coati_hip_debug_libm.argtypes = [vp, i32, vp, u64, vp]
@@ -394,6 +396,10 @@ class Batch:
         if M.size:
             _check(load().coati_hip_debug_forward_matrices(self._h, pair, _ptr(M), _ptr(D), _ptr(I), M.size))
         return M, D, I
+
+    def sampleback_prepare(self, n_samples: int, independent: bool = False):
+        """coati_hip_sampleback_prepare: the coming sampleback call's allocations now (behind forward_launch: under the kernel)."""
+        _check(load().coati_hip_sampleback_prepare(self._h, int(n_samples), int(independent)))
 
     def sampleback(self, n_samples: int, rng_states, independent: bool = False, out=None):
         """rng_states: (n, 2) uint64 (lo, hi).  Returns (log_weights (n, S), ops, ops_off (n, S), ops_len (n, S),

@@ -1064,6 +1064,8 @@ void marg_sample(alignment_t& aln, std::size_t sample_size, random_t& rand) {
     align_pair_work_t work;
     forward(work, seq_pair[0], seq_pair[1], aln);
     if(sample_size == 0) return;
+    // (the sampler's device blocks and page-locked records while the Forward kernel runs: this process makes ONE sampleback call)
+    hip_check(coati_hip_sampleback_prepare(work.batch, static_cast<uint32_t>(sample_size), aln.independent_streams ? 1 : 0));
     // all samples in one device call: the walker draws them one after the other from `rand`'s
     // stream, exactly as the loop of align_marginal.cc:590-593 does
     const uint64_t state_in[2] = {rand.lo(), rand.hi()};

@@ -36,6 +36,7 @@ int coati_hip_forward_launch(coati_hip_batch_t*) { return kNo; }
 int coati_hip_forward_final(coati_hip_batch_t*, float*) { return kNo; }
 int coati_hip_debug_forward_matrices(coati_hip_batch_t*, uint64_t, float*, float*, float*, uint64_t) { return kNo; }
 int coati_hip_sampleback(coati_hip_batch_t*, uint32_t, const uint64_t*, int, float*, uint8_t*, uint64_t, uint64_t*, uint32_t*, uint64_t*) { return kNo; }
+int coati_hip_sampleback_prepare(coati_hip_batch_t*, uint32_t, int) { return kNo; }
 int coati_hip_debug_libm(coati_hip_model_t*, int, const float*, uint64_t, float*) { return kNo; }
 int coati_hip_debug_rng_f24(coati_hip_model_t*, const uint64_t*, uint32_t, float*) { return kNo; }
 int coati_hip_viterbi_batch(coati_hip_model_t*, uint64_t, const uint8_t*, const uint64_t*, const uint8_t*, const uint64_t*, float*, uint8_t*, uint64_t, uint64_t*, uint32_t*) { return kNo; }

@@ -239,6 +239,13 @@ int coati_hip_debug_forward_matrices(coati_hip_batch_t* batch, uint64_t pair, fl
 int coati_hip_sampleback(coati_hip_batch_t* batch, uint32_t n_samples, const uint64_t* rng_state,
                          int independent_streams, float* log_weights, uint8_t* ops, uint64_t ops_capacity,
                          uint64_t* ops_off, uint32_t* ops_len, uint64_t* rng_state_out);
+/* Warm-up for a coming coati_hip_sampleback(batch, n_samples, ..., independent_streams, ...): the device blocks (result slots,
+ * the speculation's candidates and step table: ~0.25 GB for 16 pairs of 1 kb) and the page-locked round records that call would
+ * allocate first are allocated now and left in the model's caches.  Needs coati_hip_forward_launch to have been CALLED, not to
+ * have finished: made right behind it, the allocations run while the Forward kernel does (`coati-sample` does so) -- a process
+ * makes one sampleback call, and its first-call cost is then what a later call's is.  Optional; identical results.  (The
+ * reference has no counterpart: marg_sample's work matrices are allocated by forward(), align_marginal.cc:584-588.) */
+int coati_hip_sampleback_prepare(coati_hip_batch_t* batch, uint32_t n_samples, int independent_streams);
 /* Parity/debug: the device's bit-exact restatements of the libm functions the log-semiring path
  * calls (glibc 2.35; coati_amd/csrc/glibc_math.hpp), applied element-wise.
  *   op 0: expf(x), x <= 0      (log1p_exp, utils.hpp:134-146; sample_mdi, align_pair.cc:336-358)

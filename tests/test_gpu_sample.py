@@ -243,3 +243,30 @@ print(json.dumps({"ops": crc, "lw": zlib.crc32(lw.tobytes()), "len": int(ln.sum(
     assert outs[0]["packed"]
     for extra, out in zip(variants[1:], outs[1:]):
         assert out == outs[0], (extra, out, outs[0])
+
+
+def test_sampleback_prepare_changes_nothing_but_the_first_call():
+    """coati_hip_sampleback_prepare (round 6: the sampler's allocations behind forward_launch, under the Forward kernel -- what
+    `coati-sample` does): the samples of a prepared call are those of an unprepared one, for the exact-stream, the
+    independent-stream and the one-sample forms; a prepare without forward_launch is refused."""
+    from coati_amd import hip, host
+
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    enc = host.synth_encoded(0, 5, n_codons=120)
+    states = np.array([host.rng_seed(["7"]) for _ in range(5)], np.uint64)
+    for n, indep in ((40, False), (40, True), (1, False)):
+        got = []
+        for prepare in (False, True):
+            model = hip.Model(table, consts, 1)
+            batch = hip.Batch(model, *enc)
+            if prepare:
+                with pytest.raises(hip.CoatiHipError):
+                    batch.sampleback_prepare(n, indep)
+            batch.forward_launch()
+            if prepare:
+                batch.sampleback_prepare(n, indep)
+            got.append(batch.sampleback(n, states, independent=indep))
+            batch.close()
+            model.close()
+        for x, y in zip(got[0], got[1]):
+            assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))

@@ -12,12 +12,14 @@ table, consts = host.set_subst("mar-mg"), host.gap_consts()
 enc = host.synth_encoded(0, 16)
 states = np.array([host.rng_seed(["42"]) for _ in range(16)], np.uint64)
 warm = hip.Model(table, consts, 1); wb = hip.Batch(warm, *enc); wb.forward_launch(); wb.sync(); wb.close(); warm.close()  # (HIP bring-up)
-for touched in (False, True):
+for touched, prepare in ((False, False), (True, False), (True, True)):
     rows = []
     for _ in range(reps):
         m = hip.Model(table, consts, 1)
         bt = hip.Batch(m, *enc)
-        t0 = time.perf_counter(); bt.forward_launch(); bt.sync(); t_f = time.perf_counter() - t0
+        t0 = time.perf_counter(); bt.forward_launch()
+        if prepare: bt.sampleback_prepare(1000)  # (the sampler's allocations under the Forward kernel: coati-sample does this)
+        bt.sync(); t_f = time.perf_counter() - t0
         out = None
         if touched:
             total = int(1000 * bt.lens.sum())
@@ -27,4 +29,4 @@ for touched in (False, True):
         rows.append((t_f * 1e3, t1 * 1e3, t2 * 1e3))
         bt.close(); m.close()
     r = np.median(np.array(rows), axis=0)
-    print(f"result arrays {'touched' if touched else 'fresh  '}: forward {r[0]:.2f} ms, first sampleback {r[1]:.2f} ms, second {r[2]:.2f} ms")
+    print(f"result arrays {'touched' if touched else 'fresh  '}{', prepared' if prepare else ''}: forward {r[0]:.2f} ms, first sampleback {r[1]:.2f} ms, second {r[2]:.2f} ms")
