@@ -532,6 +532,11 @@ __device__ __forceinline__ uint8_t* lp_splice_area(float* bnd, const PairDesc& p
     return reinterpret_cast<uint8_t*>(bnd + pd.bnd_off + lp_splice_first_float(pd.la, pd.v_strips)) + static_cast<uint64_t>(strip) * kSpStrideBytes;
 }
 constexpr uint32_t kSpCheck = 0x5a5a5a5au, kSpCheckB = 0x3c3c3c3cu;
+// a strip whose speculative walk left no record says so in its list's first word, so that its left neighbour does not wait for one
+constexpr uint32_t kSpNoRecord = 0xfffffffeu;
+__device__ __forceinline__ void lp_mark_no_record(uint8_t* area, int lane) {
+    if(lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(area + kSpOps), kSpNoRecord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // MODE 0: the walk.  MODE 2: a strip's speculative walk -- confined to its strip (lanes whose cell lies left of body column
 // `col0` end the run; landing there is the exit), its ops stored through the L2 into the strip's record area, no requests
 // ahead (the strip's words are this wavefront's own, fresh in its L2).
@@ -730,8 +735,11 @@ __device__ __forceinline__ void lp_spec_walk(int lane, const PairDesc& pd, uint3
     const uint64_t sd = strip_dwords(la, W);
     uint32_t i_e = kWave + 1u;  // (mode 2: a walk that ends at once and leaves no record)
     if(mode != 2u) i_e = static_cast<uint32_t>(std::min<uint64_t>(la, static_cast<uint64_t>(j_e) * la / lb + 256u + ((la + lb) >> 10)));
-    if(i_e <= kWave || j_e <= kWave || col0 == 0u) return;
     uint8_t* area = lp_splice_area(bnd, pd, strip);
+    if(i_e <= kWave || j_e <= kWave || col0 == 0u) {
+        lp_mark_no_record(area, lane);
+        return;
+    }
     LpWalk w;
     lp_walk_init(w, i_e, j_e, kSpOps, COATI_HIP_OP_MATCH);
     const u32x4 rs_buf = lp_rsrc(area, kSpOps);
@@ -757,7 +765,10 @@ __device__ __forceinline__ void lp_spec_walk(int lane, const PairDesc& pd, uint3
         lp_walk_step<W, 2>(w, lane, fl, sd, win_bytes, rs_buf, 0u, col0);
     }
     asm volatile("s_nop 4\n\tbuffer_store_byte %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" ::"v"(w.pend_st), "v"(w.pend_off), "s"(rs_buf) : "memory");
-    if(!w.exited || over) return;
+    if(!w.exited || over) {
+        lp_mark_no_record(area, lane);
+        return;
+    }
     // every run start's entry, one lane each, through the L2 (both halves carry their own check: a reader may see one without the other)
     u32x4 mya{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     if(static_cast<uint32_t>(lane) < n_ent) {
@@ -779,10 +790,13 @@ __device__ __forceinline__ void lp_spec_walk(int lane, const PairDesc& pd, uint3
     {
         const uint64_t np = reinterpret_cast<uint64_t>(lp_splice_area(bnd, pd, strip + 1u) + kSpOps);
         bool there = false;
-        for(uint32_t spins = 0; spins < 4096u && !there; ++spins) {  // (~12 us behind this strip's own fill; bounded: no bridge then)
+        // (the neighbour's record is ~12 us + its walk behind this strip's own fill; a neighbour without one says so; and the wait is
+        // bounded at ~0.2 ms -- this wavefront may have other items to draw: no bridge then)
+        for(uint32_t spins = 0; spins < 128u && !there; ++spins) {
             asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(na), "=&v"(nb) : "v"(np) : "memory");
+            if(__builtin_amdgcn_readfirstlane(static_cast<int>(na.x)) == static_cast<int>(kSpNoRecord)) return;
             there = __builtin_amdgcn_readfirstlane(static_cast<int>(na.x != 0xffffffffu && nb.w == (na.x ^ na.y ^ kSpCheck))) != 0;
-            if(!there) __builtin_amdgcn_s_sleep(8);
+            if(!there) __builtin_amdgcn_s_sleep(32);
         }
         if(!there) return;
     }
