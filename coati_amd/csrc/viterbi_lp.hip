@@ -1,25 +1,27 @@
-// viterbi_lp: the gap_len-1 Viterbi fill for a FEW LONG pairs (BASELINE configs[2]: one 160 kb pair) --
-// the batches whose strip plan has fewer strips than the GPU has SIMDs, so that every strip is 4, 3 or 2 columns per
-// lane wide and every wavefront is alone on its SIMD (3 columns, round 6: the 160 kb pair is 834 strips on 1 024 SIMDs
-// where 4 columns leave 398 SIMDs without one; its decision words are kept per column, common.hpp).  Same recurrence, same five decision bits per cell in
-// the same HBM layout as viterbi_l1.hip (the traceback of common.hpp reads both), same strip pipeline through
-// self-validating boundary values; what differs is how a step is issued.
+// viterbi_lp: the gap_len-1 Viterbi fill + traceback for a FEW LONG pairs (BASELINE configs[2]: one 160 kb pair) -- the batches
+// whose strip plan has fewer strips than the GPU has SIMDs, so that every strip is 4, 3 or 2 columns per lane wide and every
+// wavefront is alone on its SIMD.  Same recurrence and the same five decision bits per cell as viterbi_l1.hip, the same strip
+// pipeline through self-validating boundary values; what differs is how a step is issued and how the path is walked.
 //
 // What it replaces in the reference: forward_impl<tropical, align_pair_work_mem_t> (src/lib/align_pair.cc:62-139)
 // and traceback<tropical> (align_pair.cc:249-303) for one pair that the CPU tool cannot hold in memory.
 //
-// A lone wavefront issues one instruction per ~4.3 cycles WHATEVER the instruction
-// (profiles/r03/ubench_issue_model.txt), so its time is its instruction count.  viterbi_l1's 4-column step is
-// ~175 instructions (27 per cell + ~67 of hand-off, stores, bookkeeping); here a step is ~87:
+// The fill.  A lone wavefront issues one instruction per ~4.5 cycles WHATEVER the instruction (an LDS or vector memory
+// instruction: ~18), so its time is its instruction count.  viterbi_l1's 4-column step is ~175 instructions; here 81
+// (4 columns), 63.5 (3) and 46 (2):
 //   * the cell's eleven additions are six (v_pk_add_f32 does two fp32 additions -- IEEE, the same bits -- in one
-//     instruction) and the five sign differences of the decisions three: 19 instructions per cell, LDS gather
-//     included (gen_viterbi_lp.py has the list);
+//     instruction) and the five sign differences of the decisions three: 17 instructions per cell (gen_viterbi_lp.py);
 //   * 16 steps are ONE block of hand-allocated instruction text: lane 0 takes the strip's left boundary straight
-//     from lane j of the chunk registers by a row_shl:j DPP, stores use immediate offsets, cell 3 ping-pongs its
+//     from lane j of the chunk registers by a row_shl:j DPP, stores use immediate offsets, the last column ping-pongs its
 //     state between two register pairs so that the diagonal hand-off needs no copy;
-//   * the left boundary arrives in 16-row chunks that are loaded one block AHEAD (at the top of the block before)
-//     and checked after it, so a strip follows its left neighbour at 63 + 32 steps, not 63 + 64 + a memory round
-//     trip per chunk -- with 626 strips in a 160 kb pair the sum of those lags is a third of the time.
+//   * the left boundary arrives in 16-row chunks, (X of row r - 1, Z of row r) as one 8-byte load per row, requested late
+//     in the block before and checked after it; the right boundary leaves as one 8-byte store per step (round 6);
+//   * 3 columns per lane (round 6: the 160 kb pair is 834 strips on 1 024 SIMDs where 4 columns leave 398 SIMDs without
+//     one) keep their decision words per column, lane-major, three stores per block (common.hpp).
+// The traceback (round 6): lp_walk_iter -- the walk away from the margins, one asm statement per iteration --, and the splice:
+// every strip's wavefront walks its strip speculatively as soon as its fill is done (lp_spec_walk: a record of run starts, and
+// a bridge from its right neighbour's exit to that record), the true walk copies what it meets (lp_list_enter,
+// lp_splice_apply).  160 002 x 160 002: 33.4 ms, of which the walk 1 ms (round 5: 43.0 / 5.9).
 // fp32 only, adds/max/compares in the reference's evaluation order; built with -ffp-contract=off.
 #include "viterbi_cell.hpp"
 
@@ -968,11 +970,10 @@ __device__ __forceinline__ void walk_pair_lp(int lane, const GapConsts& k, const
     uint32_t i = la, j = lb;  // matrix coordinates of the last cell (gap_len 1: body cell (i-1, j-1))
     uint64_t pos = pd.ops_off + la + lb;
     int st = (i < 1 && j < 1) ? kWalkEnd : start_state;
-    // The decision words along the path were written tens of milliseconds ago: every iteration's lookup is a miss all the way
-    // to HBM, ~0.75 us, and a real pair has thousands of runs (the reference's 160 kb sample: 9 521 runs, 10 333 iterations, ~8 ms
-    // of a 44.6-ms launch).  So every 64 diagonal moves the wavefront ASKS for the words of the diagonal 64 ... 230 moves ahead
-    // -- 26 groups of steps x their 5 rows, two loads per lane, nobody waits for them (their values are folded into `sink` one
-    // window later) -- and the lookups find them in the L2.
+    // (The loop for the margins' neighbourhood, below.)  The decision words along the path were written tens of milliseconds ago:
+    // a lookup would be a miss all the way to HBM.  So every 64 diagonal moves the wavefront ASKS for the words of the diagonal
+    // 64 ... 230 moves ahead -- two loads per lane, nobody waits for them (their values are folded into `sink` one window later) --
+    // and the lookups find them in the L2.
     uint32_t pf_window = 0xffffffffu, pf0 = 0u, pf1 = 0u, sink = 0u;
     // Round 6: the walk away from the margins (i, j > 64: every lane's cell is a body cell) as a loop of its own
     // (lp_walk_iter above).
