@@ -32,12 +32,16 @@ while time.time() < t_end:
     os.environ.pop("COATI_HIP_L1_LP", None)
     os.environ.pop("COATI_HIP_STRIP_W", None)
     os.environ.pop("COATI_HIP_LP_PAIRTAB", None)
+    os.environ.pop("COATI_HIP_LP_SPLICE", None)
     if forced in ("auto", "bits"):  # small batches run on viterbi_lp: both strip shapes, with and without the pair table
         w = str(rng.choice(["", "", "2", "3", "4"]))
         if w:
             os.environ["COATI_HIP_STRIP_W"] = w
         if rng.random() < 0.5:  # ... the single-column gathers (the library re-reads its switches per entry of this plumbing)
             os.environ["COATI_HIP_LP_PAIRTAB"] = "0"
+        sp = str(rng.choice(["", "", "", "0", "miss"]))  # (round 6) the spliced traceback: default (on for multi-strip pairs), off, records that never match
+        if sp:
+            os.environ["COATI_HIP_LP_SPLICE"] = sp
     if forced == "l1":  # the decision-bit kernel it replaced there
         os.environ["COATI_HIP_VITERBI_BITS"] = "1"
         os.environ["COATI_HIP_L1_LP"] = "0"
@@ -64,6 +68,9 @@ while time.time() < t_end:
         unit = 3 * L if L % 3 else L
         anc = util.random_anc(rng, max(unit // 3, (nb // 3) // (unit // 3) * (unit // 3)))
         pairs.append((anc, "".join(rng.choice(list(util.NT), nb))))
+    if L == 1 and rng.random() < 0.12:  # (round 6) a related pair of 6-10 kb with indels: dozens of strips, records, bridges
+        anc = util.random_anc(rng, int(rng.integers(2000, 3400)))
+        pairs.append((anc, util.mutate(rng, anc, n_indel=int(rng.integers(4, 60)), mean_len=int(rng.choice([4, 12, 40])))))
     enc = util.encode_pairs(pairs)
     tix = rng.integers(0, n_tables, len(enc)).astype(np.uint32)
     model = hip.Model(tables, consts, L)
