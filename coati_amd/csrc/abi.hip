@@ -94,6 +94,7 @@ const EnvOptions* read_env() {
     o->lp_pairtab_off = zero("COATI_HIP_LP_PAIRTAB");
     o->lp3_off = zero("COATI_HIP_LP3");
     if(const char* e = std::getenv("COATI_HIP_LP_SPLICE")) o->lp_splice = std::strcmp(e, "miss") == 0 ? 2 : (e[0] == '0' ? 0 : 1);
+    if(const char* e = std::getenv("COATI_HIP_CK_SPLICE")) o->ck_splice = std::strcmp(e, "miss") == 0 ? 2 : (std::strcmp(e, "nobridge") == 0 ? 3 : (e[0] == '0' ? 0 : 1));
     if(const char* e = std::getenv("COATI_HIP_FORWARD_FAST")) o->forward_fast = e[0] != '\0' && e[0] != '0';
     o->timing = set("COATI_HIP_TIMING");
     o->pipe_timing = set("COATI_HIP_PIPE_TIMING");

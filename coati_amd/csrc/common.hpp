@@ -163,6 +163,23 @@ __host__ __device__ inline uint64_t lp_splice_first_float(uint32_t la, uint32_t 
     return ((static_cast<uint64_t>(strips) - 1u) * 2u * (static_cast<uint64_t>(la) + 1u) + 3u) & ~3ull;
 }
 __host__ __device__ inline uint64_t lp_splice_floats(uint32_t strips) { return strips > 1u ? static_cast<uint64_t>(strips) * (kSpStrideBytes / 4u) + 4u : 0u; }
+// viterbi_ck's spliced traceback for pairs of several strips (round 6, second half; viterbi_ck.hip: ck_walk_pair's modes): the same
+// idea on top of the checkpoint walk.  Behind the boundary arrays every strip has a record area of kCkRecBytes:
+//   [0, kCkRecOps)                      ops of the strip's speculative walk, right to left
+//   [kCkRecList, + 64 * 16)             its run starts {i, j, state, ops recorded before}
+//   [kCkRecHead, + 32)                  {exit row, exit column, arriving move, ops in all, magic}
+//   [kCkRecBridgeOps, + kCkRecOpsB)     the BRIDGE: ops of the walk from the right neighbour's recorded exit to this strip's record
+//   [kCkRecBridgeHead, + 32)            {entry row, entry column, entry move, ops in the bridge, ops the own record had made where
+//                                        they met (0xffffffff: they did not), exit row / column / move when they did not meet}
+// The areas start every launch as 0xff bytes with the boundary arrays (launch_viterbi_ck): what was not written matches nothing.
+constexpr uint32_t kCkRecOps = 4096, kCkRecList = kCkRecOps, kCkRecHead = kCkRecList + 64u * 16u, kCkRecOpsB = 2048,
+                   kCkRecBridgeOps = kCkRecHead + 64u, kCkRecBridgeHead = kCkRecBridgeOps + kCkRecOpsB, kCkRecBytes = 8192;
+static_assert(kCkRecBridgeHead + 64u <= kCkRecBytes, "record area");
+constexpr uint32_t kCkRecMagic = 0x636b7370u;
+__host__ __device__ inline uint64_t ck_rec_first_float(uint32_t la, uint32_t strips) {  // (16-byte aligned)
+    return ((static_cast<uint64_t>(strips) - 1u) * 2u * (static_cast<uint64_t>(la) + 1u) + 3u) & ~3ull;
+}
+__host__ __device__ inline uint64_t ck_rec_floats(uint32_t strips) { return strips > 1u ? static_cast<uint64_t>(strips) * (kCkRecBytes / 4u) : 0u; }
 __host__ __device__ inline uint64_t strip_dwords(uint32_t la, uint32_t w = kW) {
     if(w == 3u) return static_cast<uint64_t>((la + kWave - 1 + 15u) / 16u) * kLp3GroupDwords;
     const uint32_t mc = 32u / w;
@@ -572,6 +589,7 @@ struct EnvOptions {
     bool lp_pairtab_off = false;     // COATI_HIP_LP_PAIRTAB=0
     bool lp3_off = false;            // COATI_HIP_LP3=0: the planner never chooses 3-column strips (A/B: the round-5 plan)
     int lp_splice = -1;              // COATI_HIP_LP_SPLICE: 0 = viterbi_lp walks every strip itself, 1 = spliced traceback, 2 ("miss") = records that never match (tests); -1: the default (on for multi-strip pairs)
+    int ck_splice = -1;              // COATI_HIP_CK_SPLICE: the same for viterbi_ck's multi-strip pairs (resident launches): 0 = the last strip's wavefront walks the pair alone, 1 = spliced, 2 ("miss") = records that never match, 3 ("nobridge") = records without bridges; -1: on
     bool forward_fast = false;       // COATI_HIP_FORWARD_FAST: hardware exp / log in the log-semiring plus (not a parity mode)
     bool timing = false;             // COATI_HIP_TIMING: host stage times on stderr
     bool pipe_timing = false;        // COATI_HIP_PIPE_TIMING: timeline of a one-shot call on stderr

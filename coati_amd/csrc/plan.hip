@@ -381,7 +381,10 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // boundary of 1024-column strips, dp_generic one (la+1)(3+2L) array
         const uint64_t nf = viterbi_only ? 1 : (b->fwd_quad && d.f_compact == 0) ? fwd_quad_strips(d.lb) : fwd_strips_w(d.lb, 1u << d.f_wlog2);
         // (viterbi_lp: the strips' record areas of the spliced traceback behind the boundary arrays, common.hpp)
-        const uint64_t need = std::max<uint64_t>({b->long_pairs && ns > 1 ? lp_splice_first_float(d.la, ns) + lp_splice_floats(ns) : (ns - 1) * 2 * (la + 1),
+        // (viterbi_ck: the same for its multi-strip pairs, ck_rec_first_float)
+        const uint64_t need = std::max<uint64_t>({b->long_pairs && ns > 1 ? lp_splice_first_float(d.la, ns) + lp_splice_floats(ns)
+                                                  : b->ck && plan_l1 && ns > 1 ? ck_rec_first_float(d.la, ns) + ck_rec_floats(ns)
+                                                                               : (ns - 1) * 2 * (la + 1),
                                                   nf > 1 ? (nf - 1) * 3 * (la + 1) : 0,
                                                   nf > 1 ? (la + 1) * (3 + 2 * L) : 0,
                                                   plan_k ? (ns - 1) * ((la / L + 1) + la) : 0,

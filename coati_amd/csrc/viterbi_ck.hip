@@ -355,7 +355,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                                               uint32_t* __restrict__ ck, float* __restrict__ bnd,
                                               float* __restrict__ scores, uint32_t* __restrict__ progress,
                                               uint32_t kbegin = 0, uint32_t kend = 0xffffffffu,
-                                              unsigned long long* bad = nullptr, uint32_t band = kCkBandOff) {
+                                              unsigned long long* bad = nullptr, uint32_t band = kCkBandOff,
+                                              bool defer_complete = false /* (kSub, not the last strip) the caller says "complete": ck_strip_complete */) {
     // [kbegin, kend): the steps of this item -- the whole strip, or one ROW PART of it (PairDesc::v_parts; whole
     // 64-step chunks).  A part that does not start at 0 takes over the lane state its predecessor left behind the
     // strip's checkpoints; one that does not end at the last step leaves it there.
@@ -517,7 +518,10 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         for(int c = 1; c < W; ++c) sc = (c == last_c) ? st.X[c] : sc;
         scores[pair] = sc;
     }
-    if(kSub && strip > 0) {
+    // (wave-uniform; spliced traceback: the speculative walk of the strip comes first; the pair's last strip waits for the chain
+    // where its walk leaves the strip -- CkSplice::chain)
+    if(kSub && defer_complete && !last_strip) return handoff_ok;
+    if(kSub && strip > 0 && !defer_complete) {
         // (the chain "every earlier strip has released its checkpoints" still runs through the progress words: this strip
         // says "complete" only after its left neighbour has)
         handoff_ok = wait_progress(progress + ticket - 1, la) && handoff_ok;
@@ -532,6 +536,20 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         // down to the one that writes the result, then knows)
         publish_progress(progress + ticket, handoff_ok ? la : kHandoffPoison, lane == kWave - 1);
     }
+    return handoff_ok;
+}
+
+// What ck_fill_strip<W, true> does last for a strip that is not its pair's last, as a call of its own (defer_complete): between
+// the two the strip's wavefront walks its strip speculatively (ck_walk_pair, mode 1) -- the record is released with the checkpoints.
+__device__ __forceinline__ bool ck_strip_complete(const PairDesc& pd, uint32_t strip, uint32_t ticket, int lane, uint32_t* __restrict__ progress,
+                                                  bool handoff_ok) {
+    if(strip > 0) {
+        handoff_ok = wait_progress(progress + ticket - 1, pd.la) && handoff_ok;
+        if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    publish_progress(progress + ticket, handoff_ok ? pd.la : kHandoffPoison, lane == kWave - 1);
     return handoff_ok;
 }
 
@@ -748,6 +766,7 @@ constexpr int kWalkUnknown = 4;  // the cell's tile is not in the round's set
 
 // COATI_HIP_CK_DEBUG bit 1: traceback statistics of a launch (rounds, valid tiles, walker iterations,
 // pairs), printed by the launcher after the kernel -- a tuning aid, not part of the product path
+__device__ unsigned int g_ck_splice_stats[4];  // strips the true walk took by their record's list, by their bridge; speculative walks, bridges walked
 __device__ unsigned long long g_ck_stats[8];  // rounds, valid tiles, walker iterations, pairs, pairs filled twice (left the kept band), hand-overs of row parts, their waits in 10 ns, waits longer than 10 us
 
 // State the walk is in after a move of kind `moved` arrives at body cell (bi, bj): from the
@@ -811,20 +830,181 @@ __device__ __forceinline__ void put_result(V* p, V v) {
     else
         *p = v;
 }
-template <bool kThrough = false>
+
+// THE SPLICED TRACEBACK OF A MULTI-STRIP PAIR (round 6; resident launches).  A pair of S strips used to be walked by the
+// wavefront of its last strip alone, ~100 recompute rounds of ~25 us in a row for a 16 kb pair while the wavefronts of the
+// other strips had nothing left to do (64 x 16 kb: 2.6 of 10.9 ms).  Now every strip's wavefront, when its fill is done,
+//   (1) walks its OWN strip speculatively (mode kCkSpec): from the cell where the pair's straight line (0,0) -> (la,lb) enters
+//       the strip on the right, with the same rounds and the same walker, into the strip's record area (common.hpp:
+//       kCkRec*) -- the ops, and every run start {i, j, state, ops so far}.  Tracebacks from neighbouring cells merge
+//       after a few columns (the decisions are a function of the cell), so from the first run start the true path shares
+//       with this walk on, the record IS the true path;
+//   (2) walks the BRIDGE (mode kCkBridge): from where the right neighbour's record LEFT that strip (three words the
+//       neighbour stores write-through, self-validating) until it meets an entry of its own record;
+// and the pair's true walk (the last strip's wavefront, mode kCkTrue) copies: where it enters a strip at the cell a bridge
+// started from, bridge + the record's remainder without a round of its own; else it walks with a look at the strip's
+// run-start list per iteration and splices at the first hit.  Whatever does not match -- a record cut short by the band, by
+// its 4 096 bytes or 64 entries, a path that never merges -- is walked as before: the records are hints, never trusted beyond
+// "this (i, j, state) was reached by a walk over the same decisions".
+constexpr int kCkPlain = 0, kCkSpec = 1, kCkTrue = 2, kCkBridge = 3;
+struct CkSplice {
+    int mode = kCkPlain;
+    uint32_t strip = 0;       // (kCkSpec, kCkBridge) the strip
+    uint8_t* rec = nullptr;   // the pair's record areas (strip s: rec + s * kCkRecBytes)
+    bool miss = false;        // COATI_HIP_CK_SPLICE=miss: entries that match nothing (tests)
+    bool bridges = false;     // (kCkTrue) look at the bridges
+    // (kCkTrue, first in its own strip) what the walk waits for before it reads another strip's checkpoints
+    const uint32_t* chain = nullptr;
+    uint32_t* splice_stats = nullptr;
+};
+__device__ __forceinline__ uint32_t ck_rec_word(const uint8_t* area, uint32_t byte) {  // another wavefront's self-validating word
+    return __hip_atomic_load(reinterpret_cast<const uint32_t*>(area + byte), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ck_rec_publish(uint8_t* area, uint32_t byte, uint32_t v) {
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(area + byte), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// (kSplice: the instantiation that knows the modes -- the kernel of launches with multi-strip pairs; everywhere else they are
+// compiled out, so that the headline's kernel is the code it was)
+// n recorded ops into the pair's slot: four bytes per lane in flight
+template <bool kThrough>
+__device__ __forceinline__ void ck_copy_ops(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int lane) {
+    for(uint32_t q0 = 0; q0 < n; q0 += 4u * kWave) {
+        uint8_t v[4];
+#pragma unroll
+        for(uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t q = q0 + u * kWave + static_cast<uint32_t>(lane);
+            v[u] = q < n ? src[q] : static_cast<uint8_t>(0);
+        }
+#pragma unroll
+        for(uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t q = q0 + u * kWave + static_cast<uint32_t>(lane);
+            if(q < n) put_result<kThrough>(&dst[q], v[u]);
+        }
+    }
+}
+
+template <bool kThrough = false, bool kSplice = false>
 __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, const PairDesc& pd, uint32_t pair,
                                              uint8_t* __restrict__ ops, uint64_t* __restrict__ ops_start,
-                                             uint32_t* __restrict__ ops_len, uint32_t* failed_strip = nullptr) {
+                                             uint32_t* __restrict__ ops_len, uint32_t* failed_strip = nullptr,
+                                             const CkSplice& sx_in = CkSplice{}) {
+    CkSplice sx = sx_in;
+    if constexpr(!kSplice) sx = CkSplice{};
     const uint32_t la = pd.la, lb = pd.lb;
     uint32_t i = la, j = lb;  // matrix coordinates of the cell whose decision is pending
     int moved = COATI_HIP_OP_MATCH;  // max_mdi of the terminal-adjusted last cell == its "after match" decision
     uint64_t pos = pd.ops_off + la + lb;
+    uint8_t* __restrict__ out = ops;
     TileSet ts{COATI_HIP_OP_MATCH, 0xffffffffu, 16u, 4u, 0u, 0u, 0, 0, 0, 0ull};
     bool ok = true;
+    // ---- the speculative walks: one strip, into its record area
+    const bool spec = sx.mode == kCkSpec || sx.mode == kCkBridge;  // (wave-uniform)
+    const uint32_t full = kWave * pd.v_wmain;
+    const uint32_t spec_col0 = sx.strip * full;  // matrix columns <= this are left of the strip
+    uint8_t* const area = spec ? sx.rec + static_cast<uint64_t>(sx.strip) * kCkRecBytes : nullptr;
+    uint32_t n_log = 0, merged_at = 0xffffffffu;
+    int logged = -1;
+    bool stop = false;
+    if(sx.mode == kCkSpec) {
+        // where the straight line enters the strip (a strip that is not its pair's last has the full width)
+        j = spec_col0 + full;
+        const uint64_t row = static_cast<uint64_t>(j) * la / lb;
+        i = static_cast<uint32_t>(row < 1u ? 1u : (row > la ? la : row));
+        out = area;
+        pos = kCkRecOps;
+    } else if(sx.mode == kCkBridge) {
+        // where the right neighbour's record left that strip: three self-validating words (they start a launch as 0xffffffff)
+        const uint8_t* nb = sx.rec + static_cast<uint64_t>(sx.strip + 1u) * kCkRecBytes + kCkRecHead;
+        uint32_t xi = 0xffffffffu, xj = 0xffffffffu, xm = 0xffffffffu;
+        for(uint32_t spins = 0; spins < (1u << 16); ++spins) {  // (~0.5 s at most; a neighbour that never reports: no bridge)
+            xi = ck_rec_word(nb, 0), xj = ck_rec_word(nb, 4), xm = ck_rec_word(nb, 8);
+            if(xi != 0xffffffffu && xj != 0xffffffffu && xm != 0xffffffffu) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        xi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xi)));
+        xj = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xj)));
+        xm = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xm)));
+        // (only an exit INTO this strip, away from the top margin, is worth a bridge)
+        if(xi == 0xffffffffu || xj == 0xffffffffu || xm > 2u || xi < 1u || xi > la || xj <= spec_col0 || xj > spec_col0 + full) return false;
+        i = xi, j = xj, moved = static_cast<int>(xm);
+        out = area + kCkRecBridgeOps;
+        pos = kCkRecOpsB;
+        if(lane == 0) {
+            uint32_t* bh = reinterpret_cast<uint32_t*>(area + kCkRecBridgeHead);
+            bh[0] = xi, bh[1] = xj, bh[2] = xm;
+        }
+    }
+    const uint32_t cap_lo = spec ? 2u * kWave : 0u;  // a speculative walk stops while an iteration's 64 ops still fit
+    // (speculative: the strip's top and left edges end the walk -- the margins are the true walk's)
+    auto arrive = [&](uint32_t ii, uint32_t jj, int mv) {
+        if(spec && (ii == 0u || jj <= spec_col0)) return static_cast<int>(kWalkUnknown);
+        return ck_arrival_state(wa.k, pd, ts, wa.wbits, ii, jj, mv);
+    };
+    bool chain_done = sx.mode != kCkTrue || sx.chain == nullptr;
     while(i >= 1 || j >= 1) {
+        if(spec && (i == 0u || j <= spec_col0 || stop)) break;
         if(i >= 1 && j >= 1) {
             // ---- a round: the tile set around body cell (i-1, j-1), recomputed one tile per lane
             const CkStrip sp = ck_strip_of(pd, wa.ck, j - 1);
+            if(!chain_done && sp.strip + 1u != pd.v_strips) {
+                // the true walk leaves its own strip: from here on it reads what the other strips' wavefronts wrote -- every
+                // earlier strip has said "complete" (a chain through the progress words) after releasing checkpoints and record
+                if(!wait_progress(sx.chain, la) || __hip_atomic_load(sx.chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                chain_done = true;
+                // the inner strips' headers and the ends of their ops areas, asked for now, a strip per lane (they lie in memory,
+                // written through other XCDs' L2s; the walk below takes the strips one after the other, two dependent reads each)
+                {
+                    const uint8_t* ar = sx.rec + static_cast<uint64_t>(min(static_cast<uint32_t>(lane), pd.v_strips - 2u)) * kCkRecBytes;
+                    uint32_t acc = 0;
+#pragma unroll
+                    for(uint32_t k2 = 0; k2 < 12u; ++k2) {
+                        const uint32_t off = k2 == 0u ? kCkRecHead : k2 == 1u ? kCkRecBridgeHead : k2 < 10u ? kCkRecOps - 128u * (k2 - 1u) : kCkRecBridgeHead - 128u * (k2 - 9u);
+                        acc ^= *reinterpret_cast<const volatile uint32_t*>(ar + off);
+                    }
+                    asm volatile("" ::"v"(acc));
+                }
+            }
+            if(sx.mode == kCkTrue && sx.bridges && sp.strip + 2u < pd.v_strips) {
+                // ---- does a bridge start at this very cell?  Then it, and what it met of the strip's record, are the path
+                const uint8_t* ar = sx.rec + static_cast<uint64_t>(sp.strip) * kCkRecBytes;
+                const uint32_t* bh = reinterpret_cast<const uint32_t*>(ar + kCkRecBridgeHead);
+                const uint32_t* rh = reinterpret_cast<const uint32_t*>(ar + kCkRecHead);
+                const uint32_t b_i = bh[0], b_j = bh[1], b_m = bh[2], b_n = bh[3], b_rp = bh[4], b_xi = bh[5], b_xj = bh[6], b_xm = bh[7];
+                const uint32_t r_xi = rh[0], r_xj = rh[1], r_xm = rh[2], r_xp = rh[3], r_magic = rh[4];
+                bool take = b_i == i && b_j == j && b_m == static_cast<uint32_t>(moved) && bh[8] == kCkRecMagic && b_n <= kCkRecOpsB;
+                const bool met = b_rp != 0xffffffffu;
+                if(met) take = take && r_magic == kCkRecMagic && r_xp <= b_rp && b_rp <= kCkRecOps;
+                else take = take && b_n > 0u && b_xm <= 2u && b_xi <= la && b_xj <= lb;
+                take = take && (b_n > 0u || !met || b_rp > r_xp);  // (a bridge that moves the walk: never the same cell again)
+                take = __builtin_amdgcn_readfirstlane(static_cast<int>(take)) != 0;
+                if(take) {
+                    const uint32_t nb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b_n)));
+                    const uint8_t* bsrc = ar + kCkRecBridgeOps + (kCkRecOpsB - nb);  // the bridge's ops in alignment order
+                    ck_copy_ops<kThrough>(out + (pos - nb), bsrc, nb, lane);
+                    pos -= nb;
+                    if(met) {
+                        const uint32_t rp = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b_rp)));
+                        const uint32_t xp = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(r_xp)));
+                        const uint32_t n = rp - xp;
+                        ck_copy_ops<kThrough>(out + (pos - n), ar + xp, n, lane);
+                        pos -= n;
+                        i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(r_xi)));
+                        j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(r_xj)));
+                        moved = __builtin_amdgcn_readfirstlane(static_cast<int>(r_xm));
+                    } else {
+                        i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b_xi)));
+                        j = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(b_xj)));
+                        moved = __builtin_amdgcn_readfirstlane(static_cast<int>(b_xm));
+                    }
+                    if(sx.splice_stats != nullptr && lane == 0) atomicAdd(sx.splice_stats + 1, 1u);
+                    continue;
+                }
+            }
             ts.mode = moved;
             ts.strip = sp.strip, ts.w = sp.w, ts.lg = sp.lg, ts.col0 = sp.col0;
             ts.bi = static_cast<int32_t>(i - 1), ts.bj = static_cast<int32_t>(j - 1);
@@ -853,7 +1033,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             // loads see them (same L1, write-through)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        int st = __builtin_amdgcn_readfirstlane(ck_arrival_state(wa.k, pd, ts, wa.wbits, i, j, moved));
+        int st = __builtin_amdgcn_readfirstlane(arrive(i, j, moved));
         if(st == kWalkUnknown) {
             // the pending cell's own tile was not recomputed: with banded checkpoints the walk has left the kept band
             // (the caller fills the pair again with everything kept); otherwise it cannot happen.  Never spin.
@@ -861,6 +1041,10 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
             if(failed_strip != nullptr && j >= 1) *failed_strip = ck_strip_of(pd, wa.ck, j - 1).strip;
             break;
         }
+        // (the strip whose list the true walk looks at: the round's -- the inner loop never leaves it)
+        const bool look = sx.mode == kCkTrue && i >= 1 && j >= 1 && ts.strip + 1u < pd.v_strips;
+        const bool look_own = sx.mode == kCkBridge;  // the bridge looks for its strip's own record
+        const uint8_t* const look_area = (look || look_own) ? sx.rec + static_cast<uint64_t>(look_own ? sx.strip : ts.strip) * kCkRecBytes : nullptr;
         while(st != kWalkEnd && st != kWalkUnknown) {
             const uint32_t di = st == COATI_HIP_OP_INS ? 0u : 1u;
             const uint32_t dj = st == COATI_HIP_OP_DEL ? 0u : 1u;
@@ -869,26 +1053,86 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
                 i = j = 0;
                 break;
             }
+            if(look_area != nullptr) {
+                // ---- is (i, j, state) a run start of the strip's recorded walk?  From there on the record is this path
+                const u32x4 e = *reinterpret_cast<const u32x4*>(look_area + kCkRecList + static_cast<uint32_t>(lane) * 16u);
+                const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(e0 == i && e1 == j && e2 == static_cast<uint32_t>(st));
+                if(hit != 0ull) {
+                    const uint32_t rp = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e3), static_cast<int>(__builtin_ctzll(hit))));
+                    if(look_own) {  // the bridge has met the record: done
+                        merged_at = rp;
+                        stop = true;
+                        break;
+                    }
+                    const uint32_t* rh = reinterpret_cast<const uint32_t*>(look_area + kCkRecHead);
+                    const uint32_t xi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rh[0])));
+                    const uint32_t xj = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rh[1])));
+                    const uint32_t xm = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rh[2])));
+                    const uint32_t xp = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rh[3])));
+                    const uint32_t magic = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rh[4])));
+                    if(magic == kCkRecMagic && xp < rp && rp <= kCkRecOps && xm <= 2u && xi <= i && xj <= j) {
+                        const uint32_t n = rp - xp;
+                        ck_copy_ops<kThrough>(out + (pos - n), look_area + xp, n, lane);
+                        pos -= n;
+                        i = xi, j = xj, moved = static_cast<int>(xm);
+                        st = kWalkUnknown;  // (a round around the record's exit comes next)
+                        if(sx.splice_stats != nullptr && lane == 0) atomicAdd(sx.splice_stats, 1u);
+                        break;
+                    }
+                }
+            }
+            if(spec) {
+                if(pos < cap_lo) {  // the area is full: the record ends here, at a cell whose arriving move is `moved`
+                    stop = true;
+                    break;
+                }
+                if(sx.mode == kCkSpec && st != logged && n_log < 64u) {
+                    // a run start of this walk: {i, j, state, ops so far}
+                    if(lane == 0) {
+                        u32x4 e = {sx.miss ? (i | 0x80000000u) : i, j, static_cast<uint32_t>(st), static_cast<uint32_t>(pos)};
+                        *reinterpret_cast<u32x4*>(area + kCkRecList + n_log * 16u) = e;
+                    }
+                    ++n_log;
+                    logged = st;
+                }
+            }
             // lane l: where the walk is after l+1 more moves of kind st, and in which state
             const uint32_t step = static_cast<uint32_t>(lane) + 1u;
             const bool valid = di * step <= i && dj * step <= j;
             int next = kWalkEnd;
-            if(valid) next = ck_arrival_state(wa.k, pd, ts, wa.wbits, i - di * step, j - dj * step, st);
+            if(valid) next = arrive(i - di * step, j - dj * step, st);
             if(wa.stats && lane == 0) atomicAdd(&g_ck_stats[2], 1ull);
             const unsigned long long cont = __builtin_amdgcn_ballot_w64(valid && next == st);
             const uint32_t run = cont == ~0ull ? kWave : static_cast<uint32_t>(__builtin_ctzll(~cont));  // lanes that continue
             const uint32_t moves = run == kWave ? kWave : run + 1u;
-            for(uint32_t q = lane; q < moves; q += kWave) put_result<kThrough>(&ops[pos - 1 - q], static_cast<uint8_t>(st));
+            for(uint32_t q = lane; q < moves; q += kWave) put_result<kThrough>(&out[pos - 1 - q], static_cast<uint8_t>(st));
             pos -= moves;
             i -= di * moves;
             j -= dj * moves;
-            if(run < kWave) {
-                const int nst = __builtin_amdgcn_readlane(next, static_cast<int>(run));
-                if(nst == kWalkUnknown) moved = st;  // arrived at (i, j) by a move of kind st: next round
-                st = nst;
-            }
+            moved = st;  // (i, j) was arrived at by a move of kind st: what a next round, or a record's exit, starts from
+            if(run < kWave) st = __builtin_amdgcn_readlane(next, static_cast<int>(run));
         }
         if(st == kWalkEnd) break;
+    }
+    if(sx.mode == kCkSpec) {
+        // the record's header: where the walk stopped -- (i, j), arrived at by `moved` --, the ops in all.  The first three also
+        // for the LEFT neighbour's bridge, which may be waiting for them: write-through, self-validating
+        if(lane == 0) {
+            ck_rec_publish(area, kCkRecHead + 0, i);
+            ck_rec_publish(area, kCkRecHead + 4, j);
+            ck_rec_publish(area, kCkRecHead + 8, static_cast<uint32_t>(moved));
+            uint32_t* rh = reinterpret_cast<uint32_t*>(area + kCkRecHead);
+            rh[3] = static_cast<uint32_t>(pos), rh[4] = kCkRecMagic;
+        }
+        return ok;
+    }
+    if(sx.mode == kCkBridge) {
+        if(lane == 0) {
+            uint32_t* bh = reinterpret_cast<uint32_t*>(area + kCkRecBridgeHead);
+            bh[3] = kCkRecOpsB - static_cast<uint32_t>(pos), bh[4] = merged_at, bh[5] = i, bh[6] = j, bh[7] = static_cast<uint32_t>(moved), bh[8] = kCkRecMagic;
+        }
+        return ok;
     }
     if(lane == 0) {
         put_result<kThrough>(&ops_start[pair], pos);
@@ -903,7 +1147,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
 // kSharedTab: the model has ONE substitution table -- one copy per workgroup in LDS (12.4 KB), which
 // lets four workgroups (16 wavefronts, 4 per SIMD) share a CU.  Otherwise (per-leaf tables of
 // `coati msa`) every wavefront keeps the table of its current pair.
-template <bool kSharedTab>
+template <bool kSharedTab, bool kSplice>
 __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
@@ -913,6 +1157,10 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     uint64_t ck_slot_dwords, uint32_t split_items_word, uint32_t dbg, uint32_t band) {
     // (the cut pairs' tracebacks as items of their own: flag in the word's top bit, abi.hip)
     const bool walk_items = (split_items_word & kCkWalkItemsFlag) != 0u;
+    // the spliced traceback of multi-strip pairs (launch_viterbi_ck): 0 off, 1 on, 2 "miss", 3 without bridges; bit 6: the launch
+    // is one round of wavefronts, so a wavefront that waits for its neighbour's record keeps nothing from running
+    const uint32_t splice_level = kSplice ? (dbg >> 4) & 3u : 0u;
+    const bool bridges_ok = kSplice && ((dbg >> 6) & 1u) != 0u;
     const uint32_t split_items = split_items_word & ~kCkWalkItemsFlag;
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
@@ -1017,15 +1265,19 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // multi-strip pair (round 4) a wider one, strips from 64 on everything; a redo everything
         const uint32_t band_pair = multi ? ck_band_half_long(band, pd.la, pd.lb) : ck_band_half(band, pd.la, pd.lb);
         const uint32_t band_now = (!redo && pd.la > 0 && pd.lb > 0 && (multi ? strip < 64u : w_item == 16)) ? band_pair : kCkBandOff;
+        // the spliced traceback of a multi-strip pair (ck_walk_pair): the strip's wavefront says "complete" itself, after its
+        // speculative walks -- and the pair's last strip only where its walk leaves the strip
+        const bool spliced = multi && !redo && splice_level != 0u && !(dbg & 1u) && pd.la > 0 && pd.lb > 0;
+        const bool defer = spliced;
         if(pd.la > 0 && pd.lb > 0 && !walk_item) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
                 handoff_ok = ck_fill_strip<16, false, true, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
             else if(multi && w_item == 16)
-                handoff_ok = ck_fill_strip<16, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+                handoff_ok = ck_fill_strip<16, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now, defer);
             else if(multi && w_item == 8)
-                handoff_ok = ck_fill_strip<8, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+                handoff_ok = ck_fill_strip<8, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now, defer);
             else if(multi)
-                handoff_ok = ck_fill_strip<4, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
+                handoff_ok = ck_fill_strip<4, true>(k, pd, pair, strip, fill_ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now, defer);
             else if(w_item == 16)  // (from here on: single-strip pairs -- `multi` took the others)
                 handoff_ok = ck_fill_strip<16, false, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, 0, 0xffffffffu, nullptr, band_now);
             else if(w_item == 8)
@@ -1046,20 +1298,22 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
 #endif
             continue;
         }
-        if((!redo && strip + 1 < pd.v_strips) || (dbg & 1u)) {  // not the last strip of its pair: no traceback here
+        const bool inner_strip = !redo && strip + 1 < pd.v_strips;  // not the last strip of its pair: no traceback here ...
+        if((inner_strip && !spliced) || (dbg & 1u)) {
 #ifdef COATI_FILL_TRACE
             COATI_CK_STAMP(1);
             trace_n += 2;
 #endif
             continue;
         }
-        // ---- traceback of this pair by the wavefront of its last strip.  What the wave wrote
+        // ---- traceback of this pair by the wavefront of its last strip (... but, spliced, the strip's speculative walks).  What the wave wrote
         // itself: wait until the stores are acknowledged.  What other wavefronts wrote (earlier
         // strips): they released before publishing "complete", which this wave polled; acquire.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (a cut pair: its earlier parts' checkpoints were stored through other wavefronts' L2s, and this wavefront's L2 may hold
         // the lines of an earlier launch: its walk reads them past the L2 -- CkWalkArgs::through -- instead of invalidating it)
-        if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (spliced: the true walk waits and acquires where it leaves its own strip -- CkSplice::chain)
+        if(pd.v_strips > 1 && !spliced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if(pd.la == 0 || pd.lb == 0) {
             float m, d, in, score;
             margin_mdi(k, 1u, pd.la, pd.lb, m, d, in);
@@ -1068,9 +1322,42 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         }
         // (multi-strip: the band the pair's strips were filled with, minus the strips filled again since)
         const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, (dbg & 2u) != 0u, multi ? band_pair : band_now, redo_kept_all, cut};
-        if((dbg & 2u) && lane == 0) atomicAdd(&g_ck_stats[redo ? 4 : 3], 1ull);
+        if((dbg & 2u) && lane == 0 && !inner_strip) atomicAdd(&g_ck_stats[redo ? 4 : 3], 1ull);
         uint32_t failed_strip = 0;
-        const bool walk_ok = ck_walk_pair(lane, wa, pd, pair, ops, ops_start, ops_len, &failed_strip);
+        CkSplice sx;
+        if(multi && splice_level != 0u && pd.la > 0 && pd.lb > 0) {
+            // (the true walk of a redo looks at the records too: they are walks over the same decisions whatever was kept)
+            sx.mode = inner_strip ? kCkSpec : kCkTrue;
+            sx.strip = strip;
+            sx.rec = reinterpret_cast<uint8_t*>(bnd + pd.bnd_off + ck_rec_first_float(pd.la, pd.v_strips));
+            sx.miss = splice_level == 2u;
+            sx.bridges = splice_level != 3u && bridges_ok;
+            sx.chain = spliced ? progress + fill_ticket - 1 : nullptr;  // (a redo: the chain was waited for the first time round)
+            sx.splice_stats = (dbg & 2u) ? g_ck_splice_stats : nullptr;
+        }
+        // (an inner strip: first its record, then its bridge -- from where the right neighbour's record leaves that strip to this
+        // record -- where that neighbour has a record, i.e. is not the pair's last strip, and nothing else is waiting for this
+        // wavefront.  ONE call site: the walk with its three recompute shapes is the largest piece of code in the kernel)
+        bool walk_ok = true;
+#pragma nounroll
+        for(int pass = 0; pass < 2; ++pass) {
+            if(pass == 1) {
+                if(!(inner_strip && sx.bridges && strip + 2 < pd.v_strips)) break;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sx.mode = kCkBridge;
+            }
+            const bool r = ck_walk_pair<false, kSplice>(lane, wa, pd, pair, ops, ops_start, ops_len, inner_strip ? nullptr : &failed_strip, sx);
+            if(pass == 0) walk_ok = r;
+            if(sx.splice_stats != nullptr && lane == 0 && inner_strip) atomicAdd(sx.splice_stats + 2 + pass, 1u);
+        }
+        if(inner_strip) {
+            (void)ck_strip_complete(pd, strip, fill_ticket, lane, progress, handoff_ok);
+#ifdef COATI_FILL_TRACE
+            COATI_CK_STAMP(1);
+            trace_n += 2;
+#endif
+            continue;
+        }
         if(!walk_ok && !multi && band_now != kCkBandOff) {
             // the walk asked for a tile outside the kept band: the same item once more, with everything kept (counted:
             // the word behind the ticket counter, zeroed with it; coati_hip_viterbi_band_stats)
@@ -1532,22 +1819,35 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     }
     const CkShape shape = ck_launch_shape(v.n_items, shared_tab);
     // timing experiments only (COATI_HIP_CK_DEBUG): bit 0 = fill only, no traceback
-    const uint32_t dbg = env_options().ck_debug;
+    uint32_t dbg = env_options().ck_debug & 15u;
+    // the spliced traceback of multi-strip pairs (ck_walk_pair): records while the launch is at most two rounds of wavefronts
+    // (a speculative walk is ~4 rounds of recompute that the strip's wavefront spends before it draws its next item), bridges
+    // -- whose wavefront WAITS for its neighbour's record -- only when every item has a wavefront of its own.
+    // COATI_HIP_CK_SPLICE = 0 / 1 / miss / nobridge forces the level.
+    if(v.multi_strip != 0) {
+        const uint32_t waves = shape.grid * kCkWaves;
+        const int forced = env_options().ck_splice;
+        const uint32_t level = forced >= 0 ? static_cast<uint32_t>(forced) : (v.n_items <= 2u * waves ? 1u : 0u);
+        dbg |= (level & 3u) << 4;
+        if(v.n_items <= waves) dbg |= 1u << 6;
+    }
     // (the debug export of every cell's decisions decodes every tile: that batch keeps every checkpoint)
     const uint32_t band = v.ck_band;
-    const void* fn = shared_tab ? reinterpret_cast<const void*>(viterbi_ck<true>) : reinterpret_cast<const void*>(viterbi_ck<false>);
-    if(shape.dynamic_lds > 0) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));
-        if(e != hipSuccess) return e;
-    }
-    if(shared_tab)
-        hipLaunchKernelGGL(viterbi_ck<true>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
+    // (the spliced instantiation only where a launch has multi-strip pairs and the level is not 0)
+    const bool spliced = ((dbg >> 4) & 3u) != 0u;
+    auto launch = [&](auto kernel) {
+        if(shape.dynamic_lds > 0) {
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));
+            if(ea != hipSuccess) return ea;
+        }
+        hipLaunchKernelGGL(kernel, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
                            v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
                            v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg, band);
-    else
-        hipLaunchKernelGGL(viterbi_ck<false>, dim3(shape.grid), dim3(kCkWaves * kWave), shape.dynamic_lds, stream, v.table,
-                           v.k, v.pairs, v.items, v.n_items, v.queue, v.progress, v.a_cat, v.b_cat, v.flags, v.bnd, v.scores,
-                           v.ops, v.ops_start, v.ops_len, v.wscratch, v.ck_slot_dwords, v.ck_split_items, dbg, band);
+        return hipSuccess;
+    };
+    e = shared_tab ? (spliced ? launch(viterbi_ck<true, true>) : launch(viterbi_ck<true, false>))
+                   : (spliced ? launch(viterbi_ck<false, true>) : launch(viterbi_ck<false, false>));
+    if(e != hipSuccess) return e;
     if(dbg & 2u) {
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         e = hipStreamSynchronize(stream);
@@ -1558,6 +1858,11 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
                      "%llu row-part hand-overs waited %.1f us on average, %llu of them more than 10 us (%.1f wavefront-ms in all)\n", st[3],
                      st[3] ? double(st[0]) / st[3] : 0.0, st[0] ? double(st[1]) / st[0] : 0.0, st[3] ? double(st[2]) / st[3] : 0.0, st[4], band, st[5],
                      st[5] ? double(st[6]) / st[5] / 100.0 : 0.0, st[7], double(st[6]) / 1e5);
+        unsigned int sp[4] = {0, 0, 0, 0}, sp0[4] = {0, 0, 0, 0};
+        e = hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_ck_splice_stats), sizeof sp);
+        if(e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ck_splice_stats), sp0, sizeof sp0);
+        if(e != hipSuccess) return e;
+        if(sp[2] != 0) std::fprintf(stderr, "viterbi_ck splice: %u speculative walks, %u bridges walked; the true walks took %u strips by a record's list, %u by a bridge\n", sp[2], sp[3], sp[0], sp[1]);
     }
     return hipGetLastError();
 }

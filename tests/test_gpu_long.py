@@ -25,7 +25,7 @@ def hip():
 
 @pytest.fixture(autouse=True)
 def decision_bit_plan(monkeypatch):
-    for v in ("COATI_HIP_VITERBI_CK", "COATI_HIP_VITERBI_BITS", "COATI_HIP_L1_LP", "COATI_HIP_STRIP_W", "COATI_HIP_FORCE_GENERIC", "COATI_HIP_LP_SPLICE"):
+    for v in ("COATI_HIP_VITERBI_CK", "COATI_HIP_VITERBI_BITS", "COATI_HIP_L1_LP", "COATI_HIP_STRIP_W", "COATI_HIP_FORCE_GENERIC", "COATI_HIP_LP_SPLICE", "COATI_HIP_CK_SPLICE"):
         monkeypatch.delenv(v, raising=False)
 
 
@@ -147,6 +147,40 @@ def test_spliced_traceback_on_lopsided_and_unrelated_pairs(hip, oracle, monkeypa
     enc = util.encode_pairs(pairs)
     want = [oracle.viterbi(table, consts, 1, a, b, lowmem=True) for a, b in enc]
     for env in ({}, {"COATI_HIP_LP_SPLICE": "0"}, {"COATI_HIP_LP_SPLICE": "miss"}, {"COATI_HIP_STRIP_W": "3"}, {"COATI_HIP_STRIP_W": "4"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        scores, ops, _ = run(hip, table, consts, enc)
+        for k in env:
+            monkeypatch.delenv(k)
+        for p, (w_ops, w_sc) in enumerate(want):
+            assert bits(scores[p]) == bits(w_sc), (env, p)
+            assert np.array_equal(ops[p], w_ops), (env, p)
+
+
+def test_viterbi_ck_spliced_traceback_of_multi_strip_pairs(hip, oracle, monkeypatch):
+    """viterbi_ck's spliced traceback (round 6: every strip's wavefront walks its strip speculatively into a record and bridges from
+    its right neighbour's exit to it; the pair's true walk copies what it meets): pairs of 5 ... 25 strips of 8 and 4 columns per
+    lane -- lopsided either way, UNRELATED (records that match nothing), one 3 kb and one 5 kb deletion (a bridge and a record that
+    overflow their areas), a deletion followed by an insertion of 2 kb (the path leaves the kept checkpoint band: strips are
+    filled again and the walk repeated over the same records) -- with the splice on (default), off, without bridges and forced
+    to miss: the oracle's score bits and ops."""
+    rng = np.random.default_rng(78)
+    table = util.random_table(rng)
+    consts = oracle.gap_consts()
+    anc_long = util.random_anc(rng, 4000)
+    noise = "".join(rng.choice(list(util.NT), 2001))
+    pairs = [(util.random_anc(rng, 700), "".join(rng.choice(list(util.NT), 12500))),        # 2 100 x 12 500
+             (anc_long, util.mutate(rng, anc_long[:2700], n_indel=6)),                        # 12 000 x ~2 700
+             (util.random_anc(rng, 2300), "".join(rng.choice(list(util.NT), 7100))),         # unrelated, 6 900 x 7 100
+             (anc_long, util.mutate(rng, anc_long[:4000] + anc_long[7000:], n_indel=10)),    # one 3 kb deletion
+             (anc_long, util.mutate(rng, anc_long[:3000] + anc_long[8000:], n_indel=6)),     # one 5 kb deletion
+             (anc_long, anc_long[:3000] + anc_long[5001:9000] + noise + anc_long[9000:]),     # 2 kb out, 2 kb in: off the band
+             (anc_long, util.mutate(rng, anc_long, n_indel=40, mean_len=9))]                  # related, many runs
+    enc = util.encode_pairs(pairs)
+    want = [oracle.viterbi(table, consts, 1, a, b, lowmem=True) for a, b in enc]
+    for env in ({}, {"COATI_HIP_CK_SPLICE": "0"}, {"COATI_HIP_CK_SPLICE": "nobridge"}, {"COATI_HIP_CK_SPLICE": "miss"}, {"COATI_HIP_STRIP_W": "4"},
+                {"COATI_HIP_STRIP_W": "4", "COATI_HIP_CK_SPLICE": "miss"}, {"COATI_HIP_STRIP_W": "16"}):
+        env = dict({"COATI_HIP_VITERBI_CK": "1", "COATI_HIP_STRIP_W": "8"}, **env)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         scores, ops, _ = run(hip, table, consts, enc)

@@ -33,6 +33,7 @@ while time.time() < t_end:
     os.environ.pop("COATI_HIP_STRIP_W", None)
     os.environ.pop("COATI_HIP_LP_PAIRTAB", None)
     os.environ.pop("COATI_HIP_LP_SPLICE", None)
+    os.environ.pop("COATI_HIP_CK_SPLICE", None)
     if forced in ("auto", "bits"):  # small batches run on viterbi_lp: both strip shapes, with and without the pair table
         w = str(rng.choice(["", "", "2", "3", "4"]))
         if w:
@@ -47,6 +48,13 @@ while time.time() < t_end:
         os.environ["COATI_HIP_L1_LP"] = "0"
     if forced == "ck":
         os.environ["COATI_HIP_VITERBI_CK"] = "1"
+        # (round 6) viterbi_ck's spliced traceback of multi-strip pairs: narrow strips make them; default (on), off, without bridges, miss
+        w = str(rng.choice(["", "", "4", "8"]))
+        if w:
+            os.environ["COATI_HIP_STRIP_W"] = w
+        sp = str(rng.choice(["", "", "0", "nobridge", "miss"]))
+        if sp:
+            os.environ["COATI_HIP_CK_SPLICE"] = sp
         if rng.random() < 0.5:  # the last pairs of the LPT order cut into row parts (default only from 4 352 pairs)
             # (round 5: equal / tapered parts / a last part 1-7 chunks shorter; the cut pairs' tracebacks with their last part or
             # as items of their own)

@@ -22,7 +22,7 @@ for k in keys:
         bt.viterbi_launch(); bt.sync(); ts.append(sum(bt.viterbi_timing()))
     sc, ops, off, ln = bt.viterbi_fetch()
     ok = all(int(np.float32(sc[p]).view(np.uint32)) == int(case["score_bits"], 16) and
-             "%08x" % zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes()) == case["ops_crc32"] for p in (0, copies - 1))
+             "%08x" % zlib.crc32(ops[int(off[p]):int(off[p]) + int(ln[p])].tobytes()) == case["ops_crc32"] for p in range(copies))
     ms = float(np.median(ts[1:]))
     out.append(f"bm_{k}x{copies}: {ms:.2f} ms {len(a) * len(b) * copies / ms / 1e6:.0f} GCUPS {'ok' if ok else 'WRONG'}")
     bt.close(); m.trim()
