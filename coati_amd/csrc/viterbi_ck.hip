@@ -908,8 +908,12 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
     bool stop = false;
     if(sx.mode == kCkSpec) {
         // where the straight line enters the strip (a strip that is not its pair's last has the full width)
+        // ... a little BELOW it (viterbi_lp.hip, lp_spec_walk: a walk that starts below the true path climbs to it by a deletion run;
+        // one from above has to wander left until the paths meet), inside the band of checkpoints the strip kept
         j = spec_col0 + full;
-        const uint64_t row = static_cast<uint64_t>(j) * la / lb;
+        const uint32_t half = wa.band_of(sx.strip, pd.v_strips);
+        const uint64_t below = min(16u + (la >> 9), half / 2u);
+        const uint64_t row = static_cast<uint64_t>(j) * la / lb + below;
         i = static_cast<uint32_t>(row < 1u ? 1u : (row > la ? la : row));
         out = area;
         pos = kCkRecOps;
@@ -917,7 +921,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
         // where the right neighbour's record left that strip: three self-validating words (they start a launch as 0xffffffff)
         const uint8_t* nb = sx.rec + static_cast<uint64_t>(sx.strip + 1u) * kCkRecBytes + kCkRecHead;
         uint32_t xi = 0xffffffffu, xj = 0xffffffffu, xm = 0xffffffffu;
-        for(uint32_t spins = 0; spins < (1u << 16); ++spins) {  // (~0.5 s at most; a neighbour that never reports: no bridge)
+        for(uint32_t spins = 0; spins < (1u << 14); ++spins) {  // (~50 ms at most; a neighbour that never reports: no bridge)
             xi = ck_rec_word(nb, 0), xj = ck_rec_word(nb, 4), xm = ck_rec_word(nb, 8);
             if(xi != 0xffffffffu && xj != 0xffffffffu && xm != 0xffffffffu) break;
             __builtin_amdgcn_s_sleep(32);
