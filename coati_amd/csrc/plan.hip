@@ -291,7 +291,13 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
             // (round 4: 8-column strips stay with viterbi_ck -- its multi-strip pairs hand their boundaries over as
             // self-validating values and keep banded checkpoints now: 256 x 4 kb 3.00 ms against viterbi_l1's 3.66,
             // 64 x 16 kb 11.9 against 14.0; 4-column plans -- every wavefront nearly alone on its SIMD -- are viterbi_lp's)
-            if(w_main < 8 || (live > 0 && cells / live < kShortPair)) b->ck = false;
+            // (round 6: viterbi_ck's multi-strip pairs have the spliced traceback, one branch-free boundary store per step and 16
+            // steps of straight-line code per sub-block: where a 4-column plan has MORE strips than the GPU has SIMDs -- two
+            // wavefronts per SIMD, which viterbi_lp's blocks are not made for -- they stay with viterbi_ck: 64 x 8 kb 4.55 ->
+            // 3.33 ms, 128 x 4 kb 2.21 -> 1.76, 32 x 16 kb 9.5 -> 6.4, 16 x 32 kb 18.9 -> 14.6; with at most a strip per SIMD
+            // viterbi_lp keeps its lead: 32 x 8 kb 2.09 against 3.21, 16 x 16 kb 4.10 against 6.21 -- tools/experiments/r6_plan_sweep.py)
+            const bool ck_narrow = w_main == 4 && count_items(4) > kSimds;
+            if((w_main < 8 && !ck_narrow) || (live > 0 && cells / live < kShortPair)) b->ck = false;
         }
         // a decision-bit plan of 4-column strips throughout is the "few long pairs" regime: viterbi_lp fills it (the same
         // layout, half the instructions per step; COATI_HIP_L1_LP=0 keeps viterbi_l1, the A/B partner)

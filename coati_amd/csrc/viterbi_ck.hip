@@ -38,6 +38,7 @@ namespace coati_hip_detail {
 // Debug build only (make trace): per-wave wall-clock stamps (s_memrealtime, 100 MHz) of the
 // persistent loop, read back by tools/trace_fill.py through coati_hip_debug_trace.
 __device__ unsigned long long g_ck_trace[4096 * 16];
+__device__ unsigned long long g_ck_poll[4];  // sub-blocks of consumer strips, those whose boundary was not there when they began, polls made for them, -
 #define COATI_CK_STAMP(slot)                                                                     \
     do {                                                                                         \
         if(lane_id == 0) /* (items from the seventh on share the last record: a wavefront's LAST stamps are always there) */ \
@@ -114,6 +115,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (num_records = 2 GiB: a lane whose offset register holds kCkDropOffset is OUT OF RANGE and its part of the store is
 // discarded by the address unit -- how a lane that keeps no checkpoint for a band skips its stores without a branch)
 constexpr uint32_t kCkDropOffset = 0x80000000u;
+constexpr uint32_t kCkPrefetchAt = 10;  // the step of a 16-step sub-block at which a strip asks for its next sub-block's left boundary (ck_chunk)
 // Cache policy of a raw buffer access (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  kAuxAgent = sc1: the store goes
 // THROUGH the XCD's L2 to memory, the load is served from memory -- what an agent-scope atomic access is.  Used for
 // everything a pair that is cut into row parts hands from one wavefront to another (round 5): with it a hand-over needs
@@ -178,8 +180,12 @@ struct CkCtx {
     uint32_t la, col0, nsteps, lds_tab;
     int lane;
     bool last_strip;
-    float *bnd_x, *bnd_z;  // (wave-uniform)
-    const uint32_t *in_x, *in_z;  // the left neighbour's boundary column as bit patterns (strip > 0; kSub: loaded 16 rows at a time)
+    // strip boundaries (wave-uniform), INTERLEAVED (round 6; viterbi_lp's layout): the pair a strip's lane 0 takes for body row r --
+    // (X of row r - 1, Z of row r) of its left neighbour's last column -- is floats 2r, 2r + 1 of the boundary array: ONE aligned
+    // 8-byte load per row, and what the neighbour's lane 63 makes at a step, (Z, X) of row r, is floats 2r + 1, 2r + 2: ONE store
+    float* bnd_out;           // written by this strip
+    const uint32_t* bnd_in;   // the left neighbour's, as bit patterns (strip > 0; kSub: loaded 16 rows at a time)
+    rsrc_t bnd_rsrc;          // bnd_out behind a buffer descriptor
     bool first_strip;
     uint32_t band;   // banded checkpoints: kCkBandOff or the half width in steps (ck_band_half)
     int32_t centre;  // this lane's centre step
@@ -223,7 +229,9 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     const GapConsts& k = cx.k;
     const int lane = cx.lane;
     const uint32_t kstep = kbase + kk;
-    if(kbase == 0 && kk == static_cast<uint32_t>(lane)) {
+    // (a scalar test first, marked unlikely: past the first chunk the step's usual way has no taken branch -- which costs a
+    // wavefront that is alone on its SIMD ~130 cycles)
+    if(__builtin_expect(kbase == 0, 0) && kk == static_cast<uint32_t>(lane)) {
         // This lane starts now: state of the margin row (matrix row 0, align_pair.cc:88-90):
         // M = D = lowest, I = go + ge*float(j-1).
         uint32_t bj0 = cx.col0 + lane * W;
@@ -252,11 +260,18 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     row_lean<W>(cx.kv, st, diag, zl, s, cx.lds_tab + arow_next, boff, std::make_integer_sequence<int, W>{});
     arow = arow_next;
     // lane 63 just did body row kstep - 63: its last column is the next strip's boundary
-    // (kSingle -- the pair has one strip, known where the call is made: no test, ~11 scalar instructions per step less)
-    if(!kSingle && !cx.last_strip && lane == kWave - 1 && kstep >= static_cast<uint32_t>(kWave - 1) && kstep - (kWave - 1) < cx.la) {
-        const uint32_t r = kstep - (kWave - 1);  // (wave-uniform: the addresses stay in SGPRs)
-        store_through(&cx.bnd_x[r + 1], st.X[W - 1]);
-        store_through(&cx.bnd_z[r], st.zlast);
+    // (kSingle -- the pair has one strip, known where the call is made: nothing here)
+    // Round 6: ONE 8-byte write-through store per step, issued by every lane with no branch -- lanes other than 63, and every lane
+    // while the row is not a body row, hold an offset out of the descriptor's range.  (Rounds 4-5: `if(lane == 63 && row in range)`
+    // around two dword stores: a scalar branch, an EXEC branch and two memory instructions per step -- the trace build showed a
+    // strip that PRODUCES a boundary 20 % slower than one that does not: 0.414 against 0.344 us per 8-column step.)
+    if constexpr(!kSingle) {
+        const uint32_t r = kstep - (kWave - 1);  // (wave-uniform; wraps while kstep < 63)
+        const bool row_ok = !cx.last_strip && r < cx.la;
+        uint32_t voff = static_cast<uint32_t>(lane);
+        asm volatile("" : "+v"(voff));  // (derived per step: not another VGPR held across the hot loop)
+        voff = (voff == static_cast<uint32_t>(kWave - 1) && row_ok) ? 0u : kCkDropOffset;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{fbits(st.zlast), fbits(st.X[W - 1])}, cx.bnd_rsrc, voff, row_ok ? r * 8u + 4u : 0u, kAuxAgent);
     }
 }
 
@@ -270,7 +285,7 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
 template <int W, bool kSub, bool kSingle, bool kThrough>
 __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem, CkLane<W>& st, uint32_t& arow,
                                          float (&s)[W], const uint32_t (&boff)[W], uint32_t kbase, uint32_t a_chunk,
-                                         float bx, float bz) {
+                                         float bx, float bz, unsigned long long& pre) {
     const uint32_t kend = min(static_cast<uint32_t>(kWave), cx.nsteps - kbase);
     bool ok = true;
     for(uint32_t kb = 0; kb < kend; kb += kCkRows) {
@@ -285,20 +300,36 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
         const uint32_t colin_band_soff = sm ? 0u : (kb >> kCkRowsLog2) * (kWave * kCkRows * 8u) - kb * 8u;
         const uint32_t colin_step_shift = sm ? 9u : 3u;
         store_rowck<W, kThrough>(mem, cx.lane, st, kb, keep, sm);
+        const uint32_t ke = min(kb + kCkRows, kend);
         if constexpr(kSub) {
+            // ---- a strip of a multi-strip pair.  Its wavefront is (nearly) alone on its SIMD: what it pays for is instructions --
+            // ~4.5 cycles each whatever they are -- and TAKEN BRANCHES, ~130 cycles each (nobody hides the
+            // instruction fetch).  Round 6: the sub-block's prologue has no taken branch on its usual way, a full sub-block is 16
+            // steps of straight-line code (rounds 2-5: a loop of step pairs -- eight back-edges per sub-block, 8 % of a lone
+            // wavefront's time), and the left boundary of the NEXT sub-block is asked for in the middle of this one (`pre`) and
+            // looked at where that one begins: the round trip past the L2 is no longer part of every sub-block.
             static_assert(kCkRows == 16, "the boundary sub-blocks are the checkpoint bands");
             uint32_t row = kbase + kb + (static_cast<uint32_t>(cx.lane) & 15u);  // (lanes 16-63 repeat lanes 0-15)
             asm volatile("" : "+v"(row));
-            bx = bz = kLowest;
-            if(cx.first_strip) {
-                // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin
-                if(row < cx.la) bx = row == 0 ? (0.0f + cx.k.ng) + cx.k.ng : ((cx.k.ng + cx.k.go) + cx.k.ge * static_cast<float>(row - 1)) + cx.k.gs;
-            } else {
-                uint32_t xb = 0, zb = 0;
+            // column 0 of the matrix (align_pair.cc:82-86): M(0,0)=0, D(i,0) margin -- computed by every strip, taken by the first
+            const float margin_x = row == 0 ? (0.0f + cx.k.ng) + cx.k.ng : ((cx.k.ng + cx.k.go) + cx.k.ge * static_cast<float>(row - 1)) + cx.k.gs;
+            uint32_t xb = static_cast<uint32_t>(pre), zb = static_cast<uint32_t>(pre >> 32);
+            const bool have = cx.first_strip || row >= cx.la || (xb != 0xffffffffu && zb != 0xffffffffu);
+#ifdef COATI_FILL_TRACE
+            if(cx.lane == 0 && !cx.first_strip) atomicAdd(&g_ck_poll[0], 1ull);
+#endif
+            if(__builtin_expect(__builtin_amdgcn_ballot_w64(have) != ~0ull, 0)) {
+                // not there yet (the strip's first sub-block; a neighbour that is slower than expected): ask until it is
+#ifdef COATI_FILL_TRACE
+                if(cx.lane == 0) atomicAdd(&g_ck_poll[1], 1ull);
+#endif
                 for(uint32_t spins = 0;; ++spins) {
+#ifdef COATI_FILL_TRACE
+                    if(cx.lane == 0) atomicAdd(&g_ck_poll[2], 1ull);
+#endif
                     if(row < cx.la) {
-                        xb = __hip_atomic_load(cx.in_x + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        zb = __hip_atomic_load(cx.in_z + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long xz = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(cx.bnd_in) + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        xb = static_cast<uint32_t>(xz), zb = static_cast<uint32_t>(xz >> 32);
                     }
                     const bool valid = row >= cx.la || (xb != 0xffffffffu && zb != 0xffffffffu);
                     if(__builtin_amdgcn_ballot_w64(valid) == ~0ull) break;
@@ -308,14 +339,23 @@ __device__ __forceinline__ bool ck_chunk(const CkCtx& cx, const CkChunkMem& mem,
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if(row < cx.la) {
-                    bx = __builtin_bit_cast(float, xb);
-                    bz = __builtin_bit_cast(float, zb);
-                }
             }
+            bx = row < cx.la ? (cx.first_strip ? margin_x : __builtin_bit_cast(float, xb)) : kLowest;
+            bz = (row < cx.la && !cx.first_strip) ? __builtin_bit_cast(float, zb) : kLowest;
             asm volatile("" : "+v"(bx), "+v"(bz));
+            pre = ~0ull;
+            // (16 columns per lane keep the loop of step pairs: unrolled they do not fit 128 VGPRs, and plans with such strips
+            // have several wavefronts per SIMD, which hide a branch)
+            if(W <= 8 && __builtin_expect(ke - kb == kCkRows, 1)) {
+#pragma unroll
+                for(uint32_t u = 0; u < kCkRows; ++u) {
+                    if(u == kCkPrefetchAt && !cx.first_strip && row + kCkRows < cx.la)  // (W = 16: `pre` stays "not there", the sub-block asks when it begins)
+                        pre = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(cx.bnd_in) + row + kCkRows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ck_step<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, kb + u, a_chunk, bx, bz, colin_voff, colin_band_soff, colin_step_shift);
+                }
+                continue;
+            }
         }
-        const uint32_t ke = min(kb + kCkRows, kend);
         // two steps per iteration: the new X of a column must not overwrite the old one before the
         // next column has taken it as its diagonal input; with two copies of the body the register
         // allocator ping-pongs X between two register sets instead of copying W values per step
@@ -370,10 +410,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     // strip-boundary columns, one array per strip boundary: [0, la] = X of the strip's last
     // column (index r = X of body row r-1; index 0 = margin row), [la+1, 2la] = Z of body row r.
     const uint64_t bstride = 2 * (static_cast<uint64_t>(la) + 1);
-    float* __restrict__ bnd_x = bnd + pd.bnd_off + strip * bstride;  // written by this strip
-    float* __restrict__ bnd_z = bnd_x + (la + 1);
-    const float* __restrict__ in_x = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
-    const float* __restrict__ in_z = in_x + (la + 1);
+    float* __restrict__ bnd_out = bnd + pd.bnd_off + strip * bstride;  // written by this strip (interleaved: CkCtx)
+    const float* __restrict__ bnd_in = bnd + pd.bnd_off + (strip - 1) * bstride;  // read by it (strip > 0)
     bool handoff_ok = true;
 
     uint32_t boff[W];  // byte offsets of this lane's W table columns
@@ -389,8 +427,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         if(bad != nullptr && worst >= static_cast<uint32_t>(kTabCols)) ck_report_bad(bad, pair, worst, true);
         if(bad != nullptr && kbegin == 0 && lane == 0 && a[0] >= kTabRows) ck_report_bad(bad, pair, a[0], false);
     }
-    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_x, bnd_z, reinterpret_cast<const uint32_t*>(in_x),
-                   reinterpret_cast<const uint32_t*>(in_z), strip == 0, band,
+    const CkCtx cx{k, gap_vec(k), la, col0, nsteps, lds_tab, lane, last_strip, bnd_out, reinterpret_cast<const uint32_t*>(bnd_in),
+                   make_rsrc(bnd_out), strip == 0, band,
                    band == kCkBandOff ? 0 : ck_lane_centre(la, lb, W, static_cast<uint32_t>(lane), col0), ck_step_major(band, kThrough)};
     const uint32_t* __restrict__ rowck_strip = ck_strip + ck_colin_dwords(la);
     // the state of the margin row (matrix row 0, align_pair.cc:88-90: M = D = lowest, I = go +
@@ -443,7 +481,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             st.X[c] = i1 + k.ng;
             st.Y[c] = i1 + k.go;
         }
-        if(!last_strip && lane == kWave - 1) store_through(&bnd_x[0], st.X[W - 1]);
+        if(!last_strip && lane == kWave - 1) store_through(&bnd_out[0], st.X[W - 1]);  // (X of the margin row: row 0's diagonal input)
         st.xlast_old = 0.0f;
         st.zlast = 0.0f;
         // table-row byte offset of the row this lane processes at the CURRENT step (every lane's first row is body row 0)
@@ -454,6 +492,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
 #pragma unroll
     for(int c = 0; c < W; ++c) s[c] = *reinterpret_cast<const float*>(tab_bytes + arow + boff[c]);
 
+    unsigned long long pre_bnd = ~0ull;  // (kSub) the left boundary of the next sub-block, asked for ahead (ck_chunk)
     for(uint32_t kbase = kbegin; kbase < kend; kbase += kWave) {
         // ---- per-64-step chunk: lane l fetches what lane 0 will need at step kbase+l (boundary
         // column) and at step kbase+l+1 (ancestor code: gathered a step ahead)
@@ -479,15 +518,15 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
             handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
             if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
             if(crow < la) {
-                bx = in_x[crow];
-                bz = in_z[crow];
+                bx = bnd_in[2 * crow];
+                bz = bnd_in[2 * crow + 1];
             }
         }
         // Consume the chunk loads HERE (one wait per 64 steps), not inside the step loop.
         asm volatile("" : "+v"(a_chunk), "+v"(bx), "+v"(bz));
         const CkChunkMem mem{make_rsrc(ck_strip + static_cast<uint64_t>(kbase) * (2 * kWave)),
                              make_rsrc(rowck_strip + static_cast<uint64_t>(kbase / kCkRows) * (2 * W * kWave))};
-        handoff_ok = ck_chunk<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz) && handoff_ok;
+        handoff_ok = ck_chunk<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz, pre_bnd) && handoff_ok;
         if(!kSub && !last_strip) {  // (kSub: the boundary values validate themselves: no per-chunk drain, no progress word)
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
@@ -1151,7 +1190,7 @@ __device__ __forceinline__ bool ck_walk_pair(int lane, const CkWalkArgs& wa, con
 // kSharedTab: the model has ONE substitution table -- one copy per workgroup in LDS (12.4 KB), which
 // lets four workgroups (16 wavefronts, 4 per SIMD) share a CU.  Otherwise (per-leaf tables of
 // `coati msa`) every wavefront keeps the table of its current pair.
-template <bool kSharedTab, bool kSplice>
+template <bool kSharedTab, bool kMulti>
 __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     const float* __restrict__ table, GapConsts k, const PairDesc* __restrict__ pairs,
     const WorkItem* __restrict__ items, uint32_t n_items, uint32_t* __restrict__ queue,
@@ -1163,8 +1202,10 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     const bool walk_items = (split_items_word & kCkWalkItemsFlag) != 0u;
     // the spliced traceback of multi-strip pairs (launch_viterbi_ck): 0 off, 1 on, 2 "miss", 3 without bridges; bit 6: the launch
     // is one round of wavefronts, so a wavefront that waits for its neighbour's record keeps nothing from running
-    const uint32_t splice_level = kSplice ? (dbg >> 4) & 3u : 0u;
-    const bool bridges_ok = kSplice && ((dbg >> 6) & 1u) != 0u;
+    // (kMulti: the instantiation for launches with multi-strip pairs -- their fill, ck_fill_strip<W, true>, and the spliced
+    // traceback are compiled out of the other, so that the headline's kernel is the single-strip code and nothing else)
+    const uint32_t splice_level = kMulti ? (dbg >> 4) & 3u : 0u;
+    const bool bridges_ok = kMulti && ((dbg >> 6) & 1u) != 0u;
     const uint32_t split_items = split_items_word & ~kCkWalkItemsFlag;
     __shared__ float tab_all[kSharedTab ? 1 : kCkWaves][kTabRows * kTabStride];
     const int lane_id = threadIdx.x & (kWave - 1);
@@ -1213,7 +1254,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         const WorkItem item = items[ticket];
         const uint32_t pair = item.pair, part = item.strip >> 16;
         const PairDesc pd = pairs[pair];
-        const bool multi = pd.v_strips > 1;
+        const bool multi = kMulti && pd.v_strips > 1;
         // (a multi-strip pair is walked by the wavefront of its LAST strip; when that walk leaves the band of strip s, this
         // wavefront fills strip s again -- its left boundary column is complete in memory -- and walks again)
         const uint32_t strip = (redo && multi) ? redo_strip : (item.strip & 0xffffu);
@@ -1350,7 +1391,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 sx.mode = kCkBridge;
             }
-            const bool r = ck_walk_pair<false, kSplice>(lane, wa, pd, pair, ops, ops_start, ops_len, inner_strip ? nullptr : &failed_strip, sx);
+            const bool r = ck_walk_pair<false, kMulti>(lane, wa, pd, pair, ops, ops_start, ops_len, inner_strip ? nullptr : &failed_strip, sx);
             if(pass == 0) walk_ok = r;
             if(sx.splice_stats != nullptr && lane == 0 && inner_strip) atomicAdd(sx.splice_stats + 2 + pass, 1u);
         }
@@ -1802,6 +1843,12 @@ extern "C" int coati_hip_debug_trace(unsigned long long* out) {
     if(e != hipSuccess) return static_cast<int>(e);
     return static_cast<int>(hipMemset(p, 0, sizeof(g_ck_trace)));  // next launch starts clean
 }
+extern "C" int coati_hip_debug_poll_stats(unsigned long long* out) {
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ck_poll), sizeof(g_ck_poll));
+    if(e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ck_poll), zero, sizeof zero);
+    return static_cast<int>(e);
+}
 #endif
 
 uint32_t ck_scratch_waves() { return 256u * 4u * 4u; }  // 4 wavefronts on each of the 1 024 SIMDs
@@ -1837,8 +1884,8 @@ hipError_t launch_viterbi_ck(const BatchDeviceView& v, bool shared_tab, hipStrea
     }
     // (the debug export of every cell's decisions decodes every tile: that batch keeps every checkpoint)
     const uint32_t band = v.ck_band;
-    // (the spliced instantiation only where a launch has multi-strip pairs and the level is not 0)
-    const bool spliced = ((dbg >> 4) & 3u) != 0u;
+    // (the second instantiation where a launch has multi-strip pairs)
+    const bool spliced = v.multi_strip != 0;
     auto launch = [&](auto kernel) {
         if(shape.dynamic_lds > 0) {
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(shape.dynamic_lds));

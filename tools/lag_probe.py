@@ -28,6 +28,11 @@ for w in [int(x) for x in sys.argv[1:]] or [8, 4, 16]:
             lib.coati_hip_debug_trace(tr.ctypes.data_as(C.c_void_p))
             batch.viterbi_launch(); batch.sync()
         total = sum(batch.viterbi_timing())
+        if hasattr(lib, "coati_hip_debug_poll_stats"):
+            ps = np.zeros(4, np.uint64)
+            lib.coati_hip_debug_poll_stats(ps.ctypes.data_as(C.c_void_p))
+            if ps[0]:
+                print(f"   {strips} strips, 3 launches: {int(ps[0])} sub-blocks of consumer strips, {int(ps[1])} began without their boundary ({100.0 * ps[1] / ps[0]:.1f} %), {int(ps[2])} polls for those")
         assert lib.coati_hip_debug_trace(tr.ctypes.data_as(C.c_void_p)) == 0
         raw = tr.reshape(4096, 16).astype(np.float64)
         used = raw[:, 2] > 0  # (only the wavefront of a pair's last strip stamps a traceback)
