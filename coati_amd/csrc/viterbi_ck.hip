@@ -231,7 +231,8 @@ __device__ __forceinline__ void ck_step(const CkCtx& cx, const CkChunkMem& mem, 
     const uint32_t kstep = kbase + kk;
     // (a scalar test first, marked unlikely: past the first chunk the step's usual way has no taken branch -- which costs a
     // wavefront that is alone on its SIMD ~130 cycles)
-    if(__builtin_expect(kbase == 0, 0) && kk == static_cast<uint32_t>(lane)) {
+    // (kSub only: with four wavefronts per SIMD the single-strip fill measured 1 % slower that way)
+    if((kSub ? __builtin_expect(kbase == 0, 0) : static_cast<long>(kbase == 0)) && kk == static_cast<uint32_t>(lane)) {
         // This lane starts now: state of the margin row (matrix row 0, align_pair.cc:88-90):
         // M = D = lowest, I = go + ge*float(j-1).
         uint32_t bj0 = cx.col0 + lane * W;
