@@ -86,7 +86,7 @@ const EnvOptions* read_env() {
     o->stream_tail_units_x10 = static_cast<int>(num("COATI_HIP_STREAM_TAIL_UNITS", 0));
     o->spec_host_rounds = set("COATI_HIP_SPEC_HOST_ROUNDS");
     if(const long long v = num("COATI_HIP_SAMPLE_BAND", 0); v >= 1 && v <= (1 << 24)) o->sample_band = static_cast<uint32_t>(v);
-    o->stream_helpers = static_cast<int>(num("COATI_HIP_STREAM_HELPERS", 7));
+    o->stream_helpers = static_cast<int>(num("COATI_HIP_STREAM_HELPERS", 55));
     o->pipe_no_d2h = set("COATI_HIP_PIPE_NO_D2H");
     o->sample_sequential = set("COATI_HIP_SAMPLE_SEQUENTIAL");
     o->sample_table_off = zero("COATI_HIP_SAMPLE_TABLE");

@@ -581,7 +581,8 @@ struct EnvOptions {
     int stream_tail_units_x10 = 0;   // COATI_HIP_STREAM_TAIL_UNITS (x 10): size of the streamed call's last chunk in units of 10^9 cells (0: 2.6)
     int stream_parts = -1;           // COATI_HIP_STREAM_PARTS: -1 (default) = ONE large last chunk of a streamed call cut into 3 row parts, 22 .. 28 = into 2 .. 8,
                                      // 0 = no row parts, 1 = row parts in the last ~1 000-pair chunks (round 3's form)
-    int stream_helpers = 7;          // COATI_HIP_STREAM_HELPERS (A/B): 1 = chunks planned ahead, 2 = results unstaged, 4 = slots allocated on the model's helper threads
+    int stream_helpers = 55;         // COATI_HIP_STREAM_HELPERS (A/B): 1 = chunks planned ahead, 2 = results unstaged, 4 = slots allocated on the model's helper threads,
+                                     // 8 = a trace line per call, 16 / 32 = the kernel stores results straight into the caller's page-locked arrays / the slot's staging block
     bool pipe_no_d2h = false;        // COATI_HIP_PIPE_NO_D2H: chunk pipeline without downloads (timing experiment)
     bool sample_sequential = false;  // COATI_HIP_SAMPLE_SEQUENTIAL: one serial walker per pair
     bool sample_table_off = false;   // COATI_HIP_SAMPLE_TABLE=0: exact-stream sampler without the step table
@@ -697,8 +698,18 @@ uint64_t ck_stream_error_offset();
 // the page-locked, device-visible block host and kernel talk through (host = its host address, host_dev = its
 // device address): chunk table entries, {chunks, items} announced, closed; completion word per slot
 uint64_t ck_stream_host_bytes();
+// Results the kernel stores straight into page-locked host memory instead of the chunk's workspace (device-visible addresses, null =
+// the workspace): the ops at the chunk's base, the three short arrays at the chunk's first pair; start_add is added to every ops
+// offset the kernel reports (the chunk's base in the caller's ops array, when ops_start is the caller's own array)
+struct CkStreamDirect {
+    uint8_t* ops = nullptr;
+    float* scores = nullptr;
+    uint64_t* ops_start = nullptr;
+    uint32_t* ops_len = nullptr;
+    uint64_t start_add = 0;
+};
 void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* arena, const BatchDeviceView& v, uint32_t n_pairs,
-                          uint32_t first_ticket, uint32_t chunk_no);
+                          uint32_t first_ticket, uint32_t chunk_no, const CkStreamDirect& direct = CkStreamDirect{});
 void ck_stream_host_announce(void* host, uint32_t chunks, uint32_t items);
 void ck_stream_host_close(void* host);
 unsigned long long ck_stream_host_bad(void* host, int slot);  // (0, or the kernel's report of a code out of range: viterbi_ck.hip ck_report_bad)

@@ -352,6 +352,31 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             std::fprintf(stderr, "viterbi_batch[stream]:   slot %d arena %p + %zx staging %p + %zx\n", q, model->sslots[q].arena, model->sslots[q].arena_bytes,
                          model->sslots[q].pinned, model->sslots[q].pinned_bytes);
     }
+    // Page-locked result arrays: the walks store a pair's ops straight into the caller's array (write-through at system scope, as
+    // they store them into the workspace otherwise; the chunk's completion word follows its pairs' acknowledged stores) -- the
+    // chunks of a call's end complete within 0.3 ms of each other, and 17 MB of downloads behind the kernel's last item were
+    // 0.2-0.25 ms of a 10 000-pair call.  COATI_HIP_STREAM_HELPERS bit 16 (A/B).
+    // Pageable result arrays (bit 32): the same into the slot's page-locked staging block, behind the three short arrays' room --
+    // what is left of the download is those three arrays, the helpers copy the ops out of the block as before.
+    // The three short arrays go the same way (a pair's score, ops offset and ops length: three stores by one lane), so that a chunk's
+    // completion word is all the host waits for: no download at all.
+    uint8_t* ops_dev = nullptr;
+    float* scores_dev = nullptr;
+    uint64_t* off_dev = nullptr;
+    uint32_t* len_dev = nullptr;
+    bool full_direct = false;  // every array the caller passed is written by the kernel
+    if(out_pinned && ops != nullptr && (env_options().stream_helpers & 16) != 0) {
+        auto dev_of = [&](void* p) -> void* {
+            void* dp = nullptr;
+            return p != nullptr && soft(hipHostGetDevicePointer(&dp, p, 0)) ? dp : nullptr;
+        };
+        ops_dev = static_cast<uint8_t*>(dev_of(ops));
+        scores_dev = static_cast<float*>(dev_of(scores)), off_dev = static_cast<uint64_t*>(dev_of(ops_off)), len_dev = static_cast<uint32_t*>(dev_of(ops_len));
+        full_direct = ops_dev != nullptr && (scores == nullptr || scores_dev != nullptr) && (ops_off == nullptr || off_dev != nullptr) &&
+                      (ops_len == nullptr || len_dev != nullptr);
+    }
+    const bool ops_into_staging = !out_pinned && ops != nullptr && (env_options().stream_helpers & 32) != 0;
+    uint8_t* stage_dev[kSlots] = {};  // (device-visible addresses of the slots' staging blocks, asked for once per call)
     void* hs = model->h_stream;
     std::memset(hs, 0, host_bytes);
     ck_stream_host_set_slots(hs, static_cast<uint32_t>(n_slots));
@@ -380,6 +405,8 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         char* out_stage = nullptr;
         uint64_t out_off = 0;
         bool ops_staged = false;
+        uint64_t kernel_ops_at = 0;  // the kernel stored the chunk's ops into the staging block, this far behind out_stage (0: it did not)
+        bool no_download = false;    // ... and the short arrays too (into the staging block, or all of it into the caller's page-locked arrays)
         std::future<void> unstage;  // the chunk's results are being copied out of the staging block by a helper thread
         double t_d2h = 0, t_copied = 0;  // (COATI_HIP_PIPE_TIMING)
     };
@@ -415,9 +442,9 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         coati_hip_batch* b = f.batch;
         f.out_stage = static_cast<char*>(sl.pinned) + f.out_off;
         const uint64_t group = static_cast<uint64_t>(reinterpret_cast<char*>(b->d_ops) - reinterpret_cast<char*>(b->d_scores));  // (the three short arrays, each padded to 256 bytes)
-        const bool ops_direct = out_pinned && ops != nullptr && c.ops_bytes > kMinDmaBytes;
-        f.ops_staged = ops != nullptr && c.ops_bytes > 0 && !ops_direct;
-        const uint64_t bytes = std::max<uint64_t>(group + (f.ops_staged ? c.ops_bytes : 0), kMinDmaBytes + 256);
+        const bool ops_direct = ops_dev == nullptr && out_pinned && ops != nullptr && c.ops_bytes > kMinDmaBytes;
+        f.ops_staged = ops_dev == nullptr && ops != nullptr && c.ops_bytes > 0 && !ops_direct;
+        const uint64_t bytes = std::max<uint64_t>(group + (f.ops_staged && f.kernel_ops_at == 0 ? c.ops_bytes : 0), kMinDmaBytes + 256);
         hipError_t e = hipMemcpyAsync(f.out_stage, b->d_scores, bytes, hipMemcpyDeviceToHost, down_stream);
         if(e == hipSuccess && ops_direct) e = hipMemcpyAsync(ops + c.ops_base, b->d_ops, c.ops_bytes, hipMemcpyDeviceToHost, down_stream);
         if(e == hipSuccess) e = hipEventRecord(copied[slot], down_stream);
@@ -436,11 +463,17 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
                     return fail(COATI_HIP_EINVAL, "batch_create: %s code %u out of range (pair %llu)", (bad >> 40) & 1 ? "descendant" : "ancestor",
                                 static_cast<unsigned>((bad >> 32) & 0xff), static_cast<unsigned long long>(pair));
                 }
-                const hipError_t e = submit_d2h(f, q);
-                if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+                if(f.no_download) {  // the kernel's stores were acknowledged before it set the word
+                    f.d2h_submitted = true;
+                    f.out_stage = static_cast<char*>(model->sslots[q].pinned) + f.out_off;
+                    f.ops_staged = !full_direct && ops != nullptr && f.chunk.ops_bytes > 0;
+                } else {
+                    const hipError_t e = submit_d2h(f, q);
+                    if(e != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(e));
+                }
                 if(pipe_timing) f.t_d2h = t_ms();
             }
-            if(!f.unstage.valid()) {
+            if(!f.unstage.valid() && !f.no_download) {
                 const hipError_t qd = hipEventQuery(copied[q]);
                 if(qd == hipErrorNotReady) continue;
                 if(qd != hipSuccess) return fail(COATI_HIP_EHIP, "viterbi_batch: %s", hipGetErrorString(qd));
@@ -450,7 +483,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             const uint64_t n = c.p1 - c.p0;
             // out of the staging block into the caller's arrays: megabytes when the ops array is pageable (a chunk of 2 000
             // pairs: 4 MB, 0.15-0.2 ms on one thread, and the chunks of a call's end complete together) -- on the helpers
-            auto unstage = [scores, ops, ops_off, ops_len, c, n, at0 = f.out_stage, staged = f.ops_staged]() {
+            auto unstage = [scores, ops, ops_off, ops_len, c, n, at0 = f.out_stage, staged = f.ops_staged, kernel_ops_at = f.kernel_ops_at]() {
                 char* at = at0;
                 if(scores != nullptr) std::memcpy(scores + c.p0, at, n * sizeof(float));
                 at += (n * sizeof(float) + 255) / 256 * 256;
@@ -461,9 +494,10 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
                 at += (n * sizeof(uint64_t) + 255) / 256 * 256;
                 if(ops_len != nullptr) std::memcpy(ops_len + c.p0, at, n * sizeof(uint32_t));
                 at += (n * sizeof(uint32_t) + 255) / 256 * 256;
-                if(staged) std::memcpy(ops + c.ops_base, at, c.ops_bytes);
+                if(staged) std::memcpy(ops + c.ops_base, kernel_ops_at != 0 ? at0 + kernel_ops_at : at, c.ops_bytes);
             };
-            if(f.unstage.valid()) {
+            if(f.no_download && full_direct) {  // (nothing to copy: the results are where the caller wants them)
+            } else if(f.unstage.valid()) {
                 if(f.unstage.wait_for(std::chrono::seconds(0)) != std::future_status::ready) continue;
                 f.unstage.get();
             } else if(f.ops_staged && c.ops_bytes > (256u << 10) && (env_options().stream_helpers & 2) != 0) {
@@ -659,7 +693,39 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
         f.d2h_submitted = false;
         f.out_off = out_off;
         hipError_t e = hipSuccess;
-        ck_stream_fill_chunk(hs, hs_dev, q, b->arena, device_view(b), static_cast<uint32_t>(n), published, static_cast<uint32_t>(ci));
+        CkStreamDirect direct;
+        f.kernel_ops_at = 0;
+        f.no_download = false;
+        if(full_direct) {
+            direct.ops = ops_dev + c.ops_base;
+            direct.scores = scores_dev != nullptr ? scores_dev + c.p0 : nullptr;
+            direct.ops_start = off_dev != nullptr ? off_dev + c.p0 : nullptr;
+            direct.ops_len = len_dev != nullptr ? len_dev + c.p0 : nullptr;
+            direct.start_add = c.ops_base;
+            f.no_download = true;
+        } else if(ops_dev != nullptr) {
+            direct.ops = ops_dev + c.ops_base;
+        } else if(ops_into_staging && c.ops_bytes > 0) {
+            coati_hip_model::StreamSlot& sl = model->sslots[q];
+            if(stage_dev[q] == nullptr) {
+                void* dp = nullptr;
+                if(soft(hipHostGetDevicePointer(&dp, sl.pinned, 0))) stage_dev[q] = static_cast<uint8_t*>(dp);
+            }
+            // the block's result part as the download would have filled it -- [scores | ops offsets | ops lengths], each padded to 256
+            // bytes as in the workspace -- and the ops behind the room a padded download of those would have taken
+            const uint64_t group = static_cast<uint64_t>(reinterpret_cast<char*>(b->d_ops) - reinterpret_cast<char*>(b->d_scores));
+            const uint64_t at = (std::max<uint64_t>(group, kMinDmaBytes + 256) + 255) / 256 * 256;
+            if(stage_dev[q] != nullptr && out_off + at + c.ops_bytes <= sl.pinned_bytes) {
+                uint8_t* const res = stage_dev[q] + out_off;
+                f.kernel_ops_at = at;
+                direct.ops = res + at;
+                direct.scores = reinterpret_cast<float*>(res + (reinterpret_cast<char*>(b->d_scores) - reinterpret_cast<char*>(b->d_scores)));
+                direct.ops_start = reinterpret_cast<uint64_t*>(res + (reinterpret_cast<char*>(b->d_ops_start) - reinterpret_cast<char*>(b->d_scores)));
+                direct.ops_len = reinterpret_cast<uint32_t*>(res + (reinterpret_cast<char*>(b->d_ops_len) - reinterpret_cast<char*>(b->d_scores)));
+                f.no_download = true;
+            }
+        }
+        ck_stream_fill_chunk(hs, hs_dev, q, b->arena, device_view(b), static_cast<uint32_t>(n), published, static_cast<uint32_t>(ci), direct);
         // Every copy under the persistent kernel must be done by the copy ENGINE: a copy the runtime does with a blit
         // kernel (HSA_ENABLE_SDMA=0, or its own choice) cannot start while viterbi_ck_stream holds every wavefront
         // slot.  So the wait is bounded -- 100 ms for the call's first chunk (a copy engine delivers it in well under

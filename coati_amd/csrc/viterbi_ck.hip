@@ -1449,7 +1449,12 @@ struct CkStreamChunk {
     uint32_t* host_flag;   // page-locked host memory: set to chunk_no + 1 when the chunk is complete
     unsigned long long* host_bad;  // page-locked host memory: a code out of range (ck_report_bad), 0 = none
     uint32_t n_pairs, n_items, first_ticket, chunk_no;
-    uint32_t done, pad_[5];  // pairs finished (device atomics)
+    uint32_t done, pad0_;  // pairs finished (device atomics)
+    // Results stored by the kernel straight into page-locked HOST memory (device-visible addresses; 0 = into the workspace, the host
+    // downloads them): the ops -- the caller's array, or the slot's staging block -- at this chunk's base; the scores / ops offsets /
+    // ops lengths of the chunk's pairs; and what the host would add to an ops offset (the chunk's base in the caller's array).
+    uint64_t ops_direct, scores_direct, start_direct, len_direct, start_add;
+    uint32_t pad_[2];
 };
 static_assert(sizeof(CkStreamChunk) % 16 == 0, "chunk table entries are copied as a block");
 struct CkStreamCtl {
@@ -1643,7 +1648,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         uint32_t* __restrict__ ch_ck = reinterpret_cast<uint32_t*>(arr(chp->off_ck));
         float* __restrict__ ch_bnd = reinterpret_cast<float*>(arr(chp->off_bnd));
         float* __restrict__ ch_scores = reinterpret_cast<float*>(arr(chp->off_scores));
-        uint8_t* __restrict__ ch_ops = reinterpret_cast<uint8_t*>(arr(chp->off_ops));
+        const uint64_t ops_direct = u64(chp->ops_direct);
+        uint8_t* __restrict__ ch_ops = ops_direct != 0 ? reinterpret_cast<uint8_t*>(ops_direct) : reinterpret_cast<uint8_t*>(arr(chp->off_ops));
         uint64_t* __restrict__ ch_start = reinterpret_cast<uint64_t*>(arr(chp->off_start));
         uint32_t* __restrict__ ch_len = reinterpret_cast<uint32_t*>(arr(chp->off_len));
         uint32_t* __restrict__ ch_progress = reinterpret_cast<uint32_t*>(arr(chp->off_progress));
@@ -1720,7 +1726,13 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
             (void)terminal_state(k, m, d, in, score);
         }
         const CkWalkArgs wa{k, lds_tab, tab_bytes, a, b, ckp, wbits, false, band_now, 0ull, cut};
-        const bool walk_ok = ck_walk_pair<true>(lane, wa, pd, pair, ch_ops, ch_start, ch_len);
+        // (results that go straight to host memory: the entry is read again here -- it cannot change while one of its pairs is
+        // unfinished -- instead of being carried in SGPRs through the fill)
+        const uint64_t start_add = u64(chp->start_add), start_direct = u64(chp->start_direct), len_direct = u64(chp->len_direct);
+        PairDesc pdw = pd;
+        pdw.ops_off += start_add;  // the walk's positions, and the offset it reports, count from the caller's array's start
+        const bool walk_ok = ck_walk_pair<true>(lane, wa, pdw, pair, ch_ops - start_add, start_direct != 0 ? reinterpret_cast<uint64_t*>(start_direct) : ch_start,
+                                                len_direct != 0 ? reinterpret_cast<uint32_t*>(len_direct) : ch_len);
         if(!walk_ok && band_now != kCkBandOff) {  // (left the kept band: the same item again, everything kept)
             redo_ticket = ticket;
             continue;
@@ -1730,7 +1742,11 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
             // write-through like the rest of the pair's results
             if(pd.la > 0 && pd.lb > 0) score = ch_scores[pair];
             if(!handoff_ok || !walk_ok) score = __builtin_nanf("");
+            // (the workspace's word too when the score goes straight to the host: the fill's plain store left its line dirty in this
+            // XCD's L2, and the slot's next chunk is uploaded around it -- written through here, nothing is left to be evicted later)
+            const uint64_t scores_direct = u64(chp->scores_direct);
             __hip_atomic_store(&ch_scores[pair], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if(scores_direct != 0) __hip_atomic_store(reinterpret_cast<float*>(scores_direct) + pair, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         // the pair's results are in memory -> count it; the last pair of a chunk tells the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1936,7 +1952,7 @@ void ck_stream_host_set_slots(void* host, uint32_t n_slots) { static_cast<CkStre
 void ck_stream_host_close(void* host) { __atomic_store_n(&static_cast<CkStreamHost*>(host)->closed, 1u, __ATOMIC_SEQ_CST); }
 
 void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* arena, const BatchDeviceView& v, uint32_t n_pairs,
-                          uint32_t first_ticket, uint32_t chunk_no) {
+                          uint32_t first_ticket, uint32_t chunk_no, const CkStreamDirect& direct) {
     void* host_entry = ck_stream_host_entry(host, slot);
     uint32_t* host_flag_dev = &static_cast<CkStreamHost*>(host_dev)->done_flag[slot];
     CkStreamChunk c{};
@@ -1945,6 +1961,8 @@ void ck_stream_fill_chunk(void* host, void* host_dev, int slot, const void* aren
     c.arena = reinterpret_cast<uint64_t>(arena);
     c.off_pairs = off(v.pairs), c.off_items = off(v.items), c.off_a = off(v.a_cat), c.off_b = off(v.b_cat), c.off_ck = off(v.flags);
     c.off_bnd = off(v.bnd), c.off_scores = off(v.scores), c.off_ops = off(v.ops), c.off_start = off(v.ops_start), c.off_len = off(v.ops_len);
+    c.ops_direct = reinterpret_cast<uint64_t>(direct.ops), c.scores_direct = reinterpret_cast<uint64_t>(direct.scores);
+    c.start_direct = reinterpret_cast<uint64_t>(direct.ops_start), c.len_direct = reinterpret_cast<uint64_t>(direct.ops_len), c.start_add = direct.start_add;
     c.off_progress = off(v.progress);
     c.split_items = v.ck_split_items;
     c.host_flag = host_flag_dev;

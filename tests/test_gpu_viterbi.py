@@ -384,17 +384,22 @@ def test_pipelined_one_shot_pinned_and_pageable(hip, oracle):
         del os.environ["COATI_HIP_MEM_BUDGET"]
 
 
-def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeypatch):
+@pytest.mark.parametrize("results", ["stored_by_the_kernel", "downloaded"])
+def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeypatch, results):
     """The streamed form of coati_hip_viterbi_batch (one persistent viterbi_ck_stream launch fed chunk by chunk;
     chosen by itself from 4 096 pairs of >= 250 x 250 cells, forced here): bit-exact against one resident
     batch of the same pairs -- page-locked and pageable arrays; many more chunks than the 12 stream slots
     (every slot reused, small unit forced); pairs of two and three strips (own checkpoints, cross-wavefront
     hand-off inside the persistent kernel), empty and one-letter sides in the same call; a model with
-    several tables; a second call on the same model.  A few pairs are checked against the oracle too."""
+    several tables; a second call on the same model.  A few pairs are checked against the oracle too.
+    Round 6: the walks store their results straight into host memory -- the caller's page-locked arrays, or the slot's
+    staging block for pageable ones -- and nothing is downloaded (the default); and the round-5 form, results downloaded."""
     from coati_amd import host
 
     if kernel_choice == "bits":
         pytest.skip("viterbi_l1 forced: the streamed form is viterbi_ck only")
+    if results == "downloaded":
+        monkeypatch.setenv("COATI_HIP_STREAM_HELPERS", "7")
     if kernel_choice == "ck":  # the last chunks cut into row parts (off by default since round 3: pipeline.hip)
         monkeypatch.setenv("COATI_HIP_STREAM_PARTS", "1")
     table, consts = host.set_subst("mar-mg"), host.gap_consts()

@@ -133,7 +133,7 @@ while time.time() < t_end:
         parts = str(rng.choice(["", "", "0", "1", "22", "24"]))
         if parts:
             os.environ["COATI_HIP_STREAM_PARTS"] = parts
-        helpers = str(rng.choice(["", "", "0", "1", "2", "6"]))
+        helpers = str(rng.choice(["", "", "", "0", "1", "2", "6", "7", "23", "39"]))  # (default 55: + 16 / 32, results stored by the kernel into host memory)
         if helpers:
             os.environ["COATI_HIP_STREAM_HELPERS"] = helpers
         form = str(rng.choice(["stream", "stream", "chunks"]))

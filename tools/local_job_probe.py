@@ -1,8 +1,8 @@
 """Where does the local-results job (coati_hip_dist_viterbi_shard_local, world 1) spend its time beside the streamed call?
-Wall time of the job against the library's own trace line of the streamed call inside it (COATI_HIP_STREAM_HELPERS=15).
+Wall time of the job against the library's own trace line of the streamed call inside it (COATI_HIP_STREAM_HELPERS=63).
 usage: python tools/local_job_probe.py [pairs]"""
 import os, sys, time
-os.environ.setdefault("COATI_HIP_STREAM_HELPERS", "15")
+os.environ.setdefault("COATI_HIP_STREAM_HELPERS", "63")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from coati_amd import hip, host, dist
