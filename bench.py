@@ -307,7 +307,8 @@ def measure_extras(hip, host, model, table, consts, a_cat, a_off, b_cat, b_off, 
                 res[f"{n_pairs}_pairs"].update(prep)
         res["what"] = ("coati_hip_viterbi_batch, wall time of ONE call from Python: plan + H2D of the encoded pairs + kernel + D2H of "
                        "scores/ops; from 4 096 pairs of >= 250 x 250 cells ONE persistent kernel (viterbi_ck_stream) fed chunk by chunk "
-                       "over 12 slots (HBM workspace + page-locked staging), copies on two other streams; caller arrays page-locked "
+                       "over 12 slots (HBM workspace + page-locked staging), uploads on another stream, results stored by the kernel straight into host memory "
+                       "(the caller's page-locked arrays, or the slot's staging block for pageable ones: round 6, no downloads); caller arrays page-locked "
                        "(coati_hip_host_alloc) resp. pageable; `ms` / `gcups` = MEDIAN of calls 2..7 (4 of the pageable form), the first "
                        "call -- slot allocation, first touch of the result arrays -- and the best one reported beside it; "
                        "inclusive_over_resident = kernel time of the same pairs as one resident batch / the median wall time")

@@ -506,7 +506,10 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
             } else {
                 unstage();
             }
-            if(pipe_timing)
+            if(pipe_timing && f.no_download)
+                std::fprintf(stderr, "viterbi_batch[stream]: chunk %u (%llu pairs) complete %.2f ms after the kernel started, seen at %.2f, on the host at %.2f ms (stored by the kernel%s)\n",
+                             f.chunk_no, static_cast<unsigned long long>(n), ck_stream_host_done_ms(hs, q), f.t_d2h, t_ms(), full_direct ? "" : " into the staging block");
+            else if(pipe_timing)
                 std::fprintf(stderr, "viterbi_batch[stream]: chunk %u (%llu pairs) complete %.2f ms after the kernel started, on the host at %.2f ms (download %.2f .. %.2f)\n",
                              f.chunk_no, static_cast<unsigned long long>(n), ck_stream_host_done_ms(hs, q), t_ms(), f.t_d2h, f.t_copied);
             coati_hip_batch_destroy(f.batch);

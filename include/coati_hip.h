@@ -264,8 +264,12 @@ int coati_hip_debug_rng_f24(coati_hip_model_t* model, const uint64_t rng_state[2
  * workspace + page-locked staging, kept by the model between calls); while such a call runs it owns the
  * device, other work on the GPU waits until it returns.  Everything else is cut into chunks that fit the
  * device's memory and pipelined with one launch per chunk over three slots.  Either way results are
- * identical to a resident batch's.  Arrays from coati_hip_host_alloc are copied from / into directly (DMA);
- * pageable ones pass through a slot's staging block.  One call at a time per model (serialised inside). */
+ * identical to a resident batch's.  Sequence arrays from coati_hip_host_alloc are copied from directly (DMA),
+ * pageable ones pass through a slot's staging block.  Results of the persistent-kernel form are stored BY THE
+ * KERNEL into host memory as each pair's traceback ends -- into page-locked result arrays themselves (nothing is
+ * downloaded; all four, or none: a NULL array is fine), or into the slot's staging block, from where helper threads
+ * copy them into pageable arrays; the chunk pipeline downloads them per chunk.  The result arrays hold unspecified
+ * bytes outside [ops_off[p], ops_off[p] + ops_len[p]).  One call at a time per model (serialised inside). */
 int coati_hip_viterbi_batch(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t* a_cat,
                             const uint64_t* a_off, const uint8_t* b_cat, const uint64_t* b_off,
                             float* scores, uint8_t* ops, uint64_t ops_capacity,
