@@ -1750,6 +1750,12 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         }
         // the pair's results are in memory -> count it; the last pair of a chunk tells the host
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // A pair that kept its checkpoints in the CHUNK's workspace (several strips, or too long for a wavefront slot) and is not cut
+        // into row parts wrote them with plain stores: its last strip's lines may still be dirty in this XCD's L2 (the earlier strips'
+        // were written back by the release in front of their "complete").  The host may upload the slot's next chunk the moment the
+        // completion word is set -- since round 6 nothing is downloaded in between --, and a line evicted after that would land in
+        // it: write them back first.  (Rare pairs: one L2 write-back each.)
+        if(pd.flags_off != kCkWaveSlot && !cut) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if(lane == 0) {
             const uint32_t done = __hip_atomic_fetch_add(&chp->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             if(done == n_pairs_chunk) {
