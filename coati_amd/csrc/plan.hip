@@ -138,11 +138,12 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
         // the plan is 1 column per lane).
         if(fwd_wlog2 == 0 && model->n_tables == 1) {
             uint64_t quads = 0;
-            for(uint64_t p = 0; p < n_pairs && quads <= 3072; ++p) {
+            const uint64_t quads_max = 3ull * 4ull * device_cu_count();  // three per SIMD (3 072 on the 256 CUs the sweep ran on)
+            for(uint64_t p = 0; p < n_pairs && quads <= quads_max; ++p) {
                 const uint64_t la = a_off[p + 1] - a_off[p], lb = b_off[p + 1] - b_off[p];
                 quads += (la > 0 && lb > 0 && lb <= 0x7fffff00ull) ? fwd_quad_strips(static_cast<uint32_t>(lb)) : 1;
             }
-            b->fwd_quad = env.fwd_quad >= 0 ? env.fwd_quad != 0 : quads <= 3072;
+            b->fwd_quad = env.fwd_quad >= 0 ? env.fwd_quad != 0 : quads <= quads_max;
         }
     }
     for(uint64_t p = 0; p < n_pairs; ++p) {
