@@ -93,7 +93,7 @@ if sq_src.exists():
     shutil.copy(sq_src, dst / "pmc_fill_sq_counters.txt")
     rec = {}
     for line in sq_src.read_text().splitlines():
-        f = line.split()
+        f = line.rsplit(None, 3)  # (the kernel's name may hold blanks: "viterbi_ck<true, true>")
         if len(f) == 4 and f[0].startswith("viterbi_ck"):
             rec[f[1]] = float(f[3])
     from coati_amd import host  # noqa: E402
