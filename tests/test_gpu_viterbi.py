@@ -512,6 +512,64 @@ def test_streamed_call_many_small_chunks_in_quick_succession(hip, kernel_choice,
     model.close()
 
 
+def test_streamed_call_result_array_kinds(hip, kernel_choice, monkeypatch):
+    """Round 6: the streamed call's kernel stores a pair's results straight into host memory -- into the caller's arrays when
+    ALL of them are page-locked, else into the slot's staging block.  Every kind of caller: all four arrays page-locked; only
+    the ops page-locked (-> the staging block); page-locked with the scores, the offsets or the lengths NULL; pageable with
+    NULL arrays; no ops at all (nothing for the kernel to store there: the round-5 download).  Chunks of a few dozen pairs, so
+    that every slot is taken again the moment its chunk's completion word is seen (what a chunk left dirty in an L2 must not
+    land in its successor's upload).  Every byte of every path against the resident batch."""
+    import ctypes as C
+
+    from coati_amd import host
+
+    if kernel_choice == "bits":
+        pytest.skip("viterbi_l1 forced: the streamed form is viterbi_ck only")
+    table, consts = host.set_subst("mar-mg"), host.gap_consts()
+    rng = np.random.default_rng(11)
+    a_cat, a_off, b_cat, b_off = host.synth_encoded(5, 900)
+    enc = [(a_cat[int(a_off[p]):int(a_off[p + 1])], b_cat[int(b_off[p]):int(b_off[p + 1])]) for p in range(900)]
+    for la, lb in [(699, 1900), (1101, 1030), (39, 2100)]:  # (two and three strips: checkpoints in the chunk's workspace)
+        enc.append((rng.integers(0, 183, la).astype(np.uint8), rng.integers(0, 4, lb).astype(np.uint8)))
+    enc = [enc[i] for i in rng.permutation(len(enc))]
+    a_cat, a_off, b_cat, b_off = hip.pack_pairs(enc)
+    n, total = len(enc), int(a_off[-1] + b_off[-1])
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, a_cat, a_off, b_cat, b_off)
+    batch.viterbi_launch()
+    want = batch.viterbi_fetch()
+    batch.close()
+    monkeypatch.setenv("COATI_HIP_PIPE", "stream")
+    monkeypatch.setenv("COATI_HIP_STREAM_UNIT", "25000000")
+    hip.reload_env()
+    pa, pb = hip.pinned_copy(a_cat), hip.pinned_copy(b_cat)
+    lib = hip.load()
+    ptr = lambda arr: None if arr is None else arr.ctypes.data_as(C.c_void_p)  # noqa: E731
+    make = {"pinned": hip.pinned_empty, "pageable": lambda shape, dtype: np.empty(shape, dtype)}
+    kinds = [("pinned",) * 4, ("pageable", "pinned", "pageable", "pageable"), ("pinned", "pinned", "pageable", "pinned"),
+             (None, "pinned", "pinned", "pinned"), ("pinned", "pinned", None, "pinned"), ("pinned", "pinned", "pinned", None),
+             (None, "pageable", "pageable", None), ("pinned", None, "pinned", "pinned"), ("pageable",) * 4]
+    for rep, kind in enumerate(kinds + kinds[:2]):
+        sc, ops, off, ln = (None if k is None else make[k](shape, dt) for k, (shape, dt) in
+                            zip(kind, ((n, np.float32), (total, np.uint8), (n, np.uint64), (n, np.uint32))))
+        for arr in (sc, ops, off, ln):
+            if arr is not None:
+                arr.view(np.uint8)[...] = 0xa5
+        rc = lib.coati_hip_viterbi_batch(model._h, n, ptr(pa), ptr(a_off), ptr(pb), ptr(b_off), ptr(sc), ptr(ops), total, ptr(off), ptr(ln))
+        assert rc == 0, (kind, lib.coati_hip_last_error())
+        if sc is not None:
+            assert (bits(sc) == bits(want[0])).all(), kind
+        if off is not None:
+            assert (off == want[2]).all(), kind
+        if ln is not None:
+            assert (ln == want[3]).all(), kind
+        if ops is not None:
+            for p in range(n):
+                s0, l0 = int(want[2][p]), int(want[3][p])
+                assert (ops[s0:s0 + l0] == want[1][s0:s0 + l0]).all(), (kind, p)
+    model.close()
+
+
 def test_streamed_call_reports_bad_input_and_recovers(hip, kernel_choice, monkeypatch):
     """An invalid pair deep inside a streamed call (the persistent kernel is already running when its chunk is
     planned): the call returns the reference's error (process_marginal, src/lib/utils.cc:822-835), the kernel is
