@@ -112,6 +112,7 @@ const EnvOptions* read_env() {
     }
     o->ck_debug = static_cast<uint32_t>(num("COATI_HIP_CK_DEBUG", 0));
     o->ck_walk_items = static_cast<int>(num("COATI_HIP_CK_WALK_ITEMS", -1));
+    o->ck_fuse = static_cast<int>(num("COATI_HIP_CK_FUSE", -1));
     if(const char* e = std::getenv("COATI_HIP_CK_SPLIT")) {  // "pairs,parts[,t]": t = tapered parts (common.hpp: ck_part_cut)
         char* rest = nullptr;
         o->ck_split_set = true;

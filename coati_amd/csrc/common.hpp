@@ -607,6 +607,7 @@ struct EnvOptions {
     bool ck_split_set = false;       // COATI_HIP_CK_SPLIT="pairs,parts[,t]"
     uint64_t ck_split_pairs = 0, ck_split_parts = 3;
     bool ck_split_taper = false;
+    int ck_fuse = -1;                  // COATI_HIP_CK_FUSE=0 / 1: a two-strip pair whose second strip is narrow as TWO items / both strips by the wavefront that draws the first (-1: the planner's rule)
     int ck_walk_items = -1;            // COATI_HIP_CK_WALK_ITEMS=0 / 1: the traceback of a pair cut into row parts stays with its last part / is an item of its own (-1: the planner's rule)
     uint32_t ck_split_short_last = 0;  // COATI_HIP_CK_SPLIT="pairs,parts,s<k>": the last part k chunks shorter (0-7)
     uint32_t spec_cands = 3u << 16;  // COATI_HIP_SPEC_CANDS (196 608: 16 x 1 000 samples 6.1 ms; 2^17: 6.4, 2^18: 6.4, 2^16: 7.8 -- tools/sample_bench.py, round 4)
@@ -626,6 +627,13 @@ const EnvOptions& env_options();
 struct WorkItem {
     uint32_t pair, strip;
 };
+// viterbi_ck, round 6 -- FUSED two-strip pairs.  A pair a little wider than one strip (the bench's synthetic set: 333 of 10 000
+// descendants are 1 025-1 082 nt long) is a full strip and one of a few columns; as two items on two wavefronts the second spends
+// the first's whole time following it -- a wavefront slot that mostly polls --, and the pair pays a release and two acquires.  In a
+// launch with (many) more items than wavefronts the planner marks the two items (upper half of `strip`, which only pairs cut into
+// row parts use otherwise): the wavefront that draws the first fills BOTH strips, one after the other, and walks the pair;
+// whoever draws the second moves on.  Same values, same order of operations per cell; nothing waits for another wavefront.
+constexpr uint32_t kCkFusedFirst = 0xfffeu, kCkFusedSecond = 0xffffu;
 
 struct BatchDeviceView {
     const float* table;

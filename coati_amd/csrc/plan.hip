@@ -579,6 +579,19 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
                                               : fwd_strips_w(b->desc[p].lb, 1u << b->desc[p].f_wlog2);
         for(uint32_t st = 0; st < nf; ++st) fwd_items.push_back(WorkItem{p, st});
     }
+    // fused two-strip pairs (common.hpp: kCkFusedFirst): where the launch has more than two rounds of wavefronts' worth of items --
+    // below that the strips of a pair are better off side by side, and the spliced traceback wants them so
+    if(b->ck && L == 1) {
+        const bool fuse = env.ck_fuse >= 0 ? env.ck_fuse != 0 : items.size() > 2ull * ck_scratch_waves();
+        for(size_t q = 0; fuse && q + 1 < items.size(); ++q) {
+            const PairDesc& d = b->desc[items[q].pair];
+            if(items[q].strip == 0 && d.v_strips == 2 && d.v_wmain == kW && d.v_wlast == 4 && d.v_parts < 2 && d.la > 0 && items[q + 1].pair == items[q].pair) {
+                items[q].strip |= kCkFusedFirst << 16;
+                items[q + 1].strip |= kCkFusedSecond << 16;
+                ++q;
+            }
+        }
+    }
     if(b->ck_split_items > 0) {
         const uint32_t parts = ck_parts_count(b->desc[order[n_pairs - 1]].v_parts);
         // (+ one item per cut pair for its traceback where that is an item of its own: "part" number `parts`)

@@ -1240,6 +1240,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
     uint32_t redo_ticket = 0xffffffffu;
     uint32_t redo_strip = 0;                 // multi-strip pairs: the strip to fill again (everything kept) before the walk is repeated
     unsigned long long redo_kept_all = 0ull;  // ... and the strips of the pair that have been (this one included)
+    uint32_t fused_next = 0xffffffffu;       // (kMulti) the second item of a FUSED two-strip pair (common.hpp), this wavefront's next item
+    bool fused_ok = true;                    // ... and whether its first strip went well
     for(;;) {
         // `lane` is made opaque in every iteration: LLVM otherwise treats `lane == 0` as a
         // loop-invariant condition and may peel/unswitch this loop per lane, after which the
@@ -1247,15 +1249,22 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
         const bool redo = redo_ticket != 0xffffffffu;  // (wave-uniform) the previous item again: its walk left the kept checkpoint band
-        uint32_t ticket = atomicAdd(queue, (lane == 0 && !redo) ? 1u : 0u);  // every lane takes part; lane 0 draws
+        const bool chained = kMulti && fused_next != 0xffffffffu;  // (wave-uniform) the second strip of a fused pair: no draw
+        uint32_t ticket = atomicAdd(queue, (lane == 0 && !redo && !chained) ? 1u : 0u);  // every lane takes part; lane 0 draws
         ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
         if(redo) ticket = redo_ticket;
+        if(chained) ticket = fused_next;
         redo_ticket = 0xffffffffu;
+        fused_next = 0xffffffffu;
         if(ticket >= n_items) break;
         const WorkItem item = items[ticket];
         const uint32_t pair = item.pair, part = item.strip >> 16;
         const PairDesc pd = pairs[pair];
         const bool multi = kMulti && pd.v_strips > 1;
+        // fused two-strip pairs (the planner marks them in launches of many items; with the spliced traceback on -- forced: the
+        // planner's rule excludes it -- the marks are ignored): the drawer of the first item does the second too, its drawer moves on
+        const bool fused = kMulti && multi && splice_level == 0u && (part == kCkFusedFirst || part == kCkFusedSecond);
+        if(fused && part == kCkFusedSecond && !chained && !redo) continue;
         // (a multi-strip pair is walked by the wavefront of its LAST strip; when that walk leaves the band of strip s, this
         // wavefront fills strip s again -- its left boundary column is complete in memory -- and walks again)
         const uint32_t strip = (redo && multi) ? redo_strip : (item.strip & 0xffffu);
@@ -1314,7 +1323,9 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // the spliced traceback of a multi-strip pair (ck_walk_pair): the strip's wavefront says "complete" itself, after its
         // speculative walks -- and the pair's last strip only where its walk leaves the strip
         const bool spliced = multi && !redo && splice_level != 0u && !(dbg & 1u) && pd.la > 0 && pd.lb > 0;
-        const bool defer = spliced;
+        // (fused: nobody waits for this strip's "complete" and nothing it wrote is read by another wavefront -- no release, no
+        // chain; ck_fill_strip returns before them)
+        const bool defer = spliced || (fused && !redo);
         if(pd.la > 0 && pd.lb > 0 && !walk_item) {  // (without body cells only the margins are walked)
             if(cut)  // (every row part of a pair keeps the same band; the redo above refills the WHOLE pair, alone, into the pair's own storage)
                 handoff_ok = ck_fill_strip<16, false, true, true>(k, pd, pair, strip, ticket, lane, lds_tab, tab_bytes, a, b, ckp, bnd, scores, progress, kbegin, kend, nullptr, band_now) && handoff_ok;
@@ -1345,6 +1356,16 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
             continue;
         }
         const bool inner_strip = !redo && strip + 1 < pd.v_strips;  // not the last strip of its pair: no traceback here ...
+        if(fused && inner_strip) {
+            // the first strip of a fused pair: its boundary column is complete in memory (stored through the L2; this wavefront
+            // waits for the acknowledgements, and says "complete" for the record -- a redo of the pair looks at the word);
+            // the second strip is this wavefront's next item
+            publish_progress(progress + ticket, handoff_ok ? pd.la : kHandoffPoison, lane == kWave - 1);
+            fused_next = ticket + 1u;
+            fused_ok = handoff_ok;
+        } else if(fused && !redo) {
+            handoff_ok = handoff_ok && fused_ok;
+        }
         if((inner_strip && !spliced) || (dbg & 1u)) {
 #ifdef COATI_FILL_TRACE
             COATI_CK_STAMP(1);
@@ -1359,7 +1380,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
         // (a cut pair: its earlier parts' checkpoints were stored through other wavefronts' L2s, and this wavefront's L2 may hold
         // the lines of an earlier launch: its walk reads them past the L2 -- CkWalkArgs::through -- instead of invalidating it)
         // (spliced: the true walk waits and acquires where it leaves its own strip -- CkSplice::chain)
-        if(pd.v_strips > 1 && !spliced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (fused, first time round: both strips' checkpoints are this wavefront's own stores)
+        if(pd.v_strips > 1 && !spliced && !(fused && !redo)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if(pd.la == 0 || pd.lb == 0) {
             float m, d, in, score;
             margin_mdi(k, 1u, pd.la, pd.lb, m, d, in);

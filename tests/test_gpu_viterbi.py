@@ -448,6 +448,53 @@ def test_streamed_one_shot_persistent_kernel(hip, oracle, kernel_choice, monkeyp
     model.close()
 
 
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_fused_two_strip_pairs(hip, oracle, kernel_choice, monkeypatch, fuse):
+    """Round 6: a pair a little wider than one strip (descendant of 1 025 .. 1 280 nt: a full strip + one of <= 256 columns, 4
+    per lane) is, in a launch with many more items than wavefronts, done by ONE wavefront -- both strips one after the other,
+    then the walk (common.hpp: kCkFusedFirst; forced here on a small batch, and off).  Related pairs, pairs whose walk leaves
+    the kept band (unrelated descendants, a long indel: the strip is filled again by the same wavefront), a second strip of ONE
+    column and of 256, neighbours that are not fused (one strip; a second strip of 8 columns per lane; three strips), twice on
+    the same batch.  Scores, ops and every decision byte as the oracle has them."""
+    if kernel_choice == "bits":
+        pytest.skip("viterbi_l1 forced: fused items are viterbi_ck's")
+    monkeypatch.setenv("COATI_HIP_CK_FUSE", fuse)
+    monkeypatch.setenv("COATI_HIP_VITERBI_CK", "1")
+    monkeypatch.setenv("COATI_HIP_STRIP_W", "16")
+    rng = np.random.default_rng(66)
+    table, consts = util.random_table(rng), oracle.gap_consts()
+    nt = list(util.NT)
+    pairs = []
+    for k in range(10):  # related, descendants of 1 025 .. 1 090 nt
+        anc = util.random_anc(rng, int(rng.integers(343, 360)))
+        des = util.mutate(rng, anc)
+        while len(des) <= 1024:
+            des += str(rng.choice(nt))
+        pairs.append((anc, des))
+    anc = util.random_anc(rng, 200)
+    pairs.append((anc, "".join(rng.choice(nt, 1025))))  # second strip: one column; unrelated -- the walk leaves the band
+    pairs.append((util.random_anc(rng, 345), "".join(rng.choice(nt, 1060))))  # unrelated
+    anc = util.random_anc(rng, 350)
+    pairs.append((anc, anc[:300] + "".join(rng.choice(nt, 200)) + anc[300:850]))  # a 200-nt insertion, then a deletion of the tail
+    pairs.append((util.random_anc(rng, 100), "".join(rng.choice(nt, 1280))))  # second strip: 256 columns (all of its lanes)
+    pairs.append((util.random_anc(rng, 120), "".join(rng.choice(nt, 1400))))  # second strip 8 columns per lane: not fused
+    pairs.append((util.random_anc(rng, 90), "".join(rng.choice(nt, 2100))))  # three strips: not fused
+    pairs += util.make_pairs(rng, 12, 100, 330, L=1)  # one strip each
+    pairs = [pairs[i] for i in rng.permutation(len(pairs))]
+    run_and_compare(hip, oracle, table, consts, pairs, check_flags=True)
+    enc = util.encode_pairs(pairs)
+    model = hip.Model(table, consts, 1)
+    batch = hip.Batch(model, *hip.pack_pairs(enc))
+    batch.viterbi_launch()
+    first = batch.viterbi_fetch()
+    assert batch.band_stats()[1] >= 3  # (the walks that leave the kept band: their strips were filled again)
+    batch.viterbi_launch()
+    second = batch.viterbi_fetch()
+    assert (bits(first[0]) == bits(second[0])).all() and (first[3] == second[3]).all() and (first[1] == second[1]).all()
+    batch.close()
+    model.close()
+
+
 @pytest.mark.parametrize("walk_items", ["0", "1"])
 @pytest.mark.parametrize("plan", ["40,3", "25,2", "60,4", "60,8", "60,3,t", "60,4,t", "60,5,t", "40,3,s3", "60,2,s7", "60,4,s1",
                                   "60,4,s5", "60,8,s3", "60,8,s7"])  # (round 6: shortenings the old guard let empty the last part)

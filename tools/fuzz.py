@@ -34,6 +34,7 @@ while time.time() < t_end:
     os.environ.pop("COATI_HIP_LP_PAIRTAB", None)
     os.environ.pop("COATI_HIP_LP_SPLICE", None)
     os.environ.pop("COATI_HIP_CK_SPLICE", None)
+    os.environ.pop("COATI_HIP_CK_FUSE", None)
     if forced in ("auto", "bits"):  # small batches run on viterbi_lp: both strip shapes, with and without the pair table
         w = str(rng.choice(["", "", "2", "3", "4"]))
         if w:
@@ -55,6 +56,11 @@ while time.time() < t_end:
         sp = str(rng.choice(["", "", "0", "nobridge", "miss"]))
         if sp:
             os.environ["COATI_HIP_CK_SPLICE"] = sp
+        # (round 6) two-strip pairs with a narrow second strip as ONE wavefront's work (the planner: only in launches of many items)
+        if not w and rng.random() < 0.6:
+            os.environ["COATI_HIP_CK_FUSE"] = "1"
+            if not sp:
+                os.environ["COATI_HIP_CK_SPLICE"] = "0"  # (the marks are honoured where the splice is off)
         if rng.random() < 0.5:  # the last pairs of the LPT order cut into row parts (default only from 4 352 pairs)
             # (round 5: equal / tapered parts / a last part 1-7 chunks shorter; the cut pairs' tracebacks with their last part or
             # as items of their own)
@@ -72,10 +78,15 @@ while time.time() < t_end:
     max_cod = int(rng.choice([20, 120, 400, 1000]))
     pairs = util.make_pairs(rng, n, 0 if rng.random() < 0.2 else 1, max_cod, L=L, amb=0.03)
     if rng.random() < 0.3:  # a pair around the strip boundaries
-        nb = int(rng.choice([1020, 1024, 1030, 2050, 3075])) // L * L
+        nb = int(rng.choice([1020, 1024, 1025, 1030, 1090, 1280, 2050, 3075])) // L * L
         unit = 3 * L if L % 3 else L
         anc = util.random_anc(rng, max(unit // 3, (nb // 3) // (unit // 3) * (unit // 3)))
         pairs.append((anc, "".join(rng.choice(list(util.NT), nb))))
+    if L == 1 and rng.random() < 0.25:  # (round 6) related pairs a little wider than one strip: fused items
+        for _ in range(int(rng.integers(1, 4))):
+            anc = util.random_anc(rng, int(rng.integers(330, 400)))
+            des = util.mutate(rng, anc, n_indel=int(rng.integers(0, 8)), mean_len=int(rng.choice([4, 12, 60])))
+            pairs.append((anc, des + "".join(rng.choice(list(util.NT), max(0, 1025 + int(rng.integers(0, 200)) - len(des))))))
     if L == 1 and rng.random() < 0.12:  # (round 6) a related pair of 6-10 kb with indels: dozens of strips, records, bridges
         anc = util.random_anc(rng, int(rng.integers(2000, 3400)))
         pairs.append((anc, util.mutate(rng, anc, n_indel=int(rng.integers(4, 60)), mean_len=int(rng.choice([4, 12, 40])))))
