@@ -582,7 +582,8 @@ int batch_create_impl(coati_hip_model_t* model, uint64_t n_pairs, const uint8_t*
     // fused two-strip pairs (common.hpp: kCkFusedFirst): where the launch has more than two rounds of wavefronts' worth of items --
     // below that the strips of a pair are better off side by side, and the spliced traceback wants them so
     if(b->ck && L == 1) {
-        const bool fuse = env.ck_fuse >= 0 ? env.ck_fuse != 0 : items.size() > 2ull * ck_scratch_waves();
+        // (the chunks of a streamed call -- any size, they share ONE persistent launch -- always)
+        const bool fuse = env.ck_fuse >= 0 ? env.ck_fuse != 0 : (items.size() > 2ull * ck_scratch_waves() || (opts != nullptr && opts->wave_slot_dwords != 0));
         for(size_t q = 0; fuse && q + 1 < items.size(); ++q) {
             const PairDesc& d = b->desc[items[q].pair];
             if(items[q].strip == 0 && d.v_strips == 2 && d.v_wmain == kW && d.v_wlast == 4 && d.v_parts < 2 && d.la > 0 && items[q + 1].pair == items[q].pair) {

@@ -397,7 +397,8 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
                                               float* __restrict__ scores, uint32_t* __restrict__ progress,
                                               uint32_t kbegin = 0, uint32_t kend = 0xffffffffu,
                                               unsigned long long* bad = nullptr, uint32_t band = kCkBandOff,
-                                              bool defer_complete = false /* (kSub, not the last strip) the caller says "complete": ck_strip_complete */) {
+                                              bool defer_complete = false /* (not the last strip) the caller says "complete": ck_strip_complete; a fused pair */,
+                                              bool own_left = false /* (!kSub, strip > 0) the left neighbour's boundary column was written by THIS wavefront, all of it (a fused pair): nothing to wait for */) {
     // [kbegin, kend): the steps of this item -- the whole strip, or one ROW PART of it (PairDesc::v_parts; whole
     // 64-step chunks).  A part that does not start at 0 takes over the lane state its predecessor left behind the
     // strip's checkpoints; one that does not end at the last step leaves it there.
@@ -516,8 +517,10 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         }
         if(!kSub && strip > 0) {
             // rows kbase .. kbase+63 of the left neighbour's last column must be published
-            handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
-            if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+            if(!own_left) {
+                handoff_ok = handoff_ok && wait_progress(progress + ticket - 1, min(la, kbase + kWave));
+                if(__hip_atomic_load(progress + ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kHandoffPoison) handoff_ok = false;
+            }
             if(crow < la) {
                 bx = bnd_in[2 * crow];
                 bz = bnd_in[2 * crow + 1];
@@ -560,7 +563,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
     }
     // (wave-uniform; spliced traceback: the speculative walk of the strip comes first; the pair's last strip waits for the chain
     // where its walk leaves the strip -- CkSplice::chain)
-    if(kSub && defer_complete && !last_strip) return handoff_ok;
+    if((kSub || !kSingle) && defer_complete && !last_strip) return handoff_ok;
     if(kSub && strip > 0 && !defer_complete) {
         // (the chain "every earlier strip has released its checkpoints" still runs through the progress words: this strip
         // says "complete" only after its left neighbour has)
@@ -1589,14 +1592,21 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
     const uint32_t lds_tab = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));
     const uint32_t wave_id = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * kCkWaves + threadIdx.x / kWave)));
     uint32_t redo_ticket = 0xffffffffu;
+    uint32_t fused_next = 0xffffffffu;  // the second item of a fused two-strip pair (common.hpp: kCkFusedFirst), this wavefront's next item
+    bool fused_ok = true, fused_redo = false;  // ... whether its first strip went well, and whether this is the pair's second time round
     for(;;) {
         int lane = lane_id;
         asm volatile("" : "+v"(lane));
-        const bool redo = redo_ticket != 0xffffffffu;  // (as in viterbi_ck; the ticket was published long ago: the wait below returns at once)
-        uint32_t ticket = atomicAdd(&ctl->queue, (lane == 0 && !redo) ? 1u : 0u);
+        const bool chained = fused_next != 0xffffffffu;  // (the next ticket of the same chunk: published with the first)
+        // (as in viterbi_ck; the ticket was published long ago: the wait below returns at once.  A fused pair is done again from its
+        // FIRST item, and its second item is a redo too)
+        const bool redo = redo_ticket != 0xffffffffu || (chained && fused_redo);
+        uint32_t ticket = atomicAdd(&ctl->queue, (lane == 0 && !redo && !chained) ? 1u : 0u);
         ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
-        if(redo) ticket = redo_ticket;
+        if(redo_ticket != 0xffffffffu) ticket = redo_ticket;
+        if(chained) ticket = fused_next;
         redo_ticket = 0xffffffffu;
+        fused_next = 0xffffffffu;
         // ---- wait until the item is published, or the call is closed (bounded)
         bool mine = false;
         const uint64_t t_wait = __builtin_amdgcn_s_memrealtime();  // (100 MHz)
@@ -1679,6 +1689,9 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         const WorkItem item = ch_items[local];
         const uint32_t pair = u32(item.pair), strip_word = u32(item.strip);
         const uint32_t strip = strip_word & 0xffffu, part = strip_word >> 16;  // (row part of a cut pair: the call's last chunks)
+        // fused two-strip pairs (every chunk of a streamed call has them marked): the drawer of the first item does both strips
+        const bool fused = part == kCkFusedFirst || part == kCkFusedSecond;
+        if(fused && part == kCkFusedSecond && !chained && !redo) continue;
         const uint32_t split_items = u32(chp->split_items);
         // (loaded through a pointer the compiler cannot trace to a kernel argument, i.e. with vector loads: made
         // wave-uniform word by word, or every address derived from it -- buffer descriptors included -- counts as
@@ -1722,17 +1735,34 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         }
         // (banded checkpoints: as in viterbi_ck)
         const uint32_t w_item = strip + 1 == pd.v_strips ? pd.v_wlast : pd.v_wmain;
-        const uint32_t band_now = (!redo && pd.v_strips == 1 && w_item == 16 && pd.la > 0 && pd.lb > 0) ? ck_band_half(band, pd.la, pd.lb) : kCkBandOff;
+        // (a FUSED two-strip pair keeps a band as the resident kernel's multi-strip pairs do -- both strips are this wavefront's, so
+        // a walk that leaves the band has the whole pair filled again with everything kept, from its first item; other multi-strip
+        // pairs of a streamed call keep everything)
+        const uint32_t band_now = (redo || pd.la == 0 || pd.lb == 0) ? kCkBandOff
+                                  : fused                            ? ck_band_half_long(band, pd.la, pd.lb)
+                                  : (pd.v_strips == 1 && w_item == 16) ? ck_band_half(band, pd.la, pd.lb)
+                                                                       : kCkBandOff;
         if(pd.la > 0 && pd.lb > 0) {
             if(cut)
                 handoff_ok = ck_fill_strip<16, false, true, true>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, kbegin, kend, host_bad, band_now) && handoff_ok;
-            else if(w_item == 16)
-                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad, band_now);
+            else if(w_item == 16)  // (fused, the first strip: no "complete" from in there -- nobody waits for it, nothing is released)
+                handoff_ok = ck_fill_strip<16>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad, band_now, fused && !redo);
             else if(w_item == 8)
                 handoff_ok = ck_fill_strip<8>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
-            else
-                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad);
+            else  // (fused, the second strip: its left boundary is this wavefront's own, complete)
+                handoff_ok = ck_fill_strip<4>(k, pd, pair, strip, local, lane, lds_tab, tab_bytes, a, b, ckp, ch_bnd, ch_scores, ch_progress, 0, 0xffffffffu, host_bad,
+                                              fused ? band_now : kCkBandOff, false, fused && chained);
         }
+        if(fused && strip + 1 < pd.v_strips) {
+            // the first strip of a fused pair is done: its boundary column is in memory once the stores are acknowledged; the word
+            // for the record; the second strip is this wavefront's next item
+            publish_progress(ch_progress + local, handoff_ok ? pd.la : kHandoffPoison, lane == kWave - 1);
+            fused_next = ticket + 1u;
+            fused_ok = handoff_ok;
+            fused_redo = redo;
+            continue;
+        }
+        if(fused && chained) handoff_ok = handoff_ok && fused_ok;
         if(cut && part + 1 < ck_parts_count(pd.v_parts)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no release fence: kThrough)
             publish_progress(ch_progress + local, handoff_ok ? kend : kHandoffPoison, lane == kWave - 1);
@@ -1740,7 +1770,7 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         }
         if(strip + 1 < pd.v_strips) continue;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if(pd.v_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if(pd.v_strips > 1 && !(fused && chained)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float score = 0.0f;
         if(pd.la == 0 || pd.lb == 0) {
             float m, d, in;
@@ -1755,8 +1785,8 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck_stream(const fl
         pdw.ops_off += start_add;  // the walk's positions, and the offset it reports, count from the caller's array's start
         const bool walk_ok = ck_walk_pair<true>(lane, wa, pdw, pair, ch_ops - start_add, start_direct != 0 ? reinterpret_cast<uint64_t*>(start_direct) : ch_start,
                                                 len_direct != 0 ? reinterpret_cast<uint32_t*>(len_direct) : ch_len);
-        if(!walk_ok && band_now != kCkBandOff) {  // (left the kept band: the same item again, everything kept)
-            redo_ticket = ticket;
+        if(!walk_ok && band_now != kCkBandOff) {  // (left the kept band: the same item again -- a fused pair: from its first --, everything kept)
+            redo_ticket = (fused && chained) ? ticket - 1u : ticket;
             continue;
         }
         if(lane == 0) {
