@@ -531,7 +531,7 @@ __device__ __forceinline__ bool ck_fill_strip(const GapConsts& k, const PairDesc
         const CkChunkMem mem{make_rsrc(ck_strip + static_cast<uint64_t>(kbase) * (2 * kWave)),
                              make_rsrc(rowck_strip + static_cast<uint64_t>(kbase / kCkRows) * (2 * W * kWave))};
         handoff_ok = ck_chunk<W, kSub, kSingle, kThrough>(cx, mem, st, arow, s, boff, kbase, a_chunk, bx, bz, pre_bnd) && handoff_ok;
-        if(!kSub && !last_strip) {  // (kSub: the boundary values validate themselves: no per-chunk drain, no progress word)
+        if(!kSub && !last_strip && !defer_complete) {  // (kSub: the boundary values validate themselves: no per-chunk drain, no progress word; a fused pair's first strip: nobody is waiting)
             const uint32_t done = min(kbase + kWave, nsteps);
             if(done > kWave - 1 && done - (kWave - 1) < la) publish_progress(progress + ticket, done - (kWave - 1), lane == kWave - 1);
         }
