@@ -722,7 +722,7 @@ int viterbi_batch_stream(coati_hip_model_t* model, uint64_t n_pairs, const uint8
                 uint8_t* const res = stage_dev[q] + out_off;
                 f.kernel_ops_at = at;
                 direct.ops = res + at;
-                direct.scores = reinterpret_cast<float*>(res + (reinterpret_cast<char*>(b->d_scores) - reinterpret_cast<char*>(b->d_scores)));
+                direct.scores = reinterpret_cast<float*>(res);
                 direct.ops_start = reinterpret_cast<uint64_t*>(res + (reinterpret_cast<char*>(b->d_ops_start) - reinterpret_cast<char*>(b->d_scores)));
                 direct.ops_len = reinterpret_cast<uint32_t*>(res + (reinterpret_cast<char*>(b->d_ops_len) - reinterpret_cast<char*>(b->d_scores)));
                 f.no_download = true;
