@@ -1459,8 +1459,10 @@ __global__ __launch_bounds__(kCkWaves* kWave, 4) void viterbi_ck(
 // planning and uploading chunks of pairs while the kernel runs and tells it through `published` (the
 // number of work items that are ready; written into HBM by the same in-order upload stream that carried
 // the chunk, so the data is there when the number is); the kernel tells the host through a flag in
-// page-locked host memory when a chunk's last pair is done, and the host downloads that chunk's results
-// while the kernel works on the next.  No ragged end between chunks, no under-filled ramp-up kernels.
+// page-locked host memory when a chunk's last pair is done -- its results are in host memory by then (round 6: the walks
+// store them straight into the caller's page-locked arrays or the slot's staging block, CkStreamChunk::ops_direct ...;
+// rounds 3-5, and still where the caller passes no ops array: into the workspace, and the host downloads the chunk's
+// results while the kernel works on the next).  No ragged end between chunks, no under-filled ramp-up kernels.
 // Visibility: a wavefront that takes a ticket invalidates its vector and scalar caches at system scope
 // before it reads anything of the chunk (the slot's addresses held another chunk's data before);
 // results are stored write-through at system scope and completed (vmcnt) before the pair is counted.
