@@ -592,8 +592,21 @@ def test_streamed_call_result_array_kinds(hip, kernel_choice, monkeypatch):
     pa, pb = hip.pinned_copy(a_cat), hip.pinned_copy(b_cat)
     lib = hip.load()
     ptr = lambda arr: None if arr is None else arr.ctypes.data_as(C.c_void_p)  # noqa: E731
-    make = {"pinned": hip.pinned_empty, "pageable": lambda shape, dtype: np.empty(shape, dtype)}
-    kinds = [("pinned",) * 4, ("pageable", "pinned", "pageable", "pageable"), ("pinned", "pinned", "pageable", "pinned"),
+    # (page-locked by registration: memory the CALLER allocated and handed to hipHostRegister -- what an embedder with its own
+    # buffers does; the kernel stores into it through the device-visible address the runtime gives for it)
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    rt.hipHostUnregister.argtypes = [C.c_void_p]
+    registered = []
+
+    def make_registered(shape, dtype):
+        arr = np.empty(shape, dtype)
+        assert rt.hipHostRegister(arr.ctypes.data_as(C.c_void_p), arr.nbytes, 0) == 0
+        registered.append(arr)
+        return arr
+
+    make = {"pinned": hip.pinned_empty, "pageable": lambda shape, dtype: np.empty(shape, dtype), "registered": make_registered}
+    kinds = [("pinned",) * 4, ("registered",) * 4, ("registered", "pinned", "pinned", "registered"), ("pageable", "pinned", "pageable", "pageable"), ("pinned", "pinned", "pageable", "pinned"),
              (None, "pinned", "pinned", "pinned"), ("pinned", "pinned", None, "pinned"), ("pinned", "pinned", "pinned", None),
              (None, "pageable", "pageable", None), ("pinned", None, "pinned", "pinned"), ("pageable",) * 4]
     for rep, kind in enumerate(kinds + kinds[:2]):
@@ -614,6 +627,8 @@ def test_streamed_call_result_array_kinds(hip, kernel_choice, monkeypatch):
             for p in range(n):
                 s0, l0 = int(want[2][p]), int(want[3][p])
                 assert (ops[s0:s0 + l0] == want[1][s0:s0 + l0]).all(), (kind, p)
+        while registered:
+            assert rt.hipHostUnregister(registered.pop().ctypes.data_as(C.c_void_p)) == 0
     model.close()
 
 
